@@ -1,0 +1,229 @@
+/*
+ * mrx.h -- C ABI of libmrx, the MI355X (gfx950) implementation of maria's
+ * atmospheric-turbulence + time-ordered-data (TOD) synthesis hot path.
+ *
+ * The reference (thomaswmorris/maria) is pure Python and has no FFI for this
+ * path; the entry points below are what a ctypes binding placed at the
+ * reference's own Python seams would call.  Each function cites the reference
+ * code (file:line under maria/) whose arithmetic it replaces.
+ *
+ * Conventions
+ *  - every function returns 0 (MRX_OK) or a negative mrx_status; nothing throws.
+ *    mrx_last_error(ctx) returns a human-readable message for the last failure.
+ *  - the CALLER owns every buffer.  Pointers named d_* are DEVICE pointers
+ *    (e.g. torch-ROCm tensor.data_ptr()); everything else is host memory that
+ *    is only read during the call.
+ *  - all work is enqueued on the HIP stream bound with mrx_set_stream()
+ *    (default: the null stream); no call synchronises the device except
+ *    mrx_read_flags() and mrx_synchronize().
+ *  - one mrx_ctx per host thread per device.
+ *  - coarse (atmosphere-rate) arrays are TIME-MAJOR: index [t * D + d] with
+ *    D = detector rows of this shard; the full-rate TOD is DETECTOR-MAJOR
+ *    [d * ld + s], the reference's (ndet, nt) layout (sim/atmosphere.py:72-82).
+ */
+#ifndef MRX_H_
+#define MRX_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MRX_VERSION 100 /* 0.1.0 */
+
+typedef enum mrx_status {
+  MRX_OK = 0,
+  MRX_ERR_INVALID = -1,  /* bad argument (null pointer, non-positive size ...) */
+  MRX_ERR_HIP = -2,      /* a HIP runtime call failed; see mrx_last_error    */
+  MRX_ERR_NO_DEVICE = -3,
+  MRX_ERR_UNSUPPORTED = -4, /* shape outside what the kernels are built for  */
+  MRX_ERR_ALLOC = -5
+} mrx_status;
+
+/* bits of the device flag word written by the sampling kernel */
+#define MRX_FLAG_SCREEN_OOB 1u /* a line of sight left a layer's screen: the
+                                  reference raises RuntimeError "introduced nans"
+                                  (atmosphere/atmosphere.py:368-369)            */
+#define MRX_FLAG_TABLE_OOB 2u  /* (pwv, el) left the emission table: jax fill
+                                  value NaN (band/band.py:283-286)              */
+#define MRX_FLAG_NAN 4u        /* a NaN reached the output                      */
+
+typedef struct mrx_ctx mrx_ctx;
+typedef struct mrx_atm_plan mrx_atm_plan;
+
+/* ---- context ------------------------------------------------------------ */
+
+int mrx_version(void);
+/* Creates a context on HIP device `device`.  Fails with MRX_ERR_NO_DEVICE when
+ * no gfx950 device is visible: there is no CPU fallback in this library. */
+int mrx_init(int device, mrx_ctx** ctx);
+int mrx_destroy(mrx_ctx* ctx);
+/* Bind the hipStream_t all later calls enqueue on (pass NULL for the null
+ * stream).  The stream stays owned by the caller. */
+int mrx_set_stream(mrx_ctx* ctx, void* hip_stream);
+int mrx_synchronize(mrx_ctx* ctx);
+const char* mrx_last_error(const mrx_ctx* ctx);
+/* Device properties the host side sizes launches with. */
+int mrx_device_info(const mrx_ctx* ctx, int* n_cu, int* lds_bytes_per_cu,
+                    size_t* hbm_bytes, char* name, int name_len);
+
+/* HIP-event timer on the bound stream (bench.py's live kernel timing; a
+ * torch.cuda.Event only sees torch's own current stream). */
+int mrx_timer_start(mrx_ctx* ctx);
+int mrx_timer_stop(mrx_ctx* ctx, float* elapsed_ms); /* synchronises */
+
+/* ---- turbulent layer stack + emission tables (the "plan") ---------------- */
+
+/* One turbulent layer = one smoothed screen on a rectilinear grid in the
+ * process frame (atmosphere/atmosphere.py:317-373).  A line of sight with
+ * unit-height ground projection (px, py) (coords/coordinates.py:333-349,
+ * z = 1) hits the layer at
+ *     e = h*(px*r00 + py*r10) + d_off_e[t]
+ *     c = h*(px*r01 + py*r11) + d_off_c[t]
+ * where (r..) is process.transform (utils/rotations.py:45-77) and
+ * d_off_*[t] = (cumsum(timestep*(vx,vy,0)) + (0,0,h)) @ transform, columns 0/1
+ * (atmosphere/atmosphere.py:318-319,346-347), evaluated by the host in f64. */
+typedef struct mrx_layer {
+  const float* d_values; /* [n_e][n_c] f32, smoothed screen (:341-344)        */
+  const float* d_axis_e; /* [n_e] f32 grid nodes = float32(process.extrusion)  */
+  const float* d_axis_c; /* [n_c] f32 = float32(process.cross_section[mask,0]) */
+  const double* d_off_e; /* [Ta] f64                                           */
+  const double* d_off_c; /* [Ta] f64                                           */
+  int32_t n_e, n_c;
+  double h;              /* layer.h, metres                                    */
+  double r00, r10, r01, r11;
+  float pwv_rms;         /* float32(layer.pwv_rms), extrusion.py:100-105       */
+  int32_t reserved;
+} mrx_layer;
+
+/* Band-integrated emission table (band/band.py:264-286).  The reference does
+ * a trilinear lookup at (T0, pwv, el) with scalar T0; the host passes the two
+ * temperature slabs that bracket T0 and T0's normalised distance between them
+ * so the kernel reproduces the reference's 8-term float32 sum term by term. */
+typedef struct mrx_band_table {
+  const float* d_values;   /* [2][n_pwv][n_el] f32: slab iT then slab iT+1    */
+  const float* d_axis_pwv; /* [n_pwv] f32, spectrum.side_zenith_pwv (mm)      */
+  const float* d_axis_el;  /* [n_el]  f32, spectrum.side_elevation (rad)      */
+  int32_t n_pwv, n_el;
+  float w_t;               /* float32 (T0 - T[iT]) / (T[iT+1] - T[iT])        */
+  int32_t t_oob;           /* 1 if T0 lies outside the table (result NaN)     */
+} mrx_band_table;
+
+/* Copies the layer and table descriptors (host structs holding device
+ * pointers) into a device-resident plan.  The buffers they point to must stay
+ * alive while the plan is in use. */
+int mrx_atm_plan_create(mrx_ctx* ctx, const mrx_layer* layers, int n_layers,
+                        const mrx_band_table* tables, int n_tables,
+                        mrx_atm_plan** plan);
+int mrx_atm_plan_destroy(mrx_ctx* ctx, mrx_atm_plan* plan);
+
+/* ---- hot path ------------------------------------------------------------- */
+
+/* Fused coarse-rate sampling: detector pointing (coords/transforms.py:10-29 via
+ * coordinates.py:378-386), ground projection (coordinates.py:333-349),
+ * wind-advected bilinear gather through the layer stack
+ * (atmosphere/atmosphere.py:346-373, jax RegularGridInterpolator "linear",
+ * float32), emission lookup (band/band.py:264-286) and Mueller weight
+ * (sim/atmosphere.py:64-65, array/array.py:204-218).
+ *
+ *  d_az, d_el     [Ta]  float32 coarse boresight (coordinates.py:286-304)
+ *  d_dx, d_dy     [D]   float32 detector offsets (radians)
+ *  d_band         [D]   table index of each detector row, 0 <= band < n_tables
+ *  d_mueller00    [D]   mueller()[:,0,0]
+ *  pwv0                 weather.pwv (mm)  (atmosphere.py:309)
+ *  d_pwv          [Ta*D] f64 zenith-scaled pwv, time-major; may be NULL
+ *  d_loading      [Ta*D] f32 band power in pW, time-major
+ *  d_flags        one uint32 device word, OR-ed with MRX_FLAG_* (never cleared
+ *                 by the kernel; clear it with mrx_clear_flags)
+ */
+int mrx_atm_sample(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d_az,
+                   const float* d_el, int Ta, const float* d_dx,
+                   const float* d_dy, const int32_t* d_band,
+                   const float* d_mueller00, int D, double pwv0, double* d_pwv,
+                   float* d_loading, uint32_t* d_flags);
+
+int mrx_clear_flags(mrx_ctx* ctx, uint32_t* d_flags);
+int mrx_read_flags(mrx_ctx* ctx, const uint32_t* d_flags, uint32_t* host_flags);
+
+/* Not-a-knot cubic spline through the coarse samples of every detector:
+ * scipy interp1d(kind="cubic") == make_interp_spline(k=3) as called at
+ * sim/atmosphere.py:72-82.  Knots are uniform (coordinates.py:292,
+ * np.arange).  Writes for every knot the pair (y, m) with m = h^2/6 * S''(x),
+ * solved in float64, so that on [x_j, x_j+1], u = (x - x_j)/h:
+ *   S = (1-u) y_j + u y_j+1 + ((1-u)^3 - (1-u)) m_j + (u^3 - u) m_j+1.
+ *  d_y  [Ta*D] f32 time-major;  d_ym [Ta*D][2] f32 time-major.  Ta >= 4. */
+int mrx_spline_prepare(mrx_ctx* ctx, const float* d_y, int D, int Ta,
+                       float* d_ym);
+
+/* Evaluates the spline at the full-rate sample times and writes the TOD
+ * (sim/atmosphere.py:72-82, cast to float32), optionally scaled per detector
+ * (gain error, sim/simulation.py:239-247; pW->K_RJ, tod/tod.py:106-142).
+ * Beyond the last knot the last polynomial piece is extended, which is what
+ * fill_value="extrapolate" does.
+ *  ta0, dta       first coarse time and coarse step (s)
+ *  d_t     [T]    f64 full-rate sample times, ascending
+ *  d_scale [D]    f32 per-detector factor, or NULL
+ *  d_out          f32, element (d, s) at d_out[d * ld_out + s] */
+int mrx_spline_upsample(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
+                        double ta0, double dta, const double* d_t, int T,
+                        const float* d_scale, float* d_out, size_t ld_out);
+
+/* Linear upsample of the coarse pwv to the full rate
+ * (sim/atmosphere.py:30-37, interp1d linear + extrapolate); only the map/cmb
+ * mixins consume it.  d_pwv [Ta*D] f64 time-major -> d_out [D][ld_out] f32. */
+int mrx_linear_upsample(mrx_ctx* ctx, const double* d_pwv, int D, int Ta,
+                        double ta0, double dta, const double* d_t, int T,
+                        float* d_out, size_t ld_out);
+
+/* ---- screens -------------------------------------------------------------- */
+
+/* Separable Gaussian filter with scipy.ndimage.gaussian_filter semantics
+ * (order 0, mode="reflect", radius int(truncate*sigma+0.5), axis 0 then axis 1,
+ * float64 accumulation, float32 storage between the passes).  Serves the
+ * per-layer screen smoothing (atmosphere/atmosphere.py:341-344) and
+ * ProjectionMap.smooth (map/projection.py:485-504).  A sigma <= 1e-15 skips
+ * that axis as scipy does.  d_tmp is ny*nx floats of scratch; in == out is
+ * allowed. */
+int mrx_gauss_smooth2d(mrx_ctx* ctx, const float* d_in, float* d_out,
+                       float* d_tmp, int ny, int nx, double sigma_y,
+                       double sigma_x, double truncate);
+
+/* ProjectionMap.smooth (map/projection.py:485-504): numer = G(data*weight),
+ * denom = G(weight), out = denom > 0 ? numer/denom : 0; d_weight may be NULL
+ * (weight == 1).  d_denom_out may be NULL.  d_tmp: 2*ny*nx floats. */
+int mrx_map_smooth(mrx_ctx* ctx, const float* d_data, const float* d_weight,
+                   float* d_out, float* d_denom_out, float* d_tmp, int ny,
+                   int nx, double sigma_y, double sigma_x);
+
+/* Turbulent screen generator: Philox-4x32-10 normals in k space, times the
+ * square root of the Matern / von Karman spectrum
+ *     PSD(k) ~ (k0^2 + |k|^2)^-(nu + 1),  k0 = sqrt(2 nu)/r0
+ * (functions/__init__.py:30-39 is the covariance this is the transform of),
+ * then a 2-D inverse FFT; the real part, scaled to unit variance, is the
+ * screen.  Replaces the autoregressive generator (atmosphere/process.py:191-209)
+ * with a different algorithm of the same target covariance; parity is
+ * statistical.  ny, nx powers of two in [64, 8192].
+ *  d_work: 2*ny*nx float2 of scratch.  d_out [ny][nx] f32. */
+int mrx_screen_generate(mrx_ctx* ctx, uint64_t seed, uint32_t stream, int ny,
+                        int nx, double dy, double dx, double r0, double nu,
+                        float* d_out, float* d_work);
+
+/* Sum over the FFT grid of the un-normalised PSD, reduced on the device
+ * (float64); mrx_screen_generate uses it internally, exposed for tests. */
+int mrx_screen_psd_sum(mrx_ctx* ctx, int ny, int nx, double dy, double dx,
+                       double r0, double nu, double* host_sum);
+
+/* Philox-4x32-10 standard normals, the generator behind the screens, exposed
+ * so tests can check the stream against the published known-answer vectors.
+ * counter = (i, 0, stream, 0), key = seed; d_out[i] for i < n. */
+int mrx_philox_normal(mrx_ctx* ctx, uint64_t seed, uint32_t stream, size_t n,
+                      float* d_out);
+int mrx_philox_raw(mrx_ctx* ctx, uint64_t seed, uint32_t c0, uint32_t c1,
+                   uint32_t c2, uint32_t c3, uint32_t host_out[4]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MRX_H_ */

@@ -1,0 +1,168 @@
+// Context, stream binding, flags and the HIP-event timer of libmrx.
+#include "mrx_internal.h"
+
+extern "C" {
+
+int mrx_version(void) { return MRX_VERSION; }
+
+int mrx_init(int device, mrx_ctx** out) {
+  if (!out) return MRX_ERR_INVALID;
+  *out = nullptr;
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0 || device < 0 || device >= n)
+    return MRX_ERR_NO_DEVICE;
+  mrx_ctx* ctx = new (std::nothrow) mrx_ctx();
+  if (!ctx) return MRX_ERR_ALLOC;
+  ctx->device = device;
+  if (hipSetDevice(device) != hipSuccess) {
+    delete ctx;
+    return MRX_ERR_NO_DEVICE;
+  }
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
+    delete ctx;
+    return MRX_ERR_HIP;
+  }
+  ctx->n_cu = prop.multiProcessorCount;
+  ctx->lds_per_cu = (int)prop.maxSharedMemoryPerMultiProcessor;
+  ctx->hbm_bytes = prop.totalGlobalMem;
+  snprintf(ctx->name, sizeof(ctx->name), "%s (%s)", prop.name,
+           prop.gcnArchName);
+  if (hipEventCreate(&ctx->ev_start) != hipSuccess ||
+      hipEventCreate(&ctx->ev_stop) != hipSuccess) {
+    delete ctx;
+    return MRX_ERR_HIP;
+  }
+  *out = ctx;
+  return MRX_OK;
+}
+
+int mrx_destroy(mrx_ctx* ctx) {
+  if (!ctx) return MRX_ERR_INVALID;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->d_taps) (void)hipFree(ctx->d_taps);
+  if (ctx->d_reduce) (void)hipFree(ctx->d_reduce);
+  if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+  if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+  delete ctx;
+  return MRX_OK;
+}
+
+int mrx_set_stream(mrx_ctx* ctx, void* hip_stream) {
+  if (!ctx) return MRX_ERR_INVALID;
+  ctx->stream = (hipStream_t)hip_stream;
+  return MRX_OK;
+}
+
+int mrx_synchronize(mrx_ctx* ctx) {
+  if (!ctx) return MRX_ERR_INVALID;
+  MRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MRX_OK;
+}
+
+const char* mrx_last_error(const mrx_ctx* ctx) {
+  return ctx ? ctx->err : "null context";
+}
+
+int mrx_device_info(const mrx_ctx* ctx, int* n_cu, int* lds_bytes_per_cu,
+                    size_t* hbm_bytes, char* name, int name_len) {
+  if (!ctx) return MRX_ERR_INVALID;
+  if (n_cu) *n_cu = ctx->n_cu;
+  if (lds_bytes_per_cu) *lds_bytes_per_cu = ctx->lds_per_cu;
+  if (hbm_bytes) *hbm_bytes = ctx->hbm_bytes;
+  if (name && name_len > 0) {
+    strncpy(name, ctx->name, (size_t)name_len - 1);
+    name[name_len - 1] = 0;
+  }
+  return MRX_OK;
+}
+
+int mrx_timer_start(mrx_ctx* ctx) {
+  if (!ctx) return MRX_ERR_INVALID;
+  MRX_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+  return MRX_OK;
+}
+
+int mrx_timer_stop(mrx_ctx* ctx, float* elapsed_ms) {
+  if (!ctx || !elapsed_ms) return MRX_ERR_INVALID;
+  MRX_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+  MRX_HIP(ctx, hipEventSynchronize(ctx->ev_stop));
+  MRX_HIP(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev_start, ctx->ev_stop));
+  return MRX_OK;
+}
+
+int mrx_clear_flags(mrx_ctx* ctx, uint32_t* d_flags) {
+  if (!ctx || !d_flags) return MRX_ERR_INVALID;
+  MRX_HIP(ctx, hipMemsetAsync(d_flags, 0, sizeof(uint32_t), ctx->stream));
+  return MRX_OK;
+}
+
+int mrx_read_flags(mrx_ctx* ctx, const uint32_t* d_flags,
+                   uint32_t* host_flags) {
+  if (!ctx || !d_flags || !host_flags) return MRX_ERR_INVALID;
+  MRX_HIP(ctx, hipMemcpyAsync(host_flags, d_flags, sizeof(uint32_t),
+                              hipMemcpyDeviceToHost, ctx->stream));
+  MRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return MRX_OK;
+}
+
+int mrx_atm_plan_create(mrx_ctx* ctx, const mrx_layer* layers, int n_layers,
+                        const mrx_band_table* tables, int n_tables,
+                        mrx_atm_plan** out) {
+  if (!ctx || !out) return MRX_ERR_INVALID;
+  *out = nullptr;
+  MRX_REQUIRE(ctx, layers != nullptr || n_layers == 0, "layers is null");
+  MRX_REQUIRE(ctx, n_layers >= 0 && n_layers <= 64, "0 <= n_layers <= 64");
+  MRX_REQUIRE(ctx, tables != nullptr && n_tables >= 1 && n_tables <= 1024,
+              "need 1..1024 band tables");
+  for (int l = 0; l < n_layers; ++l) {
+    const mrx_layer& y = layers[l];
+    MRX_REQUIRE(ctx, y.d_values && y.d_axis_e && y.d_axis_c && y.d_off_e &&
+                         y.d_off_c,
+                "layer has a null device pointer");
+    MRX_REQUIRE(ctx, y.n_e >= 2 && y.n_c >= 2, "layer grid needs >= 2 nodes");
+  }
+  for (int b = 0; b < n_tables; ++b) {
+    const mrx_band_table& t = tables[b];
+    MRX_REQUIRE(ctx, t.d_values && t.d_axis_pwv && t.d_axis_el,
+                "band table has a null device pointer");
+    MRX_REQUIRE(ctx, t.n_pwv >= 2 && t.n_el >= 2,
+                "band table needs >= 2 nodes per axis");
+  }
+  mrx_atm_plan* p = new (std::nothrow) mrx_atm_plan();
+  if (!p) return mrx_fail(ctx, MRX_ERR_ALLOC, "out of host memory");
+  p->n_layers = n_layers;
+  p->n_tables = n_tables;
+  hipError_t e = hipSuccess;
+  if (n_layers > 0) {
+    e = hipMalloc(&p->d_layers, sizeof(mrx_layer) * n_layers);
+    if (e == hipSuccess)
+      e = hipMemcpyAsync(p->d_layers, layers, sizeof(mrx_layer) * n_layers,
+                         hipMemcpyHostToDevice, ctx->stream);
+  }
+  if (e == hipSuccess) e = hipMalloc(&p->d_tables, sizeof(mrx_band_table) * n_tables);
+  if (e == hipSuccess)
+    e = hipMemcpyAsync(p->d_tables, tables, sizeof(mrx_band_table) * n_tables,
+                       hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    if (p->d_layers) (void)hipFree(p->d_layers);
+    if (p->d_tables) (void)hipFree(p->d_tables);
+    delete p;
+    return mrx_fail(ctx, MRX_ERR_HIP, "plan upload failed: %s",
+                    hipGetErrorString(e));
+  }
+  *out = p;
+  return MRX_OK;
+}
+
+int mrx_atm_plan_destroy(mrx_ctx* ctx, mrx_atm_plan* plan) {
+  if (!ctx || !plan) return MRX_ERR_INVALID;
+  if (plan->d_layers) (void)hipFree(plan->d_layers);
+  if (plan->d_tables) (void)hipFree(plan->d_tables);
+  delete plan;
+  return MRX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,265 @@
+// Separable Gaussian stencil with scipy.ndimage.gaussian_filter semantics,
+// LDS-tiled for gfx950.
+//
+// Reference call sites: atmosphere/atmosphere.py:341-344 (screen smoothing to
+// the beam) and map/projection.py:485-504 (ProjectionMap.smooth).  scipy runs
+// gaussian_filter1d along axis 0 then axis 1, each a correlation with
+// exp(-x^2/2 sigma^2) normalised over |x| <= int(truncate*sigma + 0.5), on a
+// "reflect" (edge-repeating) extension, accumulating in float64 and storing
+// the pass result in the input dtype (float32 here).
+//
+// Both passes stage the tile plus its halo in LDS once and read every tap from
+// there; lanes run along x in both passes so LDS reads are conflict-free and
+// global traffic is coalesced.
+#include <cmath>
+#include <vector>
+
+#include "mrx_internal.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+// scipy "reflect": (d c b a | a b c d | d c b a)
+__device__ __forceinline__ int reflect_index(int i, int n) {
+  if (i >= 0 && i < n) return i;
+  const int p = 2 * n;
+  int m = i % p;
+  if (m < 0) m += p;
+  return m < n ? m : p - 1 - m;
+}
+
+// pass along x (contiguous axis): one block row-segment of TX outputs x ROWS rows
+constexpr int kXRows = 4;    // rows per block
+constexpr int kXCols = 64;   // outputs per row per block (one wave per row)
+
+__global__ __launch_bounds__(kBlock) void gauss_x_kernel(
+    const float* __restrict__ in, float* __restrict__ out, int ny, int nx,
+    const double* __restrict__ taps, int radius) {
+  extern __shared__ float lds[];
+  const int span = kXCols + 2 * radius;
+  const int row_l = threadIdx.x / kXCols;   // 0..3
+  const int lane = threadIdx.x % kXCols;
+  const int y = blockIdx.y * kXRows + row_l;
+  const int x0 = blockIdx.x * kXCols;
+  float* row = lds + row_l * span;
+  if (y < ny) {
+    const float* src = in + (size_t)y * nx;
+    for (int i = lane; i < span; i += kXCols)
+      row[i] = src[reflect_index(x0 - radius + i, nx)];
+  }
+  __syncthreads();
+  const int x = x0 + lane;
+  if (y >= ny || x >= nx) return;
+  // scipy's symmetric form: centre tap, then pairs
+  double acc = taps[radius] * (double)row[lane + radius];
+  for (int k = 1; k <= radius; ++k)
+    acc += ((double)row[lane + radius - k] + (double)row[lane + radius + k]) *
+           taps[radius + k];
+  out[(size_t)y * nx + x] = (float)acc;
+}
+
+// pass along y: tile of kYRows outputs x 64 columns; 4 row groups of threads
+constexpr int kYCols = 64;
+
+__global__ __launch_bounds__(kBlock) void gauss_y_kernel(
+    const float* __restrict__ in, float* __restrict__ out, int ny, int nx,
+    const double* __restrict__ taps, int radius, int tile_rows) {
+  extern __shared__ float lds[];
+  const int lane = threadIdx.x % kYCols;
+  const int grp = threadIdx.x / kYCols;     // 0..3
+  const int x = blockIdx.x * kYCols + lane;
+  const int y0 = blockIdx.y * tile_rows;
+  const int span = tile_rows + 2 * radius;
+  const int xs = min(x, nx - 1);
+  for (int i = grp; i < span; i += kBlock / kYCols)
+    lds[i * kYCols + lane] =
+        in[(size_t)reflect_index(y0 - radius + i, ny) * nx + xs];
+  __syncthreads();
+  if (x >= nx) return;
+  for (int ry = grp; ry < tile_rows; ry += kBlock / kYCols) {
+    const int y = y0 + ry;
+    if (y >= ny) break;
+    const float* c = lds + (ry + radius) * kYCols + lane;
+    double acc = taps[radius] * (double)c[0];
+    for (int k = 1; k <= radius; ++k)
+      acc += ((double)c[-k * kYCols] + (double)c[k * kYCols]) * taps[radius + k];
+    out[(size_t)y * nx + x] = (float)acc;
+  }
+}
+
+__global__ void mul_kernel(const float* __restrict__ a,
+                           const float* __restrict__ b, float* __restrict__ o,
+                           size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) o[i] = a[i] * b[i];
+}
+
+__global__ void fill_kernel(float* __restrict__ o, float v, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) o[i] = v;
+}
+
+// out = denom > 0 ? numer/denom : 0   (map/projection.py:498-499)
+__global__ void ratio_kernel(const float* __restrict__ numer,
+                             const float* __restrict__ denom,
+                             float* __restrict__ o, size_t n) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const float dn = denom[i];
+    o[i] = dn > 0.0f ? numer[i] / dn : 0.0f;
+  }
+}
+
+// scipy.ndimage._filters._gaussian_kernel1d, order 0
+int upload_taps(mrx_ctx* ctx, double sigma, double truncate, int* radius_out) {
+  const int radius = (int)(truncate * sigma + 0.5);
+  const size_t n = (size_t)(2 * radius + 1);
+  std::vector<double> w(n);
+  const double s2 = sigma * sigma;
+  double sum = 0.0;
+  for (int k = -radius; k <= radius; ++k) {
+    const double v = std::exp(-0.5 / s2 * (double)k * (double)k);
+    w[(size_t)(k + radius)] = v;
+    sum += v;
+  }
+  for (auto& v : w) v /= sum;
+  if (ctx->taps_cap < n) {
+    if (ctx->d_taps) (void)hipFree(ctx->d_taps);
+    ctx->d_taps = nullptr;
+    ctx->taps_cap = 0;
+    size_t cap = n < 256 ? 256 : n;
+    MRX_HIP(ctx, hipMalloc(&ctx->d_taps, cap * sizeof(double)));
+    ctx->taps_cap = cap;
+  }
+  // pageable source: the runtime stages it before returning
+  MRX_HIP(ctx, hipMemcpyAsync(ctx->d_taps, w.data(), n * sizeof(double),
+                              hipMemcpyHostToDevice, ctx->stream));
+  MRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *radius_out = radius;
+  return MRX_OK;
+}
+
+constexpr size_t kMaxLds = 64 * 1024;
+
+int smooth_axis1(mrx_ctx* ctx, const float* in, float* out, int ny, int nx,
+                 double sigma, double truncate) {
+  int radius = 0;
+  int rc = upload_taps(ctx, sigma, truncate, &radius);
+  if (rc != MRX_OK) return rc;
+  const size_t lds = (size_t)kXRows * (kXCols + 2 * radius) * sizeof(float);
+  if (lds > kMaxLds)
+    return mrx_fail(ctx, MRX_ERR_UNSUPPORTED,
+                    "gaussian radius %d along x exceeds the LDS tile", radius);
+  dim3 grid(mrx_ceil_div(nx, kXCols), mrx_ceil_div(ny, kXRows));
+  MRX_REQUIRE(ctx, grid.y <= 65535u, "ny too large for one launch");
+  hipLaunchKernelGGL(gauss_x_kernel, grid, dim3(kBlock), lds, ctx->stream, in,
+                     out, ny, nx, ctx->d_taps, radius);
+  MRX_CHECK_LAUNCH(ctx);
+  return MRX_OK;
+}
+
+int smooth_axis0(mrx_ctx* ctx, const float* in, float* out, int ny, int nx,
+                 double sigma, double truncate) {
+  int radius = 0;
+  int rc = upload_taps(ctx, sigma, truncate, &radius);
+  if (rc != MRX_OK) return rc;
+  int tile_rows = 64;
+  while (tile_rows > 8 &&
+         (size_t)(tile_rows + 2 * radius) * kYCols * sizeof(float) > kMaxLds)
+    tile_rows /= 2;
+  const size_t lds = (size_t)(tile_rows + 2 * radius) * kYCols * sizeof(float);
+  if (lds > kMaxLds)
+    return mrx_fail(ctx, MRX_ERR_UNSUPPORTED,
+                    "gaussian radius %d along y exceeds the LDS tile", radius);
+  dim3 grid(mrx_ceil_div(nx, kYCols), mrx_ceil_div(ny, tile_rows));
+  MRX_REQUIRE(ctx, grid.y <= 65535u, "ny too large for one launch");
+  hipLaunchKernelGGL(gauss_y_kernel, grid, dim3(kBlock), lds, ctx->stream, in,
+                     out, ny, nx, ctx->d_taps, radius, tile_rows);
+  MRX_CHECK_LAUNCH(ctx);
+  return MRX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mrx_gauss_smooth2d(mrx_ctx* ctx, const float* d_in, float* d_out,
+                       float* d_tmp, int ny, int nx, double sigma_y,
+                       double sigma_x, double truncate) {
+  if (!ctx) return MRX_ERR_INVALID;
+  MRX_REQUIRE(ctx, d_in && d_out && d_tmp, "null pointer");
+  MRX_REQUIRE(ctx, ny >= 0 && nx >= 0, "negative size");
+  MRX_REQUIRE(ctx, sigma_y >= 0.0 && sigma_x >= 0.0 && truncate > 0.0,
+              "sigma must be >= 0 and truncate > 0");
+  if (ny == 0 || nx == 0) return MRX_OK;
+  const bool do_y = sigma_y > 1e-15, do_x = sigma_x > 1e-15;
+  const size_t bytes = (size_t)ny * nx * sizeof(float);
+  int rc = MRX_OK;
+  if (do_y && do_x) {
+    rc = smooth_axis0(ctx, d_in, d_tmp, ny, nx, sigma_y, truncate);
+    if (rc == MRX_OK) rc = smooth_axis1(ctx, d_tmp, d_out, ny, nx, sigma_x, truncate);
+  } else if (do_y || do_x) {
+    // a single pass cannot run in place: go through d_tmp when in == out
+    const float* src = d_in;
+    if (d_in == d_out) {
+      MRX_HIP(ctx, hipMemcpyAsync(d_tmp, d_in, bytes, hipMemcpyDeviceToDevice,
+                                  ctx->stream));
+      src = d_tmp;
+    }
+    rc = do_y ? smooth_axis0(ctx, src, d_out, ny, nx, sigma_y, truncate)
+              : smooth_axis1(ctx, src, d_out, ny, nx, sigma_x, truncate);
+  } else if (d_in != d_out) {
+    MRX_HIP(ctx, hipMemcpyAsync(d_out, d_in, bytes, hipMemcpyDeviceToDevice,
+                                ctx->stream));
+  }
+  return rc;
+}
+
+int mrx_map_smooth(mrx_ctx* ctx, const float* d_data, const float* d_weight,
+                   float* d_out, float* d_denom_out, float* d_tmp, int ny,
+                   int nx, double sigma_y, double sigma_x) {
+  if (!ctx) return MRX_ERR_INVALID;
+  MRX_REQUIRE(ctx, d_data && d_out && d_tmp, "null pointer");
+  MRX_REQUIRE(ctx, ny >= 0 && nx >= 0, "negative size");
+  if (ny == 0 || nx == 0) return MRX_OK;
+  const size_t n = (size_t)ny * nx;
+  float* t0 = d_tmp;      // pass scratch
+  float* t1 = d_tmp + n;  // data*weight, then denom when the caller wants none
+  const int blocks = (int)((n + kBlock - 1) / kBlock < 4096
+                               ? (n + kBlock - 1) / kBlock
+                               : 4096);
+  int rc;
+  if (d_weight) {
+    hipLaunchKernelGGL(mul_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream,
+                       d_data, d_weight, t1, n);
+    MRX_CHECK_LAUNCH(ctx);
+    rc = mrx_gauss_smooth2d(ctx, t1, d_out, t0, ny, nx, sigma_y, sigma_x, 4.0);
+    if (rc != MRX_OK) return rc;
+    float* denom = d_denom_out ? d_denom_out : t1;
+    rc = mrx_gauss_smooth2d(ctx, d_weight, denom, t0, ny, nx, sigma_y, sigma_x, 4.0);
+    if (rc != MRX_OK) return rc;
+    hipLaunchKernelGGL(ratio_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream,
+                       d_out, denom, d_out, n);
+    MRX_CHECK_LAUNCH(ctx);
+  } else {
+    // weight == 1: denom = G(1), which is 1 up to float64 rounding of the taps
+    rc = mrx_gauss_smooth2d(ctx, d_data, d_out, t0, ny, nx, sigma_y, sigma_x, 4.0);
+    if (rc != MRX_OK) return rc;
+    hipLaunchKernelGGL(fill_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream,
+                       t1, 1.0f, n);
+    MRX_CHECK_LAUNCH(ctx);
+    float* denom = d_denom_out ? d_denom_out : t1;
+    rc = mrx_gauss_smooth2d(ctx, t1, denom, t0, ny, nx, sigma_y, sigma_x, 4.0);
+    if (rc != MRX_OK) return rc;
+    hipLaunchKernelGGL(ratio_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream,
+                       d_out, denom, d_out, n);
+    MRX_CHECK_LAUNCH(ctx);
+  }
+  return MRX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,70 @@
+// Internal declarations shared by the libmrx translation units (gfx950 only).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "mrx.h"
+
+struct mrx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+  int n_cu = 0;
+  int lds_per_cu = 0;
+  size_t hbm_bytes = 0;
+  char name[128] = {0};
+  char err[512] = {0};
+  // scratch owned by the context (grown on demand, never in a hot call that
+  // already has what it needs)
+  double* d_taps = nullptr;  // Gaussian taps, f64
+  size_t taps_cap = 0;
+  double* d_reduce = nullptr;  // small reduction buffer
+  size_t reduce_cap = 0;
+};
+
+struct mrx_atm_plan {
+  mrx_layer* d_layers = nullptr;
+  mrx_band_table* d_tables = nullptr;
+  int n_layers = 0;
+  int n_tables = 0;
+};
+
+inline int mrx_fail(mrx_ctx* ctx, int code, const char* fmt, ...) {
+  if (ctx) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+    va_end(ap);
+  }
+  return code;
+}
+
+#define MRX_HIP(ctx, call)                                                   \
+  do {                                                                       \
+    hipError_t e__ = (call);                                                 \
+    if (e__ != hipSuccess)                                                   \
+      return mrx_fail((ctx), MRX_ERR_HIP, "%s failed: %s (%s:%d)", #call,    \
+                      hipGetErrorString(e__), __FILE__, __LINE__);           \
+  } while (0)
+
+#define MRX_REQUIRE(ctx, cond, msg)                                          \
+  do {                                                                       \
+    if (!(cond)) return mrx_fail((ctx), MRX_ERR_INVALID, "%s: %s", __func__, \
+                                 (msg));                                     \
+  } while (0)
+
+#define MRX_CHECK_LAUNCH(ctx)                                                \
+  do {                                                                       \
+    hipError_t e__ = hipGetLastError();                                      \
+    if (e__ != hipSuccess)                                                   \
+      return mrx_fail((ctx), MRX_ERR_HIP, "kernel launch failed: %s (%s:%d)", \
+                      hipGetErrorString(e__), __FILE__, __LINE__);           \
+  } while (0)
+
+static inline int mrx_ceil_div(long long a, long long b) {
+  return (int)((a + b - 1) / b);
+}

@@ -1,0 +1,364 @@
+// Not-a-knot cubic spline along time for every detector, gfx950.
+//
+//   spline_prepare_kernel : second-derivative solve (float64), time-parallel
+//   spline_upsample_kernel: evaluation at the full sample rate -> TOD (float32)
+//
+// Reference: scipy interp1d(kind="cubic", fill_value="extrapolate") as called
+// at sim/atmosphere.py:72-82, i.e. make_interp_spline(k=3) with not-a-knot ends
+// on the uniform knots of coordinates.py:292.
+//
+// Spline form.  With uniform spacing h and m_i = h^2/6 * S''(x_i):
+//   interior:    m_{i-1} + 4 m_i + m_{i+1} = y_{i-1} - 2 y_i + y_{i+1} = delta_i
+//   not-a-knot:  m_0 - 2 m_1 + m_2 = 0,  m_{n-3} - 2 m_{n-2} + m_{n-1} = 0
+// which gives m_1 = delta_1/6, m_{n-2} = delta_{n-2}/6 and a constant (1,4,1)
+// tridiagonal system for i = 2..n-3.
+//
+// Time-parallel solve.  A left-to-right elimination gives m_i + cL_i m_{i+1} =
+// dL_i, a right-to-left one m_i + cR_i m_{i-1} = dR_i, and equation i then
+// yields m_i from dL_{i-1} and dR_{i+1} alone (a twisted factorisation).  Both
+// sweeps are first-order recurrences whose memory of the start decays like
+// (2-sqrt 3)^k = 0.268^k, so a thread that owns a chunk of 16 knots starts its
+// sweeps 32 knots outside the chunk from a zero state: the error, 0.268^32 =
+// 5e-19, is below float64 rounding.  Near the ends the sweeps start at the true
+// boundary and are exact.  Lanes are consecutive detectors (time-major data),
+// so every index and coefficient below is wave-uniform.
+#include "mrx_internal.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+constexpr int kChunk = 16;  // knots owned by one thread
+constexpr int kHalo = 32;   // knots of run-in for each sweep
+constexpr int kQTab = 32;   // pivots tabulated before they equal alpha
+constexpr double kAlpha = 0.26794919243112270647;  // 2 - sqrt(3)
+
+// q_0 = 1/4, q_{k+1} = 1/(4 - q_k): the elimination multipliers; q_k -> alpha
+// with error ~0.072^k, i.e. equal to alpha in float64 from k = 15 on.
+struct QTable {
+  double q[kQTab];
+  constexpr QTable() : q{} {
+    double c = 0.25;
+    for (int k = 0; k < kQTab; ++k) {
+      q[k] = c;
+      c = 1.0 / (4.0 - c);
+    }
+  }
+};
+__constant__ QTable kQ = QTable();
+
+__device__ __forceinline__ double qf(int k) {
+  return k < kQTab ? kQ.q[k] : kAlpha;
+}
+
+__global__ __launch_bounds__(kBlock) void spline_prepare_kernel(
+    const float* __restrict__ y, int D, int n, float2* __restrict__ ym) {
+  const int d = blockIdx.x * kBlock + threadIdx.x;
+  if (d >= D) return;
+  const int a = blockIdx.y * kChunk;       // first knot of this chunk
+  const int b = min(a + kChunk, n);        // one past the last
+  const int lo = 2, hi = n - 3;            // interior unknowns (empty if n < 5)
+  auto Y = [&](int i) -> double { return (double)y[(size_t)i * D + d]; };
+
+  const double m1 = (Y(0) - 2.0 * Y(1) + Y(2)) * (1.0 / 6.0);
+  const double mn2 = (Y(n - 3) - 2.0 * Y(n - 2) + Y(n - 1)) * (1.0 / 6.0);
+  auto rhs = [&](int i, double ym_, double yc_, double yp_) -> double {
+    double r = (ym_ - 2.0 * yc_) + yp_;
+    if (i == lo) r -= m1;
+    if (i == hi) r -= mn2;
+    return r;
+  };
+
+  // ---- left sweep: dLm[k] = dL_{a-1+k} -----------------------------------
+  double dLm[kChunk];
+  {
+    const int target = a - 1 - kHalo;
+    const int s0 = (target - lo < 20) ? lo : target;
+    double dl = 0.0;
+    int i = s0;
+    double ym_ = 0.0, yc_ = 0.0;
+    if (s0 <= hi) {
+      ym_ = Y(s0 - 1);
+      yc_ = Y(s0);
+    }
+    for (; i < a - 1 && i <= hi; ++i) {
+      const double yp_ = Y(i + 1);
+      dl = (rhs(i, ym_, yc_, yp_) - dl) * qf(i - lo);
+      ym_ = yc_;
+      yc_ = yp_;
+    }
+#pragma unroll
+    for (int k = 0; k < kChunk; ++k) {
+      const int ii = a - 1 + k;
+      if (ii >= s0 && ii <= hi) {
+        const double yp_ = Y(ii + 1);
+        dl = (rhs(ii, ym_, yc_, yp_) - dl) * qf(ii - lo);
+        ym_ = yc_;
+        yc_ = yp_;
+      }
+      dLm[k] = dl;
+    }
+  }
+
+  // ---- right sweep down to the chunk: dr = dR_b ----------------------------
+  double dr = 0.0;
+  {
+    const int target = b + kHalo;
+    const int e0 = (hi - target < 20) ? hi : target;
+    if (e0 >= b && e0 >= lo) {
+      double yc_ = Y(e0), yp_ = Y(e0 + 1);
+      for (int i = e0; i >= b; --i) {
+        const double ym_ = Y(i - 1);
+        dr = (rhs(i, ym_, yc_, yp_) - dr) * qf(hi - i);
+        yp_ = yc_;
+        yc_ = ym_;
+      }
+    }
+  }
+
+  // ---- combine, descending through the chunk -------------------------------
+  const int top = b - 1;
+  double yc_ = Y(top);
+  double yp_ = (top + 1 < n) ? Y(top + 1) : 0.0;
+#pragma unroll
+  for (int k = kChunk - 1; k >= 0; --k) {
+    const int i = a + k;
+    if (i >= n) continue;
+    const double ym_ = (i >= 1) ? Y(i - 1) : 0.0;
+    if (i >= 1 && i <= n - 2) {
+      const double delta = (ym_ - 2.0 * yc_) + yp_;
+      double m;
+      if (i == 1 || i == n - 2) {
+        m = delta * (1.0 / 6.0);
+      } else {
+        double r = delta;
+        if (i == lo) r -= m1;
+        if (i == hi) r -= mn2;
+        double num = r, den = 4.0;
+        if (i > lo) {
+          num -= dLm[k];
+          den -= qf(i - 1 - lo);
+        }
+        if (i < hi) {
+          num -= dr;
+          den -= qf(hi - i - 1);
+        }
+        m = num / den;
+        dr = (r - dr) * qf(hi - i);  // dR_i, for knot i-1
+      }
+      ym[(size_t)i * D + d] = make_float2((float)yc_, (float)m);
+      if (i == 2)  // m_0 = 2 m_1 - m_2
+        ym[d] = make_float2((float)Y(0), (float)(2.0 * m1 - m));
+      if (i == n - 3)  // m_{n-1} = 2 m_{n-2} - m_{n-3}
+        ym[(size_t)(n - 1) * D + d] =
+            make_float2((float)Y(n - 1), (float)(2.0 * mn2 - m));
+    }
+    yp_ = yc_;
+    yc_ = ym_;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Evaluation.  A workgroup writes a tile of kTileDet detector rows x 1024
+// consecutive samples.  Each thread owns 4 consecutive samples (one 16-byte
+// store per detector row, 1 KiB contiguous per wave), computes their interval
+// index and the four basis weights once in float64 and reuses them for all
+// rows of the tile.  The (y, m) knots the tile needs are staged through LDS,
+// detector-major so that a wave's reads are consecutive 8-byte words.
+constexpr int kTileDet = 16;
+constexpr int kSamplesPerThread = 4;
+constexpr int kTileSamples = kBlock * kSamplesPerThread;  // 1024
+constexpr int kMaxKnots = 256;         // knots per tile that fit the LDS image
+constexpr int kKnotPitch = kMaxKnots + 1;
+
+template <bool kHasScale>
+__global__ __launch_bounds__(kBlock) void spline_upsample_kernel(
+    const float2* __restrict__ ym, int D, int n, double ta0, double inv_dta,
+    double dta, const double* __restrict__ t, int T,
+    const float* __restrict__ scale, float* __restrict__ out, size_t ld,
+    int vec_ok) {
+  __shared__ float2 tile[kTileDet * kKnotPitch];
+
+  const int s_tile = blockIdx.x * kTileSamples;
+  const int d0 = blockIdx.y * kTileDet;
+  const int sb = s_tile + threadIdx.x * kSamplesPerThread;
+
+  // ---- per-sample interval and weights -------------------------------------
+  int j[kSamplesPerThread];
+  float wa[kSamplesPerThread], wb[kSamplesPerThread], wc[kSamplesPerThread],
+      wd[kSamplesPerThread];
+#pragma unroll
+  for (int q = 0; q < kSamplesPerThread; ++q) {
+    const int s = min(sb + q, T - 1);
+    const double x = (t[s] - ta0) * inv_dta;
+    int jj = (int)floor(fmin(fmax(x, -1.0), 2.0e9));
+    jj = min(max(jj, 0), n - 2);
+    const double u = (t[s] - (ta0 + (double)jj * dta)) * inv_dta;
+    const double v = 1.0 - u;
+    j[q] = jj;
+    wa[q] = (float)v;
+    wb[q] = (float)u;
+    wc[q] = (float)(v * (v * v - 1.0));
+    wd[q] = (float)(u * (u * u - 1.0));
+  }
+
+  // ---- knot range of the tile (wave-uniform) --------------------------------
+  int jmin, jmax;
+  {
+    const int s_last = min(s_tile + kTileSamples, T) - 1;
+    const double x0 = (t[s_tile] - ta0) * inv_dta;
+    const double x1 = (t[s_last] - ta0) * inv_dta;
+    jmin = min(max((int)floor(fmin(fmax(x0, -1.0), 2.0e9)), 0), n - 2);
+    jmax = min(max((int)floor(fmin(fmax(x1, -1.0), 2.0e9)), 0), n - 2) + 1;
+  }
+  const int K = jmax - jmin + 1;
+  const bool use_lds = K <= kMaxKnots;  // false only for ratios below ~4
+
+  if (use_lds) {
+    // 16 lanes cover the 16 detector rows of one knot (128 contiguous bytes)
+    const int dl = threadIdx.x & (kTileDet - 1);
+    const int d = d0 + dl;
+    for (int r = threadIdx.x / kTileDet; r < K; r += kBlock / kTileDet) {
+      float2 v = make_float2(0.f, 0.f);
+      if (d < D) v = ym[(size_t)(jmin + r) * D + d];
+      tile[dl * kKnotPitch + r] = v;
+    }
+    __syncthreads();
+  }
+
+  int r[kSamplesPerThread];
+#pragma unroll
+  for (int q = 0; q < kSamplesPerThread; ++q)
+    r[q] = min(max(j[q] - jmin, 0), K - 2);  // in range even if t is unsorted
+
+  const bool full = (sb + kSamplesPerThread <= T) && vec_ok;
+  const int nd = min(kTileDet, D - d0);
+  for (int dl = 0; dl < nd; ++dl) {
+    const int d = d0 + dl;
+    float o[kSamplesPerThread];
+#pragma unroll
+    for (int q = 0; q < kSamplesPerThread; ++q) {
+      float2 k0, k1;
+      if (use_lds) {
+        k0 = tile[dl * kKnotPitch + r[q]];
+        k1 = tile[dl * kKnotPitch + r[q] + 1];
+      } else {
+        k0 = ym[(size_t)j[q] * D + d];
+        k1 = ym[(size_t)(j[q] + 1) * D + d];
+      }
+      float acc = wa[q] * k0.x;
+      acc = fmaf(wb[q], k1.x, acc);
+      acc = fmaf(wc[q], k0.y, acc);
+      acc = fmaf(wd[q], k1.y, acc);
+      o[q] = acc;
+    }
+    if (kHasScale) {
+      const float g = scale[d];
+#pragma unroll
+      for (int q = 0; q < kSamplesPerThread; ++q) o[q] *= g;
+    }
+    float* dst = out + (size_t)d * ld + sb;
+    if (full) {
+      typedef float vfloat4 __attribute__((ext_vector_type(4)));
+      const vfloat4 v = {o[0], o[1], o[2], o[3]};
+      __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(dst));
+    } else {
+#pragma unroll
+      for (int q = 0; q < kSamplesPerThread; ++q)
+        if (sb + q < T) dst[q] = o[q];
+    }
+  }
+}
+
+// Linear interpolation of the coarse pwv (float64, time-major) to the full
+// rate: sim/atmosphere.py:30-37.  Same tiling as the cubic kernel without the
+// LDS stage; only the optional map/cmb consumers need it.
+__global__ __launch_bounds__(kBlock) void linear_upsample_kernel(
+    const double* __restrict__ pwv, int D, int n, double ta0, double inv_dta,
+    double dta, const double* __restrict__ t, int T, float* __restrict__ out,
+    size_t ld) {
+  const int s = blockIdx.x * kBlock + threadIdx.x;
+  if (s >= T) return;
+  const double x = (t[s] - ta0) * inv_dta;
+  int jj = (int)floor(fmin(fmax(x, -1.0), 2.0e9));
+  jj = min(max(jj, 0), n - 2);
+  const double u = (t[s] - (ta0 + (double)jj * dta)) * inv_dta;
+  const int d0 = blockIdx.y * kTileDet;
+  const int nd = min(kTileDet, D - d0);
+  for (int dl = 0; dl < nd; ++dl) {
+    const int d = d0 + dl;
+    const double y0 = pwv[(size_t)jj * D + d];
+    const double y1 = pwv[(size_t)(jj + 1) * D + d];
+    out[(size_t)d * ld + s] = (float)(y0 + u * (y1 - y0));
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int mrx_spline_prepare(mrx_ctx* ctx, const float* d_y, int D, int Ta,
+                       float* d_ym) {
+  if (!ctx) return MRX_ERR_INVALID;
+  MRX_REQUIRE(ctx, d_y && d_ym, "null pointer");
+  MRX_REQUIRE(ctx, D >= 0, "negative D");
+  if (D == 0) return MRX_OK;
+  if (Ta < 4)
+    return mrx_fail(ctx, MRX_ERR_UNSUPPORTED,
+                    "cubic interpolation needs at least 4 coarse samples "
+                    "(got %d), as scipy interp1d(kind='cubic') does", Ta);
+  dim3 grid(mrx_ceil_div(D, kBlock), mrx_ceil_div(Ta, kChunk));
+  MRX_REQUIRE(ctx, grid.y <= 65535u, "Ta too large for one launch");
+  hipLaunchKernelGGL(spline_prepare_kernel, grid, dim3(kBlock), 0, ctx->stream,
+                     d_y, D, Ta, reinterpret_cast<float2*>(d_ym));
+  MRX_CHECK_LAUNCH(ctx);
+  return MRX_OK;
+}
+
+int mrx_spline_upsample(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
+                        double ta0, double dta, const double* d_t, int T,
+                        const float* d_scale, float* d_out, size_t ld_out) {
+  if (!ctx) return MRX_ERR_INVALID;
+  MRX_REQUIRE(ctx, d_ym && d_t && d_out, "null pointer");
+  MRX_REQUIRE(ctx, D >= 0 && T >= 0, "negative size");
+  MRX_REQUIRE(ctx, dta > 0.0, "coarse step must be positive");
+  MRX_REQUIRE(ctx, ld_out >= (size_t)T, "ld_out smaller than T");
+  if (D == 0 || T == 0) return MRX_OK;
+  if (Ta < 4)
+    return mrx_fail(ctx, MRX_ERR_UNSUPPORTED,
+                    "cubic interpolation needs at least 4 coarse samples");
+  dim3 grid(mrx_ceil_div(T, kTileSamples), mrx_ceil_div(D, kTileDet));
+  MRX_REQUIRE(ctx, grid.y <= 65535u, "D too large for one launch");
+  const int vec_ok =
+      (ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15u) == 0);
+  const float2* ym = reinterpret_cast<const float2*>(d_ym);
+  if (d_scale)
+    hipLaunchKernelGGL(spline_upsample_kernel<true>, grid, dim3(kBlock), 0,
+                       ctx->stream, ym, D, Ta, ta0, 1.0 / dta, dta, d_t, T,
+                       d_scale, d_out, ld_out, vec_ok);
+  else
+    hipLaunchKernelGGL(spline_upsample_kernel<false>, grid, dim3(kBlock), 0,
+                       ctx->stream, ym, D, Ta, ta0, 1.0 / dta, dta, d_t, T,
+                       d_scale, d_out, ld_out, vec_ok);
+  MRX_CHECK_LAUNCH(ctx);
+  return MRX_OK;
+}
+
+int mrx_linear_upsample(mrx_ctx* ctx, const double* d_pwv, int D, int Ta,
+                        double ta0, double dta, const double* d_t, int T,
+                        float* d_out, size_t ld_out) {
+  if (!ctx) return MRX_ERR_INVALID;
+  MRX_REQUIRE(ctx, d_pwv && d_t && d_out, "null pointer");
+  MRX_REQUIRE(ctx, D >= 0 && T >= 0, "negative size");
+  MRX_REQUIRE(ctx, dta > 0.0, "coarse step must be positive");
+  MRX_REQUIRE(ctx, ld_out >= (size_t)T, "ld_out smaller than T");
+  MRX_REQUIRE(ctx, Ta >= 2, "linear interpolation needs 2 coarse samples");
+  if (D == 0 || T == 0) return MRX_OK;
+  dim3 grid(mrx_ceil_div(T, kBlock), mrx_ceil_div(D, kTileDet));
+  MRX_REQUIRE(ctx, grid.y <= 65535u, "D too large for one launch");
+  hipLaunchKernelGGL(linear_upsample_kernel, grid, dim3(kBlock), 0, ctx->stream,
+                     d_pwv, D, Ta, ta0, 1.0 / dta, dta, d_t, T, d_out, ld_out);
+  MRX_CHECK_LAUNCH(ctx);
+  return MRX_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,218 @@
+"""Device-resident atmosphere -> TOD path: the host side above the C ABI.
+
+``DevicePath`` owns the device copies of one observation's inputs (as torch
+tensors: torch is the allocator and the stream owner, nothing else) and runs
+
+    mrx_atm_sample -> mrx_spline_prepare -> mrx_spline_upsample
+
+for a contiguous block of detector rows.  The stages are the reference's
+``Atmosphere.simulate_pwv`` (atmosphere/atmosphere.py:293-380) and
+``AtmosphereMixin._compute_atmospheric_loading`` (sim/atmosphere.py:39-84).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import Context, MrxBandTable, MrxLayer, ptr
+
+
+def _dev(a, dtype, device):
+    return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(device)
+
+
+def table_slabs(table, T0):
+    """Host part of the emission lookup: the two temperature slabs bracketing
+    ``T0`` and T0's float32 normalised distance, computed exactly as jax's
+    ``_find_indices`` would (band/band.py:283-286)."""
+    Tg = np.asarray(table["T"], np.float32)
+    x = np.float32(T0)
+    i = int(np.searchsorted(Tg, x, side="left")) - 1
+    i = min(max(i, 0), len(Tg) - 2)
+    w = np.float32((x - Tg[i]) / (Tg[i + 1] - Tg[i]))
+    oob = bool(x < Tg[0] or x > Tg[-1])
+    vals = np.asarray(table["values"], np.float32)[i : i + 2]
+    return np.ascontiguousarray(vals), w, oob
+
+
+class DevicePath:
+    """One observation (or one detector shard of it) on one GPU."""
+
+    def __init__(self, problem, device="cuda:0", det_slice=None, ctx=None, keep_pwv=False):
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("maria_amd runs on a gfx950 GPU only; there is no CPU path")
+        index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        torch.cuda.set_device(index)
+        self.ctx = ctx or Context(index)
+        self.ctx.set_stream(torch.cuda.current_stream(self.device))
+        self.problem = problem
+        sl = det_slice or slice(0, len(problem["offsets"]))
+        self.det_slice = sl
+        dev = self.device
+
+        off = np.asarray(problem["offsets"], float)[sl]
+        self.D = int(off.shape[0])
+        self.Ta = int(len(problem["ta"]))
+        self.T = int(len(problem["t"]))
+        # jax demotes the float64 offsets and boresight to float32 on entry
+        self.d_dx = _dev(off[:, 0], torch.float32, dev)
+        self.d_dy = _dev(off[:, 1], torch.float32, dev)
+        self.d_az = _dev(problem["az_a"], torch.float32, dev)
+        self.d_el = _dev(problem["el_a"], torch.float32, dev)
+        self.d_band = _dev(np.asarray(problem["band_index"])[sl], torch.int32, dev)
+        self.d_m00 = _dev(np.asarray(problem["m00"])[sl], torch.float32, dev)
+        self.d_t = _dev(problem["t"], torch.float64, dev)
+        gain = problem.get("gain")
+        self.d_gain = _dev(np.asarray(gain)[sl], torch.float32, dev) if gain is not None else None
+        self.ta0 = float(problem["ta"][0])
+        self.dta = float(problem["ta"][1] - problem["ta"][0])
+        self.pwv0 = float(problem["pwv0"])
+
+        self.d_flags = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.d_loading = torch.empty((self.Ta, self.D), dtype=torch.float32, device=dev)
+        self.d_ym = torch.empty((self.Ta, self.D, 2), dtype=torch.float32, device=dev)
+        self.d_pwv = torch.empty((self.Ta, self.D), dtype=torch.float64, device=dev) if keep_pwv else None
+
+        self._layer_bufs = []
+        self._table_bufs = []
+        self.plan = None
+        self._upload_tables()
+        if all(l.get("values") is not None for l in problem["layers"]):
+            self.set_screens([l["values"] for l in problem["layers"]])
+
+    # -- set-up ------------------------------------------------------------
+    def _upload_tables(self):
+        dev = self.device
+        self._tables = (MrxBandTable * len(self.problem["tables"]))()
+        for b, table in enumerate(self.problem["tables"]):
+            vals, w, oob = table_slabs(table, self.problem["T0"])
+            bufs = (
+                _dev(vals, torch.float32, dev),
+                _dev(table["pwv"], torch.float32, dev),
+                _dev(table["el"], torch.float32, dev),
+            )
+            self._table_bufs.append(bufs)
+            tb = self._tables[b]
+            tb.d_values, tb.d_axis_pwv, tb.d_axis_el = (x.data_ptr() for x in bufs)
+            tb.n_pwv, tb.n_el = len(table["pwv"]), len(table["el"])
+            tb.w_t, tb.t_oob = float(w), int(oob)
+
+    def layer_offsets(self, layer):
+        """f64 per-time offsets of mrx_layer (include/mrx.h):
+        (cumsum(timestep*(vx,vy,0)) + (0,0,h)) @ transform, columns 0 and 1
+        (atmosphere/atmosphere.py:318-319,346-347)."""
+        dt = self.problem["timestep"]
+        tr = np.cumsum(dt * np.c_[layer["vx"], layer["vy"], np.zeros(len(layer["vx"]))], axis=0)
+        q = (tr + np.array([0.0, 0.0, layer["h"]])) @ np.asarray(layer["transform"], float)
+        return q[:, 0], q[:, 1]
+
+    def set_screens(self, screens):
+        """Bind one smoothed screen per layer (numpy arrays or device tensors [E,C])."""
+        dev = self.device
+        layers = self.problem["layers"]
+        self._layers = (MrxLayer * len(layers))()
+        self._layer_bufs = []
+        for l, (layer, scr) in enumerate(zip(layers, screens)):
+            vals = scr if isinstance(scr, torch.Tensor) else _dev(scr, torch.float32, dev)
+            vals = vals.to(device=dev, dtype=torch.float32).contiguous()
+            oe, oc = self.layer_offsets(layer)
+            bufs = (
+                vals,
+                _dev(layer["extrusion"], torch.float32, dev),
+                _dev(layer["cross_section"], torch.float32, dev),
+                _dev(oe, torch.float64, dev),
+                _dev(oc, torch.float64, dev),
+            )
+            assert bufs[3].numel() == self.Ta, "layer wind arrays must have Ta entries"
+            assert tuple(vals.shape) == (len(layer["extrusion"]), len(layer["cross_section"]))
+            self._layer_bufs.append(bufs)
+            R = np.asarray(layer["transform"], float)
+            ly = self._layers[l]
+            ly.d_values, ly.d_axis_e, ly.d_axis_c, ly.d_off_e, ly.d_off_c = (x.data_ptr() for x in bufs)
+            ly.n_e, ly.n_c = vals.shape
+            ly.h = float(layer["h"])
+            ly.r00, ly.r10, ly.r01, ly.r11 = R[0, 0], R[1, 0], R[0, 1], R[1, 1]
+            ly.pwv_rms = float(np.float32(layer["pwv_rms"]))
+        if self.plan is not None:
+            self.ctx.call("mrx_atm_plan_destroy", self.plan)
+        plan = C.c_void_p()
+        self.ctx.call("mrx_atm_plan_create", self._layers, len(layers), self._tables, len(self._tables), C.byref(plan))
+        self.plan = plan
+
+    def generate_screens(self, smooth=True):
+        """Philox + k-space filter + iFFT on the device, then the beam smoothing
+        (atmosphere/atmosphere.py:328-344).  Returns the device tensors."""
+        dev = self.device
+        screens = []
+        for l, layer in enumerate(self.problem["layers"]):
+            ne, nc = len(layer["extrusion"]), len(layer["cross_section"])
+            out = torch.empty((ne, nc), dtype=torch.float32, device=dev)
+            work = torch.empty((2 * ne * nc, 2), dtype=torch.float32, device=dev)
+            de = float(layer["extrusion"][1] - layer["extrusion"][0])
+            dc = float(layer["cross_section"][1] - layer["cross_section"][0])
+            self.ctx.call(
+                "mrx_screen_generate", self.problem["seed"], l, ne, nc, de, dc,
+                float(layer["r0"]), float(layer["nu"]), ptr(out), ptr(work),
+            )
+            if smooth and layer.get("beam_sigma", 0) > 0:
+                tmp = work.view(-1)[: ne * nc]
+                self.ctx.call(
+                    "mrx_gauss_smooth2d", ptr(out), ptr(out), ptr(tmp), ne, nc,
+                    layer["beam_sigma"] / de, layer["beam_sigma"] / dc, 4.0,
+                )
+            screens.append(out)
+            del work
+        self.set_screens(screens)
+        return screens
+
+    # -- hot path ------------------------------------------------------------
+    def sample(self):
+        if self.plan is None:
+            raise RuntimeError("no screens bound: call set_screens() or generate_screens() first")
+        self.ctx.call(
+            "mrx_atm_sample", self.plan, ptr(self.d_az), ptr(self.d_el), self.Ta,
+            ptr(self.d_dx), ptr(self.d_dy), ptr(self.d_band), ptr(self.d_m00), self.D,
+            self.pwv0, ptr(self.d_pwv), ptr(self.d_loading), ptr(self.d_flags),
+        )
+
+    def prepare(self):
+        self.ctx.call("mrx_spline_prepare", ptr(self.d_loading), self.D, self.Ta, ptr(self.d_ym))
+
+    def upsample(self, out):
+        self.ctx.call(
+            "mrx_spline_upsample", ptr(self.d_ym), self.D, self.Ta, self.ta0, self.dta,
+            ptr(self.d_t), self.T, ptr(self.d_gain), ptr(out), out.stride(0),
+        )
+
+    def run(self, out=None):
+        """The whole path for this shard; returns the [D, T] float32 TOD tensor."""
+        if out is None:
+            out = torch.empty((self.D, self.T), dtype=torch.float32, device=self.device)
+        self.sample()
+        self.prepare()
+        self.upsample(out)
+        return out
+
+    def check_flags(self):
+        """Raise the reference's errors if a sample left a screen or a table."""
+        word = C.c_uint32()
+        self.ctx.call("mrx_read_flags", ptr(self.d_flags), C.byref(word))
+        if word.value & _lib.FLAG_SCREEN_OOB:
+            # atmosphere/atmosphere.py:368-369
+            raise RuntimeError("A layer introduced nans into PWV simulation (line of sight left its screen).")
+        return word.value
+
+    def clear_flags(self):
+        self.ctx.call("mrx_clear_flags", ptr(self.d_flags))
+
+    # -- accounting -------------------------------------------------------------
+    def algorithmic_bytes(self):
+        """B_alg of BASELINE.md section 4 for this shard."""
+        screens = sum(len(l["extrusion"]) * len(l["cross_section"]) for l in self.problem["layers"])
+        tables = sum(np.asarray(t["values"]).shape[1] * np.asarray(t["values"]).shape[2] for t in self.problem["tables"])
+        return 4 * self.D * self.T + 8 * self.D * self.Ta + 4 * screens + 8 * self.Ta + 8 * self.D + 4 * tables

@@ -1,0 +1,37 @@
+"""numpy spectral screen generator for CPU-only tests and the CPU baseline.
+TEST INFRASTRUCTURE ONLY (see oracle/hotpath.py).
+
+Same construction as the HIP generator (maria_amd/csrc/mrx_screen.hip): complex
+white noise in k space times sqrt(PSD), PSD ~ (k0^2 + |k|^2)^-(nu+1) with
+k0 = sqrt(2 nu)/r0, the 2-D transform of the Matern covariance of
+functions/__init__.py:30-39; inverse FFT; real part scaled to unit variance.
+The random stream is numpy's, not Philox, so screens differ sample by sample
+from the GPU's: parity of the generator is statistical.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+
+def psd_amplitude(ny, nx, dy, dx, r0, nu):
+    ky = 2 * np.pi * np.fft.fftfreq(ny, dy)[:, None]
+    kx = 2 * np.pi * np.fft.fftfreq(nx, dx)[None, :]
+    k0sq = 2.0 * nu / r0**2
+    return (k0sq + kx**2 + ky**2) ** (-(nu + 1.0) / 2.0)
+
+
+def numpy_screen(ny, nx, dy, dx, r0, nu, rng):
+    amp = psd_amplitude(ny, nx, dy, dx, r0, nu)
+    noise = rng.standard_normal((ny, nx)) + 1j * rng.standard_normal((ny, nx))
+    field = np.fft.ifft2(amp * noise).real * (ny * nx)
+    return (field / np.sqrt((amp**2).sum())).astype(np.float32)
+
+
+def radial_covariance(screen, dy, dx, lags_px):
+    """Empirical covariance of a periodic screen at integer-pixel lags along both
+    axes (FFT autocorrelation); returns (r_metres, cov) for each axis."""
+    f = np.fft.fft2(screen.astype(np.float64))
+    acf = np.fft.ifft2(np.abs(f) ** 2).real / screen.size
+    lags_px = np.asarray(lags_px)
+    return (lags_px * dy, acf[lags_px, 0]), (lags_px * dx, acf[0, lags_px])

@@ -1,0 +1,198 @@
+"""GPU tests of the screen side: Gaussian stencil vs scipy, map smoothing, the
+Philox generator and the statistics of generated screens."""
+
+import numpy as np
+import pytest
+import scipy.ndimage
+import scipy.stats
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _smooth(ctx, a, sy, sx, truncate=4.0, inplace=False):
+    import torch
+
+    from maria_amd._lib import ptr
+
+    d_in = torch.as_tensor(np.ascontiguousarray(a, np.float32)).to("cuda:0")
+    d_out = d_in if inplace else torch.empty_like(d_in)
+    d_tmp = torch.empty_like(d_in)
+    ny, nx = a.shape
+    ctx.call("mrx_gauss_smooth2d", ptr(d_in), ptr(d_out), ptr(d_tmp), ny, nx, float(sy), float(sx), float(truncate))
+    return d_out.cpu().numpy()
+
+
+@pytest.mark.parametrize(
+    "shape,sy,sx",
+    [
+        ((128, 128), 4.2, 4.2),
+        ((300, 77), 2.0, 7.5),
+        ((77, 300), 11.0, 0.6),
+        ((64, 64), 0.0, 3.0),  # scipy skips an axis with sigma 0
+        ((64, 64), 3.0, 0.0),
+        ((5, 9), 3.0, 3.0),  # radius larger than the array: multiple reflections
+        ((1, 200), 2.0, 2.0),
+        ((513, 1025), 1.3, 25.0),
+    ],
+)
+def test_gauss_matches_scipy(gpu_ctx, shape, sy, sx):
+    """scipy.ndimage.gaussian_filter on float32 input: float64 accumulation, float32
+    storage between the passes, reflect boundary, radius int(4 sigma + 0.5)
+    (atmosphere/atmosphere.py:341-344)."""
+    rng = np.random.default_rng(1)
+    a = rng.standard_normal(shape).astype(np.float32)
+    ref = scipy.ndimage.gaussian_filter(a, sigma=(sy, sx))
+    got = _smooth(gpu_ctx, a, sy, sx)
+    assert got.dtype == np.float32
+    # same float64 sums up to association: differences are float32 roundings
+    assert np.abs(got - ref).max() <= 2.5e-7 * max(1.0, np.abs(ref).max())
+    got2 = _smooth(gpu_ctx, a, sy, sx, inplace=True)
+    assert np.array_equal(got, got2)
+
+
+def test_gauss_preserves_constant_and_mass(gpu_ctx):
+    a = np.full((200, 130), 3.25, np.float32)
+    assert np.allclose(_smooth(gpu_ctx, a, 5.0, 2.0), 3.25, rtol=1e-6)
+    # reflect boundary conserves the sum
+    rng = np.random.default_rng(2)
+    b = rng.random((256, 256)).astype(np.float32)
+    assert abs(_smooth(gpu_ctx, b, 3.0, 3.0).astype(np.float64).sum() - b.astype(np.float64).sum()) < 1e-3 * b.sum()
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_map_smooth_matches_reference(gpu_ctx, weighted):
+    """ProjectionMap.smooth, map/projection.py:485-504."""
+    import torch
+
+    from maria_amd._lib import ptr
+    from oracle import hotpath
+
+    rng = np.random.default_rng(4)
+    ny, nx = 180, 250
+    data = rng.standard_normal((ny, nx)).astype(np.float32)
+    weight = None
+    if weighted:
+        weight = rng.random((ny, nx)).astype(np.float32)
+        weight[40:60, 100:140] = 0.0  # a hole larger than the kernel: denom == 0 -> 0
+    ref, ref_denom = hotpath.map_smooth(data, weight, 2.0, 3.5)
+    dev = "cuda:0"
+    d_data = torch.as_tensor(data).to(dev)
+    d_w = torch.as_tensor(weight).to(dev) if weighted else None
+    d_out = torch.empty_like(d_data)
+    d_den = torch.empty_like(d_data)
+    d_tmp = torch.empty(2 * ny * nx, dtype=torch.float32, device=dev)
+    gpu_ctx.call("mrx_map_smooth", ptr(d_data), ptr(d_w), ptr(d_out), ptr(d_den), ptr(d_tmp), ny, nx, 2.0, 3.5)
+    got = d_out.cpu().numpy()
+    assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
+    assert np.abs(d_den.cpu().numpy() - ref_denom).max() <= 1e-6
+    if weighted:
+        assert (got[45:55, 110:130] == 0).all()
+
+
+def test_philox_normals_are_standard(gpu_ctx):
+    import torch
+
+    from maria_amd._lib import ptr
+
+    n = 1 << 20
+    out = torch.empty(n, dtype=torch.float32, device="cuda:0")
+    gpu_ctx.call("mrx_philox_normal", 20260612, 3, n, ptr(out))
+    x = out.cpu().numpy().astype(np.float64)
+    assert abs(x.mean()) < 5 / np.sqrt(n)
+    assert abs(x.var() - 1) < 5 * np.sqrt(2 / n)
+    assert abs(scipy.stats.skew(x)) < 0.02 and abs(scipy.stats.kurtosis(x)) < 0.04
+    assert scipy.stats.kstest(x[:100000], "norm").pvalue > 1e-4
+    # another stream is another sequence; the same stream repeats exactly
+    out2 = torch.empty_like(out)
+    gpu_ctx.call("mrx_philox_normal", 20260612, 3, n, ptr(out2))
+    assert torch.equal(out, out2)
+    gpu_ctx.call("mrx_philox_normal", 20260612, 4, n, ptr(out2))
+    assert abs(np.corrcoef(x, out2.cpu().numpy())[0, 1]) < 0.01
+
+
+def _generate(ctx, seed, stream, ny, nx, dy, dx, r0, nu):
+    import torch
+
+    from maria_amd._lib import ptr
+
+    out = torch.empty((ny, nx), dtype=torch.float32, device="cuda:0")
+    work = torch.empty((2 * ny * nx, 2), dtype=torch.float32, device="cuda:0")
+    ctx.call("mrx_screen_generate", seed, stream, ny, nx, dy, dx, r0, nu, ptr(out), ptr(work))
+    return out.cpu().numpy()
+
+
+def test_screen_fft_matches_numpy_ifft(gpu_ctx):
+    """The hand-written LDS FFT: a screen is determined by its Philox spectrum, so
+    regenerate that spectrum on the host from the library's own Philox routine and
+    run numpy's ifft2 over it."""
+    from maria_amd._lib import philox4x32
+    from oracle import screens
+
+    ny, nx, dy, dx, r0, nu = 64, 128, 5.0, 7.0, 300.0, 5.0 / 6.0
+    seed, stream = 99, 2
+    got = _generate(gpu_ctx, seed, stream, ny, nx, dy, dx, r0, nu)
+    amp = screens.psd_amplitude(ny, nx, dy, dx, r0, nu)
+    spec = np.zeros((ny, nx), complex)
+    for iy in range(ny):
+        for ix in range(nx):
+            a, b, _, _ = philox4x32(seed, (ix, iy, stream, 0))
+            u1 = ((a >> 8) + 0.5) / 16777216.0
+            u2 = (b >> 8) / 16777216.0
+            rad = np.sqrt(-2 * np.log(u1))
+            spec[iy, ix] = rad * (np.cos(2 * np.pi * u2) + 1j * np.sin(2 * np.pi * u2))
+    ref = np.fft.ifft2(amp * spec).real * (ny * nx) / np.sqrt((amp**2).sum())
+    assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
+
+
+def test_screen_statistics_match_matern(gpu_ctx):
+    """Generator parity is statistical: unit variance and the
+    Matern(nu=5/6, r0) covariance of functions/__init__.py:30-74 at a set of lags,
+    averaged over independent screens."""
+    from oracle import functions, screens
+
+    ny = nx = 1024
+    d, r0, nu = 5.0, 1000.0, 5.0 / 6.0
+    lags = np.array([0, 1, 2, 4, 8, 16, 32, 64, 128])
+    acc = np.zeros((2, len(lags)))
+    nrep = 12
+    for rep in range(nrep):
+        s = _generate(gpu_ctx, 20260612, rep, ny, nx, d, d, r0, nu)
+        (r, cy), (_, cx) = screens.radial_covariance(s, d, d, lags)
+        acc += np.array([cy, cx]) / nrep
+    target = functions.approximate_normalized_matern(lags * d, nu=nu, r0=r0)
+    # the periodic box (5.1 km) removes power below 1/L and aliases the rest, and
+    # 12 screens leave sampling noise: compare the structure function, which is what
+    # the path is sensitive to, at 10 %.
+    sf_got = 2 * (acc[:, :1] - acc[:, 1:])
+    sf_ref = 2 * (target[0] - target[1:])
+    assert abs(acc[:, 0].mean() - 1) < 0.08, acc[:, 0]
+    assert np.abs(sf_got / sf_ref[None] - 1).max() < 0.12, (sf_got, sf_ref)
+
+
+def test_screen_is_reproducible_and_layer_independent(gpu_ctx):
+    a = _generate(gpu_ctx, 7, 0, 256, 256, 5.0, 5.0, 1000.0, 5.0 / 6.0)
+    b = _generate(gpu_ctx, 7, 0, 256, 256, 5.0, 5.0, 1000.0, 5.0 / 6.0)
+    c = _generate(gpu_ctx, 7, 1, 256, 256, 5.0, 5.0, 1000.0, 5.0 / 6.0)
+    assert np.array_equal(a, b)
+    assert abs(np.corrcoef(a.ravel(), c.ravel())[0, 1]) < 0.2
+    assert not np.isnan(a).any()
+
+
+def test_generate_screens_end_to_end(gpu_ctx):
+    """Screens made on the device feed the sampling kernel; the oracle, given the
+    same (downloaded) screens, agrees to 1e-5."""
+    from maria_amd import synthetic
+    from maria_amd.pipeline import DevicePath
+    from oracle import hotpath
+
+    p = synthetic.make_problem(n_det=100, n_bands=2, fov_deg=0.5, fs=100.0, duration=30.0, n_layers=4, side=256)
+    path = DevicePath(p, device="cuda:0", ctx=gpu_ctx)
+    scr = path.generate_screens()
+    tod = path.run().cpu().numpy()
+    assert path.check_flags() == 0
+    for layer, s in zip(p["layers"], scr):
+        layer["values"] = s.cpu().numpy()
+    ref = hotpath.run_path(p)
+    assert rel_err(tod, ref) <= 1e-5
