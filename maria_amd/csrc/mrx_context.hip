@@ -41,7 +41,8 @@ int mrx_init(int device, mrx_ctx** out) {
 int mrx_destroy(mrx_ctx* ctx) {
   if (!ctx) return MRX_ERR_INVALID;
   (void)hipSetDevice(ctx->device);
-  if (ctx->d_taps) (void)hipFree(ctx->d_taps);
+  for (auto& slot : ctx->taps)
+    if (slot.d_taps) (void)hipFree(slot.d_taps);
   if (ctx->d_reduce) (void)hipFree(ctx->d_reduce);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);

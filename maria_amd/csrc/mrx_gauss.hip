@@ -114,8 +114,15 @@ __global__ void ratio_kernel(const float* __restrict__ numer,
   }
 }
 
-// scipy.ndimage._filters._gaussian_kernel1d, order 0
-int upload_taps(mrx_ctx* ctx, double sigma, double truncate, int* radius_out) {
+// scipy.ndimage._filters._gaussian_kernel1d, order 0; device copy cached in ctx
+int get_taps(mrx_ctx* ctx, double sigma, double truncate, int* radius_out,
+             const double** d_taps_out) {
+  for (auto& slot : ctx->taps)
+    if (slot.d_taps && slot.sigma == sigma && slot.truncate == truncate) {
+      *radius_out = slot.radius;
+      *d_taps_out = slot.d_taps;
+      return MRX_OK;
+    }
   const int radius = (int)(truncate * sigma + 0.5);
   const size_t n = (size_t)(2 * radius + 1);
   std::vector<double> w(n);
@@ -127,19 +134,23 @@ int upload_taps(mrx_ctx* ctx, double sigma, double truncate, int* radius_out) {
     sum += v;
   }
   for (auto& v : w) v /= sum;
-  if (ctx->taps_cap < n) {
-    if (ctx->d_taps) (void)hipFree(ctx->d_taps);
-    ctx->d_taps = nullptr;
-    ctx->taps_cap = 0;
-    size_t cap = n < 256 ? 256 : n;
-    MRX_HIP(ctx, hipMalloc(&ctx->d_taps, cap * sizeof(double)));
-    ctx->taps_cap = cap;
+  auto& slot = ctx->taps[ctx->taps_next];
+  ctx->taps_next = (ctx->taps_next + 1) % mrx_ctx::kTapSlots;
+  if (slot.d_taps) {
+    // a kernel still in flight may be reading the evicted taps
+    MRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    (void)hipFree(slot.d_taps);
+    slot.d_taps = nullptr;
   }
-  // pageable source: the runtime stages it before returning
-  MRX_HIP(ctx, hipMemcpyAsync(ctx->d_taps, w.data(), n * sizeof(double),
+  MRX_HIP(ctx, hipMalloc(&slot.d_taps, n * sizeof(double)));
+  MRX_HIP(ctx, hipMemcpyAsync(slot.d_taps, w.data(), n * sizeof(double),
                               hipMemcpyHostToDevice, ctx->stream));
-  MRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  MRX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // w goes out of scope
+  slot.sigma = sigma;
+  slot.truncate = truncate;
+  slot.radius = radius;
   *radius_out = radius;
+  *d_taps_out = slot.d_taps;
   return MRX_OK;
 }
 
@@ -148,7 +159,8 @@ constexpr size_t kMaxLds = 64 * 1024;
 int smooth_axis1(mrx_ctx* ctx, const float* in, float* out, int ny, int nx,
                  double sigma, double truncate) {
   int radius = 0;
-  int rc = upload_taps(ctx, sigma, truncate, &radius);
+  const double* d_taps = nullptr;
+  int rc = get_taps(ctx, sigma, truncate, &radius, &d_taps);
   if (rc != MRX_OK) return rc;
   const size_t lds = (size_t)kXRows * (kXCols + 2 * radius) * sizeof(float);
   if (lds > kMaxLds)
@@ -157,7 +169,7 @@ int smooth_axis1(mrx_ctx* ctx, const float* in, float* out, int ny, int nx,
   dim3 grid(mrx_ceil_div(nx, kXCols), mrx_ceil_div(ny, kXRows));
   MRX_REQUIRE(ctx, grid.y <= 65535u, "ny too large for one launch");
   hipLaunchKernelGGL(gauss_x_kernel, grid, dim3(kBlock), lds, ctx->stream, in,
-                     out, ny, nx, ctx->d_taps, radius);
+                     out, ny, nx, d_taps, radius);
   MRX_CHECK_LAUNCH(ctx);
   return MRX_OK;
 }
@@ -165,7 +177,8 @@ int smooth_axis1(mrx_ctx* ctx, const float* in, float* out, int ny, int nx,
 int smooth_axis0(mrx_ctx* ctx, const float* in, float* out, int ny, int nx,
                  double sigma, double truncate) {
   int radius = 0;
-  int rc = upload_taps(ctx, sigma, truncate, &radius);
+  const double* d_taps = nullptr;
+  int rc = get_taps(ctx, sigma, truncate, &radius, &d_taps);
   if (rc != MRX_OK) return rc;
   int tile_rows = 64;
   while (tile_rows > 8 &&
@@ -178,7 +191,7 @@ int smooth_axis0(mrx_ctx* ctx, const float* in, float* out, int ny, int nx,
   dim3 grid(mrx_ceil_div(nx, kYCols), mrx_ceil_div(ny, tile_rows));
   MRX_REQUIRE(ctx, grid.y <= 65535u, "ny too large for one launch");
   hipLaunchKernelGGL(gauss_y_kernel, grid, dim3(kBlock), lds, ctx->stream, in,
-                     out, ny, nx, ctx->d_taps, radius, tile_rows);
+                     out, ny, nx, d_taps, radius, tile_rows);
   MRX_CHECK_LAUNCH(ctx);
   return MRX_OK;
 }

@@ -20,8 +20,15 @@ struct mrx_ctx {
   char err[512] = {0};
   // scratch owned by the context (grown on demand, never in a hot call that
   // already has what it needs)
-  double* d_taps = nullptr;  // Gaussian taps, f64
-  size_t taps_cap = 0;
+  // Gaussian taps (f64) cached per (sigma, truncate): a repeated smoothing
+  // call then needs no host->device copy and no synchronisation
+  static constexpr int kTapSlots = 32;
+  struct TapSlot {
+    double sigma = -1.0, truncate = 0.0;
+    int radius = 0;
+    double* d_taps = nullptr;
+  } taps[kTapSlots];
+  int taps_next = 0;
   double* d_reduce = nullptr;  // small reduction buffer
   size_t reduce_cap = 0;
 };

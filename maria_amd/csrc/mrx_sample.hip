@@ -205,12 +205,12 @@ extern "C" int mrx_atm_sample(mrx_ctx* ctx, const mrx_atm_plan* plan,
                               double* d_pwv, float* d_loading,
                               uint32_t* d_flags) {
   if (!ctx) return MRX_ERR_INVALID;
+  MRX_REQUIRE(ctx, D >= 0 && Ta >= 0, "negative size");
+  if (D == 0 || Ta == 0) return MRX_OK;  // empty shard: nothing to do
   MRX_REQUIRE(ctx, plan != nullptr, "plan is null");
   MRX_REQUIRE(ctx, d_az && d_el && d_dx && d_dy && d_band && d_mueller00,
               "null input pointer");
   MRX_REQUIRE(ctx, d_loading && d_flags, "null output pointer");
-  MRX_REQUIRE(ctx, D >= 0 && Ta >= 0, "negative size");
-  if (D == 0 || Ta == 0) return MRX_OK;  // empty shard: nothing to do
   dim3 grid(mrx_ceil_div(D, kBlock), mrx_ceil_div(Ta, kTimesPerBlock));
   MRX_REQUIRE(ctx, grid.y <= 65535u, "Ta too large for one launch");
   hipLaunchKernelGGL(atm_sample_kernel, grid, dim3(kBlock), 0, ctx->stream,

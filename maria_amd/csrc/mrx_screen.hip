@@ -260,12 +260,19 @@ int mrx_screen_generate(mrx_ctx* ctx, uint64_t seed, uint32_t stream, int ny,
 
   const size_t lds_y = (size_t)(ny + ny / 2) * sizeof(float2);
   const size_t lds_x = (size_t)(nx + nx / 2) * sizeof(float2);
-  MRX_HIP(ctx, hipFuncSetAttribute(
-                   reinterpret_cast<const void*>(screen_spectrum_fft_y),
-                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_y));
-  MRX_HIP(ctx, hipFuncSetAttribute(
-                   reinterpret_cast<const void*>(screen_fft_x_real),
-                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_x));
+  static size_t lds_set_y = 0, lds_set_x = 0;  // raise the dynamic-LDS cap once
+  if (lds_y > lds_set_y) {
+    MRX_HIP(ctx, hipFuncSetAttribute(
+                     reinterpret_cast<const void*>(screen_spectrum_fft_y),
+                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_y));
+    lds_set_y = lds_y;
+  }
+  if (lds_x > lds_set_x) {
+    MRX_HIP(ctx, hipFuncSetAttribute(
+                     reinterpret_cast<const void*>(screen_fft_x_real),
+                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_x));
+    lds_set_x = lds_x;
+  }
 
   hipLaunchKernelGGL(screen_spectrum_fft_y, dim3(nx), dim3(kBlock), lds_y,
                      ctx->stream, work1, ny, nx, ly, dy, dx, k0sq, expo, key0,

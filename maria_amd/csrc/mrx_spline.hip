@@ -299,9 +299,9 @@ extern "C" {
 int mrx_spline_prepare(mrx_ctx* ctx, const float* d_y, int D, int Ta,
                        float* d_ym) {
   if (!ctx) return MRX_ERR_INVALID;
-  MRX_REQUIRE(ctx, d_y && d_ym, "null pointer");
   MRX_REQUIRE(ctx, D >= 0, "negative D");
   if (D == 0) return MRX_OK;
+  MRX_REQUIRE(ctx, d_y && d_ym, "null pointer");
   if (Ta < 4)
     return mrx_fail(ctx, MRX_ERR_UNSUPPORTED,
                     "cubic interpolation needs at least 4 coarse samples "
@@ -318,11 +318,11 @@ int mrx_spline_upsample(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
                         double ta0, double dta, const double* d_t, int T,
                         const float* d_scale, float* d_out, size_t ld_out) {
   if (!ctx) return MRX_ERR_INVALID;
-  MRX_REQUIRE(ctx, d_ym && d_t && d_out, "null pointer");
   MRX_REQUIRE(ctx, D >= 0 && T >= 0, "negative size");
+  if (D == 0 || T == 0) return MRX_OK;
+  MRX_REQUIRE(ctx, d_ym && d_t && d_out, "null pointer");
   MRX_REQUIRE(ctx, dta > 0.0, "coarse step must be positive");
   MRX_REQUIRE(ctx, ld_out >= (size_t)T, "ld_out smaller than T");
-  if (D == 0 || T == 0) return MRX_OK;
   if (Ta < 4)
     return mrx_fail(ctx, MRX_ERR_UNSUPPORTED,
                     "cubic interpolation needs at least 4 coarse samples");
@@ -347,12 +347,12 @@ int mrx_linear_upsample(mrx_ctx* ctx, const double* d_pwv, int D, int Ta,
                         double ta0, double dta, const double* d_t, int T,
                         float* d_out, size_t ld_out) {
   if (!ctx) return MRX_ERR_INVALID;
-  MRX_REQUIRE(ctx, d_pwv && d_t && d_out, "null pointer");
   MRX_REQUIRE(ctx, D >= 0 && T >= 0, "negative size");
+  if (D == 0 || T == 0) return MRX_OK;
+  MRX_REQUIRE(ctx, d_pwv && d_t && d_out, "null pointer");
   MRX_REQUIRE(ctx, dta > 0.0, "coarse step must be positive");
   MRX_REQUIRE(ctx, ld_out >= (size_t)T, "ld_out smaller than T");
   MRX_REQUIRE(ctx, Ta >= 2, "linear interpolation needs 2 coarse samples");
-  if (D == 0 || T == 0) return MRX_OK;
   dim3 grid(mrx_ceil_div(T, kBlock), mrx_ceil_div(D, kTileDet));
   MRX_REQUIRE(ctx, grid.y <= 65535u, "D too large for one launch");
   hipLaunchKernelGGL(linear_upsample_kernel, grid, dim3(kBlock), 0, ctx->stream,

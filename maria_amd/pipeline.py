@@ -119,7 +119,8 @@ class DevicePath:
         self._layer_bufs = []
         for l, (layer, scr) in enumerate(zip(layers, screens)):
             vals = scr if isinstance(scr, torch.Tensor) else _dev(scr, torch.float32, dev)
-            vals = vals.to(device=dev, dtype=torch.float32).contiguous()
+            if vals.device != dev or vals.dtype != torch.float32 or not vals.is_contiguous():
+                vals = vals.to(device=dev, dtype=torch.float32).contiguous()
             oe, oc = self.layer_offsets(layer)
             bufs = (
                 vals,
@@ -146,29 +147,31 @@ class DevicePath:
 
     def generate_screens(self, smooth=True):
         """Philox + k-space filter + iFFT on the device, then the beam smoothing
-        (atmosphere/atmosphere.py:328-344).  Returns the device tensors."""
+        (atmosphere/atmosphere.py:328-344), into persistent screen buffers.  The
+        first call allocates the buffers and binds them; later calls only launch
+        kernels.  Returns the device tensors."""
         dev = self.device
-        screens = []
-        for l, layer in enumerate(self.problem["layers"]):
-            ne, nc = len(layer["extrusion"]), len(layer["cross_section"])
-            out = torch.empty((ne, nc), dtype=torch.float32, device=dev)
-            work = torch.empty((2 * ne * nc, 2), dtype=torch.float32, device=dev)
+        layers = self.problem["layers"]
+        if getattr(self, "_gen_screens", None) is None:
+            shapes = [(len(l["extrusion"]), len(l["cross_section"])) for l in layers]
+            self._gen_screens = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in shapes]
+            biggest = max(a * b for a, b in shapes)
+            self._gen_work = torch.empty(4 * biggest, dtype=torch.float32, device=dev)
+            self.set_screens(self._gen_screens)
+        for l, (layer, out) in enumerate(zip(layers, self._gen_screens)):
+            ne, nc = out.shape
             de = float(layer["extrusion"][1] - layer["extrusion"][0])
             dc = float(layer["cross_section"][1] - layer["cross_section"][0])
             self.ctx.call(
                 "mrx_screen_generate", self.problem["seed"], l, ne, nc, de, dc,
-                float(layer["r0"]), float(layer["nu"]), ptr(out), ptr(work),
+                float(layer["r0"]), float(layer["nu"]), ptr(out), ptr(self._gen_work),
             )
             if smooth and layer.get("beam_sigma", 0) > 0:
-                tmp = work.view(-1)[: ne * nc]
                 self.ctx.call(
-                    "mrx_gauss_smooth2d", ptr(out), ptr(out), ptr(tmp), ne, nc,
+                    "mrx_gauss_smooth2d", ptr(out), ptr(out), ptr(self._gen_work), ne, nc,
                     layer["beam_sigma"] / de, layer["beam_sigma"] / dc, 4.0,
                 )
-            screens.append(out)
-            del work
-        self.set_screens(screens)
-        return screens
+        return self._gen_screens
 
     # -- hot path ------------------------------------------------------------
     def sample(self):
