@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Per-kernel timing of the hot path on one GPU (development aid; bench.py is the
+contract benchmark).  Usage: python scripts/kbench.py [config] [reps]"""
+
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from maria_amd import synthetic  # noqa: E402
+from maria_amd.pipeline import DevicePath  # noqa: E402
+
+
+def timeit(fn, reps):
+    fn()
+    torch.cuda.synchronize()
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(reps)]
+    for a, b in evs:
+        a.record()
+        fn()
+        b.record()
+    torch.cuda.synchronize()
+    ms = np.array([a.elapsed_time(b) for a, b in evs])
+    return float(np.median(ms)), float(ms.min())
+
+
+def main():
+    config = sys.argv[1] if len(sys.argv) > 1 else "atlast_10k"
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
+    p = synthetic.config_problem(config)
+    path = DevicePath(p, device="cuda:0")
+    D, T, Ta = path.D, path.T, path.Ta
+    tod = torch.empty((D, T), dtype=torch.float32, device="cuda:0")
+    t0 = time.perf_counter()
+    path.generate_screens()
+    torch.cuda.synchronize()
+    print(f"config {config}: D={D} T={T} Ta={Ta} L={len(p['layers'])}; first screens {1e3*(time.perf_counter()-t0):.1f} ms")
+    L = len(p["layers"])
+    rows = [
+        ("screens(gen+smooth)", path.generate_screens, 12.0 * sum(len(l["extrusion"]) * len(l["cross_section"]) for l in p["layers"])),
+        ("sample", path.sample, 4.0 * D * Ta),
+        ("spline_prepare", path.prepare, 12.0 * D * Ta),
+        ("upsample", lambda: path.upsample(tod), 4.0 * D * T + 8.0 * D * Ta + 8.0 * T),
+    ]
+    total = 0.0
+    for name, fn, nbytes in rows:
+        med, mn = timeit(fn, reps)
+        total += med
+        print(f"{name:22s} median {med:8.3f} ms  min {mn:8.3f} ms  alg {nbytes/1e9:7.3f} GB -> {nbytes/med/1e6:8.1f} GB/s")
+    print(f"sum of medians {total:.3f} ms -> {D*T/total/1e6:.1f} G det-samples/s; point-layers/s in sample: {D*Ta*L/1e6:.1f} M")
+    assert path.check_flags() == 0
+
+
+if __name__ == "__main__":
+    main()
