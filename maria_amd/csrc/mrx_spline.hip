@@ -163,108 +163,134 @@ __global__ __launch_bounds__(kBlock) void spline_prepare_kernel(
 // store per detector row, 1 KiB contiguous per wave), computes their interval
 // index and the four basis weights once in float64 and reuses them for all
 // rows of the tile.  The (y, m) knots the tile needs are staged through LDS,
-// detector-major so that a wave's reads are consecutive 8-byte words.
+// detector-major so that a wave's reads are consecutive 8-byte words
+// (conflict-free ds_read_b64).  kMaxKnots is the LDS image's capacity in knots:
+// 64 covers upsampling ratios >= 17 with 8 KiB of LDS (8 workgroups per CU),
+// 256 covers ratios down to ~4; below that the tile reads its knots from
+// global memory (correct, slower: such ratios do not occur in maria, whose
+// coarse step is >= 0.1 s).
 constexpr int kTileDet = 16;
 constexpr int kSamplesPerThread = 4;
 constexpr int kTileSamples = kBlock * kSamplesPerThread;  // 1024
-constexpr int kMaxKnots = 256;         // knots per tile that fit the LDS image
-constexpr int kKnotPitch = kMaxKnots + 1;
 
-template <bool kHasScale>
-__global__ __launch_bounds__(kBlock) void spline_upsample_kernel(
-    const float2* __restrict__ ym, int D, int n, double ta0, double inv_dta,
-    double dta, const double* __restrict__ t, int T,
-    const float* __restrict__ scale, float* __restrict__ out, size_t ld,
-    int vec_ok) {
-  __shared__ float2 tile[kTileDet * kKnotPitch];
+typedef float vfloat4 __attribute__((ext_vector_type(4)));
 
-  const int s_tile = blockIdx.x * kTileSamples;
-  const int d0 = blockIdx.y * kTileDet;
-  const int sb = s_tile + threadIdx.x * kSamplesPerThread;
-
-  // ---- per-sample interval and weights -------------------------------------
+struct SampleWeights {
   int j[kSamplesPerThread];
   float wa[kSamplesPerThread], wb[kSamplesPerThread], wc[kSamplesPerThread],
       wd[kSamplesPerThread];
+};
+
+__device__ __forceinline__ int interval_of(double x, int n) {
+  const int jj = (int)floor(fmin(fmax(x, -1.0), 2.0e9));
+  return min(max(jj, 0), n - 2);
+}
+
+__device__ __forceinline__ void sample_weights(const double* __restrict__ t,
+                                               int sb, int T, int n, double ta0,
+                                               double inv_dta,
+                                               SampleWeights& w) {
 #pragma unroll
   for (int q = 0; q < kSamplesPerThread; ++q) {
     const int s = min(sb + q, T - 1);
     const double x = (t[s] - ta0) * inv_dta;
-    int jj = (int)floor(fmin(fmax(x, -1.0), 2.0e9));
-    jj = min(max(jj, 0), n - 2);
-    const double u = (t[s] - (ta0 + (double)jj * dta)) * inv_dta;
+    const int jj = interval_of(x, n);
+    const double u = x - (double)jj;  // may be < 0 or > 1: extrapolation
     const double v = 1.0 - u;
-    j[q] = jj;
-    wa[q] = (float)v;
-    wb[q] = (float)u;
-    wc[q] = (float)(v * (v * v - 1.0));
-    wd[q] = (float)(u * (u * u - 1.0));
+    w.j[q] = jj;
+    w.wa[q] = (float)v;
+    w.wb[q] = (float)u;
+    w.wc[q] = (float)(v * (v * v - 1.0));
+    w.wd[q] = (float)(u * (u * u - 1.0));
   }
+}
 
-  // ---- knot range of the tile (wave-uniform) --------------------------------
-  int jmin, jmax;
-  {
-    const int s_last = min(s_tile + kTileSamples, T) - 1;
-    const double x0 = (t[s_tile] - ta0) * inv_dta;
-    const double x1 = (t[s_last] - ta0) * inv_dta;
-    jmin = min(max((int)floor(fmin(fmax(x0, -1.0), 2.0e9)), 0), n - 2);
-    jmax = min(max((int)floor(fmin(fmax(x1, -1.0), 2.0e9)), 0), n - 2) + 1;
-  }
+__device__ __forceinline__ float spline_eval(const SampleWeights& w, int q,
+                                             float2 k0, float2 k1) {
+  float acc = w.wa[q] * k0.x;
+  acc = fmaf(w.wb[q], k1.x, acc);
+  acc = fmaf(w.wc[q], k0.y, acc);
+  acc = fmaf(w.wd[q], k1.y, acc);
+  return acc;
+}
+
+template <bool kHasScale, int kMaxKnots>
+__global__ __launch_bounds__(kBlock) void spline_upsample_kernel(
+    const float2* __restrict__ ym, int D, int n, double ta0, double inv_dta,
+    const double* __restrict__ t, int T, const float* __restrict__ scale,
+    float* __restrict__ out, size_t ld, int vec_ok) {
+  constexpr int kPitch = kMaxKnots + 1;
+  __shared__ float2 tile[kTileDet * kPitch];
+
+  const int s_tile = blockIdx.x * kTileSamples;
+  const int d0 = blockIdx.y * kTileDet;
+  const int sb = s_tile + threadIdx.x * kSamplesPerThread;
+  const int nd = min(kTileDet, D - d0);
+
+  SampleWeights w;
+  sample_weights(t, sb, T, n, ta0, inv_dta, w);
+
+  // knot range of the tile (wave-uniform; t ascending)
+  const int s_last = min(s_tile + kTileSamples, T) - 1;
+  const int jmin = interval_of((t[s_tile] - ta0) * inv_dta, n);
+  const int jmax = interval_of((t[s_last] - ta0) * inv_dta, n) + 1;
   const int K = jmax - jmin + 1;
-  const bool use_lds = K <= kMaxKnots;  // false only for ratios below ~4
+  const bool full = (sb + kSamplesPerThread <= T) && vec_ok;
 
-  if (use_lds) {
-    // 16 lanes cover the 16 detector rows of one knot (128 contiguous bytes)
-    const int dl = threadIdx.x & (kTileDet - 1);
-    const int d = d0 + dl;
-    for (int r = threadIdx.x / kTileDet; r < K; r += kBlock / kTileDet) {
-      float2 v = make_float2(0.f, 0.f);
-      if (d < D) v = ym[(size_t)(jmin + r) * D + d];
-      tile[dl * kKnotPitch + r] = v;
+  if (K <= kMaxKnots) {
+    {  // 16 lanes cover the 16 detector rows of one knot: 128 contiguous bytes
+      const int dl = threadIdx.x & (kTileDet - 1);
+      const int d = d0 + dl;
+      for (int r = threadIdx.x / kTileDet; r < K; r += kBlock / kTileDet) {
+        float2 v = make_float2(0.f, 0.f);
+        if (d < D) v = ym[(size_t)(jmin + r) * D + d];
+        tile[dl * kPitch + r] = v;
+      }
     }
     __syncthreads();
-  }
+    int r[kSamplesPerThread];
+#pragma unroll
+    for (int q = 0; q < kSamplesPerThread; ++q)
+      r[q] = min(max(w.j[q] - jmin, 0), K - 2);  // in range even if t is unsorted
 
-  int r[kSamplesPerThread];
-#pragma unroll
-  for (int q = 0; q < kSamplesPerThread; ++q)
-    r[q] = min(max(j[q] - jmin, 0), K - 2);  // in range even if t is unsorted
-
-  const bool full = (sb + kSamplesPerThread <= T) && vec_ok;
-  const int nd = min(kTileDet, D - d0);
-  for (int dl = 0; dl < nd; ++dl) {
-    const int d = d0 + dl;
-    float o[kSamplesPerThread];
-#pragma unroll
-    for (int q = 0; q < kSamplesPerThread; ++q) {
-      float2 k0, k1;
-      if (use_lds) {
-        k0 = tile[dl * kKnotPitch + r[q]];
-        k1 = tile[dl * kKnotPitch + r[q] + 1];
-      } else {
-        k0 = ym[(size_t)j[q] * D + d];
-        k1 = ym[(size_t)(j[q] + 1) * D + d];
-      }
-      float acc = wa[q] * k0.x;
-      acc = fmaf(wb[q], k1.x, acc);
-      acc = fmaf(wc[q], k0.y, acc);
-      acc = fmaf(wd[q], k1.y, acc);
-      o[q] = acc;
-    }
-    if (kHasScale) {
-      const float g = scale[d];
-#pragma unroll
-      for (int q = 0; q < kSamplesPerThread; ++q) o[q] *= g;
-    }
-    float* dst = out + (size_t)d * ld + sb;
     if (full) {
-      typedef float vfloat4 __attribute__((ext_vector_type(4)));
-      const vfloat4 v = {o[0], o[1], o[2], o[3]};
-      __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(dst));
+#pragma unroll 4
+      for (int dl = 0; dl < nd; ++dl) {
+        const float2* row = tile + dl * kPitch;
+        float o[kSamplesPerThread];
+#pragma unroll
+        for (int q = 0; q < kSamplesPerThread; ++q)
+          o[q] = spline_eval(w, q, row[r[q]], row[r[q] + 1]);
+        if (kHasScale) {
+          const float g = scale[d0 + dl];
+#pragma unroll
+          for (int q = 0; q < kSamplesPerThread; ++q) o[q] *= g;
+        }
+        const vfloat4 v = {o[0], o[1], o[2], o[3]};
+        __builtin_nontemporal_store(
+            v, reinterpret_cast<vfloat4*>(out + (size_t)(d0 + dl) * ld + sb));
+      }
     } else {
+      for (int dl = 0; dl < nd; ++dl) {
+        const float2* row = tile + dl * kPitch;
+        const float g = kHasScale ? scale[d0 + dl] : 1.0f;
+        float* dst = out + (size_t)(d0 + dl) * ld + sb;
+#pragma unroll
+        for (int q = 0; q < kSamplesPerThread; ++q)
+          if (sb + q < T) dst[q] = g * spline_eval(w, q, row[r[q]], row[r[q] + 1]);
+      }
+    }
+  } else {
+    // low upsampling ratio: knots straight from global memory
+    for (int dl = 0; dl < nd; ++dl) {
+      const int d = d0 + dl;
+      const float g = kHasScale ? scale[d] : 1.0f;
+      float* dst = out + (size_t)d * ld + sb;
 #pragma unroll
       for (int q = 0; q < kSamplesPerThread; ++q)
-        if (sb + q < T) dst[q] = o[q];
+        if (sb + q < T)
+          dst[q] = g * spline_eval(w, q, ym[(size_t)w.j[q] * D + d],
+                                   ym[(size_t)(w.j[q] + 1) * D + d]);
     }
   }
 }
@@ -331,14 +357,21 @@ int mrx_spline_upsample(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
   const int vec_ok =
       (ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15u) == 0);
   const float2* ym = reinterpret_cast<const float2*>(d_ym);
-  if (d_scale)
-    hipLaunchKernelGGL(spline_upsample_kernel<true>, grid, dim3(kBlock), 0,
-                       ctx->stream, ym, D, Ta, ta0, 1.0 / dta, dta, d_t, T,
-                       d_scale, d_out, ld_out, vec_ok);
-  else
-    hipLaunchKernelGGL(spline_upsample_kernel<false>, grid, dim3(kBlock), 0,
-                       ctx->stream, ym, D, Ta, ta0, 1.0 / dta, dta, d_t, T,
-                       d_scale, d_out, ld_out, vec_ok);
+  // LDS image size from the expected knots per 1024-sample tile (the sample
+  // times live on the device; a tile that needs more knots than the image
+  // holds falls back to global loads inside the kernel)
+  const double knots_per_tile = (double)kTileSamples * (double)Ta / (double)T;
+  const bool small = knots_per_tile + 4.0 <= 64.0;
+#define MRX_LAUNCH_UP(S, K)                                                   \
+  hipLaunchKernelGGL((spline_upsample_kernel<S, K>), grid, dim3(kBlock), 0,   \
+                     ctx->stream, ym, D, Ta, ta0, 1.0 / dta, d_t, T, d_scale, \
+                     d_out, ld_out, vec_ok)
+  if (d_scale) {
+    if (small) MRX_LAUNCH_UP(true, 64); else MRX_LAUNCH_UP(true, 256);
+  } else {
+    if (small) MRX_LAUNCH_UP(false, 64); else MRX_LAUNCH_UP(false, 256);
+  }
+#undef MRX_LAUNCH_UP
   MRX_CHECK_LAUNCH(ctx);
   return MRX_OK;
 }
