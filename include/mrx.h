@@ -94,6 +94,13 @@ typedef struct mrx_layer {
   int32_t n_e, n_c;
   double h;              /* layer.h, metres                                    */
   double r00, r10, r01, r11;
+  /* Optional uniform-axis hint: the float64 grids behind the two axes are
+   * extrusion[i] = e0 + i*de (np.arange, atmosphere.py:241-245) and
+   * cross_section[i] = c0 + i*dc (np.linspace, :208-219).  When
+   * float32(e0 + i*de) reproduces d_axis_e bit for bit (checked on the device
+   * at plan creation) the kernel recomputes nodes instead of fetching them; the
+   * results are identical either way.  Set de / dc to 0 when unknown. */
+  double e0, de, c0, dc;
   float pwv_rms;         /* float32(layer.pwv_rms), extrusion.py:100-105       */
   int32_t reserved;
 } mrx_layer;
@@ -111,13 +118,21 @@ typedef struct mrx_band_table {
   int32_t t_oob;           /* 1 if T0 lies outside the table (result NaN)     */
 } mrx_band_table;
 
-/* Copies the layer and table descriptors (host structs holding device
- * pointers) into a device-resident plan.  The buffers they point to must stay
- * alive while the plan is in use. */
+/* Builds the device-resident plan from the layer and table descriptors (host
+ * structs holding device pointers): packs the wind offsets of all layers
+ * [n_t][n_layers], copies the band tables into one buffer (staged in LDS by the
+ * kernel) and verifies the uniform-axis hints.  The screens (d_values) and axis
+ * arrays must stay alive while the plan is in use; the screens may be
+ * rewritten in place between calls (a new realisation), the rest may not.
+ * n_t = length of every d_off_e / d_off_c array = Ta of mrx_atm_sample. */
 int mrx_atm_plan_create(mrx_ctx* ctx, const mrx_layer* layers, int n_layers,
-                        const mrx_band_table* tables, int n_tables,
+                        const mrx_band_table* tables, int n_tables, int n_t,
                         mrx_atm_plan** plan);
 int mrx_atm_plan_destroy(mrx_ctx* ctx, mrx_atm_plan* plan);
+/* Diagnostics: number of layer axes (0..2*n_layers) that passed the uniform
+ * check, and whether the band tables fit the kernel's LDS stage. */
+int mrx_atm_plan_info(mrx_ctx* ctx, const mrx_atm_plan* plan, int* uniform_axes,
+                      int* tables_in_lds);
 
 /* ---- hot path ------------------------------------------------------------- */
 

@@ -53,6 +53,10 @@ class MrxLayer(C.Structure):
         ("r10", C.c_double),
         ("r01", C.c_double),
         ("r11", C.c_double),
+        ("e0", C.c_double),
+        ("de", C.c_double),
+        ("c0", C.c_double),
+        ("dc", C.c_double),
         ("pwv_rms", C.c_float),
         ("reserved", C.c_int32),
     ]
@@ -84,7 +88,8 @@ SIGNATURES = {
     "mrx_device_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_sz), C.c_char_p, _i]),
     "mrx_timer_start": (_i, [_vp]),
     "mrx_timer_stop": (_i, [_vp, C.POINTER(C.c_float)]),
-    "mrx_atm_plan_create": (_i, [_vp, C.POINTER(MrxLayer), _i, C.POINTER(MrxBandTable), _i, C.POINTER(_vp)]),
+    "mrx_atm_plan_create": (_i, [_vp, C.POINTER(MrxLayer), _i, C.POINTER(MrxBandTable), _i, _i, C.POINTER(_vp)]),
+    "mrx_atm_plan_info": (_i, [_vp, _vp, C.POINTER(_i), C.POINTER(_i)]),
     "mrx_atm_plan_destroy": (_i, [_vp, _vp]),
     "mrx_atm_sample": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _d, _vp, _vp, _vp]),
     "mrx_clear_flags": (_i, [_vp, _vp]),

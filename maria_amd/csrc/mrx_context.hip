@@ -108,62 +108,4 @@ int mrx_read_flags(mrx_ctx* ctx, const uint32_t* d_flags,
   return MRX_OK;
 }
 
-int mrx_atm_plan_create(mrx_ctx* ctx, const mrx_layer* layers, int n_layers,
-                        const mrx_band_table* tables, int n_tables,
-                        mrx_atm_plan** out) {
-  if (!ctx || !out) return MRX_ERR_INVALID;
-  *out = nullptr;
-  MRX_REQUIRE(ctx, layers != nullptr || n_layers == 0, "layers is null");
-  MRX_REQUIRE(ctx, n_layers >= 0 && n_layers <= 64, "0 <= n_layers <= 64");
-  MRX_REQUIRE(ctx, tables != nullptr && n_tables >= 1 && n_tables <= 1024,
-              "need 1..1024 band tables");
-  for (int l = 0; l < n_layers; ++l) {
-    const mrx_layer& y = layers[l];
-    MRX_REQUIRE(ctx, y.d_values && y.d_axis_e && y.d_axis_c && y.d_off_e &&
-                         y.d_off_c,
-                "layer has a null device pointer");
-    MRX_REQUIRE(ctx, y.n_e >= 2 && y.n_c >= 2, "layer grid needs >= 2 nodes");
-  }
-  for (int b = 0; b < n_tables; ++b) {
-    const mrx_band_table& t = tables[b];
-    MRX_REQUIRE(ctx, t.d_values && t.d_axis_pwv && t.d_axis_el,
-                "band table has a null device pointer");
-    MRX_REQUIRE(ctx, t.n_pwv >= 2 && t.n_el >= 2,
-                "band table needs >= 2 nodes per axis");
-  }
-  mrx_atm_plan* p = new (std::nothrow) mrx_atm_plan();
-  if (!p) return mrx_fail(ctx, MRX_ERR_ALLOC, "out of host memory");
-  p->n_layers = n_layers;
-  p->n_tables = n_tables;
-  hipError_t e = hipSuccess;
-  if (n_layers > 0) {
-    e = hipMalloc(&p->d_layers, sizeof(mrx_layer) * n_layers);
-    if (e == hipSuccess)
-      e = hipMemcpyAsync(p->d_layers, layers, sizeof(mrx_layer) * n_layers,
-                         hipMemcpyHostToDevice, ctx->stream);
-  }
-  if (e == hipSuccess) e = hipMalloc(&p->d_tables, sizeof(mrx_band_table) * n_tables);
-  if (e == hipSuccess)
-    e = hipMemcpyAsync(p->d_tables, tables, sizeof(mrx_band_table) * n_tables,
-                       hipMemcpyHostToDevice, ctx->stream);
-  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-  if (e != hipSuccess) {
-    if (p->d_layers) (void)hipFree(p->d_layers);
-    if (p->d_tables) (void)hipFree(p->d_tables);
-    delete p;
-    return mrx_fail(ctx, MRX_ERR_HIP, "plan upload failed: %s",
-                    hipGetErrorString(e));
-  }
-  *out = p;
-  return MRX_OK;
-}
-
-int mrx_atm_plan_destroy(mrx_ctx* ctx, mrx_atm_plan* plan) {
-  if (!ctx || !plan) return MRX_ERR_INVALID;
-  if (plan->d_layers) (void)hipFree(plan->d_layers);
-  if (plan->d_tables) (void)hipFree(plan->d_tables);
-  delete plan;
-  return MRX_OK;
-}
-
 }  // extern "C"

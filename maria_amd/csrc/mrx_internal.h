@@ -33,13 +33,6 @@ struct mrx_ctx {
   size_t reduce_cap = 0;
 };
 
-struct mrx_atm_plan {
-  mrx_layer* d_layers = nullptr;
-  mrx_band_table* d_tables = nullptr;
-  int n_layers = 0;
-  int n_tables = 0;
-};
-
 inline int mrx_fail(mrx_ctx* ctx, int code, const char* fmt, ...) {
   if (ctx) {
     va_list ap;

@@ -1,85 +1,141 @@
-// Fused coarse-rate atmosphere sampling for gfx950.
+// Fused coarse-rate atmosphere sampling for gfx950, and its device-side plan.
 //
-// One thread = one (detector, coarse time step).  Lanes of a wave are
-// consecutive detectors at the same time step, so everything that depends on
-// time only (boresight, wind offsets, layer descriptors) is wave-uniform and
-// sits in SGPRs, the time-major stores are fully coalesced, and the bilinear
-// gathers of neighbouring detectors land in the same few cache lines of the
-// screen (a focal plane is compact on every layer).
+// One thread = one detector x kTimes consecutive coarse time steps.  Lanes of a
+// wave are consecutive detectors at the same time steps, so everything that
+// depends on time only (boresight, wind offsets, layer descriptors) is
+// wave-uniform and sits in SGPRs, the time-major stores are fully coalesced,
+// and the bilinear gathers of neighbouring detectors land in the same few
+// cache lines of the screen (a focal plane is compact on every layer).
+//
+// The kernel is latency-, not bandwidth-bound, so the plan is laid out to keep
+// dependent loads off the critical path:
+//   * layer descriptors are packed scalars (one s_load burst per layer, reused
+//     for kTimes time steps);
+//   * the per-time wind offsets of all layers are packed [t][layer];
+//   * grid nodes of a uniform axis are recomputed as float32(g0 + i*dg) instead
+//     of being fetched -- only after a device-side check at plan creation that
+//     this reproduces the caller's float32 axis array bit for bit; otherwise the
+//     array is searched (same results, slower);
+//   * the band tables and their axes are staged in LDS once per workgroup.
+// Per layer and sample that leaves only the 2x2 gather itself.
 //
 // Arithmetic follows the reference's rounding points (float32 where jax
 // computes, float64 where numpy does); see oracle/hotpath.py for the CPU
 // restatement this kernel is checked against.  This TU is compiled with
 // -ffp-contract=off so that a*b+c rounds twice, like numpy / XLA do.
+#include <vector>
+
 #include "mrx_internal.h"
 
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kTimesPerBlock = 4;
+constexpr int kTimes = 4;                  // coarse time steps per thread
+constexpr int kMaxLdsTableFloats = 12288;  // 48 KiB of band tables in LDS
 
 // float32(pi/2): jax folds the weak-typed python float pi/2 to float32
 // (coords/transforms.py:22) and numpy clips float32 elevations to it
 // (sim/atmosphere.py:60).
 constexpr float kHalfPiF = 1.57079637050628662109375f;
 
+}  // namespace
+
+// Device-side layer descriptor (plan-private).
+struct mrx_layer_dev {
+  const float* values;
+  const float* axis_e;
+  const float* axis_c;
+  double h, r00, r10, r01, r11;
+  double e0, de, c0, dc;          // node(i) = float32(e0 + i*de) when uniform_*
+  float e_first, e_inv, e_last;   // axis_e[0], 1/(axis_e[1]-axis_e[0]), axis_e[n-1]
+  float c_first, c_inv, c_last;
+  float pwv_rms;
+  int n_e, n_c;
+  int uniform_e, uniform_c;
+};
+
+// Device-side band table descriptor: offsets (in floats) into the packed table
+// buffer, which is [values 2*np*ne][axis_pwv np][axis_el ne] per band.
+struct mrx_table_dev {
+  int off_values, off_pwv, off_el;
+  int n_pwv, n_el;
+  float w_t;
+  int t_oob;
+  float p_first, p_inv, e_first, e_inv;
+};
+
+struct mrx_atm_plan {
+  mrx_layer_dev* d_layers = nullptr;
+  double2* d_off = nullptr;  // [n_t][n_layers] (off_e, off_c)
+  mrx_table_dev* d_tables = nullptr;
+  float* d_table_data = nullptr;
+  int n_layers = 0, n_tables = 0, n_t = 0;
+  int table_floats = 0;
+};
+
+namespace {
+
 struct Cell {
   int i;
-  float w;    // normalised distance to the lower node
+  float w;  // normalised distance to the lower node
   bool oob;
 };
 
 // jax.scipy.interpolate.RegularGridInterpolator._find_indices for one axis:
 // i = clip(searchsorted(g, x, side="left") - 1, 0, n-2), w = (x-g[i])/(g[i+1]-g[i]),
-// out of bounds when x < g[0] or x > g[n-1].  `guess` starts the search (the
-// screens' axes are uniform up to float32 rounding, so it is off by at most one).
-__device__ __forceinline__ Cell find_cell_guess(const float* __restrict__ g,
-                                                int n, float x, int guess) {
-  int i = min(max(guess, 0), n - 2);
-  float lo = g[i], hi = g[i + 1];
+// out of bounds when x < g[0] or x > g[n-1].  NodeFn returns float32 node i.
+template <typename NodeFn>
+__device__ __forceinline__ Cell find_cell(NodeFn node, int n, float x,
+                                          float first, float inv, float last) {
+  // a NaN or huge coordinate must not become an undefined int conversion
+  const float f = fminf(fmaxf((x - first) * inv, -1.0f), 2.0e9f);
+  int i = min(max((int)f, 0), n - 2);
+  float lo = node(i), hi = node(i + 1);
   while (i < n - 2 && hi < x) {
     ++i;
     lo = hi;
-    hi = g[i + 1];
+    hi = node(i + 1);
   }
   while (i > 0 && lo >= x) {
     --i;
     hi = lo;
-    lo = g[i];
+    lo = node(i);
   }
   Cell c;
   c.i = i;
   c.w = (x - lo) / (hi - lo);
-  c.oob = !(x >= g[0] && x <= g[n - 1]);  // also true for NaN
+  c.oob = !(x >= first && x <= last);  // also true for NaN
   return c;
 }
 
-// Same contract, by bisection: for the (short, possibly non-uniform) axes of
-// the emission tables.
-__device__ __forceinline__ Cell find_cell_bisect(const float* __restrict__ g,
-                                                 int n, float x) {
-  int lo = 0, hi = n;  // first index with g[k] >= x
-  while (lo < hi) {
-    int mid = (lo + hi) >> 1;
-    if (g[mid] < x) lo = mid + 1; else hi = mid;
-  }
-  int i = min(max(lo - 1, 0), n - 2);
-  float a = g[i], b = g[i + 1];
-  Cell c;
-  c.i = i;
-  c.w = (x - a) / (b - a);
-  c.oob = !(x >= g[0] && x <= g[n - 1]);
-  return c;
+__device__ __forceinline__ Cell layer_cell(const float* __restrict__ axis,
+                                           int uniform, double g0, double dg,
+                                           int n, float x, float first,
+                                           float inv, float last) {
+  if (uniform)  // wave-uniform branch
+    return find_cell([=](int i) { return (float)((double)i * dg + g0); }, n, x,
+                     first, inv, last);
+  return find_cell([=](int i) { return axis[i]; }, n, x, first, inv, last);
 }
 
+template <bool kLdsTables>
 __global__ __launch_bounds__(kBlock) void atm_sample_kernel(
-    const mrx_layer* __restrict__ layers, int n_layers,
-    const mrx_band_table* __restrict__ tables, int n_tables,
+    const mrx_layer_dev* __restrict__ layers, int n_layers,
+    const double2* __restrict__ off, const mrx_table_dev* __restrict__ tables,
+    int n_tables, const float* __restrict__ table_data, int table_floats,
     const float* __restrict__ az, const float* __restrict__ el, int Ta,
     const float* __restrict__ dxs, const float* __restrict__ dys,
     const int32_t* __restrict__ band, const float* __restrict__ mueller00,
     int D, double pwv0, double* __restrict__ pwv_out,
     float* __restrict__ loading, uint32_t* __restrict__ flags) {
+  extern __shared__ float lds_tables[];
+  if (kLdsTables) {
+    for (int i = threadIdx.x; i < table_floats; i += kBlock)
+      lds_tables[i] = table_data[i];
+    __syncthreads();
+  }
+  const float* __restrict__ tdata = kLdsTables ? lds_tables : table_data;
+
   const int d = blockIdx.x * kBlock + threadIdx.x;
   const bool live = d < D;
   const int dd = live ? d : D - 1;  // keep addresses valid; stores are masked
@@ -94,53 +150,49 @@ __global__ __launch_bounds__(kBlock) void atm_sample_kernel(
   const float Y = sr * sp;  // sin(r) sin(p)
   const int b = band[dd];
   const float m00 = mueller00[dd];
-  const mrx_band_table tb = tables[min(max(b, 0), n_tables - 1)];
-
   uint32_t myflags = (b < 0 || b >= n_tables) ? MRX_FLAG_NAN : 0u;
 
-  const int t0 = blockIdx.y * kTimesPerBlock;
-  for (int tt = 0; tt < kTimesPerBlock; ++tt) {
-    const int t = t0 + tt;
-    if (t >= Ta) break;
+  const int t0 = blockIdx.y * kTimes;
 
-    // ---- pointing of this detector (transforms.py:20-28) ------------------
+  // ---- pointing and unit-height ground projection for kTimes steps --------
+  float theta[kTimes];
+  double px[kTimes], py[kTimes], pwv[kTimes];
+#pragma unroll
+  for (int tt = 0; tt < kTimes; ++tt) {
+    const int t = min(t0 + tt, Ta - 1);
+    // transforms.py:20-28
     const float a = el[t] - kHalfPiF;
     const float ca = cosf(a), sa = sinf(a);
     const float re = A * ca - cr * sa;
     const float im = A * sa + cr * ca;
     const float phi = atan2f(Y, re) + az[t];
-    const float theta = asinf(im);
+    theta[tt] = asinf(im);
+    // coordinates.py:339-347: numpy float32 tan/cos/sin and division, then f64
+    const float tth = tanf(theta[tt]);
+    px[tt] = (double)(cosf(phi) / tth);
+    py[tt] = (double)(sinf(phi) / tth);
+    pwv[tt] = pwv0;
+  }
 
-    // ---- unit-height ground projection (coordinates.py:339-347) -----------
-    // numpy float32 tan/cos/sin and float32 division, then float64.
-    const float tth = tanf(theta);
-    const double px = (double)(cosf(phi) / tth);
-    const double py = (double)(sinf(phi) / tth);
-
-    // ---- layer stack (atmosphere/atmosphere.py:317-373) -------------------
-    double pwv = pwv0;
-    for (int l = 0; l < n_layers; ++l) {
-      const mrx_layer& ly = layers[l];
-      const double e64 = fma(ly.h, fma(px, ly.r00, py * ly.r10), ly.d_off_e[t]);
-      const double c64 = fma(ly.h, fma(px, ly.r01, py * ly.r11), ly.d_off_c[t]);
+  // ---- layer stack (atmosphere/atmosphere.py:317-373) ---------------------
+  for (int l = 0; l < n_layers; ++l) {
+    const mrx_layer_dev& ly = layers[l];
+    const int nc = ly.n_c;
+#pragma unroll
+    for (int tt = 0; tt < kTimes; ++tt) {
+      const int t = min(t0 + tt, Ta - 1);
+      const double2 o = off[(size_t)t * n_layers + l];
+      const double e64 = fma(ly.h, fma(px[tt], ly.r00, py[tt] * ly.r10), o.x);
+      const double c64 = fma(ly.h, fma(px[tt], ly.r01, py[tt] * ly.r11), o.y);
       const float xe = (float)e64, xc = (float)c64;
-
-      const float* ge = ly.d_axis_e;
-      const float* gc = ly.d_axis_c;
-      // uniform-grid guess from the first two nodes
-      const float e0 = ge[0], c0 = gc[0];
-      const float ide = 1.0f / (ge[1] - e0), idc = 1.0f / (gc[1] - c0);
-      const float fe = (xe - e0) * ide, fc = (xc - c0) * idc;
-      // a NaN or huge coordinate must not become an undefined int conversion
-      const int gi = (int)fminf(fmaxf(fe, -1.0f), 2.0e9f) ;
-      const int gj = (int)fminf(fmaxf(fc, -1.0f), 2.0e9f);
-      const Cell ce = find_cell_guess(ge, ly.n_e, xe, gi);
-      const Cell cc = find_cell_guess(gc, ly.n_c, xc, gj);
-
-      const float* v = ly.d_values + (size_t)ce.i * ly.n_c + cc.i;
+      const Cell ce = layer_cell(ly.axis_e, ly.uniform_e, ly.e0, ly.de, ly.n_e,
+                                 xe, ly.e_first, ly.e_inv, ly.e_last);
+      const Cell cc = layer_cell(ly.axis_c, ly.uniform_c, ly.c0, ly.dc, nc, xc,
+                                 ly.c_first, ly.c_inv, ly.c_last);
+      const float* v = ly.values + (size_t)ce.i * nc + cc.i;
       const float v00 = v[0], v01 = v[1];
-      const float v10 = v[ly.n_c], v11 = v[ly.n_c + 1];
-      // jax _evaluate_linear: edges in itertools.product order, weight built
+      const float v10 = v[nc], v11 = v[nc + 1];
+      // jax _evaluate_linear: corners in itertools.product order, weight built
       // as (1*we)*wc, summed into 0.0 in float32.
       const float we0 = 1.0f - ce.w, we1 = ce.w;
       const float wc0 = 1.0f - cc.w, wc1 = cc.w;
@@ -155,16 +207,27 @@ __global__ __launch_bounds__(kBlock) void atm_sample_kernel(
       }
       // layer.pwv_rms * y is a float32 product (jax array), accumulated into
       // the float64 numpy array (atmosphere.py:373).
-      pwv += (double)(ly.pwv_rms * y);
+      pwv[tt] += (double)(ly.pwv_rms * y);
     }
+  }
 
-    // ---- band emission (band/band.py:264-286), float32 --------------------
-    const float xp = (float)pwv;
-    const float xel = fminf(theta, kHalfPiF);  // .clip(max=pi/2), sim/atmosphere.py:60
-    const Cell cp_ = find_cell_bisect(tb.d_axis_pwv, tb.n_pwv, xp);
-    const Cell cl = find_cell_bisect(tb.d_axis_el, tb.n_el, xel);
-    const size_t slab = (size_t)tb.n_pwv * tb.n_el;
-    const float* q = tb.d_values + (size_t)cp_.i * tb.n_el + cl.i;
+  // ---- band emission (band/band.py:264-286), float32 ----------------------
+  const mrx_table_dev tb = tables[min(max(b, 0), n_tables - 1)];
+  const float* __restrict__ ax_p = tdata + tb.off_pwv;
+  const float* __restrict__ ax_e = tdata + tb.off_el;
+  const float* __restrict__ tv = tdata + tb.off_values;
+  const int slab = tb.n_pwv * tb.n_el;
+  const float p_last = ax_p[tb.n_pwv - 1], e_last = ax_e[tb.n_el - 1];
+#pragma unroll
+  for (int tt = 0; tt < kTimes; ++tt) {
+    const int t = t0 + tt;
+    const float xp = (float)pwv[tt];
+    const float xel = fminf(theta[tt], kHalfPiF);  // .clip(max=pi/2), sim/atmosphere.py:60
+    const Cell cp_ = find_cell([=](int i) { return ax_p[i]; }, tb.n_pwv, xp,
+                               tb.p_first, tb.p_inv, p_last);
+    const Cell cl = find_cell([=](int i) { return ax_e[i]; }, tb.n_el, xel,
+                              tb.e_first, tb.e_inv, e_last);
+    const float* q = tv + cp_.i * tb.n_el + cl.i;
     float val = 0.0f;
 #pragma unroll
     for (int ia = 0; ia < 2; ++ia) {
@@ -175,35 +238,228 @@ __global__ __launch_bounds__(kBlock) void atm_sample_kernel(
 #pragma unroll
         for (int ic = 0; ic < 2; ++ic) {
           const float w3 = w2 * (ic ? cl.w : 1.0f - cl.w);
-          val = val + q[ia * slab + (size_t)ib * tb.n_el + ic] * w3;
+          val = val + q[ia * slab + ib * tb.n_el + ic] * w3;
         }
       }
     }
     if (cp_.oob || cl.oob || tb.t_oob) {
       val = __builtin_nanf("");
-      myflags |= MRX_FLAG_TABLE_OOB;
+      if (t < Ta) myflags |= MRX_FLAG_TABLE_OOB;
     }
     const float out = m00 * val;
-    if (out != out) myflags |= MRX_FLAG_NAN;
-
-    if (live) {
+    if (out != out && t < Ta) myflags |= MRX_FLAG_NAN;
+    if (live && t < Ta) {
       const size_t o = (size_t)t * D + d;
       loading[o] = out;
-      if (pwv_out) pwv_out[o] = pwv;
+      if (pwv_out) pwv_out[o] = pwv[tt];
     }
   }
   if (live && myflags) atomicOr(flags, myflags);
 }
 
+// ---- plan construction ------------------------------------------------------
+
+// Fills the axis-derived fields of each layer descriptor and checks whether
+// float32(g0 + i*dg) reproduces the axis arrays exactly.
+__global__ void plan_finish_layers(mrx_layer_dev* layers, int n_layers) {
+  const int l = blockIdx.x;
+  mrx_layer_dev& ly = layers[l];
+  __shared__ int ok_e, ok_c;
+  if (threadIdx.x == 0) {
+    ok_e = ly.de != 0.0;
+    ok_c = ly.dc != 0.0;
+  }
+  __syncthreads();
+  int bad_e = 0, bad_c = 0;
+  for (int i = threadIdx.x; i < ly.n_e; i += blockDim.x)
+    bad_e |= (float)((double)i * ly.de + ly.e0) != ly.axis_e[i];
+  for (int i = threadIdx.x; i < ly.n_c; i += blockDim.x)
+    bad_c |= (float)((double)i * ly.dc + ly.c0) != ly.axis_c[i];
+  if (bad_e) atomicAnd(&ok_e, 0);
+  if (bad_c) atomicAnd(&ok_c, 0);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    ly.uniform_e = ok_e;
+    ly.uniform_c = ok_c;
+    ly.e_first = ly.axis_e[0];
+    ly.e_inv = 1.0f / (ly.axis_e[1] - ly.axis_e[0]);
+    ly.e_last = ly.axis_e[ly.n_e - 1];
+    ly.c_first = ly.axis_c[0];
+    ly.c_inv = 1.0f / (ly.axis_c[1] - ly.axis_c[0]);
+    ly.c_last = ly.axis_c[ly.n_c - 1];
+  }
+}
+
+__global__ void plan_pack_offsets(double2* off, const double* off_e,
+                                  const double* off_c, int l, int n_layers,
+                                  int n_t) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n_t) off[(size_t)t * n_layers + l] = make_double2(off_e[t], off_c[t]);
+}
+
+__global__ void plan_pack_table(float* data, mrx_table_dev* tables, int b,
+                                const float* values, const float* axis_pwv,
+                                const float* axis_el) {
+  mrx_table_dev& tb = tables[b];
+  const int nv = 2 * tb.n_pwv * tb.n_el;
+  for (int i = threadIdx.x; i < nv; i += blockDim.x)
+    data[tb.off_values + i] = values[i];
+  for (int i = threadIdx.x; i < tb.n_pwv; i += blockDim.x)
+    data[tb.off_pwv + i] = axis_pwv[i];
+  for (int i = threadIdx.x; i < tb.n_el; i += blockDim.x)
+    data[tb.off_el + i] = axis_el[i];
+  if (threadIdx.x == 0) {
+    tb.p_first = axis_pwv[0];
+    tb.p_inv = 1.0f / (axis_pwv[1] - axis_pwv[0]);
+    tb.e_first = axis_el[0];
+    tb.e_inv = 1.0f / (axis_el[1] - axis_el[0]);
+  }
+}
+
+void plan_free(mrx_atm_plan* p) {
+  if (!p) return;
+  if (p->d_layers) (void)hipFree(p->d_layers);
+  if (p->d_off) (void)hipFree(p->d_off);
+  if (p->d_tables) (void)hipFree(p->d_tables);
+  if (p->d_table_data) (void)hipFree(p->d_table_data);
+  delete p;
+}
+
 }  // namespace
 
-extern "C" int mrx_atm_sample(mrx_ctx* ctx, const mrx_atm_plan* plan,
-                              const float* d_az, const float* d_el, int Ta,
-                              const float* d_dx, const float* d_dy,
-                              const int32_t* d_band,
-                              const float* d_mueller00, int D, double pwv0,
-                              double* d_pwv, float* d_loading,
-                              uint32_t* d_flags) {
+extern "C" {
+
+int mrx_atm_plan_create(mrx_ctx* ctx, const mrx_layer* layers, int n_layers,
+                        const mrx_band_table* tables, int n_tables, int n_t,
+                        mrx_atm_plan** out) {
+  if (!ctx || !out) return MRX_ERR_INVALID;
+  *out = nullptr;
+  MRX_REQUIRE(ctx, layers != nullptr || n_layers == 0, "layers is null");
+  MRX_REQUIRE(ctx, n_layers >= 0 && n_layers <= 64, "0 <= n_layers <= 64");
+  MRX_REQUIRE(ctx, tables != nullptr && n_tables >= 1 && n_tables <= 1024,
+              "need 1..1024 band tables");
+  MRX_REQUIRE(ctx, n_t >= 1, "n_t must be positive");
+  for (int l = 0; l < n_layers; ++l) {
+    const mrx_layer& y = layers[l];
+    MRX_REQUIRE(ctx, y.d_values && y.d_axis_e && y.d_axis_c && y.d_off_e &&
+                         y.d_off_c,
+                "layer has a null device pointer");
+    MRX_REQUIRE(ctx, y.n_e >= 2 && y.n_c >= 2, "layer grid needs >= 2 nodes");
+  }
+  std::vector<mrx_table_dev> htab((size_t)n_tables);
+  int floats = 0;
+  for (int b = 0; b < n_tables; ++b) {
+    const mrx_band_table& t = tables[b];
+    MRX_REQUIRE(ctx, t.d_values && t.d_axis_pwv && t.d_axis_el,
+                "band table has a null device pointer");
+    MRX_REQUIRE(ctx, t.n_pwv >= 2 && t.n_el >= 2 && t.n_pwv <= 4096 &&
+                         t.n_el <= 4096,
+                "band table needs 2..4096 nodes per axis");
+    mrx_table_dev& h = htab[(size_t)b];
+    h.n_pwv = t.n_pwv;
+    h.n_el = t.n_el;
+    h.w_t = t.w_t;
+    h.t_oob = t.t_oob;
+    h.off_values = floats;
+    floats += 2 * t.n_pwv * t.n_el;
+    h.off_pwv = floats;
+    floats += t.n_pwv;
+    h.off_el = floats;
+    floats += t.n_el;
+    h.p_first = h.p_inv = h.e_first = h.e_inv = 0.f;
+  }
+  std::vector<mrx_layer_dev> hlay((size_t)n_layers);
+  for (int l = 0; l < n_layers; ++l) {
+    const mrx_layer& y = layers[l];
+    mrx_layer_dev& h = hlay[(size_t)l];
+    h.values = y.d_values;
+    h.axis_e = y.d_axis_e;
+    h.axis_c = y.d_axis_c;
+    h.h = y.h;
+    h.r00 = y.r00; h.r10 = y.r10; h.r01 = y.r01; h.r11 = y.r11;
+    h.e0 = y.e0; h.de = y.de; h.c0 = y.c0; h.dc = y.dc;
+    h.pwv_rms = y.pwv_rms;
+    h.n_e = y.n_e;
+    h.n_c = y.n_c;
+    h.uniform_e = h.uniform_c = 0;
+    h.e_first = h.e_inv = h.e_last = h.c_first = h.c_inv = h.c_last = 0.f;
+  }
+
+  mrx_atm_plan* p = new (std::nothrow) mrx_atm_plan();
+  if (!p) return mrx_fail(ctx, MRX_ERR_ALLOC, "out of host memory");
+  p->n_layers = n_layers;
+  p->n_tables = n_tables;
+  p->n_t = n_t;
+  p->table_floats = floats;
+  hipError_t e = hipSuccess;
+  auto ok = [&]() { return e == hipSuccess; };
+  if (n_layers > 0) {
+    e = hipMalloc(&p->d_layers, sizeof(mrx_layer_dev) * n_layers);
+    if (ok()) e = hipMalloc(&p->d_off, sizeof(double2) * (size_t)n_layers * n_t);
+    if (ok())
+      e = hipMemcpyAsync(p->d_layers, hlay.data(),
+                         sizeof(mrx_layer_dev) * n_layers,
+                         hipMemcpyHostToDevice, ctx->stream);
+  }
+  if (ok()) e = hipMalloc(&p->d_tables, sizeof(mrx_table_dev) * n_tables);
+  if (ok()) e = hipMalloc(&p->d_table_data, sizeof(float) * (size_t)floats);
+  if (ok())
+    e = hipMemcpyAsync(p->d_tables, htab.data(),
+                       sizeof(mrx_table_dev) * n_tables, hipMemcpyHostToDevice,
+                       ctx->stream);
+  if (ok() && n_layers > 0) {
+    hipLaunchKernelGGL(plan_finish_layers, dim3(n_layers), dim3(256), 0,
+                       ctx->stream, p->d_layers, n_layers);
+    for (int l = 0; l < n_layers; ++l)
+      hipLaunchKernelGGL(plan_pack_offsets, dim3(mrx_ceil_div(n_t, 256)),
+                         dim3(256), 0, ctx->stream, p->d_off,
+                         layers[l].d_off_e, layers[l].d_off_c, l, n_layers,
+                         n_t);
+  }
+  if (ok())
+    for (int b = 0; b < n_tables; ++b)
+      hipLaunchKernelGGL(plan_pack_table, dim3(1), dim3(256), 0, ctx->stream,
+                         p->d_table_data, p->d_tables, b, tables[b].d_values,
+                         tables[b].d_axis_pwv, tables[b].d_axis_el);
+  if (ok()) e = hipGetLastError();
+  if (ok()) e = hipStreamSynchronize(ctx->stream);  // host vectors go away
+  if (!ok()) {
+    plan_free(p);
+    return mrx_fail(ctx, MRX_ERR_HIP, "plan upload failed: %s",
+                    hipGetErrorString(e));
+  }
+  *out = p;
+  return MRX_OK;
+}
+
+int mrx_atm_plan_destroy(mrx_ctx* ctx, mrx_atm_plan* plan) {
+  if (!ctx || !plan) return MRX_ERR_INVALID;
+  plan_free(plan);
+  return MRX_OK;
+}
+
+int mrx_atm_plan_info(mrx_ctx* ctx, const mrx_atm_plan* plan,
+                      int* uniform_axes, int* tables_in_lds) {
+  if (!ctx || !plan) return MRX_ERR_INVALID;
+  std::vector<mrx_layer_dev> h((size_t)plan->n_layers);
+  if (plan->n_layers > 0) {
+    MRX_HIP(ctx, hipMemcpyAsync(h.data(), plan->d_layers,
+                                sizeof(mrx_layer_dev) * plan->n_layers,
+                                hipMemcpyDeviceToHost, ctx->stream));
+    MRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  int n = 0;
+  for (auto& l : h) n += (l.uniform_e != 0) + (l.uniform_c != 0);
+  if (uniform_axes) *uniform_axes = n;
+  if (tables_in_lds) *tables_in_lds = plan->table_floats <= kMaxLdsTableFloats;
+  return MRX_OK;
+}
+
+int mrx_atm_sample(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d_az,
+                   const float* d_el, int Ta, const float* d_dx,
+                   const float* d_dy, const int32_t* d_band,
+                   const float* d_mueller00, int D, double pwv0, double* d_pwv,
+                   float* d_loading, uint32_t* d_flags) {
   if (!ctx) return MRX_ERR_INVALID;
   MRX_REQUIRE(ctx, D >= 0 && Ta >= 0, "negative size");
   if (D == 0 || Ta == 0) return MRX_OK;  // empty shard: nothing to do
@@ -211,12 +467,22 @@ extern "C" int mrx_atm_sample(mrx_ctx* ctx, const mrx_atm_plan* plan,
   MRX_REQUIRE(ctx, d_az && d_el && d_dx && d_dy && d_band && d_mueller00,
               "null input pointer");
   MRX_REQUIRE(ctx, d_loading && d_flags, "null output pointer");
-  dim3 grid(mrx_ceil_div(D, kBlock), mrx_ceil_div(Ta, kTimesPerBlock));
+  MRX_REQUIRE(ctx, plan->n_layers == 0 || Ta == plan->n_t,
+              "Ta differs from the plan's n_t (length of the wind offsets)");
+  dim3 grid(mrx_ceil_div(D, kBlock), mrx_ceil_div(Ta, kTimes));
   MRX_REQUIRE(ctx, grid.y <= 65535u, "Ta too large for one launch");
-  hipLaunchKernelGGL(atm_sample_kernel, grid, dim3(kBlock), 0, ctx->stream,
-                     plan->d_layers, plan->n_layers, plan->d_tables,
-                     plan->n_tables, d_az, d_el, Ta, d_dx, d_dy, d_band,
-                     d_mueller00, D, pwv0, d_pwv, d_loading, d_flags);
+  const bool lds = plan->table_floats <= kMaxLdsTableFloats;
+  const size_t lds_bytes = lds ? sizeof(float) * (size_t)plan->table_floats : 0;
+#define MRX_LAUNCH_SAMPLE(L)                                                   \
+  hipLaunchKernelGGL(atm_sample_kernel<L>, grid, dim3(kBlock), lds_bytes,      \
+                     ctx->stream, plan->d_layers, plan->n_layers, plan->d_off, \
+                     plan->d_tables, plan->n_tables, plan->d_table_data,       \
+                     plan->table_floats, d_az, d_el, Ta, d_dx, d_dy, d_band,   \
+                     d_mueller00, D, pwv0, d_pwv, d_loading, d_flags)
+  if (lds) MRX_LAUNCH_SAMPLE(true); else MRX_LAUNCH_SAMPLE(false);
+#undef MRX_LAUNCH_SAMPLE
   MRX_CHECK_LAUNCH(ctx);
   return MRX_OK;
 }
+
+}  // extern "C"

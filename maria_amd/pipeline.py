@@ -139,11 +139,21 @@ class DevicePath:
             ly.h = float(layer["h"])
             ly.r00, ly.r10, ly.r01, ly.r11 = R[0, 0], R[1, 0], R[0, 1], R[1, 1]
             ly.pwv_rms = float(np.float32(layer["pwv_rms"]))
+            # uniform-axis hint (include/mrx.h): the f64 grids behind the f32 axes
+            ex, cs = np.asarray(layer["extrusion"], float), np.asarray(layer["cross_section"], float)
+            ly.e0, ly.de = float(ex[0]), float(ex[1] - ex[0])
+            ly.c0, ly.dc = float(cs[0]), float(cs[1] - cs[0])
         if self.plan is not None:
             self.ctx.call("mrx_atm_plan_destroy", self.plan)
         plan = C.c_void_p()
-        self.ctx.call("mrx_atm_plan_create", self._layers, len(layers), self._tables, len(self._tables), C.byref(plan))
+        self.ctx.call("mrx_atm_plan_create", self._layers, len(layers), self._tables, len(self._tables), self.Ta, C.byref(plan))
         self.plan = plan
+
+    def plan_info(self):
+        """(number of layer axes on the recomputed-node fast path, tables staged in LDS)."""
+        ua, tl = C.c_int(), C.c_int()
+        self.ctx.call("mrx_atm_plan_info", self.plan, C.byref(ua), C.byref(tl))
+        return ua.value, bool(tl.value)
 
     def generate_screens(self, smooth=True):
         """Philox + k-space filter + iFFT on the device, then the beam smoothing

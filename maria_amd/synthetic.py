@@ -157,8 +157,9 @@ def make_problem(
         c = -(h * px + tx[None]) * se + (h * py + ty[None]) * ce
         extent = max(np.ptp(e), np.ptp(c))
         res = max(min_res, extent * 1.02 / (side - 8))
-        axis_e = 0.5 * (e.min() + e.max()) + res * (np.arange(side) - 0.5 * (side - 1))
-        axis_c = 0.5 * (c.min() + c.max()) + res * (np.arange(side) - 0.5 * (side - 1))
+        # start + i*step, the form np.arange / np.linspace produce (atmosphere.py:208-245)
+        axis_e = (0.5 * (e.min() + e.max()) - 0.5 * res * (side - 1)) + res * np.arange(side)
+        axis_c = (0.5 * (c.min() + c.max()) - 0.5 * res * (side - 1)) + res * np.arange(side)
         layers.append(
             dict(
                 h=float(h),

@@ -50,6 +50,32 @@ def test_sample_matches_oracle(gpu_ctx, n_det, n_layers, n_bands):
     assert _fluct_err(got, inter["loading_a"]) <= 1e-3
 
 
+def test_nonuniform_axes_take_the_array_path(gpu_ctx):
+    """A layer whose axis is not float32(g0 + i*dg) (here: a stretched grid, and a
+    uniform one given without a usable hint) is searched in the axis array; results
+    still match the oracle, which interpolates on the same arrays."""
+    from oracle import hotpath
+
+    p = small_problem(n_det=40, n_layers=3, n_bands=1)
+    uniform_path = _device_path(p, ctx=gpu_ctx)
+    assert uniform_path.plan_info() == (6, True)
+    # stretch layer 1's cross-section axis smoothly (still ascending, covers the samples)
+    ax = p["layers"][1]["cross_section"]
+    mid = 0.5 * (ax[0] + ax[-1])
+    p["layers"][1]["cross_section"] = mid + (ax - mid) * (1.0 + 0.3 * ((ax - mid) / (ax[-1] - mid)) ** 2)
+    # and perturb one node of layer 2's extrusion axis by less than a step
+    ex = p["layers"][2]["extrusion"].copy()
+    ex[len(ex) // 2] += 0.4 * (ex[1] - ex[0])
+    p["layers"][2]["extrusion"] = ex
+    path = _device_path(p, ctx=gpu_ctx, keep_pwv=True)
+    assert path.plan_info()[0] == 4
+    path.sample()
+    assert path.check_flags() == 0
+    _, inter = hotpath.run_path(p, return_intermediates=True)
+    assert rel_err(path.d_pwv.cpu().numpy().T, inter["pwv"]) <= 2e-6
+    assert rel_err(path.d_loading.cpu().numpy().T, inter["loading_a"]) <= TOL_TOD
+
+
 def test_full_path_matches_oracle(gpu_ctx):
     from oracle import hotpath
 
