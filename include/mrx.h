@@ -64,6 +64,23 @@ int mrx_destroy(mrx_ctx* ctx);
  * stream).  The stream stays owned by the caller. */
 int mrx_set_stream(mrx_ctx* ctx, void* hip_stream);
 int mrx_synchronize(mrx_ctx* ctx);
+/* Options (default 0).
+ *  MRX_OPT_POINTING_CHAIN = 1: mrx_atm_sample follows the reference's float32
+ *    chain literally (atan2 -> phi, asin -> theta, tan/cos/sin of those).  The
+ *    default evaluates the same ground projection directly from the unit
+ *    line-of-sight vector: equal up to the float32 rounding noise of the chain,
+ *    better conditioned near the zenith, and ~3x fewer instructions.
+ *  MRX_OPT_AXIS_ARRAYS = 1: always fetch grid nodes from the axis arrays, even
+ *    for axes whose uniform hint verified (results identical; for A/B timing).
+ *  MRX_OPT_SAMPLE_TIMES = 1|2|4: coarse time steps per thread in mrx_atm_sample
+ *    (tuning; 0 = library default). */
+enum {
+  MRX_OPT_POINTING_CHAIN = 0,
+  MRX_OPT_AXIS_ARRAYS = 1,
+  MRX_OPT_SAMPLE_TIMES = 2,
+  MRX_OPT_COUNT = 4
+};
+int mrx_set_option(mrx_ctx* ctx, int option, int value);
 const char* mrx_last_error(const mrx_ctx* ctx);
 /* Device properties the host side sizes launches with. */
 int mrx_device_info(const mrx_ctx* ctx, int* n_cu, int* lds_bytes_per_cu,

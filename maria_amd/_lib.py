@@ -18,6 +18,7 @@ MRX_OK = 0
 FLAG_SCREEN_OOB = 1
 FLAG_TABLE_OOB = 2
 FLAG_NAN = 4
+OPT_POINTING_CHAIN = 0
 
 _STATUS = {
     0: "MRX_OK",
@@ -84,6 +85,7 @@ SIGNATURES = {
     "mrx_destroy": (_i, [_vp]),
     "mrx_set_stream": (_i, [_vp, _vp]),
     "mrx_synchronize": (_i, [_vp]),
+    "mrx_set_option": (_i, [_vp, _i, _i]),
     "mrx_last_error": (C.c_char_p, [_vp]),
     "mrx_device_info": (_i, [_vp, C.POINTER(_i), C.POINTER(_i), C.POINTER(_sz), C.c_char_p, _i]),
     "mrx_timer_start": (_i, [_vp]),
@@ -175,6 +177,9 @@ class Context:
 
     def synchronize(self):
         self.call("mrx_synchronize")
+
+    def set_option(self, option: int, value: int):
+        self.call("mrx_set_option", int(option), int(value))
 
     def device_info(self) -> dict:
         n_cu, lds, hbm = _i(), _i(), _sz()

@@ -56,6 +56,13 @@ int mrx_set_stream(mrx_ctx* ctx, void* hip_stream) {
   return MRX_OK;
 }
 
+int mrx_set_option(mrx_ctx* ctx, int option, int value) {
+  if (!ctx) return MRX_ERR_INVALID;
+  MRX_REQUIRE(ctx, option >= 0 && option < MRX_OPT_COUNT, "unknown option");
+  ctx->options[option] = value;
+  return MRX_OK;
+}
+
 int mrx_synchronize(mrx_ctx* ctx) {
   if (!ctx) return MRX_ERR_INVALID;
   MRX_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -29,6 +29,7 @@ struct mrx_ctx {
     double* d_taps = nullptr;
   } taps[kTapSlots];
   int taps_next = 0;
+  int options[MRX_OPT_COUNT] = {0};
   double* d_reduce = nullptr;  // small reduction buffer
   size_t reduce_cap = 0;
 };

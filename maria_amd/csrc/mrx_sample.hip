@@ -30,7 +30,7 @@
 namespace {
 
 constexpr int kBlock = 256;
-constexpr int kTimes = 4;                  // coarse time steps per thread
+constexpr int kTimes = 2;                  // coarse time steps per thread (default)
 constexpr int kMaxLdsTableFloats = 12288;  // 48 KiB of band tables in LDS
 
 // float32(pi/2): jax folds the weak-typed python float pi/2 to float32
@@ -108,17 +108,61 @@ __device__ __forceinline__ Cell find_cell(NodeFn node, int n, float x,
   return c;
 }
 
-__device__ __forceinline__ Cell layer_cell(const float* __restrict__ axis,
-                                           int uniform, double g0, double dg,
-                                           int n, float x, float first,
-                                           float inv, float last) {
-  if (uniform)  // wave-uniform branch
-    return find_cell([=](int i) { return (float)((double)i * dg + g0); }, n, x,
-                     first, inv, last);
-  return find_cell([=](int i) { return axis[i]; }, n, x, first, inv, last);
+typedef __attribute__((address_space(1))) const float gfloat;  // global memory
+
+// One-probe variant: takes the arithmetic guess, fetches the two nodes that
+// bracket it (PairFn: recomputed, or loaded from the axis array) and reports in
+// `miss` whether the guess was not the searchsorted cell -- x within float32
+// rounding of a node (~1e-4 of the samples), or a non-uniform axis; the caller
+// then redoes that sample through find_cell.  Straight-line code, so the
+// compiler interleaves the kTimes samples of a thread.  kExactDiv selects the
+// IEEE division the reference performs; otherwise x * v_rcp_f32 (1 ulp).
+template <bool kExactDiv, typename PairFn>
+__device__ __forceinline__ Cell probe_cell(PairFn pair, int n, float x,
+                                           float first, float inv, float last,
+                                           bool& miss) {
+  const float f = fminf(fmaxf((x - first) * inv, -1.0f), 2.0e9f);
+  const int i = min(max((int)f, 0), n - 2);
+  float lo, hi;
+  pair(i, lo, hi);
+  miss |= (i < n - 2 && hi < x) || (i > 0 && lo >= x);
+  Cell c;
+  c.i = i;
+  c.w = kExactDiv ? (x - lo) / (hi - lo)
+                  : (x - lo) * __builtin_amdgcn_rcpf(hi - lo);
+  c.oob = !(x >= first && x <= last);
+  return c;
 }
 
-template <bool kLdsTables>
+// The 2x2 gather and blend of jax _evaluate_linear: corners in
+// itertools.product order, weight built as (1*we)*wc, summed into 0.0 in
+// float32; NaN outside the grid.
+__device__ __forceinline__ float bilinear(gfloat* values, int nc,
+                                          const Cell& ce, const Cell& cc) {
+  gfloat* v = values + (size_t)ce.i * nc + cc.i;
+  const float v00 = v[0], v01 = v[1];
+  const float v10 = v[nc], v11 = v[nc + 1];
+  const float we0 = 1.0f - ce.w, we1 = ce.w;
+  const float wc0 = 1.0f - cc.w, wc1 = cc.w;
+  float y = 0.0f;
+  y = y + v00 * (we0 * wc0);
+  y = y + v01 * (we0 * wc1);
+  y = y + v10 * (we1 * wc0);
+  y = y + v11 * (we1 * wc1);
+  return (ce.oob || cc.oob) ? __builtin_nanf("") : y;
+}
+
+// kChain = true follows the reference's float32 chain literally (atan2 -> phi,
+// asin -> theta, then tan/cos/sin of those: coords/transforms.py:20-28 and
+// coordinates.py:339-347).  kChain = false (default) uses the identity behind
+// that chain: (Y, re, im) is the unit line-of-sight vector in the local frame
+// before the azimuth turn, so the unit-height ground projection is
+//     px = (re cos az - Y sin az)/im,   py = (Y cos az + re sin az)/im
+// with no inverse trigonometry and no cancellation near the zenith; only
+// theta = asin(im) is still needed (elevation axis of the emission table).  The
+// two differ by the float32 rounding noise of the chain itself (<= ~1e-6
+// relative in px, py near the zenith), far inside the 1e-5 parity tolerance.
+template <bool kLdsTables, bool kChain, int kT>
 __global__ __launch_bounds__(kBlock) void atm_sample_kernel(
     const mrx_layer_dev* __restrict__ layers, int n_layers,
     const double2* __restrict__ off, const mrx_table_dev* __restrict__ tables,
@@ -127,13 +171,21 @@ __global__ __launch_bounds__(kBlock) void atm_sample_kernel(
     const float* __restrict__ dxs, const float* __restrict__ dys,
     const int32_t* __restrict__ band, const float* __restrict__ mueller00,
     int D, double pwv0, double* __restrict__ pwv_out,
-    float* __restrict__ loading, uint32_t* __restrict__ flags) {
+    float* __restrict__ loading, uint32_t* __restrict__ flags,
+    int force_arrays) {
   extern __shared__ float lds_tables[];
-  if (kLdsTables) {
+  __shared__ float4 bore[kT];  // per time step: cos/sin of (el - pi/2), az
+  const int t0 = blockIdx.y * kT;
+  if (threadIdx.x < kT) {
+    const int t = min(t0 + (int)threadIdx.x, Ta - 1);
+    const float a = el[t] - kHalfPiF;  // transforms.py:22
+    const float z = az[t];
+    bore[threadIdx.x] = make_float4(cosf(a), sinf(a), cosf(z), sinf(z));
+  }
+  if (kLdsTables)
     for (int i = threadIdx.x; i < table_floats; i += kBlock)
       lds_tables[i] = table_data[i];
-    __syncthreads();
-  }
+  __syncthreads();
   const float* __restrict__ tdata = kLdsTables ? lds_tables : table_data;
 
   const int d = blockIdx.x * kBlock + threadIdx.x;
@@ -152,25 +204,27 @@ __global__ __launch_bounds__(kBlock) void atm_sample_kernel(
   const float m00 = mueller00[dd];
   uint32_t myflags = (b < 0 || b >= n_tables) ? MRX_FLAG_NAN : 0u;
 
-  const int t0 = blockIdx.y * kTimes;
-
-  // ---- pointing and unit-height ground projection for kTimes steps --------
-  float theta[kTimes];
-  double px[kTimes], py[kTimes], pwv[kTimes];
+  // ---- pointing and unit-height ground projection for kT steps --------
+  float theta[kT];
+  double px[kT], py[kT], pwv[kT];
 #pragma unroll
-  for (int tt = 0; tt < kTimes; ++tt) {
-    const int t = min(t0 + tt, Ta - 1);
+  for (int tt = 0; tt < kT; ++tt) {
     // transforms.py:20-28
-    const float a = el[t] - kHalfPiF;
-    const float ca = cosf(a), sa = sinf(a);
-    const float re = A * ca - cr * sa;
-    const float im = A * sa + cr * ca;
-    const float phi = atan2f(Y, re) + az[t];
+    const float4 bt = bore[tt];
+    const float re = A * bt.x - cr * bt.y;
+    const float im = A * bt.y + cr * bt.x;
     theta[tt] = asinf(im);
-    // coordinates.py:339-347: numpy float32 tan/cos/sin and division, then f64
-    const float tth = tanf(theta[tt]);
-    px[tt] = (double)(cosf(phi) / tth);
-    py[tt] = (double)(sinf(phi) / tth);
+    if (kChain) {
+      const int t = min(t0 + tt, Ta - 1);
+      const float phi = atan2f(Y, re) + az[t];
+      // coordinates.py:339-347: numpy float32 tan/cos/sin and division, then f64
+      const float tth = tanf(theta[tt]);
+      px[tt] = (double)(cosf(phi) / tth);
+      py[tt] = (double)(sinf(phi) / tth);
+    } else {
+      px[tt] = (double)((re * bt.z - Y * bt.w) / im);
+      py[tt] = (double)((Y * bt.z + re * bt.w) / im);
+    }
     pwv[tt] = pwv0;
   }
 
@@ -178,36 +232,71 @@ __global__ __launch_bounds__(kBlock) void atm_sample_kernel(
   for (int l = 0; l < n_layers; ++l) {
     const mrx_layer_dev& ly = layers[l];
     const int nc = ly.n_c;
+    float xe[kT], xc[kT], y[kT];
 #pragma unroll
-    for (int tt = 0; tt < kTimes; ++tt) {
+    for (int tt = 0; tt < kT; ++tt) {
       const int t = min(t0 + tt, Ta - 1);
       const double2 o = off[(size_t)t * n_layers + l];
-      const double e64 = fma(ly.h, fma(px[tt], ly.r00, py[tt] * ly.r10), o.x);
-      const double c64 = fma(ly.h, fma(px[tt], ly.r01, py[tt] * ly.r11), o.y);
-      const float xe = (float)e64, xc = (float)c64;
-      const Cell ce = layer_cell(ly.axis_e, ly.uniform_e, ly.e0, ly.de, ly.n_e,
-                                 xe, ly.e_first, ly.e_inv, ly.e_last);
-      const Cell cc = layer_cell(ly.axis_c, ly.uniform_c, ly.c0, ly.dc, nc, xc,
-                                 ly.c_first, ly.c_inv, ly.c_last);
-      const float* v = ly.values + (size_t)ce.i * nc + cc.i;
-      const float v00 = v[0], v01 = v[1];
-      const float v10 = v[nc], v11 = v[nc + 1];
-      // jax _evaluate_linear: corners in itertools.product order, weight built
-      // as (1*we)*wc, summed into 0.0 in float32.
-      const float we0 = 1.0f - ce.w, we1 = ce.w;
-      const float wc0 = 1.0f - cc.w, wc1 = cc.w;
-      float y = 0.0f;
-      y = y + v00 * (we0 * wc0);
-      y = y + v01 * (we0 * wc1);
-      y = y + v10 * (we1 * wc0);
-      y = y + v11 * (we1 * wc1);
-      if (ce.oob || cc.oob) {
-        y = __builtin_nanf("");
-        myflags |= MRX_FLAG_SCREEN_OOB;
+      xe[tt] = (float)fma(ly.h, fma(px[tt], ly.r00, py[tt] * ly.r10), o.x);
+      xc[tt] = (float)fma(ly.h, fma(px[tt], ly.r01, py[tt] * ly.r11), o.y);
+    }
+    gfloat* values = (gfloat*)ly.values;
+    gfloat* axis_e = (gfloat*)ly.axis_e;
+    gfloat* axis_c = (gfloat*)ly.axis_c;
+    bool miss[kT];
+    if (ly.uniform_e && ly.uniform_c && !force_arrays) {  // wave-uniform
+      // nodes recomputed as float32(g0 + i*dg): verified at plan creation
+      const double e0 = ly.e0, de = ly.de, c0 = ly.c0, dc = ly.dc;
+#pragma unroll
+      for (int tt = 0; tt < kT; ++tt) {
+        miss[tt] = false;
+        const Cell ce = probe_cell<kChain>(
+            [=](int i, float& lo, float& hi) {
+              const double fi = (double)i;
+              lo = (float)(fi * de + e0);
+              hi = (float)((fi + 1.0) * de + e0);
+            },
+            ly.n_e, xe[tt], ly.e_first, ly.e_inv, ly.e_last, miss[tt]);
+        const Cell cc = probe_cell<kChain>(
+            [=](int i, float& lo, float& hi) {
+              const double fi = (double)i;
+              lo = (float)(fi * dc + c0);
+              hi = (float)((fi + 1.0) * dc + c0);
+            },
+            nc, xc[tt], ly.c_first, ly.c_inv, ly.c_last, miss[tt]);
+        y[tt] = bilinear(values, nc, ce, cc);
       }
+    } else {
+      // nodes fetched from the caller's axis arrays (L1-resident)
+#pragma unroll
+      for (int tt = 0; tt < kT; ++tt) {
+        miss[tt] = false;
+        const Cell ce = probe_cell<kChain>(
+            [=](int i, float& lo, float& hi) { lo = axis_e[i]; hi = axis_e[i + 1]; },
+            ly.n_e, xe[tt], ly.e_first, ly.e_inv, ly.e_last, miss[tt]);
+        const Cell cc = probe_cell<kChain>(
+            [=](int i, float& lo, float& hi) { lo = axis_c[i]; hi = axis_c[i + 1]; },
+            nc, xc[tt], ly.c_first, ly.c_inv, ly.c_last, miss[tt]);
+        y[tt] = bilinear(values, nc, ce, cc);
+      }
+    }
+#pragma unroll
+    for (int tt = 0; tt < kT; ++tt)
+      if (__builtin_amdgcn_ballot_w64(miss[tt]) != 0) {
+        // some lane's guess was not the cell: full search on the axis arrays
+        const Cell ce = find_cell([=](int i) { return axis_e[i]; }, ly.n_e,
+                                  xe[tt], ly.e_first, ly.e_inv, ly.e_last);
+        const Cell cc = find_cell([=](int i) { return axis_c[i]; }, nc, xc[tt],
+                                  ly.c_first, ly.c_inv, ly.c_last);
+        const float ys = bilinear(values, nc, ce, cc);
+        if (miss[tt]) y[tt] = ys;
+      }
+#pragma unroll
+    for (int tt = 0; tt < kT; ++tt) {
+      if (y[tt] != y[tt]) myflags |= MRX_FLAG_SCREEN_OOB;
       // layer.pwv_rms * y is a float32 product (jax array), accumulated into
       // the float64 numpy array (atmosphere.py:373).
-      pwv[tt] += (double)(ly.pwv_rms * y);
+      pwv[tt] += (double)(ly.pwv_rms * y[tt]);
     }
   }
 
@@ -219,7 +308,7 @@ __global__ __launch_bounds__(kBlock) void atm_sample_kernel(
   const int slab = tb.n_pwv * tb.n_el;
   const float p_last = ax_p[tb.n_pwv - 1], e_last = ax_e[tb.n_el - 1];
 #pragma unroll
-  for (int tt = 0; tt < kTimes; ++tt) {
+  for (int tt = 0; tt < kT; ++tt) {
     const int t = t0 + tt;
     const float xp = (float)pwv[tt];
     const float xel = fminf(theta[tt], kHalfPiF);  // .clip(max=pi/2), sim/atmosphere.py:60
@@ -281,12 +370,19 @@ __global__ void plan_finish_layers(mrx_layer_dev* layers, int n_layers) {
   if (threadIdx.x == 0) {
     ly.uniform_e = ok_e;
     ly.uniform_c = ok_c;
+    // inverse step for the cell guess: from the float64 hint when it verified
+    // (the difference of two float32 nodes carries a ~1e-4 relative error, which
+    // would put the guess in the wrong cell far from the origin), else the mean
     ly.e_first = ly.axis_e[0];
-    ly.e_inv = 1.0f / (ly.axis_e[1] - ly.axis_e[0]);
     ly.e_last = ly.axis_e[ly.n_e - 1];
+    ly.e_inv = ok_e ? (float)(1.0 / ly.de)
+                    : (float)((double)(ly.n_e - 1) /
+                              ((double)ly.e_last - (double)ly.e_first));
     ly.c_first = ly.axis_c[0];
-    ly.c_inv = 1.0f / (ly.axis_c[1] - ly.axis_c[0]);
     ly.c_last = ly.axis_c[ly.n_c - 1];
+    ly.c_inv = ok_c ? (float)(1.0 / ly.dc)
+                    : (float)((double)(ly.n_c - 1) /
+                              ((double)ly.c_last - (double)ly.c_first));
   }
 }
 
@@ -469,17 +565,32 @@ int mrx_atm_sample(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d_az,
   MRX_REQUIRE(ctx, d_loading && d_flags, "null output pointer");
   MRX_REQUIRE(ctx, plan->n_layers == 0 || Ta == plan->n_t,
               "Ta differs from the plan's n_t (length of the wind offsets)");
-  dim3 grid(mrx_ceil_div(D, kBlock), mrx_ceil_div(Ta, kTimes));
+  int kt = ctx->options[MRX_OPT_SAMPLE_TIMES];
+  if (kt != 1 && kt != 2 && kt != 4) kt = kTimes;
+  dim3 grid(mrx_ceil_div(D, kBlock), mrx_ceil_div(Ta, kt));
   MRX_REQUIRE(ctx, grid.y <= 65535u, "Ta too large for one launch");
   const bool lds = plan->table_floats <= kMaxLdsTableFloats;
   const size_t lds_bytes = lds ? sizeof(float) * (size_t)plan->table_floats : 0;
-#define MRX_LAUNCH_SAMPLE(L)                                                   \
-  hipLaunchKernelGGL(atm_sample_kernel<L>, grid, dim3(kBlock), lds_bytes,      \
-                     ctx->stream, plan->d_layers, plan->n_layers, plan->d_off, \
-                     plan->d_tables, plan->n_tables, plan->d_table_data,       \
-                     plan->table_floats, d_az, d_el, Ta, d_dx, d_dy, d_band,   \
-                     d_mueller00, D, pwv0, d_pwv, d_loading, d_flags)
-  if (lds) MRX_LAUNCH_SAMPLE(true); else MRX_LAUNCH_SAMPLE(false);
+  const bool chain = ctx->options[MRX_OPT_POINTING_CHAIN] != 0;
+#define MRX_LAUNCH_SAMPLE(L, C, T)                                             \
+  hipLaunchKernelGGL((atm_sample_kernel<L, C, T>), grid, dim3(kBlock),         \
+                     lds_bytes, ctx->stream, plan->d_layers, plan->n_layers,   \
+                     plan->d_off, plan->d_tables, plan->n_tables,              \
+                     plan->d_table_data, plan->table_floats, d_az, d_el, Ta,   \
+                     d_dx, d_dy, d_band, d_mueller00, D, pwv0, d_pwv,          \
+                     d_loading, d_flags, ctx->options[MRX_OPT_AXIS_ARRAYS])
+#define MRX_LAUNCH_SAMPLE_T(L, C)                                              \
+  do {                                                                         \
+    if (kt == 1) MRX_LAUNCH_SAMPLE(L, C, 1);                                   \
+    else if (kt == 2) MRX_LAUNCH_SAMPLE(L, C, 2);                              \
+    else MRX_LAUNCH_SAMPLE(L, C, 4);                                           \
+  } while (0)
+  if (lds) {
+    if (chain) MRX_LAUNCH_SAMPLE_T(true, true); else MRX_LAUNCH_SAMPLE_T(true, false);
+  } else {
+    if (chain) MRX_LAUNCH_SAMPLE_T(false, true); else MRX_LAUNCH_SAMPLE_T(false, false);
+  }
+#undef MRX_LAUNCH_SAMPLE_T
 #undef MRX_LAUNCH_SAMPLE
   MRX_CHECK_LAUNCH(ctx);
   return MRX_OK;

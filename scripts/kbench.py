@@ -53,6 +53,20 @@ def main():
         total += med
         print(f"{name:22s} median {med:8.3f} ms  min {mn:8.3f} ms  alg {nbytes/1e9:7.3f} GB -> {nbytes/med/1e6:8.1f} GB/s")
     print(f"sum of medians {total:.3f} ms -> {D*T/total/1e6:.1f} G det-samples/s; point-layers/s in sample: {D*Ta*L/1e6:.1f} M")
+    print("plan_info (uniform axes, tables in LDS):", path.plan_info())
+    for chain in (0, 1):
+        for arrays in (0, 1):
+            path.ctx.set_option(0, chain)
+            path.ctx.set_option(1, arrays)
+            med, mn = timeit(path.sample, reps)
+            print(f"sample chain={chain} axis_arrays={arrays}: median {med:.3f} ms min {mn:.3f} ms")
+    path.ctx.set_option(0, 0)
+    path.ctx.set_option(1, 0)
+    for kt in (1, 2, 4):
+        path.ctx.set_option(2, kt)
+        med, mn = timeit(path.sample, reps)
+        print(f"sample times_per_thread={kt}: median {med:.3f} ms min {mn:.3f} ms")
+    path.ctx.set_option(2, 0)
     assert path.check_flags() == 0
 
 

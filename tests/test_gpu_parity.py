@@ -33,13 +33,21 @@ def _fluct_err(a, b):
     return np.abs(fa - fb).max() / max(np.abs(fb).max(), 1e-300)
 
 
+@pytest.mark.parametrize("chain", [0, 1], ids=["direct", "chain"])
 @pytest.mark.parametrize("n_det,n_layers,n_bands", [(67, 3, 2), (300, 1, 1), (16, 8, 3)])
-def test_sample_matches_oracle(gpu_ctx, n_det, n_layers, n_bands):
+def test_sample_matches_oracle(gpu_ctx, n_det, n_layers, n_bands, chain):
+    """Both pointing modes of mrx_atm_sample (MRX_OPT_POINTING_CHAIN) against the
+    oracle, which restates the reference's float32 chain."""
+    from maria_amd import _lib
     from oracle import hotpath
 
     p = small_problem(n_det=n_det, n_layers=n_layers, n_bands=n_bands)
     path = _device_path(p, ctx=gpu_ctx, keep_pwv=True)
-    path.sample()
+    gpu_ctx.set_option(_lib.OPT_POINTING_CHAIN, chain)
+    try:
+        path.sample()
+    finally:
+        gpu_ctx.set_option(_lib.OPT_POINTING_CHAIN, 0)
     assert path.check_flags() == 0
     got_pwv = path.d_pwv.cpu().numpy().T
     got = path.d_loading.cpu().numpy().T
