@@ -51,3 +51,15 @@ def compute_angular_fwhm(fwhm_0, z=np.inf, n=1.0, nu=None, l=None):  # noqa: E74
 def compute_physical_fwhm(fwhm_0, z=np.inf, n=1, nu=None, l=None):  # noqa: E741
     """beam/__init__.py:28-29."""
     return z * compute_angular_fwhm(fwhm_0=fwhm_0, z=z, n=n, nu=nu, l=l)
+
+H_PLANCK = 6.62607015e-34  # maria/constants.py
+
+
+def rayleigh_jeans_spectrum(T_RJ, nu):
+    """functions/radiometry.py:6-7."""
+    return 2 * K_B * nu**2 * T_RJ / C_LIGHT**2
+
+
+def planck_spectrum(T_b, nu):
+    """functions/radiometry.py:14-15."""
+    return 2 * H_PLANCK * nu**3 / (C_LIGHT**2 * np.expm1(H_PLANCK * nu / (K_B * T_b)))

@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/leaves.json from the reference's own importable modules.
+
+Run in the build container only (``/root/reference`` is read-only and does not
+exist on the GPU box):
+
+    python oracle/gen_golden.py
+
+``import maria`` fails here with an ordinary ModuleNotFoundError (jax, dask,
+astropy, h5py ... are not installed).  Registering bare parent
+packages lets the leaf modules that only need numpy/scipy load unmodified:
+``maria.constants``, ``maria.functions``, ``maria.beam``, ``maria.utils.linalg``,
+``maria.utils.rotations``.  No third-party library is stubbed.  The outputs below
+are data (inputs and the reference's answers); no reference source is copied.
+"""
+
+from __future__ import annotations
+
+import json
+import os
+import sys
+import types
+
+import numpy as np
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "leaves.json")
+
+
+def _load_reference_leaves():
+    for pk in ("maria", "maria.utils"):
+        m = types.ModuleType(pk)
+        m.__path__ = [os.path.join(REF, *pk.split("."))]
+        sys.modules[pk] = m
+    import maria.beam as beam
+    import maria.constants as constants
+    import maria.functions as functions
+    import maria.utils.linalg as linalg
+    import maria.utils.rotations as rotations
+
+    return constants, functions, beam, linalg, rotations
+
+
+def main():
+    constants, functions, beam, linalg, rotations = _load_reference_leaves()
+    g = {"_generator": "oracle/gen_golden.py", "_reference": "thomaswmorris/maria @ /root/reference"}
+
+    g["constants"] = {"k_B": constants.k_B, "c": constants.c}
+
+    r = np.array([0, 0.5, 2, 17, 250, 1000, 3333, 2e4, 2e6], float)
+    g["matern"] = {"r": r.tolist(), "cases": []}
+    for nu, r0 in [(5 / 6, 1e3), (1 / 3, 1e3), (5 / 6, 2345.0), (1 / 3, 17.0)]:
+        g["matern"]["cases"].append(
+            {
+                "nu": nu,
+                "r0": r0,
+                "approximate_normalized_matern": functions.approximate_normalized_matern(r, nu=nu, r0=r0).tolist(),
+                "normalized_matern": functions.normalized_matern(r / r0, nu).tolist(),
+            }
+        )
+    rr = np.geomspace(1e-3, 5e4, 64)
+    g["matern_dense"] = {
+        "r": rr.tolist(),
+        "nu": 5 / 6,
+        "r0": 1e3,
+        "value": functions.approximate_normalized_matern(rr, nu=5 / 6, r0=1e3).tolist(),
+    }
+
+    z = np.array([250.0, 750.0, 2500.0, 1e4])
+    g["beam"] = {
+        "z": z.tolist(),
+        "physical_fwhm_100m_90GHz": beam.compute_physical_fwhm(100, z=z, nu=90e9).tolist(),
+        "physical_fwhm_6m_150GHz": beam.compute_physical_fwhm(6, z=z, nu=150e9).tolist(),
+        "angular_fwhm_50m_inf_150GHz": float(beam.compute_angular_fwhm(50, z=np.inf, nu=150e9)),
+        "angular_fwhm_12m_z_230GHz": beam.compute_angular_fwhm(12, z=z, nu=230e9).tolist(),
+    }
+    g["radiometry"] = {
+        "rayleigh_jeans_spectrum_1K_150GHz": float(functions.rayleigh_jeans_spectrum(1, 150e9)),
+        "planck_spectrum_2.72548K_150GHz": float(functions.planck_spectrum(2.72548, 150e9)),
+    }
+
+    # fast_psd_inverse on a seeded SPD matrix (utils/linalg.py:95-102)
+    rng = np.random.default_rng(11)
+    a = rng.standard_normal((7, 7))
+    spd = a @ a.T + 7 * np.eye(7)
+    g["fast_psd_inverse"] = {"M": spd.tolist(), "inv": linalg.fast_psd_inverse(spd).tolist()}
+
+    # rotations (utils/rotations.py:25-77)
+    g["orthogonal_transform"] = {
+        "signature": [True, True, False],
+        "entries": [0.37],
+        "R": rotations.get_orthogonal_transform((True, True, False), [0.37]).tolist(),
+        "signature3": [True, True, True],
+        "entries3": [0.1, -0.2, 0.3],
+        "R3": rotations.get_orthogonal_transform((True, True, True), [0.1, -0.2, 0.3]).tolist(),
+    }
+    # an elongated, rotated cloud: drifting footprint like atmosphere.py:161-186
+    pts_rng = np.random.default_rng(5)
+    n = 400
+    along = np.linspace(0, 3000, n) + 20 * pts_rng.standard_normal(n)
+    across = 40 * pts_rng.standard_normal(n)
+    ang = np.radians(33.0)
+    pts = np.c_[along * np.cos(ang) - across * np.sin(ang), along * np.sin(ang) + across * np.cos(ang), 1500 + 1e-6 * pts_rng.standard_normal(n)]
+    np.random.seed(1234)
+    R = rotations.compute_aligning_transform(pts, signature=(True, True, False))
+    g["aligning_transform"] = {"points": pts.tolist(), "numpy_seed": 1234, "R": R.tolist()}
+
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    with open(OUT, "w") as f:
+        json.dump(g, f, indent=1)
+    print("wrote", OUT, os.path.getsize(OUT), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,173 @@
+"""CPU tier: the oracle's leaves against golden vectors made by the reference's own
+modules (oracle/gen_golden.py -> tests/golden/leaves.json), and the oracle's
+hot-path restatement against independent scipy formulations."""
+
+import json
+import os
+
+import numpy as np
+import pytest
+import scipy.interpolate
+import scipy.ndimage
+
+from oracle import ar_process, functions, geometry, hotpath
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "leaves.json")))
+
+
+def test_constants():
+    assert functions.K_B == GOLD["constants"]["k_B"]
+    assert functions.C_LIGHT == GOLD["constants"]["c"]
+
+
+@pytest.mark.parametrize("case", GOLD["matern"]["cases"], ids=lambda c: f"nu{c['nu']:.3f}_r0{c['r0']:g}")
+def test_matern_matches_reference(case):
+    r = np.array(GOLD["matern"]["r"])
+    got = functions.approximate_normalized_matern(r, nu=case["nu"], r0=case["r0"])
+    np.testing.assert_allclose(got, case["approximate_normalized_matern"], rtol=1e-13, atol=1e-300)
+    np.testing.assert_allclose(functions.normalized_matern(r / case["r0"], case["nu"]), case["normalized_matern"], rtol=1e-13)
+
+
+def test_matern_dense_and_survey_known_answers():
+    d = GOLD["matern_dense"]
+    got = functions.approximate_normalized_matern(np.array(d["r"]), nu=d["nu"], r0=d["r0"])
+    np.testing.assert_allclose(got, d["value"], rtol=1e-13)
+    # values recorded independently in SURVEY.md 8(c)
+    r = np.array([0, 0.5, 2, 17, 250, 1000, 3333, 2e4, 2e6])
+    survey = [9.999999997172e-01, 9.999916387679e-01, 9.999194244035e-01, 9.975157453459e-01, 8.709138267833e-01,
+              4.252151354674e-01, 2.873067497953e-02, 2.271356537443e-11, 0]
+    np.testing.assert_allclose(functions.approximate_normalized_matern(r, nu=5 / 6, r0=1e3), survey, rtol=2e-12)
+
+
+def test_beam_matches_reference():
+    b = GOLD["beam"]
+    z = np.array(b["z"])
+    np.testing.assert_allclose(functions.compute_physical_fwhm(100, z=z, nu=90e9), b["physical_fwhm_100m_90GHz"], rtol=1e-14)
+    np.testing.assert_allclose(functions.compute_physical_fwhm(6, z=z, nu=150e9), b["physical_fwhm_6m_150GHz"], rtol=1e-14)
+    assert functions.compute_angular_fwhm(50, z=np.inf, nu=150e9) == pytest.approx(b["angular_fwhm_50m_inf_150GHz"], rel=1e-14)
+    np.testing.assert_allclose(functions.compute_angular_fwhm(12, z=z, nu=230e9), b["angular_fwhm_12m_z_230GHz"], rtol=1e-14)
+    with pytest.raises(ValueError):
+        functions.compute_angular_fwhm(10.0)
+
+
+def test_radiometry_matches_reference():
+    g = GOLD["radiometry"]
+    assert functions.rayleigh_jeans_spectrum(1, 150e9) == pytest.approx(g["rayleigh_jeans_spectrum_1K_150GHz"], rel=1e-15)
+    assert functions.planck_spectrum(2.72548, 150e9) == pytest.approx(g["planck_spectrum_2.72548K_150GHz"], rel=1e-14)
+
+
+def test_fast_psd_inverse_matches_reference():
+    g = GOLD["fast_psd_inverse"]
+    M = np.array(g["M"])
+    inv = geometry.fast_psd_inverse(M)
+    np.testing.assert_allclose(inv, g["inv"], rtol=1e-12)
+    np.testing.assert_allclose(inv @ M, np.eye(len(M)), atol=1e-12)
+
+
+def test_rotations_match_reference():
+    g = GOLD["orthogonal_transform"]
+    np.testing.assert_allclose(geometry.get_orthogonal_transform(g["signature"], g["entries"]), g["R"], atol=1e-15)
+    np.testing.assert_allclose(geometry.get_orthogonal_transform(g["signature3"], g["entries3"]), g["R3"], atol=1e-15)
+    a = GOLD["aligning_transform"]
+    np.random.seed(a["numpy_seed"])
+    R = geometry.compute_aligning_transform(np.array(a["points"]), signature=(True, True, False))
+    np.testing.assert_allclose(R, a["R"], atol=1e-9)
+    # it aligns the cloud with the first axis: the cross extent is the cloud's width
+    tp = np.array(a["points"]) @ R
+    assert np.ptp(tp[:, 1]) < 0.15 * np.ptp(tp[:, 0])
+
+
+# ---- restatement checks that need no reference run ---------------------------------
+
+
+def test_rgi_linear_agrees_with_scipy_in_the_interior_and_nans_outside():
+    rng = np.random.default_rng(0)
+    ax = (np.linspace(-3, 5, 17), np.linspace(10, 20, 9))
+    vals = rng.standard_normal((17, 9))
+    x = rng.uniform(-3, 5, 500)
+    y = rng.uniform(10, 20, 500)
+    got = hotpath.rgi_linear_f32(ax, vals, (x, y))
+    ref = scipy.interpolate.RegularGridInterpolator(ax, vals, method="linear")(np.c_[x, y])
+    assert got.dtype == np.float32
+    np.testing.assert_allclose(got, ref, atol=2e-6)
+    out = hotpath.rgi_linear_f32(ax, vals, (np.array([-3.1, 5.1, 0.0, 0.0]), np.array([12.0, 12.0, 9.9, 20.1])))
+    assert np.isnan(out).all()
+    # a point exactly on a node belongs to the cell on its left (searchsorted side="left")
+    on = hotpath.rgi_linear_f32(ax, vals, (np.array([ax[0][4]]), np.array([ax[1][3]])))
+    assert on[0] == pytest.approx(np.float32(vals[4, 3]), rel=1e-6)
+    edge = hotpath.rgi_linear_f32(ax, vals, (np.array([-3.0, 5.0]), np.array([10.0, 20.0])))
+    np.testing.assert_allclose(edge, [vals[0, 0], vals[-1, -1]], rtol=1e-6)
+
+
+def test_pointing_is_float32_and_round_trips():
+    """coords/transforms.py: offsets -> (phi, theta); at zero offset it is the boresight."""
+    az = np.array([0.3, 1.0, 2.5])
+    el = np.array([0.5, 1.0, 1.4])
+    phi, theta = hotpath.broadcast(np.zeros((1, 2)), az, el)
+    assert phi.dtype == np.float32 and theta.dtype == np.float32
+    np.testing.assert_allclose(phi[0], az, atol=3e-7)
+    np.testing.assert_allclose(theta[0], el, atol=3e-7)
+    # a detector offset upwards (dy > 0) points higher
+    _, th2 = hotpath.broadcast(np.array([[0.0, 0.01]]), az, el)
+    assert (th2[0] > theta[0]).all()
+
+
+def test_upsample_is_scipy_not_a_knot():
+    rng = np.random.default_rng(2)
+    ta = 1.7e9 + 0.1 * np.arange(40)
+    y = rng.standard_normal((3, 40)).astype(np.float32)
+    t = np.linspace(ta[0], ta[-1] + 0.09, 333)
+    ref = scipy.interpolate.make_interp_spline(ta, y, k=3, axis=-1)(t)  # default bc: not-a-knot
+    np.testing.assert_allclose(hotpath.upsample_cubic(ta, y, t, dtype=np.float64), ref, rtol=0, atol=1e-9)
+
+
+def test_ar_process_reproduces_its_covariance():
+    """atmosphere/process.py: the generator's stationary covariance is the Matern the
+    callback describes (rows: lag along the extrusion axis)."""
+    np.random.seed(3)
+    cross = np.c_[np.linspace(0, 90, 10), 1000.0 * np.ones(10)]
+    extr = np.arange(0, 40000, 10.0)
+    proc = ar_process.AutoregressiveProcess(cross, extr, callback_kwargs={"nu": 5 / 6, "r0": 200.0}, jitter=1e-8)
+    proc.compute_covariance_matrices()
+    assert proc.A.shape == (10, proc.n_sample) and (proc.A.sum(axis=-1) <= 1.0).all()
+    v = proc.run()
+    assert v.shape == (4000, 10)
+    assert abs(v.var() - 1) < 0.3
+    lags = np.array([1, 3, 10, 30])
+    emp = np.array([(v[:-k] * v[k:]).mean() for k in lags]) / v.var()
+    target = functions.approximate_normalized_matern(lags * 10.0, nu=5 / 6, r0=200.0)
+    assert np.abs(emp - target).max() < 0.15
+
+
+def test_numpy_screen_statistics():
+    """The spectral construction the GPU generator uses, in numpy: unit variance and
+    Matern structure function (checks the PSD exponent and k0 = sqrt(2 nu)/r0)."""
+    from oracle import screens
+
+    rng = np.random.default_rng(8)
+    lags = np.array([0, 1, 2, 4, 8, 16, 32])
+    acc = np.zeros(len(lags))
+    for _ in range(6):
+        s = screens.numpy_screen(512, 512, 5.0, 5.0, 600.0, 5 / 6, rng)
+        (_, cy), (_, cx) = screens.radial_covariance(s, 5.0, 5.0, lags)
+        acc += 0.5 * (cy + cx) / 6
+    target = functions.approximate_normalized_matern(lags * 5.0, nu=5 / 6, r0=600.0)
+    assert abs(acc[0] - 1) < 0.1
+    sf_got, sf_ref = acc[0] - acc[1:], target[0] - target[1:]
+    assert np.abs(sf_got / sf_ref - 1).max() < 0.15
+
+
+def test_generate_layers_follows_extrusion_py():
+    weather = dict(
+        altitude=np.linspace(0, 25000, 60),
+        absolute_humidity=5e-3 * np.exp(-np.linspace(0, 25000, 60) / 2000),
+        temperature=288 - 6.5e-3 * np.linspace(0, 25000, 60),
+        wind_east=5 + 1e-3 * np.linspace(0, 25000, 60),
+        wind_north=-2 + 5e-4 * np.linspace(0, 25000, 60),
+        divergence=np.ones(60),
+    )
+    layers = geometry.generate_layers(np.radians(0.07), [(100.0, 90e9)], np.radians(45), weather, 800.0, pwv=2.0)
+    np.testing.assert_allclose(layers["h"], [250, 750, 1250, 1750, 2500, 4000, 6500, 10000])
+    assert np.sqrt((layers["pwv_rms"] ** 2).sum()) == pytest.approx(0.03 * 2.0)
+    assert (layers["res"] >= 2.0).all() and (layers["res"] <= 1e3).all()
+    np.testing.assert_allclose(layers["z"], layers["h"] / np.sin(np.radians(45)))
