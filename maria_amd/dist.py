@@ -1,0 +1,54 @@
+"""Detector sharding across the GPUs of a node.
+
+Every detector row is independent given the (small, replicated) screens,
+boresight and tables, so ranks take contiguous detector blocks and regenerate
+identical screens from the same Philox key: the data path needs no collective.
+``all_gather_tod`` is the optional epilogue the north star names (one all-gather of
+the TOD over xGMI, ``nccl`` = RCCL on ROCm; ``gloo`` on CPU tensors in tests).
+"""
+
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(n_det: int, world_size: int, rank: int, align: int = 16):
+    """Contiguous block [lo, hi) of rank ``rank``; blocks are multiples of ``align``
+    (the upsample kernel's detector tile) except the last, and cover [0, n_det)."""
+    per = -(-n_det // world_size)
+    per = -(-per // align) * align
+    lo = min(rank * per, n_det)
+    return lo, min(lo + per, n_det)
+
+
+def shard_slice(n_det: int, world_size: int = None, rank: int = None, align: int = 16) -> slice:
+    if world_size is None:
+        world_size = dist.get_world_size() if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    return slice(*shard_bounds(n_det, world_size, rank, align))
+
+
+def all_gather_tod(local: torch.Tensor, n_det: int, align: int = 16, time_chunk: int = None) -> torch.Tensor:
+    """Gather the [D_rank, T] shards into the full [n_det, T] TOD on every rank.
+
+    Shards produced by ``shard_slice`` are equal-sized except the last, so the
+    gather pads to the common size and trims.  ``time_chunk`` bounds the staging
+    buffer (the full gather of config 5 does not fit one GPU: gather chunk by chunk
+    and consume each chunk before the next)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local
+    world = dist.get_world_size()
+    per = shard_bounds(n_det, world, 0, align)[1]
+    T = local.shape[1]
+    out = torch.empty((n_det, T), dtype=local.dtype, device=local.device)
+    step = time_chunk or T
+    for s in range(0, T, step):
+        e = min(s + step, T)
+        send = torch.zeros((per, e - s), dtype=local.dtype, device=local.device)
+        send[: local.shape[0]] = local[:, s:e]
+        recv = torch.empty((world * per, e - s), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(recv, send)
+        out[:, s:e] = recv[:n_det]
+    return out

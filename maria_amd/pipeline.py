@@ -162,20 +162,31 @@ class DevicePath:
         kernels.  Returns the device tensors."""
         dev = self.device
         layers = self.problem["layers"]
+        shapes = [(len(l["extrusion"]), len(l["cross_section"])) for l in layers]
+        # a layer may ask for a larger periodic FFT domain ("fft_shape") than its grid:
+        # the screen is then the top-left block of it (atmosphere.py ribbons are not
+        # periodic; the padding decorrelates opposite edges)
+        fft_shapes = [tuple(l.get("fft_shape") or sh) for l, sh in zip(layers, shapes)]
         if getattr(self, "_gen_screens", None) is None:
-            shapes = [(len(l["extrusion"]), len(l["cross_section"])) for l in layers]
             self._gen_screens = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in shapes]
-            biggest = max(a * b for a, b in shapes)
+            biggest = max(a * b for a, b in fft_shapes)
             self._gen_work = torch.empty(4 * biggest, dtype=torch.float32, device=dev)
+            self._gen_big = None
+            if any(f != s for f, s in zip(fft_shapes, shapes)):
+                self._gen_big = torch.empty(biggest, dtype=torch.float32, device=dev)
             self.set_screens(self._gen_screens)
         for l, (layer, out) in enumerate(zip(layers, self._gen_screens)):
-            ne, nc = out.shape
+            ne, nc = shapes[l]
+            fe, fc = fft_shapes[l]
             de = float(layer["extrusion"][1] - layer["extrusion"][0])
             dc = float(layer["cross_section"][1] - layer["cross_section"][0])
+            target = out if (fe, fc) == (ne, nc) else self._gen_big[: fe * fc].view(fe, fc)
             self.ctx.call(
-                "mrx_screen_generate", self.problem["seed"], l, ne, nc, de, dc,
-                float(layer["r0"]), float(layer["nu"]), ptr(out), ptr(self._gen_work),
+                "mrx_screen_generate", self.problem["seed"], l, fe, fc, de, dc,
+                float(layer["r0"]), float(layer["nu"]), ptr(target), ptr(self._gen_work),
             )
+            if target is not out:
+                out.copy_(target[:ne, :nc])  # crop (a strided device copy; plumbing)
             if smooth and layer.get("beam_sigma", 0) > 0:
                 self.ctx.call(
                     "mrx_gauss_smooth2d", ptr(out), ptr(out), ptr(self._gen_work), ne, nc,

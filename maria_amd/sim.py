@@ -1,0 +1,253 @@
+"""``Simulation``: the reference's driver for the atmosphere path, device-backed.
+
+Mirrors ``maria.sim.Simulation`` (sim/simulation.py:66-272) and the atmosphere
+mixin (sim/atmosphere.py:24-84) for what BASELINE.json's north star covers:
+``Simulation(instrument, plans, site, atmosphere="2d", atmosphere_kwargs=...)``
+and ``.run(units)`` returning one ``TOD`` per plan.  The CMB, map and noise mixins
+and unit conversions other than pW are follow-on rows and say so.
+"""
+
+from __future__ import annotations
+
+import logging
+import time as ttime
+
+import numpy as np
+
+from .atmosphere import Atmosphere
+from .instrument import Instrument, Site
+
+logger = logging.getLogger("maria")
+
+MIN_ELEVATION_WARN = 10  # sim/observation.py
+MIN_ELEVATION_ERROR = 5
+HALF_PI_F32 = np.float32(np.pi / 2)
+
+
+class PointingError(Exception):
+    """maria/errors/__init__.py:8."""
+
+
+class Coordinates:
+    """az/el pointing of a boresight or of detectors around it (host-side numpy).
+
+    The slice of ``maria.coords.Coordinates`` the atmosphere set-up needs:
+    ``downsample`` (coordinates.py:286-304), ``broadcast`` to detector offsets in
+    float32 like jax does (coordinates.py:378-386, transforms.py:10-29) and the
+    unit-height ground projection (coordinates.py:333-349)."""
+
+    def __init__(self, t, az, el, offsets=None):
+        self.t = np.asarray(t, float)
+        self._baz, self._bel = np.asarray(az, float), np.asarray(el, float)
+        self.offsets = None if offsets is None else np.atleast_2d(np.asarray(offsets, float))
+        self._azel = None
+
+    def _pointing(self):
+        if self.offsets is None:
+            return self._baz, self._bel
+        if self._azel is None:
+            f32 = np.float32
+            dx, dy = self.offsets[:, 0, None].astype(f32), self.offsets[:, 1, None].astype(f32)
+            r = np.sqrt(dx * dx + dy * dy)
+            p = np.arctan2(-dx, -dy)
+            a = self._bel[None].astype(f32) - HALF_PI_F32
+            a_re, a_im = np.sin(r) * np.cos(p), np.cos(r)
+            re = a_re * np.cos(a) - a_im * np.sin(a)
+            im = a_re * np.sin(a) + a_im * np.cos(a)
+            self._azel = (np.arctan2(np.sin(r) * np.sin(p), re) + self._baz[None].astype(f32), np.arcsin(im))
+        return self._azel
+
+    @property
+    def az(self):
+        return self._pointing()[0]
+
+    @property
+    def el(self):
+        return self._pointing()[1]
+
+    @property
+    def shape(self):
+        return self.az.shape
+
+    def downsample(self, timestep):
+        ds_t = np.arange(self.t.min(), self.t.max(), timestep)
+        return Coordinates(ds_t, np.interp(ds_t, self.t, self._baz), np.interp(ds_t, self.t, self._bel))
+
+    def broadcast(self, offsets):
+        return Coordinates(self.t, self._baz, self._bel, offsets=offsets)
+
+    def project_unit(self):
+        """(cos az / tan el, sin az / tan el) [.., Ta, 2]: ``project(z=1)`` from the origin."""
+        az, el = self._pointing()
+        tan_el = np.tan(el)
+        return np.stack([np.cos(az) / tan_el, np.sin(az) / tan_el], axis=-1).astype(np.float64)
+
+
+class Plan:
+    """Time-ordered boresight in the az/el frame (``maria.plan.Plan``'s ``time``,
+    ``phi``, ``theta``; other frames need astropy and stay with maria's front end)."""
+
+    def __init__(self, time, az, el, roll=0.0):
+        self.time = np.asarray(time, float)
+        self.phi, self.theta = np.asarray(az, float), np.asarray(el, float)
+        self.frame, self.roll = "az/el", roll
+        if self.time.ndim != 1 or self.phi.shape != self.time.shape or self.theta.shape != self.time.shape:
+            raise ValueError("time, az and el must be one-dimensional and of equal length")
+
+    @classmethod
+    def daisy(cls, start_time=0.0, duration=60.0, sample_rate=50.0, scan_center=(45.0, 60.0), radius=0.5, speed=0.5):
+        """plan/plan.py:55-140 with ``scan_pattern="daisy"`` in az/el, degrees."""
+        from .synthetic import daisy_scan
+
+        t = np.arange(start_time, start_time + duration, 1.0 / sample_rate)  # plan.py:83
+        az, el = daisy_scan(t, radius, speed, scan_center[0], scan_center[1])
+        return cls(t, az, el)
+
+    @property
+    def duration(self):
+        return float(self.time[-1] - self.time[0])
+
+
+class Observation:
+    """sim/observation.py:27-100."""
+
+    def __init__(self, instrument, plan, site, atmosphere=None, atmosphere_kwargs={}):
+        self.instrument, self.plan, self.site = instrument, plan, site
+        self.boresight = Coordinates(plan.time, plan.phi, plan.theta)
+        c, s = np.cos(np.radians(plan.roll)), np.sin(np.radians(plan.roll))
+        self.coords = self.boresight.broadcast(instrument.dets.offsets @ np.array([[c, -s], [s, c]]).T)
+        # the elevation checks of observation.py:61-71, on the hull detectors (the extremes)
+        el_min = float(self.boresight.downsample(1.0).broadcast(instrument.dets.outer().offsets).el.min()) if len(plan.time) > 1 else float(plan.theta.min())
+        el_min = min(el_min, float(plan.theta.min()))
+        if el_min < np.radians(MIN_ELEVATION_WARN):
+            logger.warning(f"Some detectors come within {MIN_ELEVATION_WARN} degrees of the horizon (el_min = {np.degrees(el_min):.01f} deg)")
+        if el_min <= np.radians(MIN_ELEVATION_ERROR):
+            raise PointingError(f"Some detectors come within {MIN_ELEVATION_ERROR} degrees of the horizon (el_min = {np.degrees(el_min):.01f} deg)")
+        if atmosphere:
+            self.atmosphere_kwargs = atmosphere_kwargs
+            if isinstance(atmosphere, Atmosphere):
+                self.atmosphere = atmosphere
+            else:
+                self.atmosphere = Atmosphere(model=atmosphere, timestamp=float(plan.time.mean()), region=site.region, altitude=site.altitude, **atmosphere_kwargs)
+        self.loading = {}
+
+
+class TOD:
+    """The slice of ``maria.tod.TOD`` this path fills: ``data`` (dict of [ndet, nt]
+    float32 arrays, numpy or device tensors), ``dets``, ``coords``, ``units``, ``metadata``."""
+
+    def __init__(self, data, dets, coords, units="pW", metadata=None):
+        self.data, self.dets, self.coords, self.units = data, dets, coords, units
+        self.metadata = metadata or {}
+
+    @property
+    def fields(self):
+        return list(self.data)
+
+    @property
+    def signal(self):
+        return sum(self.data.values())
+
+    @property
+    def time(self):
+        return self.coords.t
+
+    def to(self, units):
+        if units == self.units:
+            return self
+        raise NotImplementedError(
+            f"conversion {self.units} -> {units} (tod/tod.py:106-142) needs per-sample elevations at the full "
+            "rate: a follow-on row (SURVEY 8(f) rank 1 and 4); ask run() for units='pW'"
+        )
+
+
+class Simulation:
+    def __init__(
+        self,
+        instrument,
+        plans,
+        site,
+        atmosphere=None,
+        atmosphere_kwargs: dict = {},
+        cmb=None,
+        cmb_kwargs: dict = {},
+        map=None,
+        map_kwargs: dict = {},
+        noise: bool = True,
+        noise_kwargs: dict = {},
+        progress_bars: bool = True,
+        keep_mean_signal: bool = False,
+        dtype: type = np.float32,
+        *,
+        gain_seed: int = None,
+        device_output: bool = False,
+    ):
+        """sim/simulation.py:76-198.  ``device_output=True`` leaves the TOD on the GPU as
+        a torch tensor (a 10 k x 240 k TOD is 9.6 GB; the PCIe copy dwarfs the synthesis)."""
+        if cmb is not None or map is not None:
+            raise NotImplementedError("the CMB and map mixins are follow-on rows (SURVEY 8(f)); only the atmosphere path is built")
+        if np.dtype(dtype) != np.float32:
+            raise NotImplementedError("the device path writes float32 TODs (the reference default)")
+        if not isinstance(instrument, Instrument):
+            raise ValueError("'instrument' must be an Instrument (named configs stay with maria's front end)")
+        if not isinstance(site, Site):
+            raise ValueError("'site' must be either a Site object or a string.")
+        if isinstance(plans, Plan):
+            plans = [plans]
+        elif not isinstance(plans, list):
+            raise TypeError("plans must be a plan or a list of plans")
+        self.instrument, self.site, self.plans = instrument, site, plans
+        self.atmosphere, self.atmosphere_kwargs = atmosphere, dict(atmosphere_kwargs)
+        self.noise, self.dtype = noise, dtype
+        self.disable_progress_bars = not progress_bars
+        self.device_output = device_output
+        self._gain_rng = np.random.default_rng(gain_seed)
+        if noise:
+            logger.warning("detector noise synthesis is a follow-on row (SURVEY 8(f) rank 2): this run has no noise field")
+        self.obs_list = []
+        for plan in self.plans:
+            obs = Observation(instrument, plan, site, atmosphere, self.atmosphere_kwargs)
+            if hasattr(obs, "atmosphere"):
+                obs.atmosphere.initialize(obs)
+            self.obs_list.append(obs)
+
+    def run(self, units: str = "K_RJ"):
+        """sim/simulation.py:201-211."""
+        tods = []
+        for k, obs in enumerate(self.obs_list):
+            t0 = ttime.monotonic()
+            tods.append(self.run_obs(obs).to(units))
+            logger.info(f"Simulated observation {k + 1} of {len(self.obs_list)} in {ttime.monotonic() - t0:.2f} s")
+        return tods
+
+    # -- sim/atmosphere.py:24-84 -------------------------------------------------------
+    def _simulate_atmosphere(self, obs):
+        obs.atmosphere.simulate_pwv(instrument=obs.instrument)
+
+    def _compute_atmospheric_loading(self, obs, gain=None):
+        """Spline solve + cubic upsample of the coarse loading the sampling kernel already
+        wrote (emission and Mueller weight are fused into it), scaled by ``gain``."""
+        import torch
+
+        path = obs.atmosphere._device_path()
+        path.d_gain = None if gain is None else torch.as_tensor(np.asarray(gain, np.float32)).to(path.device)
+        out = torch.empty((path.D, path.T), dtype=torch.float32, device=path.device)
+        path.prepare()
+        path.upsample(out)
+        return out
+
+    def run_obs(self, obs) -> TOD:
+        """sim/simulation.py:213-272."""
+        obs.loading = {}
+        dets = obs.instrument.dets
+        # per-detector gain error (simulation.py:239-247), fused into the upsample's store
+        gain_error = np.array([dets.bands[b].gain_error for b in dets.band_index])
+        gain = np.exp(gain_error * self._gain_rng.standard_normal(dets.n))
+        metadata = {"atmosphere": False, "altitude": float(obs.site.altitude), "region": obs.site.region}
+        if hasattr(obs, "atmosphere"):
+            self._simulate_atmosphere(obs)
+            loading = self._compute_atmospheric_loading(obs, gain=gain if np.any(gain_error) else None)
+            obs.loading["atmosphere"] = loading if self.device_output else loading.cpu().numpy()
+            metadata.update(atmosphere=True, pwv=float(np.round(obs.atmosphere.weather.pwv, 3)),
+                            base_temperature=float(np.round(obs.atmosphere.weather.temperature[0], 3)))
+        return TOD(data=obs.loading, dets=dets, coords=obs.coords, units="pW", metadata=metadata)

@@ -1,0 +1,120 @@
+"""GPU tests of the reference-shaped front end: Simulation(...).run() and Atmosphere."""
+
+import numpy as np
+import pytest
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(n=61, fov=0.3, duration=40.0, fs=50.0, **atm):
+    from maria_amd.instrument import Band, Detectors, Instrument, Site
+    from maria_amd.sim import Plan
+
+    bands = [Band(center=93e9, width=27e9, shape="top_hat", name="f093", gain_error=0.05),
+             Band(center=150e9, width=41e9, shape="top_hat", name="f150", gain_error=0.05)]
+    inst = Instrument(Detectors.hexagon(n, fov, bands, primary_size=6.0))
+    plan = Plan.daisy(start_time=1.7e9, duration=duration, sample_rate=fs, scan_center=(45.0, 55.0), radius=0.4, speed=0.4)
+    return inst, plan, Site(altitude=1000.0, region="synthetic")
+
+
+def _oracle_problem(sim, obs):
+    """The oracle's input dict from the objects the front end built (screens downloaded)."""
+    atm = obs.atmosphere
+    path = atm._device_path()
+    layers = []
+    for l, bufs in zip(sorted(atm.processes), path._layer_bufs):
+        layers.append(dict(atm.processes[l], values=bufs[0].cpu().numpy()))
+    dets = obs.instrument.dets
+    return dict(
+        t=obs.coords.t, ta=atm.boresight.t, az_a=atm.boresight.az, el_a=atm.boresight.el,
+        offsets=dets.offsets, band_index=dets.band_index, m00=dets.mueller00(), layers=layers,
+        tables=atm._tables(dets), T0=float(atm.weather.temperature[0]), pwv0=float(atm.weather.pwv),
+        timestep=float(atm.timestep), gain=None,
+    )
+
+
+def test_simulation_run_matches_oracle(gpu_ctx):
+    from maria_amd.sim import Simulation
+    from oracle import hotpath
+
+    inst, plan, site = _setup()
+    sim = Simulation(inst, plan, site, atmosphere="2d", atmosphere_kwargs={"weather": {"pwv": 1.5}, "seed": 5, "n_layers": 4},
+                     noise=False, gain_seed=1)
+    (tod,) = sim.run(units="pW")
+    data = tod.data["atmosphere"]
+    D, T = inst.dets.n, len(plan.time)
+    assert data.shape == (D, T) and data.dtype == np.float32 and tod.units == "pW"
+    assert not np.isnan(data).any()
+    assert tod.metadata["atmosphere"] and tod.metadata["pwv"] == 1.5
+    obs = sim.obs_list[0]
+    atm = obs.atmosphere
+    assert atm.zenith_scaled_pwv.shape == (D, len(atm.boresight.t))
+    assert len(atm.processes) == 4 and atm.timestep >= 0.1
+    # the reference's chain on the same screens, then the same gains
+    ref = hotpath.run_path(_oracle_problem(sim, obs))
+    gain = data[:, T // 2] / ref[:, T // 2]  # per-detector gain error exp(0.05 N(0,1))
+    assert 0.7 < gain.min() and gain.max() < 1.4 and gain.std() > 0.01
+    assert rel_err(data, ref * gain[:, None]) <= 2e-5
+    # pwv: mean near the weather value, fluctuations of the order pwv_rms_frac
+    pwv = atm.zenith_scaled_pwv
+    assert abs(pwv.mean() - 1.5) < 0.1 and 1e-4 < pwv.std() < 0.1
+    # a second run is a new realisation (reference: fresh noise every run)
+    (tod2,) = sim.run(units="pW")
+    assert not np.array_equal(tod2.data["atmosphere"], data)
+
+
+def test_reference_error_behaviour(gpu_ctx):
+    from maria_amd.atmosphere import Atmosphere
+    from maria_amd.sim import Plan, PointingError, Simulation
+
+    inst, plan, site = _setup(n=19, duration=10.0)
+    with pytest.raises(ValueError, match="Invalid model"):
+        Atmosphere(model="4d")
+    with pytest.raises(RuntimeError, match="must be initialized"):
+        Atmosphere().simulate_pwv()
+    low = Plan(plan.time, plan.phi, np.full_like(plan.theta, np.radians(4.0)))
+    with pytest.raises(PointingError):
+        Simulation(inst, low, site, atmosphere="2d", noise=False)
+    with pytest.raises(TypeError):
+        Simulation(inst, "daisy", site)
+    with pytest.raises(NotImplementedError):
+        Simulation(inst, plan, site, atmosphere="2d", map="something")
+    sim = Simulation(inst, plan, site, atmosphere="2d", noise=False)
+    with pytest.raises(NotImplementedError, match="K_RJ"):
+        sim.run()  # the reference's default units need the calibration pass (follow-on)
+
+
+def test_screen_statistics_through_the_front_end(gpu_ctx):
+    """Ribbon screens cropped from the padded periodic domain keep unit variance and
+    the beam smoothing lowers it."""
+    from maria_amd.sim import Simulation
+
+    inst, plan, site = _setup(n=37, duration=120.0, fs=20.0)
+    sim = Simulation(inst, plan, site, atmosphere="2d", atmosphere_kwargs={"n_layers": 2}, noise=False)
+    atm = sim.obs_list[0].atmosphere
+    atm.simulate_pwv(instrument=None)  # no smoothing
+    raw = [b[0].cpu().numpy() for b in atm._device_path()._layer_bufs]
+    assert all(0.2 < s.var() < 2.5 for s in raw), [s.var() for s in raw]  # one ribbon: few outer scales
+    atm._realisation -= 1  # same realisation, smoothed
+    atm.simulate_pwv(instrument=inst)
+    smooth = [b[0].cpu().numpy() for b in atm._device_path()._layer_bufs]
+    assert all(a.var() < b.var() for a, b in zip(smooth, raw))
+
+
+def test_map_smooth_front_end(gpu_ctx):
+    from maria_amd import map as mmap
+    from oracle import hotpath
+
+    rng = np.random.default_rng(0)
+    data = rng.standard_normal((2, 3, 64, 96)).astype(np.float32)  # [stokes, nu, ny, nx]
+    weight = rng.random((2, 3, 64, 96)).astype(np.float32)
+    got, den = mmap.smooth(data, weight, fwhm=3.0, x_res=-1.0, y_res=0.8)
+    sig = 3.0 / np.sqrt(8 * np.log(2))
+    ref, ref_den = hotpath.map_smooth(data, weight, sig / 0.8, sig / 1.0)
+    assert got.shape == data.shape
+    assert np.abs(got - ref).max() <= 1e-5 * np.abs(ref).max()
+    assert np.abs(den - ref_den).max() <= 1e-6
+    with pytest.raises(ValueError):
+        mmap.smooth(data, weight)
