@@ -70,14 +70,17 @@ int mrx_synchronize(mrx_ctx* ctx);
  *    default evaluates the same ground projection directly from the unit
  *    line-of-sight vector: equal up to the float32 rounding noise of the chain,
  *    better conditioned near the zenith, and ~3x fewer instructions.
- *  MRX_OPT_AXIS_ARRAYS = 1: always fetch grid nodes from the axis arrays, even
- *    for axes whose uniform hint verified (results identical; for A/B timing).
+ *  MRX_OPT_AXIS_RECOMPUTE = 1: recompute the grid nodes of axes whose uniform
+ *    hint verified as float32(g0 + i*dg) instead of fetching them from the axis
+ *    arrays (identical results; measured 7 % slower on MI355X because the
+ *    float64 node arithmetic costs more than two cached loads, so off by default).
  *  MRX_OPT_SAMPLE_TIMES = 1|2|4: coarse time steps per thread in mrx_atm_sample
  *    (tuning; 0 = library default). */
 enum {
   MRX_OPT_POINTING_CHAIN = 0,
-  MRX_OPT_AXIS_ARRAYS = 1,
+  MRX_OPT_AXIS_RECOMPUTE = 1,
   MRX_OPT_SAMPLE_TIMES = 2,
+  MRX_OPT_SAMPLE_CHUNK = 3, /* time steps per workgroup (tuning; 0 = automatic) */
   MRX_OPT_COUNT = 4
 };
 int mrx_set_option(mrx_ctx* ctx, int option, int value);
@@ -197,10 +200,14 @@ int mrx_spline_prepare(mrx_ctx* ctx, const float* d_y, int D, int Ta,
  *  ta0, dta       first coarse time and coarse step (s)
  *  d_t     [T]    f64 full-rate sample times, ascending
  *  d_scale [D]    f32 per-detector factor, or NULL
+ *  d_rows  [D]    destination row of each detector, or NULL for the identity:
+ *                 a caller that keeps its detectors in a locality order (see
+ *                 maria_amd/pipeline.py) still gets the TOD in its own row order
  *  d_out          f32, element (d, s) at d_out[d * ld_out + s] */
 int mrx_spline_upsample(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
                         double ta0, double dta, const double* d_t, int T,
-                        const float* d_scale, float* d_out, size_t ld_out);
+                        const float* d_scale, const int32_t* d_rows,
+                        float* d_out, size_t ld_out);
 
 /* Linear upsample of the coarse pwv to the full rate
  * (sim/atmosphere.py:30-37, interp1d linear + extrapolate); only the map/cmb

@@ -29,61 +29,63 @@ __device__ __forceinline__ int reflect_index(int i, int n) {
   return m < n ? m : p - 1 - m;
 }
 
-// pass along x (contiguous axis): one block row-segment of TX outputs x ROWS rows
-constexpr int kXRows = 4;    // rows per block
-constexpr int kXCols = 64;   // outputs per row per block (one wave per row)
+// Both passes stage tile + halo in LDS already widened to float64 (one
+// conversion per element instead of one per tap) and follow scipy's symmetric
+// summation: centre tap, then (left + right) * w_k.
+
+// pass along x (contiguous axis): one workgroup = 256 consecutive outputs of a row
+constexpr int kXCols = kBlock;
 
 __global__ __launch_bounds__(kBlock) void gauss_x_kernel(
     const float* __restrict__ in, float* __restrict__ out, int ny, int nx,
     const double* __restrict__ taps, int radius) {
-  extern __shared__ float lds[];
+  extern __shared__ double ldsd[];
   const int span = kXCols + 2 * radius;
-  const int row_l = threadIdx.x / kXCols;   // 0..3
-  const int lane = threadIdx.x % kXCols;
-  const int y = blockIdx.y * kXRows + row_l;
+  double* w = ldsd + span;  // taps[radius + k], k = 0..radius: LDS broadcast reads
+  const int y = blockIdx.y;
   const int x0 = blockIdx.x * kXCols;
-  float* row = lds + row_l * span;
-  if (y < ny) {
-    const float* src = in + (size_t)y * nx;
-    for (int i = lane; i < span; i += kXCols)
-      row[i] = src[reflect_index(x0 - radius + i, nx)];
-  }
+  const float* src = in + (size_t)y * nx;
+  for (int i = threadIdx.x; i < span; i += kBlock)
+    ldsd[i] = (double)src[reflect_index(x0 - radius + i, nx)];
+  for (int k = threadIdx.x; k <= radius; k += kBlock) w[k] = taps[radius + k];
   __syncthreads();
-  const int x = x0 + lane;
-  if (y >= ny || x >= nx) return;
-  // scipy's symmetric form: centre tap, then pairs
-  double acc = taps[radius] * (double)row[lane + radius];
-  for (int k = 1; k <= radius; ++k)
-    acc += ((double)row[lane + radius - k] + (double)row[lane + radius + k]) *
-           taps[radius + k];
+  const int x = x0 + threadIdx.x;
+  if (x >= nx) return;
+  const double* c = ldsd + threadIdx.x + radius;
+  double acc = w[0] * c[0];
+#pragma unroll 4
+  for (int k = 1; k <= radius; ++k) acc += (c[-k] + c[k]) * w[k];
   out[(size_t)y * nx + x] = (float)acc;
 }
 
-// pass along y: tile of kYRows outputs x 64 columns; 4 row groups of threads
+// pass along y: tile of tile_rows outputs x 64 columns; 4 row groups of threads
 constexpr int kYCols = 64;
 
 __global__ __launch_bounds__(kBlock) void gauss_y_kernel(
     const float* __restrict__ in, float* __restrict__ out, int ny, int nx,
     const double* __restrict__ taps, int radius, int tile_rows) {
-  extern __shared__ float lds[];
+  extern __shared__ double ldsd[];
   const int lane = threadIdx.x % kYCols;
   const int grp = threadIdx.x / kYCols;     // 0..3
   const int x = blockIdx.x * kYCols + lane;
   const int y0 = blockIdx.y * tile_rows;
   const int span = tile_rows + 2 * radius;
+  double* w = ldsd + span * kYCols;
   const int xs = min(x, nx - 1);
   for (int i = grp; i < span; i += kBlock / kYCols)
-    lds[i * kYCols + lane] =
-        in[(size_t)reflect_index(y0 - radius + i, ny) * nx + xs];
+    ldsd[i * kYCols + lane] =
+        (double)in[(size_t)reflect_index(y0 - radius + i, ny) * nx + xs];
+  for (int k = threadIdx.x; k <= radius; k += kBlock) w[k] = taps[radius + k];
   __syncthreads();
   if (x >= nx) return;
   for (int ry = grp; ry < tile_rows; ry += kBlock / kYCols) {
     const int y = y0 + ry;
     if (y >= ny) break;
-    const float* c = lds + (ry + radius) * kYCols + lane;
-    double acc = taps[radius] * (double)c[0];
+    const double* c = ldsd + (ry + radius) * kYCols + lane;
+    double acc = w[0] * c[0];
+#pragma unroll 4
     for (int k = 1; k <= radius; ++k)
-      acc += ((double)c[-k * kYCols] + (double)c[k * kYCols]) * taps[radius + k];
+      acc += (c[-k * kYCols] + c[k * kYCols]) * w[k];
     out[(size_t)y * nx + x] = (float)acc;
   }
 }
@@ -154,7 +156,21 @@ int get_taps(mrx_ctx* ctx, double sigma, double truncate, int* radius_out,
   return MRX_OK;
 }
 
-constexpr size_t kMaxLds = 64 * 1024;
+constexpr size_t kMaxLds = 128 * 1024;  // of the CU's 160 KiB
+
+int raise_lds_cap(mrx_ctx* ctx) {
+  static bool done = false;
+  if (!done) {
+    MRX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_x_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)kMaxLds));
+    MRX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_y_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)kMaxLds));
+    done = true;
+  }
+  return MRX_OK;
+}
 
 int smooth_axis1(mrx_ctx* ctx, const float* in, float* out, int ny, int nx,
                  double sigma, double truncate) {
@@ -162,11 +178,12 @@ int smooth_axis1(mrx_ctx* ctx, const float* in, float* out, int ny, int nx,
   const double* d_taps = nullptr;
   int rc = get_taps(ctx, sigma, truncate, &radius, &d_taps);
   if (rc != MRX_OK) return rc;
-  const size_t lds = (size_t)kXRows * (kXCols + 2 * radius) * sizeof(float);
+  const size_t lds = (size_t)(kXCols + 3 * radius + 1) * sizeof(double);
+  if ((rc = raise_lds_cap(ctx)) != MRX_OK) return rc;
   if (lds > kMaxLds)
     return mrx_fail(ctx, MRX_ERR_UNSUPPORTED,
                     "gaussian radius %d along x exceeds the LDS tile", radius);
-  dim3 grid(mrx_ceil_div(nx, kXCols), mrx_ceil_div(ny, kXRows));
+  dim3 grid(mrx_ceil_div(nx, kXCols), ny);
   MRX_REQUIRE(ctx, grid.y <= 65535u, "ny too large for one launch");
   hipLaunchKernelGGL(gauss_x_kernel, grid, dim3(kBlock), lds, ctx->stream, in,
                      out, ny, nx, d_taps, radius);
@@ -180,11 +197,13 @@ int smooth_axis0(mrx_ctx* ctx, const float* in, float* out, int ny, int nx,
   const double* d_taps = nullptr;
   int rc = get_taps(ctx, sigma, truncate, &radius, &d_taps);
   if (rc != MRX_OK) return rc;
+  if ((rc = raise_lds_cap(ctx)) != MRX_OK) return rc;
+  // output rows per tile: up to 64 while the image stays under 40 KiB (4 per CU)
   int tile_rows = 64;
   while (tile_rows > 8 &&
-         (size_t)(tile_rows + 2 * radius) * kYCols * sizeof(float) > kMaxLds)
+         (size_t)(tile_rows + 2 * radius) * kYCols * sizeof(double) > 40 * 1024)
     tile_rows /= 2;
-  const size_t lds = (size_t)(tile_rows + 2 * radius) * kYCols * sizeof(float);
+  const size_t lds = ((size_t)(tile_rows + 2 * radius) * kYCols + radius + 1) * sizeof(double);
   if (lds > kMaxLds)
     return mrx_fail(ctx, MRX_ERR_UNSUPPORTED,
                     "gaussian radius %d along y exceeds the LDS tile", radius);

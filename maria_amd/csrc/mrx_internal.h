@@ -30,7 +30,16 @@ struct mrx_ctx {
   } taps[kTapSlots];
   int taps_next = 0;
   int options[MRX_OPT_COUNT] = {0};
-  double* d_reduce = nullptr;  // small reduction buffer
+  // screen normalisations (sum of the PSD over the FFT grid), one device double
+  // per distinct (grid, spectrum)
+  static constexpr int kPsdSlots = 64;
+  struct PsdKey {
+    bool valid = false;
+    int ny = 0, nx = 0;
+    double dy = 0, dx = 0, r0 = 0, nu = 0;
+  } psd[kPsdSlots];
+  int psd_next = 0;
+  double* d_reduce = nullptr;  // kPsdSlots doubles
   size_t reduce_cap = 0;
 };
 

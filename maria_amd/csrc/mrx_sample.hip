@@ -32,6 +32,7 @@ namespace {
 constexpr int kBlock = 256;
 constexpr int kTimes = 2;                  // coarse time steps per thread (default)
 constexpr int kMaxLdsTableFloats = 12288;  // 48 KiB of band tables in LDS
+constexpr int kMaxChunk = 64;              // time steps per workgroup, at most
 
 // float32(pi/2): jax folds the weak-typed python float pi/2 to float32
 // (coords/transforms.py:22) and numpy clips float32 elevations to it
@@ -109,6 +110,8 @@ __device__ __forceinline__ Cell find_cell(NodeFn node, int n, float x,
 }
 
 typedef __attribute__((address_space(1))) const float gfloat;  // global memory
+typedef float pair4 __attribute__((ext_vector_type(2), aligned(4)));
+typedef __attribute__((address_space(1))) const pair4 gpair;
 
 // One-probe variant: takes the arithmetic guess, fetches the two nodes that
 // bracket it (PairFn: recomputed, or loaded from the axis array) and reports in
@@ -140,8 +143,12 @@ __device__ __forceinline__ Cell probe_cell(PairFn pair, int n, float x,
 __device__ __forceinline__ float bilinear(gfloat* values, int nc,
                                           const Cell& ce, const Cell& cc) {
   gfloat* v = values + (size_t)ce.i * nc + cc.i;
-  const float v00 = v[0], v01 = v[1];
-  const float v10 = v[nc], v11 = v[nc + 1];
+  // each row's two corners as ONE 8-byte load (4-byte aligned is enough for
+  // global_load_dwordx2): the kernel is bound by vector-memory instruction issue
+  const pair4 r0 = *(gpair*)v;
+  const pair4 r1 = *(gpair*)(v + nc);
+  const float v00 = r0.x, v01 = r0.y;
+  const float v10 = r1.x, v11 = r1.y;
   const float we0 = 1.0f - ce.w, we1 = ce.w;
   const float wc0 = 1.0f - cc.w, wc1 = cc.w;
   float y = 0.0f;
@@ -172,12 +179,15 @@ __global__ __launch_bounds__(kBlock) void atm_sample_kernel(
     const int32_t* __restrict__ band, const float* __restrict__ mueller00,
     int D, double pwv0, double* __restrict__ pwv_out,
     float* __restrict__ loading, uint32_t* __restrict__ flags,
-    int force_arrays) {
+    int force_arrays, int chunk) {
+  // A workgroup = 256 detectors x `chunk` consecutive time steps (a multiple of
+  // kT, <= kMaxChunk), walked kT steps at a time: the table staging and the
+  // per-detector constants are paid once per chunk.
   extern __shared__ float lds_tables[];
-  __shared__ float4 bore[kT];  // per time step: cos/sin of (el - pi/2), az
-  const int t0 = blockIdx.y * kT;
-  if (threadIdx.x < kT) {
-    const int t = min(t0 + (int)threadIdx.x, Ta - 1);
+  __shared__ float4 bore[kMaxChunk];  // per time step: cos/sin of (el - pi/2), az
+  const int t_first = blockIdx.y * chunk;
+  if ((int)threadIdx.x < chunk) {
+    const int t = min(t_first + (int)threadIdx.x, Ta - 1);
     const float a = el[t] - kHalfPiF;  // transforms.py:22
     const float z = az[t];
     bore[threadIdx.x] = make_float4(cosf(a), sinf(a), cosf(z), sinf(z));
@@ -203,14 +213,22 @@ __global__ __launch_bounds__(kBlock) void atm_sample_kernel(
   const int b = band[dd];
   const float m00 = mueller00[dd];
   uint32_t myflags = (b < 0 || b >= n_tables) ? MRX_FLAG_NAN : 0u;
+  const mrx_table_dev tb = tables[min(max(b, 0), n_tables - 1)];
+  const float* __restrict__ ax_p = tdata + tb.off_pwv;
+  const float* __restrict__ ax_e = tdata + tb.off_el;
+  const float* __restrict__ tv = tdata + tb.off_values;
+  const int slab = tb.n_pwv * tb.n_el;
+  const float p_last = ax_p[tb.n_pwv - 1], e_last = ax_e[tb.n_el - 1];
 
+  for (int it = 0; it < chunk && t_first + it < Ta; it += kT) {
+  const int t0 = t_first + it;
   // ---- pointing and unit-height ground projection for kT steps --------
   float theta[kT];
   double px[kT], py[kT], pwv[kT];
 #pragma unroll
   for (int tt = 0; tt < kT; ++tt) {
     // transforms.py:20-28
-    const float4 bt = bore[tt];
+    const float4 bt = bore[it + tt];
     const float re = A * bt.x - cr * bt.y;
     const float im = A * bt.y + cr * bt.x;
     theta[tt] = asinf(im);
@@ -301,12 +319,6 @@ __global__ __launch_bounds__(kBlock) void atm_sample_kernel(
   }
 
   // ---- band emission (band/band.py:264-286), float32 ----------------------
-  const mrx_table_dev tb = tables[min(max(b, 0), n_tables - 1)];
-  const float* __restrict__ ax_p = tdata + tb.off_pwv;
-  const float* __restrict__ ax_e = tdata + tb.off_el;
-  const float* __restrict__ tv = tdata + tb.off_values;
-  const int slab = tb.n_pwv * tb.n_el;
-  const float p_last = ax_p[tb.n_pwv - 1], e_last = ax_e[tb.n_el - 1];
 #pragma unroll
   for (int tt = 0; tt < kT; ++tt) {
     const int t = t0 + tt;
@@ -343,6 +355,7 @@ __global__ __launch_bounds__(kBlock) void atm_sample_kernel(
       if (pwv_out) pwv_out[o] = pwv[tt];
     }
   }
+  }  // chunk loop
   if (live && myflags) atomicOr(flags, myflags);
 }
 
@@ -567,7 +580,16 @@ int mrx_atm_sample(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d_az,
               "Ta differs from the plan's n_t (length of the wind offsets)");
   int kt = ctx->options[MRX_OPT_SAMPLE_TIMES];
   if (kt != 1 && kt != 2 && kt != 4) kt = kTimes;
-  dim3 grid(mrx_ceil_div(D, kBlock), mrx_ceil_div(Ta, kt));
+  // time steps per workgroup: as many as keep >= ~8 workgroups per CU in flight
+  int chunk = ctx->options[MRX_OPT_SAMPLE_CHUNK];
+  if (chunk <= 0) {
+    chunk = kMaxChunk;
+    const long long want = 8LL * (ctx->n_cu > 0 ? ctx->n_cu : 256);
+    while (chunk > kt && (long long)mrx_ceil_div(D, kBlock) * mrx_ceil_div(Ta, chunk) < want)
+      chunk /= 2;
+  }
+  chunk = ((chunk < kt ? kt : chunk > kMaxChunk ? kMaxChunk : chunk) / kt) * kt;
+  dim3 grid(mrx_ceil_div(D, kBlock), mrx_ceil_div(Ta, chunk));
   MRX_REQUIRE(ctx, grid.y <= 65535u, "Ta too large for one launch");
   const bool lds = plan->table_floats <= kMaxLdsTableFloats;
   const size_t lds_bytes = lds ? sizeof(float) * (size_t)plan->table_floats : 0;
@@ -578,7 +600,7 @@ int mrx_atm_sample(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d_az,
                      plan->d_off, plan->d_tables, plan->n_tables,              \
                      plan->d_table_data, plan->table_floats, d_az, d_el, Ta,   \
                      d_dx, d_dy, d_band, d_mueller00, D, pwv0, d_pwv,          \
-                     d_loading, d_flags, ctx->options[MRX_OPT_AXIS_ARRAYS])
+                     d_loading, d_flags, ctx->options[MRX_OPT_AXIS_RECOMPUTE] == 0, chunk)
 #define MRX_LAUNCH_SAMPLE_T(L, C)                                              \
   do {                                                                         \
     if (kt == 1) MRX_LAUNCH_SAMPLE(L, C, 1);                                   \

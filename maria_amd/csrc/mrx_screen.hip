@@ -59,38 +59,75 @@ __device__ __forceinline__ double wavenumber(int i, int n, double d) {
   return 6.283185307179586476925 * (double)s / ((double)n * d);
 }
 
-// ---- in-LDS radix-2 inverse FFT --------------------------------------------
-// data: n complex values already stored in bit-reversed order; tw[k] =
-// exp(+2 pi i k / n), k < n/2.  Unnormalised (sum convention of numpy ifft * n).
-__device__ __forceinline__ void fft_lds_inverse(float2* data, const float2* tw,
-                                                int n, int log2n) {
-  for (int s = 1; s <= log2n; ++s) {
-    const int half = 1 << (s - 1);
-    const int tstride = n >> s;
-    for (int bfly = threadIdx.x; bfly < n / 2; bfly += kBlock) {
-      const int pos = bfly & (half - 1);
-      const int i0 = ((bfly >> (s - 1)) << s) + pos;
-      const int i1 = i0 + half;
-      const float2 w = tw[pos * tstride];
-      const float2 a = data[i0], b = data[i1];
-      const float2 t = make_float2(w.x * b.x - w.y * b.y, w.x * b.y + w.y * b.x);
-      data[i0] = make_float2(a.x + t.x, a.y + t.y);
-      data[i1] = make_float2(a.x - t.x, a.y - t.y);
+// ---- in-LDS Stockham inverse FFT, radix 4 (+ one radix-2 stage) ------------
+// Autosort (natural order in and out, no bit reversal), ping-pong between two
+// LDS images of n complex values.  tw[m] = exp(+2 pi i m / n) for m < n/4; the
+// other twiddles follow from w^2 = w*w, w^3 = w^2*w and exp(i(a + pi/2)) = i exp(ia).
+// Unnormalised (numpy.fft.ifft * n).  Returns the image that holds the result.
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) {
+  return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
+}
+
+__device__ __forceinline__ float2* fft_lds_inverse(float2* a, float2* b,
+                                                   const float2* tw, int n,
+                                                   int log2n) {
+  float2* in = a;
+  float2* out = b;
+  int ns = 1, s = 0;
+  const int q = n >> 2;
+  for (; s + 2 <= log2n; s += 2, ns <<= 2) {
+    const int tstride = q / ns;  // n / (4 ns)
+    for (int j = threadIdx.x; j < q; j += kBlock) {
+      const int k = j & (ns - 1);
+      float2 v0 = in[j], v1 = in[j + q], v2 = in[j + 2 * q], v3 = in[j + 3 * q];
+      if (ns > 1) {
+        const float2 w1 = tw[k * tstride];
+        const float2 w2 = cmul(w1, w1);
+        const float2 w3 = cmul(w2, w1);
+        v1 = cmul(v1, w1);
+        v2 = cmul(v2, w2);
+        v3 = cmul(v3, w3);
+      }
+      const float2 t0 = make_float2(v0.x + v2.x, v0.y + v2.y);
+      const float2 t1 = make_float2(v0.x - v2.x, v0.y - v2.y);
+      const float2 t2 = make_float2(v1.x + v3.x, v1.y + v3.y);
+      const float2 t3 = make_float2(-(v1.y - v3.y), v1.x - v3.x);  // +i (v1 - v3)
+      const int j0 = ((j - k) << 2) + k;
+      out[j0] = make_float2(t0.x + t2.x, t0.y + t2.y);
+      out[j0 + ns] = make_float2(t1.x + t3.x, t1.y + t3.y);
+      out[j0 + 2 * ns] = make_float2(t0.x - t2.x, t0.y - t2.y);
+      out[j0 + 3 * ns] = make_float2(t1.x - t3.x, t1.y - t3.y);
     }
     __syncthreads();
+    float2* t = in;
+    in = out;
+    out = t;
   }
+  if (s < log2n) {  // one radix-2 stage left (odd log2 n): ns == n/2
+    const int h = n >> 1;
+    for (int j = threadIdx.x; j < h; j += kBlock) {
+      // twiddle exp(2 pi i j / n), j < n/2
+      float2 w = tw[j & (q - 1)];
+      if (j >= q) w = make_float2(-w.y, w.x);
+      const float2 v0 = in[j];
+      const float2 v1 = cmul(in[j + h], w);
+      out[j] = make_float2(v0.x + v1.x, v0.y + v1.y);
+      out[j + h] = make_float2(v0.x - v1.x, v0.y - v1.y);
+    }
+    __syncthreads();
+    float2* t = in;
+    in = out;
+    out = t;
+  }
+  return in;
 }
 
 __device__ __forceinline__ void fill_twiddles(float2* tw, int n) {
-  for (int k = threadIdx.x; k < n / 2; k += kBlock) {
+  for (int k = threadIdx.x; k < n / 4; k += kBlock) {
     float s, c;
     sincospif(2.0f * (float)k / (float)n, &s, &c);
     tw[k] = make_float2(c, s);
   }
-}
-
-__device__ __forceinline__ int bitrev(int i, int log2n) {
-  return (int)(__brev((unsigned)i) >> (32 - log2n));
 }
 
 // pass 1: spectrum column kx, all ky; FFT along y
@@ -100,7 +137,7 @@ __global__ __launch_bounds__(kBlock) void screen_spectrum_fft_y(
     uint32_t stream) {
   extern __shared__ float2 lds2[];
   float2* data = lds2;
-  float2* tw = lds2 + ny;
+  float2* tw = lds2 + 2 * ny;
   const int ix = blockIdx.x;
   const double kx = wavenumber(ix, nx, dx);
   fill_twiddles(tw, ny);
@@ -110,12 +147,12 @@ __global__ __launch_bounds__(kBlock) void screen_spectrum_fft_y(
     const U4 rnd = philox4x32_10(U4{(uint32_t)ix, (uint32_t)iy, stream, 0u},
                                  key0, key1);
     const float2 g = box_muller(rnd.x, rnd.y);
-    data[bitrev(iy, log2ny)] = make_float2(amp * g.x, amp * g.y);
+    data[iy] = make_float2(amp * g.x, amp * g.y);
   }
   __syncthreads();
-  fft_lds_inverse(data, tw, ny, log2ny);
+  const float2* res = fft_lds_inverse(data, data + ny, tw, ny, log2ny);
   float2* dst = work1 + (size_t)ix * ny;
-  for (int y = threadIdx.x; y < ny; y += kBlock) dst[y] = data[y];
+  for (int y = threadIdx.x; y < ny; y += kBlock) dst[y] = res[y];
 }
 
 // pass 2: transpose [rows][cols] -> [cols][rows], 32x32 tiles, padded LDS
@@ -142,16 +179,16 @@ __global__ __launch_bounds__(kBlock) void screen_fft_x_real(
     int log2nx, const double* __restrict__ psd_sum) {
   extern __shared__ float2 lds2[];
   float2* data = lds2;
-  float2* tw = lds2 + nx;
+  float2* tw = lds2 + 2 * nx;
   const int y = blockIdx.x;
   fill_twiddles(tw, nx);
   const float2* src = work2 + (size_t)y * nx;
-  for (int x = threadIdx.x; x < nx; x += kBlock) data[bitrev(x, log2nx)] = src[x];
+  for (int x = threadIdx.x; x < nx; x += kBlock) data[x] = src[x];
   __syncthreads();
-  fft_lds_inverse(data, tw, nx, log2nx);
+  const float2* res = fft_lds_inverse(data, data + nx, tw, nx, log2nx);
   const float norm = (float)(1.0 / sqrt(*psd_sum));
   float* dst = out + (size_t)y * nx;
-  for (int x = threadIdx.x; x < nx; x += kBlock) dst[x] = data[x].x * norm;
+  for (int x = threadIdx.x; x < nx; x += kBlock) dst[x] = res[x].x * norm;
 }
 
 // sum over the grid of amp^2 (what Var[real part] equals), float64
@@ -195,28 +232,37 @@ int ilog2_exact(int n) {
   return (1 << l) == n ? l : -1;
 }
 
-int ensure_reduce(mrx_ctx* ctx) {
+// The normalisation depends on the grid and spectrum only, not on the draw: it
+// is reduced once per (ny, nx, dy, dx, r0, nu) and kept in a device slot.
+int psd_sum_slot(mrx_ctx* ctx, int ny, int nx, double dy, double dx, double r0,
+                 double nu, const double** d_sum) {
   if (!ctx->d_reduce) {
-    MRX_HIP(ctx, hipMalloc(&ctx->d_reduce, 8 * sizeof(double)));
-    ctx->reduce_cap = 8;
+    MRX_HIP(ctx, hipMalloc(&ctx->d_reduce, mrx_ctx::kPsdSlots * sizeof(double)));
+    ctx->reduce_cap = mrx_ctx::kPsdSlots;
   }
-  return MRX_OK;
-}
-
-int launch_psd_sum(mrx_ctx* ctx, int ny, int nx, double dy, double dx,
-                   double r0, double nu) {
-  int rc = ensure_reduce(ctx);
-  if (rc != MRX_OK) return rc;
+  for (int i = 0; i < mrx_ctx::kPsdSlots; ++i) {
+    const auto& k = ctx->psd[i];
+    if (k.valid && k.ny == ny && k.nx == nx && k.dy == dy && k.dx == dx &&
+        k.r0 == r0 && k.nu == nu) {
+      *d_sum = ctx->d_reduce + i;
+      return MRX_OK;
+    }
+  }
+  const int slot = ctx->psd_next;
+  ctx->psd_next = (ctx->psd_next + 1) % mrx_ctx::kPsdSlots;
+  double* dst = ctx->d_reduce + slot;
   const double k0sq = 2.0 * nu / (r0 * r0);
   const float expo = (float)(-(nu + 1.0) / 2.0);
-  MRX_HIP(ctx, hipMemsetAsync(ctx->d_reduce, 0, sizeof(double), ctx->stream));
+  MRX_HIP(ctx, hipMemsetAsync(dst, 0, sizeof(double), ctx->stream));
   const size_t n = (size_t)ny * nx;
   const int blocks = (int)((n + kBlock - 1) / kBlock < 2048
                                ? (n + kBlock - 1) / kBlock
                                : 2048);
   hipLaunchKernelGGL(psd_sum_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream,
-                     ctx->d_reduce, ny, nx, dy, dx, k0sq, expo);
+                     dst, ny, nx, dy, dx, k0sq, expo);
   MRX_CHECK_LAUNCH(ctx);
+  ctx->psd[slot] = {true, ny, nx, dy, dx, r0, nu};
+  *d_sum = dst;
   return MRX_OK;
 }
 
@@ -229,9 +275,10 @@ int mrx_screen_psd_sum(mrx_ctx* ctx, int ny, int nx, double dy, double dx,
   if (!ctx || !host_sum) return MRX_ERR_INVALID;
   MRX_REQUIRE(ctx, ny > 0 && nx > 0 && dy > 0 && dx > 0 && r0 > 0 && nu > 0,
               "sizes, steps, r0 and nu must be positive");
-  int rc = launch_psd_sum(ctx, ny, nx, dy, dx, r0, nu);
+  const double* d_sum = nullptr;
+  int rc = psd_sum_slot(ctx, ny, nx, dy, dx, r0, nu, &d_sum);
   if (rc != MRX_OK) return rc;
-  MRX_HIP(ctx, hipMemcpyAsync(host_sum, ctx->d_reduce, sizeof(double),
+  MRX_HIP(ctx, hipMemcpyAsync(host_sum, d_sum, sizeof(double),
                               hipMemcpyDeviceToHost, ctx->stream));
   MRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MRX_OK;
@@ -249,7 +296,8 @@ int mrx_screen_generate(mrx_ctx* ctx, uint64_t seed, uint32_t stream, int ny,
     return mrx_fail(ctx, MRX_ERR_UNSUPPORTED,
                     "screen sides must be powers of two in [64, 8192] "
                     "(got %d x %d)", ny, nx);
-  int rc = launch_psd_sum(ctx, ny, nx, dy, dx, r0, nu);
+  const double* d_sum = nullptr;
+  int rc = psd_sum_slot(ctx, ny, nx, dy, dx, r0, nu, &d_sum);
   if (rc != MRX_OK) return rc;
 
   const double k0sq = 2.0 * nu / (r0 * r0);
@@ -258,8 +306,9 @@ int mrx_screen_generate(mrx_ctx* ctx, uint64_t seed, uint32_t stream, int ny,
   float2* work2 = work1 + (size_t)ny * nx;
   const uint32_t key0 = (uint32_t)seed, key1 = (uint32_t)(seed >> 32);
 
-  const size_t lds_y = (size_t)(ny + ny / 2) * sizeof(float2);
-  const size_t lds_x = (size_t)(nx + nx / 2) * sizeof(float2);
+  // two ping-pong images + n/4 twiddles
+  const size_t lds_y = (size_t)(2 * ny + ny / 4) * sizeof(float2);
+  const size_t lds_x = (size_t)(2 * nx + nx / 4) * sizeof(float2);
   static size_t lds_set_y = 0, lds_set_x = 0;  // raise the dynamic-LDS cap once
   if (lds_y > lds_set_y) {
     MRX_HIP(ctx, hipFuncSetAttribute(
@@ -283,7 +332,7 @@ int mrx_screen_generate(mrx_ctx* ctx, uint64_t seed, uint32_t stream, int ny,
                      ctx->stream, work1, work2, nx, ny);
   MRX_CHECK_LAUNCH(ctx);
   hipLaunchKernelGGL(screen_fft_x_real, dim3(ny), dim3(kBlock), lds_x,
-                     ctx->stream, work2, d_out, ny, nx, lx, ctx->d_reduce);
+                     ctx->stream, work2, d_out, ny, nx, lx, d_sum);
   MRX_CHECK_LAUNCH(ctx);
   return MRX_OK;
 }

@@ -18,9 +18,10 @@
 // yields m_i from dL_{i-1} and dR_{i+1} alone (a twisted factorisation).  Both
 // sweeps are first-order recurrences whose memory of the start decays like
 // (2-sqrt 3)^k = 0.268^k, so a thread that owns a chunk of 16 knots starts its
-// sweeps 32 knots outside the chunk from a zero state: the error, 0.268^32 =
-// 5e-19, is below float64 rounding.  Near the ends the sweeps start at the true
-// boundary and are exact.  Lanes are consecutive detectors (time-major data),
+// sweeps 16 knots outside the chunk from a zero state: the error in m, 0.268^16 =
+// 7e-10 of a second difference of y, is 100x below the float32 rounding of m
+// itself (the form m is stored in) and ~1e-12 of y.  Within 16 knots of an end
+// the sweeps start at the true boundary and are exact.  Lanes are consecutive detectors (time-major data),
 // so every index and coefficient below is wave-uniform.
 #include "mrx_internal.h"
 
@@ -28,7 +29,7 @@ namespace {
 
 constexpr int kBlock = 256;
 constexpr int kChunk = 16;  // knots owned by one thread
-constexpr int kHalo = 32;   // knots of run-in for each sweep
+constexpr int kHalo = 16;   // knots of run-in for each sweep
 constexpr int kQTab = 32;   // pivots tabulated before they equal alpha
 constexpr double kAlpha = 0.26794919243112270647;  // 2 - sqrt(3)
 
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(kBlock) void spline_prepare_kernel(
   double dLm[kChunk];
   {
     const int target = a - 1 - kHalo;
-    const int s0 = (target - lo < 20) ? lo : target;
+    const int s0 = (target - lo < 16) ? lo : target;
     double dl = 0.0;
     int i = s0;
     double ym_ = 0.0, yc_ = 0.0;
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(kBlock) void spline_prepare_kernel(
   double dr = 0.0;
   {
     const int target = b + kHalo;
-    const int e0 = (hi - target < 20) ? hi : target;
+    const int e0 = (hi - target < 16) ? hi : target;
     if (e0 >= b && e0 >= lo) {
       double yc_ = Y(e0), yp_ = Y(e0 + 1);
       for (int i = e0; i >= b; --i) {
@@ -218,8 +219,12 @@ template <bool kHasScale, int kMaxKnots>
 __global__ __launch_bounds__(kBlock) void spline_upsample_kernel(
     const float2* __restrict__ ym, int D, int n, double ta0, double inv_dta,
     const double* __restrict__ t, int T, const float* __restrict__ scale,
-    float* __restrict__ out, size_t ld, int vec_ok) {
+    const int32_t* __restrict__ rows, float* __restrict__ out, size_t ld,
+    int vec_ok) {
   constexpr int kPitch = kMaxKnots + 1;
+  // destination row of detector d (wave-uniform): the caller may keep its
+  // detectors in a locality order and still get the TOD in its own row order
+  auto row_of = [&](int d) -> size_t { return rows ? (size_t)rows[d] : (size_t)d; };
   __shared__ float2 tile[kTileDet * kPitch];
 
   const int s_tile = blockIdx.x * kTileSamples;
@@ -268,13 +273,13 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_kernel(
         }
         const vfloat4 v = {o[0], o[1], o[2], o[3]};
         __builtin_nontemporal_store(
-            v, reinterpret_cast<vfloat4*>(out + (size_t)(d0 + dl) * ld + sb));
+            v, reinterpret_cast<vfloat4*>(out + row_of(d0 + dl) * ld + sb));
       }
     } else {
       for (int dl = 0; dl < nd; ++dl) {
         const float2* row = tile + dl * kPitch;
         const float g = kHasScale ? scale[d0 + dl] : 1.0f;
-        float* dst = out + (size_t)(d0 + dl) * ld + sb;
+        float* dst = out + row_of(d0 + dl) * ld + sb;
 #pragma unroll
         for (int q = 0; q < kSamplesPerThread; ++q)
           if (sb + q < T) dst[q] = g * spline_eval(w, q, row[r[q]], row[r[q] + 1]);
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_kernel(
     for (int dl = 0; dl < nd; ++dl) {
       const int d = d0 + dl;
       const float g = kHasScale ? scale[d] : 1.0f;
-      float* dst = out + (size_t)d * ld + sb;
+      float* dst = out + row_of(d) * ld + sb;
 #pragma unroll
       for (int q = 0; q < kSamplesPerThread; ++q)
         if (sb + q < T)
@@ -342,7 +347,8 @@ int mrx_spline_prepare(mrx_ctx* ctx, const float* d_y, int D, int Ta,
 
 int mrx_spline_upsample(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
                         double ta0, double dta, const double* d_t, int T,
-                        const float* d_scale, float* d_out, size_t ld_out) {
+                        const float* d_scale, const int32_t* d_rows,
+                        float* d_out, size_t ld_out) {
   if (!ctx) return MRX_ERR_INVALID;
   MRX_REQUIRE(ctx, D >= 0 && T >= 0, "negative size");
   if (D == 0 || T == 0) return MRX_OK;
@@ -361,11 +367,13 @@ int mrx_spline_upsample(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
   // times live on the device; a tile that needs more knots than the image
   // holds falls back to global loads inside the kernel)
   const double knots_per_tile = (double)kTileSamples * (double)Ta / (double)T;
-  const bool small = knots_per_tile + 4.0 <= 64.0;
+  // the 64-knot image (8 workgroups per CU) measured 8 % slower than the 256-knot
+  // one (4 per CU) on the streaming write, so it is kept for reference only
+  const bool small = false && knots_per_tile + 4.0 <= 64.0;
 #define MRX_LAUNCH_UP(S, K)                                                   \
   hipLaunchKernelGGL((spline_upsample_kernel<S, K>), grid, dim3(kBlock), 0,   \
                      ctx->stream, ym, D, Ta, ta0, 1.0 / dta, d_t, T, d_scale, \
-                     d_out, ld_out, vec_ok)
+                     d_rows, d_out, ld_out, vec_ok)
   if (d_scale) {
     if (small) MRX_LAUNCH_UP(true, 64); else MRX_LAUNCH_UP(true, 256);
   } else {

@@ -25,6 +25,26 @@ def _dev(a, dtype, device):
     return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(device)
 
 
+def morton_order(offsets):
+    """Permutation that sorts focal-plane offsets along a Z-order curve, so that
+    consecutive detectors (the lanes of a wave, the 256 rows of a workgroup) form a
+    compact patch on the sky: their lines of sight then hit the same few cache lines
+    of every screen.  Pure host-side indexing; results do not depend on it."""
+    off = np.asarray(offsets, float)
+    if len(off) < 2:
+        return np.arange(len(off))
+    lo, span = off.min(axis=0), np.maximum(np.ptp(off, axis=0), 1e-300)
+    q = np.minimum(((off - lo) / span * 65535.0).astype(np.uint64), 65535)
+
+    def spread(v):  # 16 bits -> every other bit of 32
+        v = (v | (v << 8)) & 0x00FF00FF
+        v = (v | (v << 4)) & 0x0F0F0F0F
+        v = (v | (v << 2)) & 0x33333333
+        return (v | (v << 1)) & 0x55555555
+
+    return np.argsort(spread(q[:, 0]) | (spread(q[:, 1]) << 1), kind="stable")
+
+
 def table_slabs(table, T0):
     """Host part of the emission lookup: the two temperature slabs bracketing
     ``T0`` and T0's float32 normalised distance, computed exactly as jax's
@@ -42,7 +62,7 @@ def table_slabs(table, T0):
 class DevicePath:
     """One observation (or one detector shard of it) on one GPU."""
 
-    def __init__(self, problem, device="cuda:0", det_slice=None, ctx=None, keep_pwv=False):
+    def __init__(self, problem, device="cuda:0", det_slice=None, ctx=None, keep_pwv=False, locality_sort=True):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("maria_amd runs on a gfx950 GPU only; there is no CPU path")
@@ -57,6 +77,13 @@ class DevicePath:
 
         off = np.asarray(problem["offsets"], float)[sl]
         self.D = int(off.shape[0])
+        # internal detector order (Z-order on the focal plane); `order[k]` is the
+        # caller's row of internal detector k.  The coarse arrays live in internal
+        # order; the TOD is written straight into the caller's rows (d_rows).
+        self.order = morton_order(off) if locality_sort else np.arange(self.D)
+        self.inverse = np.argsort(self.order)
+        off = off[self.order]
+        pick = lambda a: np.asarray(a)[sl][self.order]  # noqa: E731
         self.Ta = int(len(problem["ta"]))
         self.T = int(len(problem["t"]))
         # jax demotes the float64 offsets and boresight to float32 on entry
@@ -64,11 +91,13 @@ class DevicePath:
         self.d_dy = _dev(off[:, 1], torch.float32, dev)
         self.d_az = _dev(problem["az_a"], torch.float32, dev)
         self.d_el = _dev(problem["el_a"], torch.float32, dev)
-        self.d_band = _dev(np.asarray(problem["band_index"])[sl], torch.int32, dev)
-        self.d_m00 = _dev(np.asarray(problem["m00"])[sl], torch.float32, dev)
+        self.d_band = _dev(pick(problem["band_index"]), torch.int32, dev)
+        self.d_m00 = _dev(pick(problem["m00"]), torch.float32, dev)
+        self.d_rows = _dev(self.order, torch.int32, dev) if locality_sort else None
+        self._d_inverse = _dev(self.inverse, torch.int64, dev)
         self.d_t = _dev(problem["t"], torch.float64, dev)
         gain = problem.get("gain")
-        self.d_gain = _dev(np.asarray(gain)[sl], torch.float32, dev) if gain is not None else None
+        self.d_gain = _dev(pick(gain), torch.float32, dev) if gain is not None else None
         self.ta0 = float(problem["ta"][0])
         self.dta = float(problem["ta"][1] - problem["ta"][0])
         self.pwv0 = float(problem["pwv0"])
@@ -210,8 +239,20 @@ class DevicePath:
     def upsample(self, out):
         self.ctx.call(
             "mrx_spline_upsample", ptr(self.d_ym), self.D, self.Ta, self.ta0, self.dta,
-            ptr(self.d_t), self.T, ptr(self.d_gain), ptr(out), out.stride(0),
+            ptr(self.d_t), self.T, ptr(self.d_gain), ptr(self.d_rows), ptr(out), out.stride(0),
         )
+
+    def set_gain(self, gain):
+        """Per-detector scale of the TOD, in the caller's detector order (or None)."""
+        self.d_gain = None if gain is None else _dev(np.asarray(gain, np.float32)[self.order], torch.float32, self.device)
+
+    def coarse_loading(self):
+        """[D, Ta] float32 coarse loading in the caller's detector order (device tensor)."""
+        return self.d_loading.T.index_select(0, self._d_inverse)
+
+    def coarse_pwv(self):
+        """[D, Ta] float64 zenith-scaled pwv in the caller's detector order."""
+        return self.d_pwv.T.index_select(0, self._d_inverse)
 
     def run(self, out=None):
         """The whole path for this shard; returns the [D, T] float32 TOD tensor."""

@@ -230,7 +230,7 @@ class Simulation:
         import torch
 
         path = obs.atmosphere._device_path()
-        path.d_gain = None if gain is None else torch.as_tensor(np.asarray(gain, np.float32)).to(path.device)
+        path.set_gain(gain)
         out = torch.empty((path.D, path.T), dtype=torch.float32, device=path.device)
         path.prepare()
         path.upsample(out)

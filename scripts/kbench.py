@@ -59,7 +59,7 @@ def main():
             path.ctx.set_option(0, chain)
             path.ctx.set_option(1, arrays)
             med, mn = timeit(path.sample, reps)
-            print(f"sample chain={chain} axis_arrays={arrays}: median {med:.3f} ms min {mn:.3f} ms")
+            print(f"sample chain={chain} axis_recompute={arrays}: median {med:.3f} ms min {mn:.3f} ms")
     path.ctx.set_option(0, 0)
     path.ctx.set_option(1, 0)
     for kt in (1, 2, 4):
@@ -67,6 +67,14 @@ def main():
         med, mn = timeit(path.sample, reps)
         print(f"sample times_per_thread={kt}: median {med:.3f} ms min {mn:.3f} ms")
     path.ctx.set_option(2, 0)
+    for kt in (2, 4):
+        for chunk in (4, 8, 16, 32, 64):
+            path.ctx.set_option(2, kt)
+            path.ctx.set_option(3, chunk)
+            med, mn = timeit(path.sample, reps)
+            print(f"sample times_per_thread={kt} chunk={chunk}: median {med:.3f} ms min {mn:.3f} ms")
+    path.ctx.set_option(2, 0)
+    path.ctx.set_option(3, 0)
     assert path.check_flags() == 0
 
 

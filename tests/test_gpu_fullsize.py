@@ -43,7 +43,7 @@ def test_spline_interpolates_its_knots(full):
     p, path, tod = full
     ratio = round(p["fs"] * p["timestep"])
     at_knots = tod[:, ::ratio][:, : path.Ta]
-    coarse = path.d_loading.T
+    coarse = path.coarse_loading()
     err = (at_knots - coarse).abs().max() / coarse.abs().max()
     assert float(err) <= 1e-6
     # and between knots the cubic stays within the local range of the knots (no ringing)
@@ -74,10 +74,10 @@ def test_gain_is_linear(full):
     import torch
 
     p, path, tod = full
-    path.d_gain = torch.full((path.D,), 2.0, dtype=torch.float32, device=path.device)
+    path.set_gain(np.full(path.D, 2.0, np.float32))
     out = torch.empty_like(tod)
     path.upsample(out)
-    path.d_gain = None
+    path.set_gain(None)
     assert torch.equal(out, 2.0 * tod)
 
 

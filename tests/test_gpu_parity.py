@@ -49,8 +49,8 @@ def test_sample_matches_oracle(gpu_ctx, n_det, n_layers, n_bands, chain):
     finally:
         gpu_ctx.set_option(_lib.OPT_POINTING_CHAIN, 0)
     assert path.check_flags() == 0
-    got_pwv = path.d_pwv.cpu().numpy().T
-    got = path.d_loading.cpu().numpy().T
+    got_pwv = path.coarse_pwv().cpu().numpy()
+    got = path.coarse_loading().cpu().numpy()
 
     _, inter = hotpath.run_path(p, return_intermediates=True)
     assert rel_err(got_pwv, inter["pwv"]) <= 2e-6
@@ -80,8 +80,24 @@ def test_nonuniform_axes_take_the_array_path(gpu_ctx):
     path.sample()
     assert path.check_flags() == 0
     _, inter = hotpath.run_path(p, return_intermediates=True)
-    assert rel_err(path.d_pwv.cpu().numpy().T, inter["pwv"]) <= 2e-6
-    assert rel_err(path.d_loading.cpu().numpy().T, inter["loading_a"]) <= TOL_TOD
+    assert rel_err(path.coarse_pwv().cpu().numpy(), inter["pwv"]) <= 2e-6
+    assert rel_err(path.coarse_loading().cpu().numpy(), inter["loading_a"]) <= TOL_TOD
+
+
+def test_recomputed_nodes_are_bit_identical_to_fetched_ones(gpu_ctx):
+    """MRX_OPT_AXIS_RECOMPUTE only changes where the grid nodes come from."""
+    import torch
+
+    p = small_problem(n_det=200, n_layers=4, n_bands=2)
+    path = _device_path(p, ctx=gpu_ctx, keep_pwv=True)
+    path.sample()
+    a_load, a_pwv = path.d_loading.clone(), path.d_pwv.clone()
+    gpu_ctx.set_option(1, 1)
+    try:
+        path.sample()
+    finally:
+        gpu_ctx.set_option(1, 0)
+    assert torch.equal(path.d_loading, a_load) and torch.equal(path.d_pwv, a_pwv)
 
 
 def test_full_path_matches_oracle(gpu_ctx):
@@ -123,7 +139,7 @@ def test_spline_matches_scipy_all_lengths(gpu_ctx, Ta):
     ld = T + 3  # odd pitch: exercises the scalar-store path
     d_out = torch.full((D, ld), -7.0, dtype=torch.float32, device=dev)
     gpu_ctx.call("mrx_spline_prepare", ptr(d_y), D, Ta, ptr(d_ym))
-    gpu_ctx.call("mrx_spline_upsample", ptr(d_ym), D, Ta, float(ta[0]), float(ta[1] - ta[0]), ptr(d_t), T, None, ptr(d_out), ld)
+    gpu_ctx.call("mrx_spline_upsample", ptr(d_ym), D, Ta, float(ta[0]), float(ta[1] - ta[0]), ptr(d_t), T, None, None, ptr(d_out), ld)
     out = d_out.cpu().numpy()
     assert (out[:, T:] == -7.0).all(), "wrote past T"
     assert rel_err(out[:, :T], ref) <= 2e-6
@@ -156,7 +172,7 @@ def test_upsample_ratios(gpu_ctx, ratio):
     scale = rng.uniform(0.5, 2.0, D).astype(np.float32)
     d_scale = torch.as_tensor(scale).to(dev)
     gpu_ctx.call("mrx_spline_prepare", ptr(d_y), D, Ta, ptr(d_ym))
-    gpu_ctx.call("mrx_spline_upsample", ptr(d_ym), D, Ta, float(ta[0]), 0.1, ptr(d_t), T, ptr(d_scale), ptr(d_out), T)
+    gpu_ctx.call("mrx_spline_upsample", ptr(d_ym), D, Ta, float(ta[0]), 0.1, ptr(d_t), T, ptr(d_scale), None, ptr(d_out), T)
     assert rel_err(d_out.cpu().numpy(), ref * scale[:, None]) <= 2e-6
 
 
