@@ -188,6 +188,17 @@ def main():
         "flags": int(flags),
     }
 
+    # HBM bytes per launch of the dominant kernel from the PMC counters: collected in
+    # separate rocprofv3 --pmc passes (gpurun refuses --pmc inside an ordinary run), stored
+    # with their method under profiles/, and quoted here for the matching configuration
+    traffic_file = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if os.path.exists(traffic_file):
+        with open(traffic_file) as f:
+            tr = json.load(f)
+        if tr.get("config") == args.config and tr.get("kernel") == result["roofline"]["kernel"]:
+            result["roofline"]["traffic"] = tr["hbm_bytes_per_launch"]
+            result["roofline"]["traffic_source"] = tr["source"]
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         n_sub = min(args.cpu_dets, D)
         screens = [b[0].cpu().numpy() for b in path._layer_bufs]
