@@ -104,8 +104,13 @@ def main():
     from maria_amd import synthetic
     from maria_amd.pipeline import DevicePath
 
-    problem = synthetic.config_problem(args.config)
-    path = DevicePath(problem, device=device)
+    from maria_amd.dist import shard_slice
+
+    # weak scaling: the focal plane grows with the node (n_det of the named
+    # configuration per GPU) and each rank takes its own contiguous detector block
+    n_total = synthetic.CONFIGS[args.config]["n_det"] * world
+    problem = synthetic.config_problem(args.config, n_det=n_total)
+    path = DevicePath(problem, device=device, det_slice=shard_slice(n_total, world, rank))
     D, T, Ta = path.D, path.T, path.Ta
     tod = torch.empty((D, T), dtype=torch.float32, device=device)
 
@@ -210,7 +215,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         n_sub = min(args.cpu_dets, D)
         screens = [b[0].cpu().numpy() for b in path._layer_bufs]
-        ref, cpu_s = cpu_baseline(problem, screens, n_sub)
+        ref, cpu_s = cpu_baseline(problem, screens, n_sub)  # world == 1: the shard is the array
         got = tod[:n_sub].cpu().numpy()
         err = float(np.abs(got.astype(np.float64) - ref).max() / np.abs(ref).max())
         try:

@@ -58,6 +58,46 @@ __global__ __launch_bounds__(kBlock) void spline_prepare_kernel(
   const int a = blockIdx.y * kChunk;       // first knot of this chunk
   const int b = min(a + kChunk, n);        // one past the last
   const int lo = 2, hi = n - 3;            // interior unknowns (empty if n < 5)
+
+  // ---- chunks far from both ends (all but a few): fixed trip counts -----------
+  // Every knot the two sweeps touch is loaded up front (static indices, so the
+  // window lives in registers and all loads are in flight together); the pivots
+  // have converged to alpha and no boundary term applies.
+  if (b == a + kChunk && a - 1 - kHalo - lo >= 16 && hi - (b + kHalo) >= 16) {
+    constexpr int kWin = kChunk + 2 * kHalo + 4;  // knots a-2-kHalo .. b+kHalo+1
+    const float* base = y + (size_t)(a - 2 - kHalo) * D + d;
+    float w[kWin];
+#pragma unroll
+    for (int k = 0; k < kWin; ++k) w[k] = base[(size_t)k * D];
+    // delta of knot (a - 2 - kHalo + k), 1 <= k <= kWin - 2
+    auto delta = [&](int k) -> double {
+      return ((double)w[k - 1] - 2.0 * (double)w[k]) + (double)w[k + 1];
+    };
+    double dLm[kChunk];
+    double dl = 0.0;
+#pragma unroll
+    for (int k = 1; k <= kHalo; ++k) dl = (delta(k) - dl) * kAlpha;  // a-1-kHalo .. a-2
+#pragma unroll
+    for (int k = 0; k < kChunk; ++k) {  // a-1 .. b-2
+      dl = (delta(kHalo + 1 + k) - dl) * kAlpha;
+      dLm[k] = dl;
+    }
+    double dr = 0.0;
+#pragma unroll
+    for (int k = kWin - 2; k >= kChunk + kHalo + 2; --k)  // b+kHalo .. b
+      dr = (delta(k) - dr) * kAlpha;
+    constexpr double kInvDen = 1.0 / (4.0 - 2.0 * kAlpha);
+    float2* dst = ym + (size_t)a * D + d;
+#pragma unroll
+    for (int k = kChunk - 1; k >= 0; --k) {  // knot a + k
+      const double r = delta(kHalo + 2 + k);
+      const double m = (r - dLm[k] - dr) * kInvDen;
+      dr = (r - dr) * kAlpha;
+      dst[(size_t)k * D] = make_float2(w[kHalo + 2 + k], (float)m);
+    }
+    return;
+  }
+
   auto Y = [&](int i) -> double { return (double)y[(size_t)i * D + d]; };
 
   const double m1 = (Y(0) - 2.0 * Y(1) + Y(2)) * (1.0 / 6.0);
@@ -170,7 +210,10 @@ __global__ __launch_bounds__(kBlock) void spline_prepare_kernel(
 // 256 covers ratios down to ~4; below that the tile reads its knots from
 // global memory (correct, slower: such ratios do not occur in maria, whose
 // coarse step is >= 0.1 s).
-constexpr int kTileDet = 16;
+#ifndef MRX_TILE_DET
+#define MRX_TILE_DET 16
+#endif
+constexpr int kTileDet = MRX_TILE_DET;
 constexpr int kSamplesPerThread = 4;
 constexpr int kTileSamples = kBlock * kSamplesPerThread;  // 1024
 
@@ -272,8 +315,12 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_kernel(
           for (int q = 0; q < kSamplesPerThread; ++q) o[q] *= g;
         }
         const vfloat4 v = {o[0], o[1], o[2], o[3]};
+#ifdef MRX_PLAIN_STORE
+        *reinterpret_cast<vfloat4*>(out + row_of(d0 + dl) * ld + sb) = v;
+#else
         __builtin_nontemporal_store(
             v, reinterpret_cast<vfloat4*>(out + row_of(d0 + dl) * ld + sb));
+#endif
       }
     } else {
       for (int dl = 0; dl < nd; ++dl) {
