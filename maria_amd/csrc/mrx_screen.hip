@@ -44,14 +44,19 @@ __host__ __device__ inline U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
   return c;
 }
 
-// Box-Muller on two 32-bit words: a pair of independent standard normals.
+// Box-Muller on two 32-bit words: a pair of independent standard normals.  The
+// hardware transcendentals (v_log_f32 = log2, v_sin/v_cos_f32 take revolutions)
+// are accurate to ~1e-6, far below what a noise draw needs.
 __device__ __forceinline__ float2 box_muller(uint32_t a, uint32_t b) {
   const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
   const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);           // [0,1)
-  const float rad = sqrtf(-2.0f * logf(u1));
-  float s, c;
-  sincospif(2.0f * u2, &s, &c);
-  return make_float2(rad * c, rad * s);
+  const float rad = sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // -2 ln u1
+  return make_float2(rad * __builtin_amdgcn_cosf(u2), rad * __builtin_amdgcn_sinf(u2));
+}
+
+// sqrt of the von Karman / Matern spectrum: (k0^2 + |k|^2)^expo via exp2/log2
+__device__ __forceinline__ float spectrum_amp(double k2, float expo) {
+  return __builtin_amdgcn_exp2f(expo * __builtin_amdgcn_logf((float)k2));
 }
 
 __device__ __forceinline__ double wavenumber(int i, int n, double d) {
@@ -141,13 +146,17 @@ __global__ __launch_bounds__(kBlock) void screen_spectrum_fft_y(
   const int ix = blockIdx.x;
   const double kx = wavenumber(ix, nx, dx);
   fill_twiddles(tw, ny);
-  for (int iy = threadIdx.x; iy < ny; iy += kBlock) {
-    const double ky = wavenumber(iy, ny, dy);
-    const float amp = powf((float)(k0sq + kx * kx + ky * ky), expo);
+  // one Philox call feeds two cells: words (x, y) -> ky index iy, (z, w) -> iy + ny/2
+  const int half = ny >> 1;
+  for (int iy = threadIdx.x; iy < half; iy += kBlock) {
     const U4 rnd = philox4x32_10(U4{(uint32_t)ix, (uint32_t)iy, stream, 0u},
                                  key0, key1);
-    const float2 g = box_muller(rnd.x, rnd.y);
-    data[iy] = make_float2(amp * g.x, amp * g.y);
+    const double ky0 = wavenumber(iy, ny, dy), ky1 = wavenumber(iy + half, ny, dy);
+    const float amp0 = spectrum_amp(k0sq + kx * kx + ky0 * ky0, expo);
+    const float amp1 = spectrum_amp(k0sq + kx * kx + ky1 * ky1, expo);
+    const float2 g0 = box_muller(rnd.x, rnd.y), g1 = box_muller(rnd.z, rnd.w);
+    data[iy] = make_float2(amp0 * g0.x, amp0 * g0.y);
+    data[iy + half] = make_float2(amp1 * g1.x, amp1 * g1.y);
   }
   __syncthreads();
   const float2* res = fft_lds_inverse(data, data + ny, tw, ny, log2ny);
@@ -203,7 +212,7 @@ __global__ __launch_bounds__(kBlock) void psd_sum_kernel(
     const int iy = (int)(i / nx), ix = (int)(i % nx);
     const double kx = wavenumber(ix, nx, dx), ky = wavenumber(iy, ny, dy);
     // the same float32 amplitude the generator uses
-    const float amp = powf((float)(k0sq + kx * kx + ky * ky), expo);
+    const float amp = spectrum_amp(k0sq + kx * kx + ky * ky, expo);
     acc += (double)amp * (double)amp;
   }
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);

@@ -137,7 +137,9 @@ def test_screen_fft_matches_numpy_ifft(gpu_ctx):
     spec = np.zeros((ny, nx), complex)
     for iy in range(ny):
         for ix in range(nx):
-            a, b, _, _ = philox4x32(seed, (ix, iy, stream, 0))
+            # one Philox call feeds cells iy (words 0,1) and iy + ny/2 (words 2,3)
+            words = philox4x32(seed, (ix, iy % (ny // 2), stream, 0))
+            a, b = words[:2] if iy < ny // 2 else words[2:]
             u1 = ((a >> 8) + 0.5) / 16777216.0
             u2 = (b >> 8) / 16777216.0
             rad = np.sqrt(-2 * np.log(u1))
