@@ -46,6 +46,9 @@ def parse_args():
     ap.add_argument("--no-screens-in-step", action="store_true", help="time TOD synthesis only (screens generated once)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the launch on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
+                    help="2: pipeline independent observations (steps) on two HIP streams so the VALU-bound "
+                    "stages of one overlap the HBM-bound upsample of the other; per-kernel times then include contention")
     return ap.parse_args()
 
 
@@ -110,43 +113,52 @@ def main():
     # configuration per GPU) and each rank takes its own contiguous detector block
     n_total = synthetic.CONFIGS[args.config]["n_det"] * world
     problem = synthetic.config_problem(args.config, n_det=n_total)
-    path = DevicePath(problem, device=device, det_slice=shard_slice(n_total, world, rank))
+    sl = shard_slice(n_total, world, rank)
+    lanes = []  # one (stream, DevicePath, TOD buffer) per HIP stream
+    for k in range(args.streams):
+        st = torch.cuda.current_stream() if args.streams == 1 else torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            pth = DevicePath(problem, device=device, det_slice=sl)
+            pth.ctx.set_stream(st)
+            lanes.append((st, pth, torch.empty((pth.D, pth.T), dtype=torch.float32, device=device)))
+    path, tod = lanes[0][1], lanes[0][2]
     D, T, Ta = path.D, path.T, path.Ta
-    tod = torch.empty((D, T), dtype=torch.float32, device=device)
 
-    def step():
-        if not args.no_screens_in_step:
-            path.generate_screens()
-        path.sample()
-        path.prepare()
-        path.upsample(tod)
+    def step(k=0, ev=None):
+        st, pth, out = lanes[k % len(lanes)]
+        with torch.cuda.stream(st):
+            if ev: ev[0].record(st)
+            if not args.no_screens_in_step:
+                pth.generate_screens()
+            if ev: ev[1].record(st)
+            pth.sample()
+            if ev: ev[2].record(st)
+            pth.prepare()
+            if ev: ev[3].record(st)
+            pth.upsample(out)
+            if ev: ev[4].record(st)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    path.generate_screens()
-    for _ in range(args.warmup):
-        step()
+    for st, pth, _ in lanes:
+        with torch.cuda.stream(st):
+            pth.generate_screens()
+    for w in range(args.warmup if len(lanes) == 1 else max(args.warmup, len(lanes))):
+        step(w)
     barrier()
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(args.steps)]
     t_start = time.perf_counter()
     for k in range(args.steps):
-        ev[k][0].record()
-        if not args.no_screens_in_step:
-            path.generate_screens()
-        ev[k][1].record()
-        path.sample()
-        ev[k][2].record()
-        path.prepare()
-        ev[k][3].record()
-        path.upsample(tod)
-        ev[k][4].record()
+        step(k, ev[k])
     barrier()
     elapsed = time.perf_counter() - t_start
-    flags = path.check_flags()
+    flags = 0
+    for _, pth, _ in lanes:
+        flags |= pth.check_flags()
 
     if world > 1:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
@@ -178,6 +190,7 @@ def main():
             "n_det_per_gpu": D,
             "n_samples": T,
             "screens_in_step": not args.no_screens_in_step,
+            "streams": args.streams,
             "parallelism": f"detector-sharded x{world}, no data-path collective",
         },
         "stage_ms": {
