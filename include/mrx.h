@@ -209,6 +209,37 @@ int mrx_spline_upsample(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
                         const float* d_scale, const int32_t* d_rows,
                         float* d_out, size_t ld_out);
 
+/* mrx_spline_upsample fused with TOD.to("K_RJ") (tod/tod.py:106-142): each sample
+ * is divided by den_b(el) = (0.5 if polarized else 1) * k_B * 1e12 *
+ * Int tau_b(nu) exp(-opacity(nu)) dnu (calibration/functions.py:73-90,
+ * band/band.py:235-255), looked up on the elevation axis at the detector's own
+ * full-rate elevation, which the kernel recomputes from the full-rate boresight
+ * elevation and the (rolled) detector offsets (sim/observation.py:55-58,
+ * coords/transforms.py:14-28, float32).  The host collapses each band's
+ * transmission-integral table at the observation's scalar base temperature and
+ * zenith pwv (tod.py:94-97) onto the elevation axis:
+ *  d_bore_el     [T]   float32 full-rate boresight elevation
+ *  d_dx, d_dy    [D]   float32 offsets of observation.coords (rolled), radians
+ *  d_band        [D]   band index of each detector row
+ *  d_cal_axis_el [n_el] float32 elevation axis (rad); d_cal_values [n_bands][n_el]
+ * A detector elevation outside the axis gives NaN, as jax's interpolator does. */
+int mrx_spline_upsample_krj(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
+                            double ta0, double dta, const double* d_t, int T,
+                            const float* d_scale, const int32_t* d_rows,
+                            const float* d_bore_el, const float* d_dx,
+                            const float* d_dy, const int32_t* d_band,
+                            const float* d_cal_axis_el,
+                            const float* d_cal_values, int n_el, int n_bands,
+                            float* d_out, size_t ld_out);
+
+/* Full-rate detector pointing: Coordinates.broadcast at the sample rate
+ * (coords/coordinates.py:378-386 via transforms.py:10-29, float32;
+ * sim/observation.py:55-58).  d_az, d_el [T] float32 boresight; d_dx, d_dy [D];
+ * outputs [D][ld_out] float32 azimuth and elevation (radians). */
+int mrx_pointing_broadcast(mrx_ctx* ctx, const float* d_az, const float* d_el,
+                           int T, const float* d_dx, const float* d_dy, int D,
+                           float* d_az_out, float* d_el_out, size_t ld_out);
+
 /* Linear upsample of the coarse pwv to the full rate
  * (sim/atmosphere.py:30-37, interp1d linear + extrapolate); only the map/cmb
  * mixins consume it.  d_pwv [Ta*D] f64 time-major -> d_out [D][ld_out] f32. */

@@ -98,6 +98,8 @@ SIGNATURES = {
     "mrx_read_flags": (_i, [_vp, _vp, C.POINTER(C.c_uint32)]),
     "mrx_spline_prepare": (_i, [_vp, _vp, _i, _i, _vp]),
     "mrx_spline_upsample": (_i, [_vp, _vp, _i, _i, _d, _d, _vp, _i, _vp, _vp, _vp, _sz]),
+    "mrx_spline_upsample_krj": (_i, [_vp, _vp, _i, _i, _d, _d, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _sz]),
+    "mrx_pointing_broadcast": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _sz]),
     "mrx_linear_upsample": (_i, [_vp, _vp, _i, _i, _d, _d, _vp, _i, _vp, _sz]),
     "mrx_gauss_smooth2d": (_i, [_vp, _vp, _vp, _vp, _i, _i, _d, _d, _d]),
     "mrx_map_smooth": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _d]),

@@ -347,6 +347,133 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_kernel(
   }
 }
 
+// ---------------------------------------------------------------------------
+// Evaluation fused with TOD.to("K_RJ") (tod/tod.py:106-142,
+// calibration/functions.py:73-90): every sample is divided by
+//     den_b(el) = (0.5 if polarized else 1) k_B  Int tau_b(nu) exp(-opacity) dnu
+// looked up at the detector's own full-rate elevation (tod.py:90-93), which is
+// recomputed here from the full-rate boresight elevation and the detector
+// offsets exactly as coords/transforms.py:14-28 does (float32): el = asin(im),
+// im = sin(r)cos(p) sin(a) + cos(r) cos(a), a = el_bore - pi/2.  den_b is the
+// band's transmission-integral table collapsed by the host at the observation's
+// scalar (base temperature, zenith pwv) onto the elevation axis
+// (band/band.py:235-255), so the lookup is a 1-D lerp with jax's index rule.
+// Same tiling as spline_upsample_kernel (knot image fixed at 256 knots).
+struct CalDet {
+  float a_re;  // sin(r) cos(p)
+  float a_im;  // cos(r)
+  int band;
+  float scale;
+};
+
+__global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
+    const float2* __restrict__ ym, int D, int n, double ta0, double inv_dta,
+    const double* __restrict__ t, int T, const float* __restrict__ scale,
+    const int32_t* __restrict__ rows, const float* __restrict__ bore_el,
+    const float* __restrict__ dxs, const float* __restrict__ dys,
+    const int32_t* __restrict__ band, const float* __restrict__ cal_axis,
+    const float* __restrict__ cal_values, int n_el, int n_bands,
+    float* __restrict__ out, size_t ld, int vec_ok) {
+  constexpr int kMaxKnots = 256;
+  constexpr int kPitch = kMaxKnots + 1;
+  extern __shared__ float cal_lds[];  // [n_el axis][n_bands * n_el values]
+  __shared__ float2 tile[kTileDet * kPitch];
+  __shared__ CalDet cdet[kTileDet];
+  auto row_of = [&](int d) -> size_t { return rows ? (size_t)rows[d] : (size_t)d; };
+
+  const int s_tile = blockIdx.x * kTileSamples;
+  const int d0 = blockIdx.y * kTileDet;
+  const int sb = s_tile + threadIdx.x * kSamplesPerThread;
+  const int nd = min(kTileDet, D - d0);
+
+  SampleWeights w;
+  sample_weights(t, sb, T, n, ta0, inv_dta, w);
+  // boresight tilt of this thread's samples: cos/sin of (el - pi/2), float32
+  float ca[kSamplesPerThread], sa[kSamplesPerThread];
+#pragma unroll
+  for (int q = 0; q < kSamplesPerThread; ++q) {
+    const float a = bore_el[min(sb + q, T - 1)] - 1.57079637050628662109375f;
+    ca[q] = cosf(a);
+    sa[q] = sinf(a);
+  }
+
+  for (int i = threadIdx.x; i < n_el * (1 + n_bands); i += kBlock)
+    cal_lds[i] = i < n_el ? cal_axis[i] : cal_values[i - n_el];
+  if ((int)threadIdx.x < nd) {
+    const int d = d0 + threadIdx.x;
+    const float dx = dxs[d], dy = dys[d];
+    const float r = sqrtf(dx * dx + dy * dy);
+    const float p = atan2f(-dx, -dy);
+    CalDet c;
+    c.a_re = __fmul_rn(sinf(r), cosf(p));
+    c.a_im = cosf(r);
+    c.band = min(max(band[d], 0), n_bands - 1);
+    c.scale = scale ? scale[d] : 1.0f;
+    cdet[threadIdx.x] = c;
+  }
+
+  const int s_last = min(s_tile + kTileSamples, T) - 1;
+  const int jmin = interval_of((t[s_tile] - ta0) * inv_dta, n);
+  const int jmax = interval_of((t[s_last] - ta0) * inv_dta, n) + 1;
+  const int K = jmax - jmin + 1;
+  const bool use_lds = K <= kMaxKnots;
+  if (use_lds) {
+    const int dl = threadIdx.x & (kTileDet - 1);
+    const int d = d0 + dl;
+    for (int r = threadIdx.x / kTileDet; r < K; r += kBlock / kTileDet) {
+      float2 v = make_float2(0.f, 0.f);
+      if (d < D) v = ym[(size_t)(jmin + r) * D + d];
+      tile[dl * kPitch + r] = v;
+    }
+  }
+  __syncthreads();
+
+  const float* axis = cal_lds;
+  const float el_first = axis[0], el_last = axis[n_el - 1];
+  const float el_inv = (float)(n_el - 1) / (el_last - el_first);
+  const bool full = (sb + kSamplesPerThread <= T) && vec_ok;
+  for (int dl = 0; dl < nd; ++dl) {
+    const CalDet c = cdet[dl];
+    const float* G = cal_lds + n_el + c.band * n_el;
+    float o[kSamplesPerThread];
+#pragma unroll
+    for (int q = 0; q < kSamplesPerThread; ++q) {
+      float2 k0, k1;
+      if (use_lds) {
+        const int r = min(max(w.j[q] - jmin, 0), K - 2);
+        k0 = tile[dl * kPitch + r];
+        k1 = tile[dl * kPitch + r + 1];
+      } else {
+        k0 = ym[(size_t)w.j[q] * D + d0 + dl];
+        k1 = ym[(size_t)(w.j[q] + 1) * D + d0 + dl];
+      }
+      const float s = c.scale * spline_eval(w, q, k0, k1);
+      // detector elevation, transforms.py:20-28
+      const float im = __fadd_rn(__fmul_rn(c.a_re, sa[q]), __fmul_rn(c.a_im, ca[q]));
+      const float el = asinf(im);
+      // jax _find_indices on the elevation axis: guess, then settle
+      int i = min(max((int)fminf(fmaxf((el - el_first) * el_inv, -1.0f), 2.0e9f), 0), n_el - 2);
+      while (i < n_el - 2 && axis[i + 1] < el) ++i;
+      while (i > 0 && axis[i] >= el) --i;
+      const float lo = axis[i], hi = axis[i + 1];
+      const float wt = (el - lo) / (hi - lo);
+      float den = 0.0f + G[i] * (1.0f - wt);
+      den = den + G[i + 1] * wt;
+      if (!(el >= el_first && el <= el_last)) den = __builtin_nanf("");
+      o[q] = s / den;
+    }
+    float* dst = out + row_of(d0 + dl) * ld + sb;
+    if (full) {
+      const vfloat4 v = {o[0], o[1], o[2], o[3]};
+      __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(dst));
+    } else {
+#pragma unroll
+      for (int q = 0; q < kSamplesPerThread; ++q)
+        if (sb + q < T) dst[q] = o[q];
+    }
+  }
+}
+
 // Linear interpolation of the coarse pwv (float64, time-major) to the full
 // rate: sim/atmosphere.py:30-37.  Same tiling as the cubic kernel without the
 // LDS stage; only the optional map/cmb consumers need it.
@@ -367,6 +494,65 @@ __global__ __launch_bounds__(kBlock) void linear_upsample_kernel(
     const double y0 = pwv[(size_t)jj * D + d];
     const double y1 = pwv[(size_t)(jj + 1) * D + d];
     out[(size_t)d * ld + s] = (float)(y0 + u * (y1 - y0));
+  }
+}
+
+// Full-rate detector pointing (coords/coordinates.py:378-386 at the sample rate,
+// sim/observation.py:55-58): az/el [D][T] float32 from the boresight and the
+// detector offsets, the float32 chain of coords/transforms.py:10-29.  Same tile
+// as the TOD writer: 16 rows x 1024 samples, two 16-byte stores per row.
+__global__ __launch_bounds__(kBlock) void pointing_broadcast_kernel(
+    const float* __restrict__ az, const float* __restrict__ el, int T,
+    const float* __restrict__ dxs, const float* __restrict__ dys, int D,
+    float* __restrict__ az_out, float* __restrict__ el_out, size_t ld,
+    int vec_ok) {
+  __shared__ float4 pdet[kTileDet];  // sin(r)cos(p), cos(r), sin(r)sin(p)
+  const int d0 = blockIdx.y * kTileDet;
+  const int sb = blockIdx.x * kTileSamples + threadIdx.x * kSamplesPerThread;
+  const int nd = min(kTileDet, D - d0);
+  if ((int)threadIdx.x < nd) {
+    const float dx = dxs[d0 + threadIdx.x], dy = dys[d0 + threadIdx.x];
+    const float r = sqrtf(dx * dx + dy * dy);
+    const float p = atan2f(-dx, -dy);
+    const float sr = sinf(r);
+    pdet[threadIdx.x] = make_float4(__fmul_rn(sr, cosf(p)), cosf(r), __fmul_rn(sr, sinf(p)), 0.f);
+  }
+  float ca[kSamplesPerThread], sa[kSamplesPerThread], zz[kSamplesPerThread];
+#pragma unroll
+  for (int q = 0; q < kSamplesPerThread; ++q) {
+    const int s = min(sb + q, T - 1);
+    const float a = el[s] - 1.57079637050628662109375f;
+    ca[q] = cosf(a);
+    sa[q] = sinf(a);
+    zz[q] = az[s];
+  }
+  __syncthreads();
+  const bool full = (sb + kSamplesPerThread <= T) && vec_ok;
+  for (int dl = 0; dl < nd; ++dl) {
+    const float4 c = pdet[dl];
+    float oa[kSamplesPerThread], oe[kSamplesPerThread];
+#pragma unroll
+    for (int q = 0; q < kSamplesPerThread; ++q) {
+      const float re = __fsub_rn(__fmul_rn(c.x, ca[q]), __fmul_rn(c.y, sa[q]));
+      const float im = __fadd_rn(__fmul_rn(c.x, sa[q]), __fmul_rn(c.y, ca[q]));
+      oa[q] = __fadd_rn(atan2f(c.z, re), zz[q]);
+      oe[q] = asinf(im);
+    }
+    float* da = az_out + (size_t)(d0 + dl) * ld + sb;
+    float* de = el_out + (size_t)(d0 + dl) * ld + sb;
+    if (full) {
+      const vfloat4 va = {oa[0], oa[1], oa[2], oa[3]};
+      const vfloat4 ve = {oe[0], oe[1], oe[2], oe[3]};
+      __builtin_nontemporal_store(va, reinterpret_cast<vfloat4*>(da));
+      __builtin_nontemporal_store(ve, reinterpret_cast<vfloat4*>(de));
+    } else {
+#pragma unroll
+      for (int q = 0; q < kSamplesPerThread; ++q)
+        if (sb + q < T) {
+          da[q] = oa[q];
+          de[q] = oe[q];
+        }
+    }
   }
 }
 
@@ -427,6 +613,63 @@ int mrx_spline_upsample(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
     if (small) MRX_LAUNCH_UP(false, 64); else MRX_LAUNCH_UP(false, 256);
   }
 #undef MRX_LAUNCH_UP
+  MRX_CHECK_LAUNCH(ctx);
+  return MRX_OK;
+}
+
+int mrx_spline_upsample_krj(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
+                            double ta0, double dta, const double* d_t, int T,
+                            const float* d_scale, const int32_t* d_rows,
+                            const float* d_bore_el, const float* d_dx,
+                            const float* d_dy, const int32_t* d_band,
+                            const float* d_cal_axis_el,
+                            const float* d_cal_values, int n_el, int n_bands,
+                            float* d_out, size_t ld_out) {
+  if (!ctx) return MRX_ERR_INVALID;
+  MRX_REQUIRE(ctx, D >= 0 && T >= 0, "negative size");
+  if (D == 0 || T == 0) return MRX_OK;
+  MRX_REQUIRE(ctx, d_ym && d_t && d_out, "null pointer");
+  MRX_REQUIRE(ctx, d_bore_el && d_dx && d_dy && d_band && d_cal_axis_el &&
+                       d_cal_values,
+              "null calibration pointer");
+  MRX_REQUIRE(ctx, n_el >= 2 && n_bands >= 1 && (size_t)n_el * (1 + n_bands) <= 8192,
+              "calibration tables need 2 <= n_el and n_el*(1+n_bands) <= 8192");
+  MRX_REQUIRE(ctx, dta > 0.0, "coarse step must be positive");
+  MRX_REQUIRE(ctx, ld_out >= (size_t)T, "ld_out smaller than T");
+  if (Ta < 4)
+    return mrx_fail(ctx, MRX_ERR_UNSUPPORTED,
+                    "cubic interpolation needs at least 4 coarse samples");
+  dim3 grid(mrx_ceil_div(T, kTileSamples), mrx_ceil_div(D, kTileDet));
+  MRX_REQUIRE(ctx, grid.y <= 65535u, "D too large for one launch");
+  const int vec_ok =
+      (ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15u) == 0);
+  const size_t lds = sizeof(float) * (size_t)n_el * (1 + n_bands);
+  hipLaunchKernelGGL(spline_upsample_krj_kernel, grid, dim3(kBlock), lds,
+                     ctx->stream, reinterpret_cast<const float2*>(d_ym), D, Ta,
+                     ta0, 1.0 / dta, d_t, T, d_scale, d_rows, d_bore_el, d_dx,
+                     d_dy, d_band, d_cal_axis_el, d_cal_values, n_el, n_bands,
+                     d_out, ld_out, vec_ok);
+  MRX_CHECK_LAUNCH(ctx);
+  return MRX_OK;
+}
+
+int mrx_pointing_broadcast(mrx_ctx* ctx, const float* d_az, const float* d_el,
+                           int T, const float* d_dx, const float* d_dy, int D,
+                           float* d_az_out, float* d_el_out, size_t ld_out) {
+  if (!ctx) return MRX_ERR_INVALID;
+  MRX_REQUIRE(ctx, D >= 0 && T >= 0, "negative size");
+  if (D == 0 || T == 0) return MRX_OK;
+  MRX_REQUIRE(ctx, d_az && d_el && d_dx && d_dy && d_az_out && d_el_out,
+              "null pointer");
+  MRX_REQUIRE(ctx, ld_out >= (size_t)T, "ld_out smaller than T");
+  dim3 grid(mrx_ceil_div(T, kTileSamples), mrx_ceil_div(D, kTileDet));
+  MRX_REQUIRE(ctx, grid.y <= 65535u, "D too large for one launch");
+  const int vec_ok = (ld_out % 4 == 0) &&
+                     ((reinterpret_cast<uintptr_t>(d_az_out) & 15u) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(d_el_out) & 15u) == 0);
+  hipLaunchKernelGGL(pointing_broadcast_kernel, grid, dim3(kBlock), 0,
+                     ctx->stream, d_az, d_el, T, d_dx, d_dy, D, d_az_out,
+                     d_el_out, ld_out, vec_ok);
   MRX_CHECK_LAUNCH(ctx);
   return MRX_OK;
 }

@@ -66,6 +66,12 @@ class Band:
         return 1e12 * K_B * np.trapezoid(spectrum._emission * self.passband(spectrum.side_nu), spectrum.side_nu, axis=-1)
 
 
+    def transmission_table(self, spectrum):
+        """band/band.py:248-252: trapezoid(passband x exp(-opacity), nu) on the spectrum's
+        (T, pwv, el) grid, the integral ``TOD.to("K_RJ")`` divides by."""
+        return np.trapezoid(self.passband(spectrum.side_nu) * np.exp(-spectrum._opacity), x=spectrum.side_nu, axis=-1)
+
+
 def compute_angular_fwhm(fwhm_0, z=np.inf, n=1.0, nu=None):
     """beam/__init__.py:9-25."""
     w_0 = fwhm_0 / 2

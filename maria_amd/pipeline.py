@@ -263,6 +263,57 @@ class DevicePath:
         self.upsample(out)
         return out
 
+    # -- TOD.to("K_RJ") fused into the upsample -----------------------------------------
+    def set_calibration(self, cal_tables, base_temperature, zenith_pwv, bore_el, coords_offsets, polarized=None):
+        """Host part of the pW -> K_RJ conversion (tod/tod.py:90-142,
+        calibration/functions.py:73-90, band/band.py:235-255).
+
+        ``cal_tables``: per band a dict with axes ``T``, ``pwv``, ``el`` and ``values``
+        [nT, npwv, nel] = trapezoid(passband * exp(-opacity), nu); all bands share the
+        elevation axis (one spectrum).  The table is collapsed at the scalar
+        (``base_temperature``, ``zenith_pwv``) with jax's float32 index/weight rule onto the
+        elevation axis and scaled to den = factor * k_B * 1e12 * integral, so that
+        K_RJ = pW / den.  ``bore_el``: full-rate boresight elevation [T]; ``coords_offsets``:
+        the (rolled) offsets of observation.coords [D, 2] in the caller's detector order."""
+        dev = self.device
+        k_B = 1.380649e-23
+        nb = len(cal_tables)
+        el_axis = np.asarray(cal_tables[0]["el"], float)
+        polarized = np.zeros(nb, bool) if polarized is None else np.asarray(polarized, bool)
+        dens = np.zeros((nb, len(el_axis)), np.float32)
+        for b, tab in enumerate(cal_tables):
+            assert np.array_equal(np.asarray(tab["el"], float), el_axis), "bands must share the elevation axis"
+            vals = np.asarray(tab["values"], np.float32).astype(np.float64)
+            wts = []
+            for axis, x in ((tab["T"], base_temperature), (tab["pwv"], zenith_pwv)):
+                g = np.asarray(axis, np.float32)
+                xf = np.float32(x)
+                i = int(np.searchsorted(g, xf, side="left")) - 1
+                i = min(max(i, 0), len(g) - 2)
+                w = np.float32((xf - g[i]) / (g[i + 1] - g[i]))
+                oob = bool(xf < g[0] or xf > g[-1])
+                wts.append((i, float(w), oob))
+            (it, wt, ot), (ip, wp, op) = wts
+            sl = vals[it : it + 2, ip : ip + 2]  # [2, 2, nel]
+            col = ((1 - wt) * (1 - wp)) * sl[0, 0] + ((1 - wt) * wp) * sl[0, 1] + (wt * (1 - wp)) * sl[1, 0] + (wt * wp) * sl[1, 1]
+            if ot or op:
+                col = np.full_like(col, np.nan)
+            dens[b] = ((0.5 if polarized[b] else 1.0) * k_B * 1e12 * col).astype(np.float32)
+        off = np.asarray(coords_offsets, float)[self.det_slice][self.order]
+        self._cal = dict(
+            axis=_dev(el_axis, torch.float32, dev), values=_dev(dens, torch.float32, dev), n_el=len(el_axis), n_bands=nb,
+            bore_el=_dev(bore_el, torch.float32, dev), dx=_dev(off[:, 0], torch.float32, dev), dy=_dev(off[:, 1], torch.float32, dev),
+        )
+
+    def upsample_krj(self, out):
+        """mrx_spline_upsample_krj: the TOD in K_RJ (set_calibration first)."""
+        c = self._cal
+        self.ctx.call(
+            "mrx_spline_upsample_krj", ptr(self.d_ym), self.D, self.Ta, self.ta0, self.dta, ptr(self.d_t), self.T,
+            ptr(self.d_gain), ptr(self.d_rows), ptr(c["bore_el"]), ptr(c["dx"]), ptr(c["dy"]), ptr(self.d_band),
+            ptr(c["axis"]), ptr(c["values"]), c["n_el"], c["n_bands"], ptr(out), out.stride(0),
+        )
+
     def check_flags(self):
         """Raise the reference's errors if a sample left a screen or a table."""
         word = C.c_uint32()

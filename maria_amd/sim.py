@@ -153,11 +153,14 @@ class TOD:
         return self.coords.t
 
     def to(self, units):
+        """tod/tod.py:106-142.  ``Simulation.run(units=...)`` writes pW or K_RJ directly (the
+        K_RJ division is fused into the kernel that writes the TOD); other conversions of an
+        existing TOD stay with maria's calibration graph."""
         if units == self.units:
             return self
         raise NotImplementedError(
-            f"conversion {self.units} -> {units} (tod/tod.py:106-142) needs per-sample elevations at the full "
-            "rate: a follow-on row (SURVEY 8(f) rank 1 and 4); ask run() for units='pW'"
+            f"conversion {self.units} -> {units} of an existing TOD is not built; ask Simulation.run() "
+            "for units='K_RJ' or 'pW'"
         )
 
 
@@ -212,11 +215,14 @@ class Simulation:
             self.obs_list.append(obs)
 
     def run(self, units: str = "K_RJ"):
-        """sim/simulation.py:201-211."""
+        """sim/simulation.py:201-211: one TOD per plan, in ``units`` ("K_RJ", the reference
+        default, or "pW")."""
+        if units not in ("K_RJ", "pW"):
+            raise NotImplementedError(f"units '{units}': only 'K_RJ' and 'pW' are built (tod/tod.py:106-142)")
         tods = []
         for k, obs in enumerate(self.obs_list):
             t0 = ttime.monotonic()
-            tods.append(self.run_obs(obs).to(units))
+            tods.append(self.run_obs(obs, units=units))
             logger.info(f"Simulated observation {k + 1} of {len(self.obs_list)} in {ttime.monotonic() - t0:.2f} s")
         return tods
 
@@ -224,20 +230,33 @@ class Simulation:
     def _simulate_atmosphere(self, obs):
         obs.atmosphere.simulate_pwv(instrument=obs.instrument)
 
-    def _compute_atmospheric_loading(self, obs, gain=None):
+    def _compute_atmospheric_loading(self, obs, gain=None, units="pW", metadata=None):
         """Spline solve + cubic upsample of the coarse loading the sampling kernel already
-        wrote (emission and Mueller weight are fused into it), scaled by ``gain``."""
+        wrote (emission and Mueller weight are fused into it), scaled by ``gain``; with
+        ``units="K_RJ"`` the division of ``TOD.to`` (tod/tod.py:90-142) is fused in."""
         import torch
 
-        path = obs.atmosphere._device_path()
+        atm = obs.atmosphere
+        path = atm._device_path()
         path.set_gain(gain)
         out = torch.empty((path.D, path.T), dtype=torch.float32, device=path.device)
         path.prepare()
-        path.upsample(out)
+        if units == "K_RJ":
+            dets = obs.instrument.dets
+            sp = atm.spectrum
+            tables = [{"T": sp.side_base_temperature, "pwv": sp.side_zenith_pwv, "el": sp.side_elevation,
+                       "values": band.transmission_table(sp)} for band in dets.bands]
+            polarized = [bool((~np.isnan(dets.gamma[dets.band_index == b])).all()) for b in range(len(dets.bands))]
+            # the scalars TOD.to reads back from the metadata, rounded as run_obs stores them
+            path.set_calibration(tables, metadata["base_temperature"], metadata["pwv"], obs.boresight.el,
+                                 obs.coords.offsets, polarized)
+            path.upsample_krj(out)
+        else:
+            path.upsample(out)
         return out
 
-    def run_obs(self, obs) -> TOD:
-        """sim/simulation.py:213-272."""
+    def run_obs(self, obs, units: str = "pW") -> TOD:
+        """sim/simulation.py:213-272 (followed by ``.to(units)`` of :206)."""
         obs.loading = {}
         dets = obs.instrument.dets
         # per-detector gain error (simulation.py:239-247), fused into the upsample's store
@@ -245,9 +264,10 @@ class Simulation:
         gain = np.exp(gain_error * self._gain_rng.standard_normal(dets.n))
         metadata = {"atmosphere": False, "altitude": float(obs.site.altitude), "region": obs.site.region}
         if hasattr(obs, "atmosphere"):
-            self._simulate_atmosphere(obs)
-            loading = self._compute_atmospheric_loading(obs, gain=gain if np.any(gain_error) else None)
-            obs.loading["atmosphere"] = loading if self.device_output else loading.cpu().numpy()
             metadata.update(atmosphere=True, pwv=float(np.round(obs.atmosphere.weather.pwv, 3)),
                             base_temperature=float(np.round(obs.atmosphere.weather.temperature[0], 3)))
-        return TOD(data=obs.loading, dets=dets, coords=obs.coords, units="pW", metadata=metadata)
+            self._simulate_atmosphere(obs)
+            loading = self._compute_atmospheric_loading(obs, gain=gain if np.any(gain_error) else None,
+                                                        units=units, metadata=metadata)
+            obs.loading["atmosphere"] = loading if self.device_output else loading.cpu().numpy()
+        return TOD(data=obs.loading, dets=dets, coords=obs.coords, units=units, metadata=metadata)

@@ -227,6 +227,46 @@ def upsample_linear(ta, pwv, t):
 
 
 # ---------------------------------------------------------------------------
+# TOD.to("K_RJ")
+# ---------------------------------------------------------------------------
+
+K_B = 1.380649e-23  # maria/constants.py
+
+
+def transmission_integral_grid(passband, side_nu, opacity):
+    """band/band.py:248-252 with the default nu range: trapezoid over nu of
+    passband(nu) * exp(-opacity) on the spectrum's (T, pwv, el) grid."""
+    return np.trapezoid(passband(side_nu) * np.exp(-opacity), x=side_nu, axis=-1)
+
+
+def power_to_rayleigh_jeans(P_pW, table, base_temperature, zenith_pwv, elevation, polarized=False):
+    """tod/tod.py:106-142 -> Calibration("pW -> K_RJ") -> calibration/functions.py:73-90.
+
+    ``P_pW`` [Db, T] float32 is first brought to base units (x 1e-12, float32 array times
+    python float), the transmission integral is the float32 trilinear lookup of
+    ``table["values"]`` at (scalar T0, scalar pwv, per-sample elevation) (band.py:253-255), and
+    the quotient is taken in float32: python-float factors fold to float32 next to a float32
+    array (NEP 50)."""
+    P = np.asarray(P_pW, f32) * f32(1e-12)
+    integral = rgi_linear_f32((table["T"], table["pwv"], table["el"]), table["values"],
+                              (np.asarray(base_temperature), np.asarray(zenith_pwv), np.asarray(elevation, f32)))
+    den = f32((0.5 if polarized else 1.0) * K_B) * integral
+    return (P / den).astype(f32)
+
+
+def calibrate_to_krj(tod_pW, band_index, cal_tables, base_temperature, zenith_pwv, el_full, polarized=None):
+    """Per band as ``TOD.to`` loops (tod.py:124-137); ``el_full`` [D, T] float32 are the
+    detector elevations of observation.coords (observation.py:55-58)."""
+    out = np.empty_like(np.asarray(tod_pW, f32))
+    for b, table in enumerate(cal_tables):
+        mask = np.asarray(band_index) == b
+        if mask.any():
+            pol = bool(polarized[b]) if polarized is not None else False
+            out[mask] = power_to_rayleigh_jeans(tod_pW[mask], table, base_temperature, zenith_pwv, el_full[mask], pol)
+    return out
+
+
+# ---------------------------------------------------------------------------
 # screens
 # ---------------------------------------------------------------------------
 

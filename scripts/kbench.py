@@ -53,6 +53,22 @@ def main():
         total += med
         print(f"{name:22s} median {med:8.3f} ms  min {mn:8.3f} ms  alg {nbytes/1e9:7.3f} GB -> {nbytes/med/1e6:8.1f} GB/s")
     print(f"sum of medians {total:.3f} ms -> {D*T/total/1e6:.1f} G det-samples/s; point-layers/s in sample: {D*Ta*L/1e6:.1f} M")
+    # follow-on rows: K_RJ-fused writer and full-rate pointing
+    from maria_amd._lib import ptr
+    az_full, el_full = synthetic.daisy_scan(p["t"])
+    T_, pw_, el_ = np.array([250.0, 270.0, 290.0]), np.linspace(0, 10, 21), np.radians(np.linspace(10, 90, 33))
+    el_[-1] = np.radians(90.1)
+    tabs = [{"T": T_, "pwv": pw_, "el": el_, "values": 2e10 * np.exp(-(0.03 + 0.01 * pw_[None, :, None]) / np.sin(np.minimum(el_, np.pi / 2))[None, None, :]) * np.ones((3, 1, 1))}
+            for _ in p["tables"]]
+    path.set_calibration(tabs, 273.15, 1.0, el_full, p["offsets"])
+    med, mn = timeit(lambda: path.upsample_krj(tod), reps)
+    print(f"upsample + K_RJ        median {med:8.3f} ms  min {mn:8.3f} ms  -> {(4.0*D*T)/med/1e6:8.1f} GB/s written")
+    d_az = torch.as_tensor(az_full.astype(np.float32)).cuda()
+    d_el = torch.as_tensor(el_full.astype(np.float32)).cuda()
+    out_el = torch.empty_like(tod)
+    med, mn = timeit(lambda: path.ctx.call("mrx_pointing_broadcast", ptr(d_az), ptr(d_el), T, ptr(path.d_dx), ptr(path.d_dy), D, ptr(tod), ptr(out_el), T), reps)
+    print(f"pointing_broadcast     median {med:8.3f} ms  min {mn:8.3f} ms  -> {(8.0*D*T)/med/1e6:8.1f} GB/s written")
+    del out_el
     print("plan_info (uniform axes, tables in LDS):", path.plan_info())
     for chain in (0, 1):
         for arrays in (0, 1):

@@ -1,0 +1,116 @@
+"""GPU tests of the follow-on rows built behind the path:
+full-rate detector pointing and the pW -> K_RJ conversion fused into the TOD writer."""
+
+import numpy as np
+import pytest
+
+from helpers import rel_err, small_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def test_full_rate_pointing_matches_oracle(gpu_ctx):
+    """mrx_pointing_broadcast vs coords/transforms.py:10-29 restated in numpy float32."""
+    import torch
+
+    from maria_amd._lib import ptr
+    from oracle import hotpath
+
+    rng = np.random.default_rng(0)
+    D, T = 77, 4099  # neither a multiple of the tile
+    az = np.cumsum(rng.normal(0, 1e-4, T)) + 0.8
+    el = np.cumsum(rng.normal(0, 1e-4, T)) + 1.0
+    off = rng.normal(0, 0.01, (D, 2))
+    ref_az, ref_el = hotpath.broadcast(off, az, el)
+    dev = "cuda:0"
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)  # noqa: E731
+    ld = T + 1
+    out_az = torch.full((D, ld), -9.0, dtype=torch.float32, device=dev)
+    out_el = torch.full((D, ld), -9.0, dtype=torch.float32, device=dev)
+    d_az, d_el, d_dx, d_dy = t(az), t(el), t(off[:, 0]), t(off[:, 1])  # keep the inputs alive
+    gpu_ctx.call("mrx_pointing_broadcast", ptr(d_az), ptr(d_el), T, ptr(d_dx), ptr(d_dy), D, ptr(out_az), ptr(out_el), ld)
+    ga, ge = out_az.cpu().numpy(), out_el.cpu().numpy()
+    assert (ga[:, T:] == -9).all() and (ge[:, T:] == -9).all()
+    # float32 trigonometry of two libraries: a few ulp at most
+    assert np.abs(ga[:, :T] - ref_az).max() <= 6e-7 and np.abs(ge[:, :T] - ref_el).max() <= 6e-7
+
+
+def _cal_tables(n_bands):
+    """Synthetic transmission-integral tables on a (T, pwv, el) grid (band.py:248-252 shape)."""
+    T = np.array([250.0, 270.0, 290.0])
+    pwv = np.linspace(0.0, 10.0, 21)
+    el = np.radians(np.linspace(10.0, 90.0, 33))
+    el[-1] = np.radians(90.1)
+    tables = []
+    for b in range(n_bands):
+        tau = (0.03 + 0.02 * b + (0.01 + 0.02 * b) * pwv[None, :, None]) / np.sin(np.minimum(el, np.pi / 2))[None, None, :]
+        tables.append({"T": T, "pwv": pwv, "el": el, "values": (20e9 + 5e9 * b) * (T[:, None, None] / 270.0) ** 0.1 * np.exp(-tau)})
+    return tables
+
+
+def test_krj_upsample_matches_oracle(gpu_ctx):
+    """mrx_spline_upsample_krj vs TOD.to("K_RJ") restated (tod/tod.py:106-142,
+    calibration/functions.py:73-90): the oracle divides the oracle's pW TOD by the
+    float32 trilinear transmission integral at the detectors' full-rate elevations."""
+    import torch
+
+    from maria_amd.pipeline import DevicePath
+    from maria_amd import synthetic
+    from oracle import hotpath
+
+    p = small_problem(n_det=45, n_bands=2, n_layers=2, gain=True)
+    az_full, el_full = synthetic.daisy_scan(p["t"])  # the boresight the coarse grid came from
+    roll = np.radians(17.0)
+    R = np.array([[np.cos(roll), -np.sin(roll)], [np.sin(roll), np.cos(roll)]])
+    coords_offsets = p["offsets"] @ R.T  # observation.py:55-58
+    tables = _cal_tables(2)
+    T0r, pwvr = 273.15, 1.0
+    polarized = [False, True]
+
+    path = DevicePath(p, device="cuda:0", ctx=gpu_ctx)
+    path.sample()
+    path.prepare()
+    path.set_calibration(tables, T0r, pwvr, el_full, coords_offsets, polarized)
+    out = torch.empty((path.D, path.T), dtype=torch.float32, device="cuda:0")
+    path.upsample_krj(out)
+    got = out.cpu().numpy()
+
+    tod_pw = hotpath.run_path(p)
+    _, el_det = hotpath.broadcast(coords_offsets, az_full, el_full)
+    ref = hotpath.calibrate_to_krj(tod_pw, p["band_index"], tables, T0r, pwvr, el_det, polarized)
+    assert got.shape == ref.shape and np.isfinite(got).all()
+    assert rel_err(got, ref) <= 1e-5
+    # the polarized band is divided by half the integral: exactly twice the unpolarized value
+    path.set_calibration(tables, T0r, pwvr, el_full, coords_offsets, [False, False])
+    out2 = torch.empty_like(out)
+    path.upsample_krj(out2)
+    got2 = out2.cpu().numpy()
+    b1 = p["band_index"] == 1
+    assert np.array_equal(got[b1], 2.0 * got2[b1]) and np.array_equal(got[~b1], got2[~b1])
+
+
+def test_run_default_units_are_krj(gpu_ctx):
+    """Simulation.run() with the reference's default units against the oracle chain."""
+    from maria_amd.instrument import Band, Detectors, Instrument, Site
+    from maria_amd.sim import Plan, Simulation
+    from oracle import hotpath
+
+    bands = [Band(center=93e9, width=27e9, shape="top_hat", name="f093"), Band(center=150e9, width=41e9, shape="top_hat", name="f150")]
+    inst = Instrument(Detectors.hexagon(37, 0.3, bands, primary_size=6.0))
+    plan = Plan.daisy(start_time=1.7e9, duration=30.0, sample_rate=50.0, scan_center=(45.0, 55.0), radius=0.4, speed=0.4)
+    sim = Simulation(inst, plan, Site(altitude=1000.0), atmosphere="2d", atmosphere_kwargs={"n_layers": 3, "seed": 2}, noise=False)
+    (tod,) = sim.run()
+    assert tod.units == "K_RJ"
+    k = tod.data["atmosphere"]
+    obs = sim.obs_list[0]
+    atm, dets = obs.atmosphere, inst.dets
+    # same realisation in pW through the plain writer
+    path = atm._device_path()
+    pw = path.run().cpu().numpy()
+    sp = atm.spectrum
+    tables = [{"T": sp.side_base_temperature, "pwv": sp.side_zenith_pwv, "el": sp.side_elevation,
+               "values": hotpath.transmission_integral_grid(b.passband, sp.side_nu, sp._opacity)} for b in dets.bands]
+    _, el_det = hotpath.broadcast(obs.coords.offsets, obs.boresight.az, obs.boresight.el)
+    ref = hotpath.calibrate_to_krj(pw, dets.band_index, tables, tod.metadata["base_temperature"], tod.metadata["pwv"], el_det)
+    assert rel_err(k, ref) <= 1e-5
+    assert 1.0 < np.median(k) < 300.0  # Rayleigh-Jeans kelvin of a ~1 mm pwv sky

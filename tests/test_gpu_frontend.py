@@ -82,8 +82,11 @@ def test_reference_error_behaviour(gpu_ctx):
     with pytest.raises(NotImplementedError):
         Simulation(inst, plan, site, atmosphere="2d", map="something")
     sim = Simulation(inst, plan, site, atmosphere="2d", noise=False)
-    with pytest.raises(NotImplementedError, match="K_RJ"):
-        sim.run()  # the reference's default units need the calibration pass (follow-on)
+    with pytest.raises(NotImplementedError, match="K_CMB"):
+        sim.run(units="K_CMB")  # only the reference's default K_RJ and pW are built
+    (tod,) = sim.run(units="pW")
+    with pytest.raises(NotImplementedError):
+        tod.to("K_RJ")  # converting an existing TOD stays with maria's calibration graph
 
 
 def test_screen_statistics_through_the_front_end(gpu_ctx):
