@@ -23,6 +23,8 @@
 // itself (the form m is stored in) and ~1e-12 of y.  Within 16 knots of an end
 // the sweeps start at the true boundary and are exact.  Lanes are consecutive detectors (time-major data),
 // so every index and coefficient below is wave-uniform.
+#include <type_traits>
+
 #include "mrx_internal.h"
 
 namespace {
@@ -364,7 +366,20 @@ struct CalDet {
   float a_im;  // cos(r)
   int band;
   float scale;
+  float dy, sdy, cdy;  // vertical offset and its sine / cosine
 };
+
+// K_RJ of one sample: s / lerp(den) with jax's weight (x - lo)/(hi - lo); NaN
+// outside the axis (jax fill value).
+__device__ __forceinline__ float krj_value(float s, float el, float2 lo,
+                                           float2 hi, float el_first,
+                                           float el_last) {
+  const float wt = (el - lo.x) * __builtin_amdgcn_rcpf(hi.x - lo.x);
+  float den = 0.0f + lo.y * (1.0f - wt);
+  den = den + hi.y * wt;
+  if (!(el >= el_first && el <= el_last)) den = __builtin_nanf("");
+  return s * __builtin_amdgcn_rcpf(den);
+}
 
 __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
     const float2* __restrict__ ym, int D, int n, double ta0, double inv_dta,
@@ -376,7 +391,7 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
     float* __restrict__ out, size_t ld, int vec_ok) {
   constexpr int kMaxKnots = 256;
   constexpr int kPitch = kMaxKnots + 1;
-  extern __shared__ float cal_lds[];  // [n_el axis][n_bands * n_el values]
+  extern __shared__ float2 cal_lds[];  // [n_bands][n_el] pairs (axis node, den value)
   __shared__ float2 tile[kTileDet * kPitch];
   __shared__ CalDet cdet[kTileDet];
   auto row_of = [&](int d) -> size_t { return rows ? (size_t)rows[d] : (size_t)d; };
@@ -389,16 +404,17 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
   SampleWeights w;
   sample_weights(t, sb, T, n, ta0, inv_dta, w);
   // boresight tilt of this thread's samples: cos/sin of (el - pi/2), float32
-  float ca[kSamplesPerThread], sa[kSamplesPerThread];
+  float ca[kSamplesPerThread], sa[kSamplesPerThread], eb[kSamplesPerThread];
 #pragma unroll
   for (int q = 0; q < kSamplesPerThread; ++q) {
-    const float a = bore_el[min(sb + q, T - 1)] - 1.57079637050628662109375f;
-    ca[q] = cosf(a);
-    sa[q] = sinf(a);
+    eb[q] = bore_el[min(sb + q, T - 1)];
+    const float a = eb[q] - 1.57079637050628662109375f;
+    ca[q] = cosf(a);  // = sin(el_bore) up to the rounding of float32(pi/2)
+    sa[q] = sinf(a);  // = -cos(el_bore)
   }
 
-  for (int i = threadIdx.x; i < n_el * (1 + n_bands); i += kBlock)
-    cal_lds[i] = i < n_el ? cal_axis[i] : cal_values[i - n_el];
+  for (int i = threadIdx.x; i < n_el * n_bands; i += kBlock)
+    cal_lds[i] = make_float2(cal_axis[i % n_el], cal_values[i]);
   if ((int)threadIdx.x < nd) {
     const int d = d0 + threadIdx.x;
     const float dx = dxs[d], dy = dys[d];
@@ -409,6 +425,9 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
     c.a_im = cosf(r);
     c.band = min(max(band[d], 0), n_bands - 1);
     c.scale = scale ? scale[d] : 1.0f;
+    c.dy = dy;
+    c.sdy = sinf(dy);
+    c.cdy = cosf(dy);
     cdet[threadIdx.x] = c;
   }
 
@@ -428,18 +447,21 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
   }
   __syncthreads();
 
-  const float* axis = cal_lds;
-  const float el_first = axis[0], el_last = axis[n_el - 1];
+  const float el_first = cal_lds[0].x, el_last = cal_lds[n_el - 1].x;
   const float el_inv = (float)(n_el - 1) / (el_last - el_first);
   const bool full = (sb + kSamplesPerThread <= T) && vec_ok;
+  // the loop body is instantiated once per knot source so that each instance
+  // addresses one memory space (a runtime select would force flat loads)
+  auto body = [&](auto from_lds) {
   for (int dl = 0; dl < nd; ++dl) {
     const CalDet c = cdet[dl];
-    const float* G = cal_lds + n_el + c.band * n_el;
-    float o[kSamplesPerThread];
+    const float2* G = cal_lds + c.band * n_el;  // (axis node, den)
+    float o[kSamplesPerThread], sv[kSamplesPerThread], ev[kSamplesPerThread];
+    bool miss = false;
 #pragma unroll
     for (int q = 0; q < kSamplesPerThread; ++q) {
       float2 k0, k1;
-      if (use_lds) {
+      if constexpr (decltype(from_lds)::value) {
         const int r = min(max(w.j[q] - jmin, 0), K - 2);
         k0 = tile[dl * kPitch + r];
         k1 = tile[dl * kPitch + r + 1];
@@ -447,20 +469,43 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
         k0 = ym[(size_t)w.j[q] * D + d0 + dl];
         k1 = ym[(size_t)(w.j[q] + 1) * D + d0 + dl];
       }
-      const float s = c.scale * spline_eval(w, q, k0, k1);
-      // detector elevation, transforms.py:20-28
+      sv[q] = c.scale * spline_eval(w, q, k0, k1);
+      // detector elevation (transforms.py:20-28): im = sin(el) as the chain computes
+      // it, then el = asin(im) by one Newton step from el0 = el_bore + dy, whose
+      // sine and cosine follow from the angle-addition formulas (no inverse
+      // trigonometry per sample); |el - el0| <= r^2 tan(el)/2 ~ 3e-4 rad, so the
+      // second-order step is exact to float32 rounding
       const float im = __fadd_rn(__fmul_rn(c.a_re, sa[q]), __fmul_rn(c.a_im, ca[q]));
-      const float el = asinf(im);
-      // jax _find_indices on the elevation axis: guess, then settle
+      const float s0 = ca[q] * c.cdy - sa[q] * c.sdy;   // sin(el_bore + dy)
+      const float c0 = -sa[q] * c.cdy - ca[q] * c.sdy;  // cos(el_bore + dy)
+      const float rc0 = __builtin_amdgcn_rcpf(c0);
+      const float dl1 = (im - s0) * rc0;
+      float el = (eb[q] + c.dy) + dl1 * (1.0f + 0.5f * dl1 * s0 * rc0);
+      // within ~15 deg of the zenith the expansion loses accuracy: take asin there
+      const bool steep = !(c0 > 0.25f);
+      if (__builtin_amdgcn_ballot_w64(steep) != 0)
+        if (steep) el = asinf(im);
+      ev[q] = el;
+      // jax _find_indices on the elevation axis: arithmetic guess and one corrective
+      // step either way (the axis is uniform but for its last node)
       int i = min(max((int)fminf(fmaxf((el - el_first) * el_inv, -1.0f), 2.0e9f), 0), n_el - 2);
-      while (i < n_el - 2 && axis[i + 1] < el) ++i;
-      while (i > 0 && axis[i] >= el) --i;
-      const float lo = axis[i], hi = axis[i + 1];
-      const float wt = (el - lo) / (hi - lo);
-      float den = 0.0f + G[i] * (1.0f - wt);
-      den = den + G[i + 1] * wt;
-      if (!(el >= el_first && el <= el_last)) den = __builtin_nanf("");
-      o[q] = s / den;
+      float2 lo = G[i], hi = G[i + 1];
+      i += (int)(hi.x < el && i < n_el - 2) - (int)(lo.x >= el && i > 0);
+      lo = G[i];
+      hi = G[i + 1];
+      miss |= (i < n_el - 2 && hi.x < el) || (i > 0 && lo.x >= el);
+      o[q] = krj_value(sv[q], el, lo, hi, el_first, el_last);
+    }
+    if (__builtin_amdgcn_ballot_w64(miss) != 0) {
+      // an axis that is not near-uniform: full search (never for am tables)
+#pragma unroll 1
+      for (int q = 0; q < kSamplesPerThread; ++q) {
+        const float el = ev[q];
+        int i = min(max((int)fminf(fmaxf((el - el_first) * el_inv, -1.0f), 2.0e9f), 0), n_el - 2);
+        while (i < n_el - 2 && G[i + 1].x < el) ++i;
+        while (i > 0 && G[i].x >= el) --i;
+        o[q] = krj_value(sv[q], el, G[i], G[i + 1], el_first, el_last);
+      }
     }
     float* dst = out + row_of(d0 + dl) * ld + sb;
     if (full) {
@@ -472,6 +517,8 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
         if (sb + q < T) dst[q] = o[q];
     }
   }
+  };
+  if (use_lds) body(std::true_type{}); else body(std::false_type{});
 }
 
 // Linear interpolation of the coarse pwv (float64, time-major) to the full
@@ -643,7 +690,7 @@ int mrx_spline_upsample_krj(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
   MRX_REQUIRE(ctx, grid.y <= 65535u, "D too large for one launch");
   const int vec_ok =
       (ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15u) == 0);
-  const size_t lds = sizeof(float) * (size_t)n_el * (1 + n_bands);
+  const size_t lds = sizeof(float2) * (size_t)n_el * n_bands;
   hipLaunchKernelGGL(spline_upsample_krj_kernel, grid, dim3(kBlock), lds,
                      ctx->stream, reinterpret_cast<const float2*>(d_ym), D, Ta,
                      ta0, 1.0 / dta, d_t, T, d_scale, d_rows, d_bore_el, d_dx,
