@@ -46,6 +46,7 @@ def parse_args():
     ap.add_argument("--no-screens-in-step", action="store_true", help="time TOD synthesis only (screens generated once)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the launch on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--no-allgather", action="store_true", help="skip the untimed all-gather epilogue at N > 1")
     ap.add_argument("--streams", type=int, default=1, choices=[1, 2],
                     help="2: pipeline independent observations (steps) on two HIP streams so the VALU-bound "
                     "stages of one overlap the HBM-bound upsample of the other; per-kernel times then include contention")
@@ -248,6 +249,33 @@ def main():
             f"(sampling + emission + cubic upsample; numpy/scipy single-threaded): {cpu_s:.2f} s",
             "parity_max_rel_err_vs_gpu": err,
         }
+    # Outside the timed region: the optional epilogue the north star names, one RCCL
+    # all-gather of the TOD over xGMI, streamed in time chunks (the data path
+    # itself needs no collective).  Reported, never part of `value`; a failure here must not
+    # lose the benchmark line.
+    if world > 1 and not args.no_allgather:
+        try:
+            from maria_amd.dist import stream_gathered_tod
+
+            checksum = torch.zeros((), dtype=torch.float64, device=device)
+
+            def consume(s, block):
+                checksum.add_(block[:, ::4096].sum(dtype=torch.float64))
+
+            barrier()
+            t0 = time.perf_counter()
+            gather_src = tod if args.backend == "nccl" else tod[:, : 4 * 24000].cpu()
+            nbytes = stream_gathered_tod(gather_src, n_total, 24000, consume if args.backend == "nccl" else None)
+            barrier()
+            dt = time.perf_counter() - t0
+            result["allgather_epilogue"] = {
+                "ms": 1e3 * dt, "received_GB_per_rank": nbytes / 1e9,
+                "GBps_per_rank": nbytes / dt / 1e9 if dt > 0 else None,
+                "time_chunk": 24000, "in_timed_region": False,
+            }
+        except Exception as exc:  # pragma: no cover - depends on the node
+            result["allgather_epilogue"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+
     if rank == 0:
         print(json.dumps(result))
     if world > 1:

@@ -52,3 +52,36 @@ def all_gather_tod(local: torch.Tensor, n_det: int, align: int = 16, time_chunk:
         dist.all_gather_into_tensor(recv, send)
         out[:, s:e] = recv[:n_det]
     return out
+
+
+def stream_gathered_tod(local: torch.Tensor, n_det: int, time_chunk: int, consume=None, align: int = 16) -> int:
+    """All-gather the TOD one time chunk at a time into a reusable staging buffer and
+    hand each gathered [n_det, chunk] block to ``consume`` (the full gather of a large
+    configuration does not fit one GPU; a consumer writes or reduces each block before the
+    next arrives).  Returns the number of bytes received per rank."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        if consume is not None:
+            consume(0, local)
+        return 0
+    world = dist.get_world_size()
+    per = shard_bounds(n_det, world, 0, align)[1]
+    T = local.shape[1]
+    send = torch.zeros((per, time_chunk), dtype=local.dtype, device=local.device)
+    recv = torch.empty((world * per, time_chunk), dtype=local.dtype, device=local.device)
+    received = 0
+    for s in range(0, T, time_chunk):
+        e = min(s + time_chunk, T)
+        if e - s == time_chunk:
+            send[: local.shape[0]].copy_(local[:, s:e])
+            dist.all_gather_into_tensor(recv, send)
+            block = recv[:n_det]
+        else:  # ragged tail
+            snd = torch.zeros((per, e - s), dtype=local.dtype, device=local.device)
+            snd[: local.shape[0]] = local[:, s:e]
+            rcv = torch.empty((world * per, e - s), dtype=local.dtype, device=local.device)
+            dist.all_gather_into_tensor(rcv, snd)
+            block = rcv[:n_det]
+        received += (world - 1) * per * (e - s) * local.element_size()
+        if consume is not None:
+            consume(s, block)
+    return received

@@ -53,6 +53,20 @@ def main():
         total += med
         print(f"{name:22s} median {med:8.3f} ms  min {mn:8.3f} ms  alg {nbytes/1e9:7.3f} GB -> {nbytes/med/1e6:8.1f} GB/s")
     print(f"sum of medians {total:.3f} ms -> {D*T/total/1e6:.1f} G det-samples/s; point-layers/s in sample: {D*Ta*L/1e6:.1f} M")
+    # does the writer slow down in sequence?  (event-timed inside the sequence)
+    def timed_in_sequence(pre):
+        evs = []
+        for _ in range(reps):
+            pre()
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(); path.upsample(tod); b.record(); evs.append((a, b))
+        torch.cuda.synchronize()
+        return float(np.median([a.elapsed_time(b) for a, b in evs]))
+    print(f"upsample after upsample : {timed_in_sequence(lambda: path.upsample(tod)):.3f} ms")
+    print(f"upsample after prepare  : {timed_in_sequence(path.prepare):.3f} ms")
+    print(f"upsample after sample   : {timed_in_sequence(path.sample):.3f} ms")
+    print(f"upsample after screens  : {timed_in_sequence(path.generate_screens):.3f} ms")
+    print(f"upsample after full step: {timed_in_sequence(lambda: (path.generate_screens(), path.sample(), path.prepare())):.3f} ms")
     # follow-on rows: K_RJ-fused writer and full-rate pointing
     from maria_amd._lib import ptr
     az_full, el_full = synthetic.daisy_scan(p["t"])

@@ -34,6 +34,10 @@ def _worker(rank, world, port, n_det, T, q):
         local = rows * 1000 + torch.arange(T, dtype=torch.float32)[None]  # value identifies (det, sample)
         full = mdist.all_gather_tod(local, n_det, time_chunk=7)
         expect = torch.arange(n_det, dtype=torch.float32)[:, None] * 1000 + torch.arange(T, dtype=torch.float32)[None]
+        # streamed variant: every gathered chunk equals the matching columns of the whole
+        seen = []
+        nbytes = mdist.stream_gathered_tod(local, n_det, 5, lambda s0, blk: seen.append(bool(torch.equal(blk, expect[:, s0 : s0 + blk.shape[1]]))))
+        assert all(seen) and len(seen) == -(-T // 5) and nbytes > 0
         # weak-scaling accounting as bench.py does it: max over ranks of the elapsed time
         tmax = torch.tensor([float(rank + 1)], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
