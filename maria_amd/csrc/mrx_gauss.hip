@@ -41,20 +41,21 @@ __global__ __launch_bounds__(kBlock) void gauss_x_kernel(
     const double* __restrict__ taps, int radius) {
   extern __shared__ double ldsd[];
   const int span = kXCols + 2 * radius;
-  double* w = ldsd + span;  // taps[radius + k], k = 0..radius: LDS broadcast reads
   const int y = blockIdx.y;
   const int x0 = blockIdx.x * kXCols;
   const float* src = in + (size_t)y * nx;
   for (int i = threadIdx.x; i < span; i += kBlock)
     ldsd[i] = (double)src[reflect_index(x0 - radius + i, nx)];
-  for (int k = threadIdx.x; k <= radius; k += kBlock) w[k] = taps[radius + k];
   __syncthreads();
   const int x = x0 + threadIdx.x;
   if (x >= nx) return;
+  // the pass is LDS-bound (35 data reads per output): keep the taps out of LDS,
+  // they are wave-uniform and come through the scalar cache
   const double* c = ldsd + threadIdx.x + radius;
-  double acc = w[0] * c[0];
-#pragma unroll 4
-  for (int k = 1; k <= radius; ++k) acc += (c[-k] + c[k]) * w[k];
+  const double* tw = taps + radius;
+  double acc = tw[0] * c[0];
+#pragma unroll 8
+  for (int k = 1; k <= radius; ++k) acc += (c[-k] + c[k]) * tw[k];
   out[(size_t)y * nx + x] = (float)acc;
 }
 
@@ -69,6 +70,8 @@ constexpr int kYBlockRows = 4;  // output rows per thread per sweep
 __global__ __launch_bounds__(kBlock) void gauss_y_kernel(
     const float* __restrict__ in, float* __restrict__ out, int ny, int nx,
     const double* __restrict__ taps, int radius, int tile_rows) {
+  // float32 image (this pass waits on memory, not on LDS: a small image keeps
+  // 8 workgroups per CU in flight); values widen to float64 as they are read
   extern __shared__ double ldsd[];
   const int lane = threadIdx.x % kYCols;
   const int grp = threadIdx.x / kYCols;     // 0..3
@@ -76,11 +79,12 @@ __global__ __launch_bounds__(kBlock) void gauss_y_kernel(
   const int y0 = blockIdx.y * tile_rows;
   const int span = tile_rows + 2 * radius;
   const int ntap = 2 * radius + 1;
-  double* wz = ldsd + span * kYCols;  // [3 zeros][ntap taps][3 zeros]
+  double* wz = ldsd;                          // [3 zeros][ntap taps][3 zeros]
+  float* img = reinterpret_cast<float*>(ldsd + ntap + 6);
   const int xs = min(x, nx - 1);
   for (int i = grp; i < span; i += kBlock / kYCols)
-    ldsd[i * kYCols + lane] =
-        (double)in[(size_t)reflect_index(y0 - radius + i, ny) * nx + xs];
+    img[i * kYCols + lane] =
+        in[(size_t)reflect_index(y0 - radius + i, ny) * nx + xs];
   for (int k = threadIdx.x; k < ntap + 6; k += kBlock)
     wz[k] = (k >= 3 && k < ntap + 3) ? taps[k - 3] : 0.0;
   __syncthreads();
@@ -89,11 +93,11 @@ __global__ __launch_bounds__(kBlock) void gauss_y_kernel(
   for (int r0 = grp * rows_per_grp; r0 < (grp + 1) * rows_per_grp; r0 += kYBlockRows) {
     if (y0 + r0 >= ny) break;
     // outputs r0 .. r0+3 read LDS rows r0 .. r0 + 2 radius + 3
-    const double* c = ldsd + r0 * kYCols + lane;
+    const float* c = img + r0 * kYCols + lane;
     double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
     double t1 = 0.0, t2 = 0.0, t3 = 0.0;  // wz[k+2], wz[k+1], wz[k]
     for (int k = 0; k < ntap + 3; ++k) {
-      const double v = c[k * kYCols];
+      const double v = (double)c[k * kYCols];
       const double t0 = wz[k + 3];  // tap of output row 0 at window step k
       acc0 += t0 * v;
       acc1 += t1 * v;
@@ -198,7 +202,7 @@ int smooth_axis1(mrx_ctx* ctx, const float* in, float* out, int ny, int nx,
   const double* d_taps = nullptr;
   int rc = get_taps(ctx, sigma, truncate, &radius, &d_taps);
   if (rc != MRX_OK) return rc;
-  const size_t lds = (size_t)(kXCols + 3 * radius + 1) * sizeof(double);
+  const size_t lds = (size_t)(kXCols + 2 * radius) * sizeof(double);
   if ((rc = raise_lds_cap(ctx)) != MRX_OK) return rc;
   if (lds > kMaxLds)
     return mrx_fail(ctx, MRX_ERR_UNSUPPORTED,
@@ -221,10 +225,10 @@ int smooth_axis0(mrx_ctx* ctx, const float* in, float* out, int ny, int nx,
   // output rows per tile: up to 64 while the image stays under 40 KiB (4 per CU)
   int tile_rows = 64;
   while (tile_rows > 16 &&
-         (size_t)(tile_rows + 2 * radius) * kYCols * sizeof(double) > 40 * 1024)
+         (size_t)(tile_rows + 2 * radius) * kYCols * sizeof(float) > 20 * 1024)
     tile_rows /= 2;
-  // + 3 rows of slack: the 4-row sweep reads up to row r0 + 2 radius + 3
-  const size_t lds = ((size_t)(tile_rows + 2 * radius + 3) * kYCols + 2 * radius + 8) * sizeof(double);
+  const size_t lds = (size_t)(2 * radius + 8) * sizeof(double) +
+                     (size_t)(tile_rows + 2 * radius) * kYCols * sizeof(float);
   if (lds > kMaxLds)
     return mrx_fail(ctx, MRX_ERR_UNSUPPORTED,
                     "gaussian radius %d along y exceeds the LDS tile", radius);
