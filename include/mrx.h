@@ -81,7 +81,9 @@ enum {
   MRX_OPT_AXIS_RECOMPUTE = 1,
   MRX_OPT_SAMPLE_TIMES = 2,
   MRX_OPT_SAMPLE_CHUNK = 3, /* time steps per workgroup (tuning; 0 = automatic) */
-  MRX_OPT_COUNT = 4
+  MRX_OPT_UPSAMPLE_GROUPS = 4, /* 16-row detector tiles per workgroup of the TOD
+                                  writer (tuning; 0 = automatic) */
+  MRX_OPT_COUNT = 8
 };
 int mrx_set_option(mrx_ctx* ctx, int option, int value);
 const char* mrx_last_error(const mrx_ctx* ctx);

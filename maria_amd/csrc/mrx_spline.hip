@@ -265,7 +265,7 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_kernel(
     const float2* __restrict__ ym, int D, int n, double ta0, double inv_dta,
     const double* __restrict__ t, int T, const float* __restrict__ scale,
     const int32_t* __restrict__ rows, float* __restrict__ out, size_t ld,
-    int vec_ok) {
+    int vec_ok, int groups) {
   constexpr int kPitch = kMaxKnots + 1;
   // destination row of detector d (wave-uniform): the caller may keep its
   // detectors in a locality order and still get the TOD in its own row order
@@ -273,10 +273,10 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_kernel(
   __shared__ float2 tile[kTileDet * kPitch];
 
   const int s_tile = blockIdx.x * kTileSamples;
-  const int d0 = blockIdx.y * kTileDet;
   const int sb = s_tile + threadIdx.x * kSamplesPerThread;
-  const int nd = min(kTileDet, D - d0);
 
+  // per-sample interval and weights: computed once, reused for `groups` tiles of
+  // 16 detector rows each (the float64 prologue is amortised over 16*groups rows)
   SampleWeights w;
   sample_weights(t, sb, T, n, ta0, inv_dta, w);
 
@@ -286,65 +286,70 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_kernel(
   const int jmax = interval_of((t[s_last] - ta0) * inv_dta, n) + 1;
   const int K = jmax - jmin + 1;
   const bool full = (sb + kSamplesPerThread <= T) && vec_ok;
+  int r[kSamplesPerThread];
+#pragma unroll
+  for (int q = 0; q < kSamplesPerThread; ++q)
+    r[q] = min(max(w.j[q] - jmin, 0), max(K - 2, 0));  // in range even if t is unsorted
 
-  if (K <= kMaxKnots) {
-    {  // 16 lanes cover the 16 detector rows of one knot: 128 contiguous bytes
-      const int dl = threadIdx.x & (kTileDet - 1);
-      const int d = d0 + dl;
-      for (int r = threadIdx.x / kTileDet; r < K; r += kBlock / kTileDet) {
-        float2 v = make_float2(0.f, 0.f);
-        if (d < D) v = ym[(size_t)(jmin + r) * D + d];
-        tile[dl * kPitch + r] = v;
-      }
-    }
-    __syncthreads();
-    int r[kSamplesPerThread];
-#pragma unroll
-    for (int q = 0; q < kSamplesPerThread; ++q)
-      r[q] = min(max(w.j[q] - jmin, 0), K - 2);  // in range even if t is unsorted
-
-    if (full) {
-#pragma unroll 4
-      for (int dl = 0; dl < nd; ++dl) {
-        const float2* row = tile + dl * kPitch;
-        float o[kSamplesPerThread];
-#pragma unroll
-        for (int q = 0; q < kSamplesPerThread; ++q)
-          o[q] = spline_eval(w, q, row[r[q]], row[r[q] + 1]);
-        if (kHasScale) {
-          const float g = scale[d0 + dl];
-#pragma unroll
-          for (int q = 0; q < kSamplesPerThread; ++q) o[q] *= g;
+  for (int g = 0; g < groups; ++g) {
+    const int d0 = (blockIdx.y * groups + g) * kTileDet;
+    if (d0 >= D) break;
+    const int nd = min(kTileDet, D - d0);
+    if (K <= kMaxKnots) {
+      if (g > 0) __syncthreads();  // the previous group is done with the image
+      {  // 16 lanes cover the 16 detector rows of one knot: 128 contiguous bytes
+        const int dl = threadIdx.x & (kTileDet - 1);
+        const int d = d0 + dl;
+        for (int rr = threadIdx.x / kTileDet; rr < K; rr += kBlock / kTileDet) {
+          float2 v = make_float2(0.f, 0.f);
+          if (d < D) v = ym[(size_t)(jmin + rr) * D + d];
+          tile[dl * kPitch + rr] = v;
         }
-        const vfloat4 v = {o[0], o[1], o[2], o[3]};
+      }
+      __syncthreads();
+      if (full) {
+#pragma unroll 4
+        for (int dl = 0; dl < nd; ++dl) {
+          const float2* row = tile + dl * kPitch;
+          float o[kSamplesPerThread];
+#pragma unroll
+          for (int q = 0; q < kSamplesPerThread; ++q)
+            o[q] = spline_eval(w, q, row[r[q]], row[r[q] + 1]);
+          if (kHasScale) {
+            const float gsc = scale[d0 + dl];
+#pragma unroll
+            for (int q = 0; q < kSamplesPerThread; ++q) o[q] *= gsc;
+          }
+          const vfloat4 v = {o[0], o[1], o[2], o[3]};
 #ifdef MRX_PLAIN_STORE
-        *reinterpret_cast<vfloat4*>(out + row_of(d0 + dl) * ld + sb) = v;
+          *reinterpret_cast<vfloat4*>(out + row_of(d0 + dl) * ld + sb) = v;
 #else
-        __builtin_nontemporal_store(
-            v, reinterpret_cast<vfloat4*>(out + row_of(d0 + dl) * ld + sb));
+          __builtin_nontemporal_store(
+              v, reinterpret_cast<vfloat4*>(out + row_of(d0 + dl) * ld + sb));
 #endif
+        }
+      } else {
+        for (int dl = 0; dl < nd; ++dl) {
+          const float2* row = tile + dl * kPitch;
+          const float gsc = kHasScale ? scale[d0 + dl] : 1.0f;
+          float* dst = out + row_of(d0 + dl) * ld + sb;
+#pragma unroll
+          for (int q = 0; q < kSamplesPerThread; ++q)
+            if (sb + q < T) dst[q] = gsc * spline_eval(w, q, row[r[q]], row[r[q] + 1]);
+        }
       }
     } else {
+      // low upsampling ratio: knots straight from global memory
       for (int dl = 0; dl < nd; ++dl) {
-        const float2* row = tile + dl * kPitch;
-        const float g = kHasScale ? scale[d0 + dl] : 1.0f;
-        float* dst = out + row_of(d0 + dl) * ld + sb;
+        const int d = d0 + dl;
+        const float gsc = kHasScale ? scale[d] : 1.0f;
+        float* dst = out + row_of(d) * ld + sb;
 #pragma unroll
         for (int q = 0; q < kSamplesPerThread; ++q)
-          if (sb + q < T) dst[q] = g * spline_eval(w, q, row[r[q]], row[r[q] + 1]);
+          if (sb + q < T)
+            dst[q] = gsc * spline_eval(w, q, ym[(size_t)w.j[q] * D + d],
+                                       ym[(size_t)(w.j[q] + 1) * D + d]);
       }
-    }
-  } else {
-    // low upsampling ratio: knots straight from global memory
-    for (int dl = 0; dl < nd; ++dl) {
-      const int d = d0 + dl;
-      const float g = kHasScale ? scale[d] : 1.0f;
-      float* dst = out + row_of(d) * ld + sb;
-#pragma unroll
-      for (int q = 0; q < kSamplesPerThread; ++q)
-        if (sb + q < T)
-          dst[q] = g * spline_eval(w, q, ym[(size_t)w.j[q] * D + d],
-                                   ym[(size_t)(w.j[q] + 1) * D + d]);
     }
   }
 }
@@ -638,7 +643,13 @@ int mrx_spline_upsample(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
   if (Ta < 4)
     return mrx_fail(ctx, MRX_ERR_UNSUPPORTED,
                     "cubic interpolation needs at least 4 coarse samples");
-  dim3 grid(mrx_ceil_div(T, kTileSamples), mrx_ceil_div(D, kTileDet));
+  // detector tiles per workgroup: the per-sample prologue is shared by all of them
+  int groups = ctx->options[MRX_OPT_UPSAMPLE_GROUPS];
+  if (groups <= 0) groups = 2;  // measured best of 1, 2, 4, 8, 16 on atlast_10k
+  while (groups > 1 && (long long)mrx_ceil_div(T, kTileSamples) *
+                               mrx_ceil_div(D, kTileDet * groups) < 4LL * 256 * 4)
+    groups /= 2;  // keep the chip full on small problems
+  dim3 grid(mrx_ceil_div(T, kTileSamples), mrx_ceil_div(D, kTileDet * groups));
   MRX_REQUIRE(ctx, grid.y <= 65535u, "D too large for one launch");
   const int vec_ok =
       (ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15u) == 0);
@@ -653,7 +664,7 @@ int mrx_spline_upsample(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
 #define MRX_LAUNCH_UP(S, K)                                                   \
   hipLaunchKernelGGL((spline_upsample_kernel<S, K>), grid, dim3(kBlock), 0,   \
                      ctx->stream, ym, D, Ta, ta0, 1.0 / dta, d_t, T, d_scale, \
-                     d_rows, d_out, ld_out, vec_ok)
+                     d_rows, d_out, ld_out, vec_ok, groups)
   if (d_scale) {
     if (small) MRX_LAUNCH_UP(true, 64); else MRX_LAUNCH_UP(true, 256);
   } else {

@@ -110,11 +110,11 @@ int main() {
     dim3 grid((T + kTileSamples - 1) / kTileSamples, (D + kTileDet - 1) / kTileDet);
     report("library upsample kernel K64", time_ms([&] {
              hipLaunchKernelGGL((spline_upsample_kernel<false, 64>), grid, dim3(kBlock), 0, 0, ym, D, Ta, 0.0, 10.0, t, T,
-                                (const float*)nullptr, (const int32_t*)nullptr, out, (size_t)T, 1);
+                                (const float*)nullptr, (const int32_t*)nullptr, out, (size_t)T, 1, 1);
            }));
     report("library upsample kernel K256", time_ms([&] {
              hipLaunchKernelGGL((spline_upsample_kernel<false, 256>), grid, dim3(kBlock), 0, 0, ym, D, Ta, 0.0, 10.0, t, T,
-                                (const float*)nullptr, (const int32_t*)nullptr, out, (size_t)T, 1);
+                                (const float*)nullptr, (const int32_t*)nullptr, out, (size_t)T, 1, 1);
            }));
   }
   return 0;

@@ -53,6 +53,11 @@ def main():
         total += med
         print(f"{name:22s} median {med:8.3f} ms  min {mn:8.3f} ms  alg {nbytes/1e9:7.3f} GB -> {nbytes/med/1e6:8.1f} GB/s")
     print(f"sum of medians {total:.3f} ms -> {D*T/total/1e6:.1f} G det-samples/s; point-layers/s in sample: {D*Ta*L/1e6:.1f} M")
+    for g in (1, 2, 4, 8, 16):
+        path.ctx.set_option(4, g)
+        med, mn = timeit(lambda: path.upsample(tod), reps)
+        print(f"upsample groups={g}: median {med:.3f} ms min {mn:.3f} ms")
+    path.ctx.set_option(4, 0)
     # does the writer slow down in sequence?  (event-timed inside the sequence)
     def timed_in_sequence(pre):
         evs = []
