@@ -21,6 +21,25 @@ from . import _lib
 from ._lib import Context, MrxBandTable, MrxLayer, ptr
 
 
+class _range:
+    """Profiler range (no-op if the marker library is unavailable)."""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        try:
+            torch.cuda.nvtx.range_push(self.name)
+            self.ok = True
+        except Exception:
+            self.ok = False
+
+    def __exit__(self, *exc):
+        if self.ok:
+            torch.cuda.nvtx.range_pop()
+        return False
+
+
 def _dev(a, dtype, device):
     return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(device)
 
@@ -191,6 +210,7 @@ class DevicePath:
         kernels.  Returns the device tensors."""
         dev = self.device
         layers = self.problem["layers"]
+        torch.cuda.nvtx.range_push("Generating turbulence") if hasattr(torch.cuda, "nvtx") else None
         shapes = [(len(l["extrusion"]), len(l["cross_section"])) for l in layers]
         # a layer may ask for a larger periodic FFT domain ("fft_shape") than its grid:
         # the screen is then the top-left block of it (atmosphere.py ribbons are not
@@ -221,6 +241,7 @@ class DevicePath:
                     "mrx_gauss_smooth2d", ptr(out), ptr(out), ptr(self._gen_work), ne, nc,
                     layer["beam_sigma"] / de, layer["beam_sigma"] / dc, 4.0,
                 )
+        torch.cuda.nvtx.range_pop() if hasattr(torch.cuda, "nvtx") else None
         return self._gen_screens
 
     # -- hot path ------------------------------------------------------------
@@ -255,12 +276,16 @@ class DevicePath:
         return self.d_pwv.T.index_select(0, self._d_inverse)
 
     def run(self, out=None):
-        """The whole path for this shard; returns the [D, T] float32 TOD tensor."""
+        """The whole path for this shard; returns the [D, T] float32 TOD tensor.  The
+        stages carry the reference's progress-bar names as profiler ranges (roctx via
+        torch.cuda.nvtx)."""
         if out is None:
             out = torch.empty((self.D, self.T), dtype=torch.float32, device=self.device)
-        self.sample()
-        self.prepare()
-        self.upsample(out)
+        with _range("Sampling turbulence + Computing atmospheric emission"):
+            self.sample()
+        with _range("Upsampling atmospheric loading"):
+            self.prepare()
+            self.upsample(out)
         return out
 
     # -- TOD.to("K_RJ") fused into the upsample -----------------------------------------
