@@ -53,6 +53,17 @@ def parse_args():
     return ap.parse_args()
 
 
+def _cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def cpu_baseline(problem, screens, n_dets):
     """Time the oracle (kind 'port') on the first n_dets detector rows, full duration."""
     import numpy as np
@@ -244,6 +255,8 @@ def main():
             "cores": 1,
             "blas_threads_available": threads,
             "host_cpus": os.cpu_count(),
+            "cpu_model": _cpu_model(),
+            "threads_note": "numpy fancy indexing and scipy interp1d are single-threaded: all-core and one-core timings coincide",
             "kind": "port",
             "sample": f"first {n_sub} of {D} detector rows, full {T} samples, screens given "
             f"(sampling + emission + cubic upsample; numpy/scipy single-threaded): {cpu_s:.2f} s",

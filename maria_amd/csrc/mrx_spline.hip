@@ -453,7 +453,7 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
   __syncthreads();
 
   const float el_first = cal_lds[0].x, el_last = cal_lds[n_el - 1].x;
-  const float el_inv = (float)(n_el - 1) / (el_last - el_first);
+  const float el_inv = 1.0f / (cal_lds[1].x - el_first);
   const bool full = (sb + kSamplesPerThread <= T) && vec_ok;
   // the loop body is instantiated once per knot source so that each instance
   // addresses one memory space (a runtime select would force flat loads)
@@ -491,18 +491,17 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
       if (__builtin_amdgcn_ballot_w64(steep) != 0)
         if (steep) el = asinf(im);
       ev[q] = el;
-      // jax _find_indices on the elevation axis: arithmetic guess and one corrective
-      // step either way (the axis is uniform but for its last node)
-      int i = min(max((int)fminf(fmaxf((el - el_first) * el_inv, -1.0f), 2.0e9f), 0), n_el - 2);
-      float2 lo = G[i], hi = G[i + 1];
-      i += (int)(hi.x < el && i < n_el - 2) - (int)(lo.x >= el && i > 0);
-      lo = G[i];
-      hi = G[i + 1];
+      // jax _find_indices on the elevation axis: arithmetic guess from the first
+      // interval's step (am's axis is uniform but for its last node, which the clamp
+      // absorbs); a sample within rounding of a node, or a non-uniform axis, is
+      // redone by the full search below
+      const int i = min(max((int)fminf(fmaxf((el - el_first) * el_inv, -1.0f), 2.0e9f), 0), n_el - 2);
+      const float2 lo = G[i], hi = G[i + 1];
       miss |= (i < n_el - 2 && hi.x < el) || (i > 0 && lo.x >= el);
       o[q] = krj_value(sv[q], el, lo, hi, el_first, el_last);
     }
     if (__builtin_amdgcn_ballot_w64(miss) != 0) {
-      // an axis that is not near-uniform: full search (never for am tables)
+      // full search for this detector row's 4 samples (rare)
 #pragma unroll 1
       for (int q = 0; q < kSamplesPerThread; ++q) {
         const float el = ev[q];

@@ -84,6 +84,37 @@ def test_nonuniform_axes_take_the_array_path(gpu_ctx):
     assert rel_err(path.coarse_loading().cpu().numpy(), inter["loading_a"]) <= TOL_TOD
 
 
+def test_large_band_tables_take_the_global_path(gpu_ctx):
+    """Band tables too large for the kernel's 48 KiB LDS stage are read from global
+    memory (mrx_atm_plan_info reports it); same results."""
+    from maria_amd import synthetic
+    from oracle import hotpath
+
+    p = small_problem(n_det=90, n_layers=2, n_bands=3)
+    p["tables"] = synthetic.emission_tables(3, n_pwv=80, n_el=90)
+    path = _device_path(p, ctx=gpu_ctx, keep_pwv=True)
+    assert path.plan_info()[1] is False
+    path.sample()
+    assert path.check_flags() == 0
+    _, inter = hotpath.run_path(p, return_intermediates=True)
+    assert rel_err(path.coarse_loading().cpu().numpy(), inter["loading_a"]) <= TOL_TOD
+
+
+def test_emission_table_out_of_range_gives_nan_like_jax(gpu_ctx):
+    """pwv outside the table: jax's interpolator fills NaN (band/band.py:283-286); the
+    kernel writes NaN and raises MRX_FLAG_TABLE_OOB, the screens are fine."""
+    from maria_amd import _lib
+
+    p = small_problem(n_det=20, n_layers=1, n_bands=1)
+    p["pwv0"] = 25.0  # the synthetic table ends at 10 mm
+    path = _device_path(p, ctx=gpu_ctx)
+    path.clear_flags()
+    path.sample()
+    flags = path.check_flags()
+    assert flags & _lib.FLAG_TABLE_OOB and flags & _lib.FLAG_NAN and not flags & _lib.FLAG_SCREEN_OOB
+    assert np.isnan(path.d_loading.cpu().numpy()).all()
+
+
 def test_recomputed_nodes_are_bit_identical_to_fetched_ones(gpu_ctx):
     """MRX_OPT_AXIS_RECOMPUTE only changes where the grid nodes come from."""
     import torch
