@@ -24,7 +24,7 @@ def smooth(data, weight=None, sigma=None, fwhm=None, x_res=1.0, y_res=1.0, devic
     d = torch.as_tensor(np.ascontiguousarray(data, np.float32)).to(dev) if as_numpy else data.to(dev, torch.float32).contiguous()
     w = None
     if weight is not None:
-        w = torch.as_tensor(np.ascontiguousarray(np.broadcast_to(weight, data.shape), np.float32)).to(dev) if as_numpy else weight.to(dev, torch.float32).expand_as(d).contiguous()
+        w = torch.as_tensor(np.array(np.broadcast_to(weight, data.shape), dtype=np.float32)).to(dev) if as_numpy else weight.to(dev, torch.float32).expand_as(d).contiguous()
     torch.cuda.set_device(dev)
     ctx = ctx or Context(dev.index or 0)
     ctx.set_stream(torch.cuda.current_stream(dev))
