@@ -234,6 +234,15 @@ int mrx_spline_upsample_krj(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
                             const float* d_cal_values, int n_el, int n_bands,
                             float* d_out, size_t ld_out);
 
+/* TOD.to("K_RJ") of a field that is already at the full rate -- the noise (and later map /
+ * cmb) fields, tod/tod.py:106-142 -- in place: d_data[row(d) * ld + s] *= d_scale[d] /
+ * den_band(d)(el(d, s)), with the arguments of mrx_spline_upsample_krj. */
+int mrx_tod_to_krj(mrx_ctx* ctx, float* d_data, size_t ld, int D, int T,
+                   const float* d_scale, const int32_t* d_rows,
+                   const float* d_bore_el, const float* d_dx, const float* d_dy,
+                   const int32_t* d_band, const float* d_cal_axis_el,
+                   const float* d_cal_values, int n_el, int n_bands);
+
 /* Full-rate detector pointing: Coordinates.broadcast at the sample rate
  * (coords/coordinates.py:378-386 via transforms.py:10-29, float32;
  * sim/observation.py:55-58).  d_az, d_el [T] float32 boresight; d_dx, d_dy [D];
@@ -286,6 +295,36 @@ int mrx_screen_generate(mrx_ctx* ctx, uint64_t seed, uint32_t stream, int ny,
  * (float64); mrx_screen_generate uses it internally, exposed for tests. */
 int mrx_screen_psd_sum(mrx_ctx* ctx, int ny, int nx, double dy, double dx,
                        double r0, double nu, double* host_sum);
+
+/* ---- detector noise ----------------------------------------- */
+
+/* White + 1/f noise with spatially correlated modes: sim/noise.py:18-63 and
+ * noise/generation.py:11-51,
+ *   noise[d,t] = scale_d (sqrt(fs) w[d,t] + sqrt(c) sum_m B[d,m] M_m[t] + sqrt(1-c) p_d[t]),
+ * w white N(0,1); p_d independent pink series with two-sided spectrum (knee/2)/|f| (equal
+ * to the white level at f = knee); M_m = sqrt(fs) w'_m + P_m the modes (white + pink, the
+ * generator applied to itself, generation.py:41-43); c = corr_prop.  The reference
+ * filters white noise with a length-T FFT per detector; here each pink series is
+ * synthesised in the frequency domain on a power-of-two period N >= T (a four-step
+ * LDS FFT) and cut to T samples: same spectrum, different realisation and period --
+ * statistical parity, like the screens.
+ *  d_basis [D][n_modes] spatial basis (utils/linalg.py:105-126, host), or NULL with n_modes 0
+ *  d_scale [D]  1e12 * NEP per detector (noise.py:62), or NULL
+ *  d_loading    [D][ld_loading] float32 total optical loading (pW) or NULL: the amplitude of
+ *               sample (d,t) is d_scale[d] + per_loading * d_loading[d,t], per_loading =
+ *               1e12 * NEP_per_loading (noise.py:35-37); must not alias an accumulating d_out
+ *  d_out        [D][ld_out] float32, written (accumulate = 0) or added to (accumulate = 1:
+ *               noise straight into an existing TOD)
+ *  d_work       scratch of work_floats floats; mrx_noise_work_floats(T, n_modes, batch) gives
+ *               the size that processes `batch` detectors per pass. */
+int mrx_noise_period(int T, int* n1, int* n2);
+int mrx_noise_work_floats(int T, int n_modes, int batch, size_t* floats);
+int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int T,
+                       double sample_rate, double knee, double corr_prop,
+                       const float* d_basis, int n_modes, const float* d_scale,
+                       const float* d_loading, size_t ld_loading, double per_loading,
+                       float* d_out, size_t ld_out, int accumulate,
+                       float* d_work, size_t work_floats);
 
 /* Philox-4x32-10 standard normals, the generator behind the screens, exposed
  * so tests can check the stream against the published known-answer vectors.

@@ -99,12 +99,16 @@ SIGNATURES = {
     "mrx_spline_prepare": (_i, [_vp, _vp, _i, _i, _vp]),
     "mrx_spline_upsample": (_i, [_vp, _vp, _i, _i, _d, _d, _vp, _i, _vp, _vp, _vp, _sz]),
     "mrx_spline_upsample_krj": (_i, [_vp, _vp, _i, _i, _d, _d, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _sz]),
+    "mrx_tod_to_krj": (_i, [_vp, _vp, _sz, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i]),
     "mrx_pointing_broadcast": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _sz]),
     "mrx_linear_upsample": (_i, [_vp, _vp, _i, _i, _d, _d, _vp, _i, _vp, _sz]),
     "mrx_gauss_smooth2d": (_i, [_vp, _vp, _vp, _vp, _i, _i, _d, _d, _d]),
     "mrx_map_smooth": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _d]),
     "mrx_screen_generate": (_i, [_vp, C.c_uint64, C.c_uint32, _i, _i, _d, _d, _d, _d, _vp, _vp]),
     "mrx_screen_psd_sum": (_i, [_vp, _i, _i, _d, _d, _d, _d, C.POINTER(_d)]),
+    "mrx_noise_period": (_i, [_i, C.POINTER(_i), C.POINTER(_i)]),
+    "mrx_noise_work_floats": (_i, [_i, _i, _i, C.POINTER(_sz)]),
+    "mrx_noise_generate": (_i, [_vp, C.c_uint64, _i, _i, _d, _d, _d, _vp, _i, _vp, _vp, _sz, _d, _vp, _sz, _i, _vp, _sz]),
     "mrx_philox_normal": (_i, [_vp, C.c_uint64, C.c_uint32, _sz, _vp]),
     "mrx_philox_raw": (_i, [_vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
 }

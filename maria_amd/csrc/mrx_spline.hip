@@ -386,6 +386,52 @@ __device__ __forceinline__ float krj_value(float s, float el, float2 lo,
   return s * __builtin_amdgcn_rcpf(den);
 }
 
+// detector elevation (transforms.py:20-28): im = sin(el) as the chain computes
+// it, then el = asin(im) by one Newton step from el0 = el_bore + dy, whose
+// sine and cosine follow from the angle-addition formulas (no inverse
+// trigonometry per sample); |el - el0| <= r^2 tan(el)/2 ~ 3e-4 rad, so the
+// second-order step is exact to float32 rounding.  eb: boresight elevation,
+// ca / sa: cos / sin of (eb - pi/2).
+__device__ __forceinline__ float det_elevation(const CalDet& c, float eb, float ca, float sa) {
+  const float im = __fadd_rn(__fmul_rn(c.a_re, sa), __fmul_rn(c.a_im, ca));
+  const float s0 = ca * c.cdy - sa * c.sdy;   // sin(el_bore + dy)
+  const float c0 = -sa * c.cdy - ca * c.sdy;  // cos(el_bore + dy)
+  const float rc0 = __builtin_amdgcn_rcpf(c0);
+  const float dl1 = (im - s0) * rc0;
+  float el = (eb + c.dy) + dl1 * (1.0f + 0.5f * dl1 * s0 * rc0);
+  // within ~15 deg of the zenith the expansion loses accuracy: take asin there
+  const bool steep = !(c0 > 0.25f);
+  if (__builtin_amdgcn_ballot_w64(steep) != 0)
+    if (steep) el = asinf(im);
+  return el;
+}
+
+__device__ __forceinline__ CalDet make_cal_det(float dx, float dy, int band, float scale) {
+  const float r = sqrtf(dx * dx + dy * dy);
+  const float p = atan2f(-dx, -dy);
+  CalDet c;
+  c.a_re = __fmul_rn(sinf(r), cosf(p));
+  c.a_im = cosf(r);
+  c.band = band;
+  c.scale = scale;
+  c.dy = dy;
+  c.sdy = sinf(dy);
+  c.cdy = cosf(dy);
+  return c;
+}
+
+// den lookup with jax's _find_indices on the elevation axis: arithmetic guess from the
+// first interval's step (am's axis is uniform but for its last node, which the clamp
+// absorbs), corrected by a short walk when the guess is off (non-uniform axis, a sample
+// within rounding of a node)
+__device__ __forceinline__ float krj_lookup(float s, float el, const float2* G, int n_el,
+                                            float el_first, float el_last, float el_inv) {
+  int i = min(max((int)fminf(fmaxf((el - el_first) * el_inv, -1.0f), 2.0e9f), 0), n_el - 2);
+  while (i < n_el - 2 && G[i + 1].x < el) ++i;
+  while (i > 0 && G[i].x >= el) --i;
+  return krj_value(s, el, G[i], G[i + 1], el_first, el_last);
+}
+
 __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
     const float2* __restrict__ ym, int D, int n, double ta0, double inv_dta,
     const double* __restrict__ t, int T, const float* __restrict__ scale,
@@ -422,17 +468,7 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
     cal_lds[i] = make_float2(cal_axis[i % n_el], cal_values[i]);
   if ((int)threadIdx.x < nd) {
     const int d = d0 + threadIdx.x;
-    const float dx = dxs[d], dy = dys[d];
-    const float r = sqrtf(dx * dx + dy * dy);
-    const float p = atan2f(-dx, -dy);
-    CalDet c;
-    c.a_re = __fmul_rn(sinf(r), cosf(p));
-    c.a_im = cosf(r);
-    c.band = min(max(band[d], 0), n_bands - 1);
-    c.scale = scale ? scale[d] : 1.0f;
-    c.dy = dy;
-    c.sdy = sinf(dy);
-    c.cdy = cosf(dy);
+    const CalDet c = make_cal_det(dxs[d], dys[d], min(max(band[d], 0), n_bands - 1), scale ? scale[d] : 1.0f);
     cdet[threadIdx.x] = c;
   }
 
@@ -475,21 +511,7 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
         k1 = ym[(size_t)(w.j[q] + 1) * D + d0 + dl];
       }
       sv[q] = c.scale * spline_eval(w, q, k0, k1);
-      // detector elevation (transforms.py:20-28): im = sin(el) as the chain computes
-      // it, then el = asin(im) by one Newton step from el0 = el_bore + dy, whose
-      // sine and cosine follow from the angle-addition formulas (no inverse
-      // trigonometry per sample); |el - el0| <= r^2 tan(el)/2 ~ 3e-4 rad, so the
-      // second-order step is exact to float32 rounding
-      const float im = __fadd_rn(__fmul_rn(c.a_re, sa[q]), __fmul_rn(c.a_im, ca[q]));
-      const float s0 = ca[q] * c.cdy - sa[q] * c.sdy;   // sin(el_bore + dy)
-      const float c0 = -sa[q] * c.cdy - ca[q] * c.sdy;  // cos(el_bore + dy)
-      const float rc0 = __builtin_amdgcn_rcpf(c0);
-      const float dl1 = (im - s0) * rc0;
-      float el = (eb[q] + c.dy) + dl1 * (1.0f + 0.5f * dl1 * s0 * rc0);
-      // within ~15 deg of the zenith the expansion loses accuracy: take asin there
-      const bool steep = !(c0 > 0.25f);
-      if (__builtin_amdgcn_ballot_w64(steep) != 0)
-        if (steep) el = asinf(im);
+      const float el = det_elevation(c, eb[q], ca[q], sa[q]);
       ev[q] = el;
       // jax _find_indices on the elevation axis: arithmetic guess from the first
       // interval's step (am's axis is uniform but for its last node, which the clamp
@@ -524,6 +546,70 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
   };
   if (use_lds) body(std::true_type{}); else body(std::false_type{});
 }
+
+// TOD.to("K_RJ") of a field that is already at the full rate (noise, map, cmb;
+// tod/tod.py:106-142), in place: data[row(d)][s] *= scale_d / den_band(d)(el(d, s)).
+// Same tile as the fused writer: 16 detectors x 1024 samples per workgroup, 16-byte
+// loads and non-temporal stores; 8 B of HBM traffic per sample.
+__global__ __launch_bounds__(kBlock) void tod_krj_kernel(
+    float* __restrict__ data, size_t ld, int D, int T, const float* __restrict__ scale,
+    const int32_t* __restrict__ rows, const float* __restrict__ bore_el,
+    const float* __restrict__ dxs, const float* __restrict__ dys,
+    const int32_t* __restrict__ band, const float* __restrict__ cal_axis,
+    const float* __restrict__ cal_values, int n_el, int n_bands, int vec_ok) {
+  extern __shared__ float2 cal_lds[];
+  __shared__ CalDet cdet[kTileDet];
+  const int s_tile = blockIdx.x * kTileSamples;
+  const int d0 = blockIdx.y * kTileDet;
+  const int sb = s_tile + threadIdx.x * kSamplesPerThread;
+  const int nd = min(kTileDet, D - d0);
+  float ca[kSamplesPerThread], sa[kSamplesPerThread], eb[kSamplesPerThread];
+#pragma unroll
+  for (int q = 0; q < kSamplesPerThread; ++q) {
+    eb[q] = bore_el[min(sb + q, T - 1)];
+    const float a = eb[q] - 1.57079637050628662109375f;
+    ca[q] = cosf(a);
+    sa[q] = sinf(a);
+  }
+  for (int i = threadIdx.x; i < n_el * n_bands; i += kBlock)
+    cal_lds[i] = make_float2(cal_axis[i % n_el], cal_values[i]);
+  if ((int)threadIdx.x < nd) {
+    const int d = d0 + threadIdx.x;
+    cdet[threadIdx.x] = make_cal_det(dxs[d], dys[d], min(max(band[d], 0), n_bands - 1), scale ? scale[d] : 1.0f);
+  }
+  __syncthreads();
+  if (sb >= T) return;
+  const float el_first = cal_lds[0].x, el_last = cal_lds[n_el - 1].x;
+  const float el_inv = 1.0f / (cal_lds[1].x - el_first);
+  const bool full = (sb + kSamplesPerThread <= T) && vec_ok;
+  for (int dl = 0; dl < nd; ++dl) {
+    const CalDet c = cdet[dl];
+    const float2* G = cal_lds + c.band * n_el;
+    float* row = data + (rows ? (size_t)rows[d0 + dl] : (size_t)(d0 + dl)) * ld + sb;
+    float v[kSamplesPerThread];
+    if (full) {
+      const vfloat4 x = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(row));
+      v[0] = x[0]; v[1] = x[1]; v[2] = x[2]; v[3] = x[3];
+    } else {
+#pragma unroll
+      for (int q = 0; q < kSamplesPerThread; ++q) v[q] = sb + q < T ? row[q] : 0.0f;
+    }
+#pragma unroll
+    for (int q = 0; q < kSamplesPerThread; ++q) {
+      const float el = det_elevation(c, eb[q], ca[q], sa[q]);
+      v[q] = krj_lookup(c.scale * v[q], el, G, n_el, el_first, el_last, el_inv);
+    }
+    if (full) {
+      const vfloat4 x = {v[0], v[1], v[2], v[3]};
+      __builtin_nontemporal_store(x, reinterpret_cast<vfloat4*>(row));
+    } else {
+#pragma unroll
+      for (int q = 0; q < kSamplesPerThread; ++q)
+        if (sb + q < T) row[q] = v[q];
+    }
+  }
+}
+
 
 // Linear interpolation of the coarse pwv (float64, time-major) to the full
 // rate: sim/atmosphere.py:30-37.  Same tiling as the cubic kernel without the
@@ -706,6 +792,30 @@ int mrx_spline_upsample_krj(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
                      ta0, 1.0 / dta, d_t, T, d_scale, d_rows, d_bore_el, d_dx,
                      d_dy, d_band, d_cal_axis_el, d_cal_values, n_el, n_bands,
                      d_out, ld_out, vec_ok);
+  MRX_CHECK_LAUNCH(ctx);
+  return MRX_OK;
+}
+
+int mrx_tod_to_krj(mrx_ctx* ctx, float* d_data, size_t ld, int D, int T,
+                   const float* d_scale, const int32_t* d_rows,
+                   const float* d_bore_el, const float* d_dx, const float* d_dy,
+                   const int32_t* d_band, const float* d_cal_axis_el,
+                   const float* d_cal_values, int n_el, int n_bands) {
+  if (!ctx) return MRX_ERR_INVALID;
+  MRX_REQUIRE(ctx, D >= 0 && T >= 0, "negative size");
+  if (D == 0 || T == 0) return MRX_OK;
+  MRX_REQUIRE(ctx, d_data && d_bore_el && d_dx && d_dy && d_band && d_cal_axis_el && d_cal_values,
+              "null pointer");
+  MRX_REQUIRE(ctx, n_el >= 2 && n_bands >= 1 && (size_t)n_el * (1 + n_bands) <= 8192,
+              "calibration tables need 2 <= n_el and n_el*(1+n_bands) <= 8192");
+  MRX_REQUIRE(ctx, ld >= (size_t)T, "ld smaller than T");
+  dim3 grid(mrx_ceil_div(T, kTileSamples), mrx_ceil_div(D, kTileDet));
+  MRX_REQUIRE(ctx, grid.y <= 65535u, "D too large for one launch");
+  const int vec_ok = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_data) & 15u) == 0);
+  const size_t lds = sizeof(float2) * (size_t)n_el * n_bands;
+  hipLaunchKernelGGL(tod_krj_kernel, grid, dim3(kBlock), lds, ctx->stream, d_data, ld, D, T,
+                     d_scale, d_rows, d_bore_el, d_dx, d_dy, d_band, d_cal_axis_el,
+                     d_cal_values, n_el, n_bands, vec_ok);
   MRX_CHECK_LAUNCH(ctx);
   return MRX_OK;
 }

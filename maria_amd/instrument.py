@@ -36,7 +36,8 @@ def generate_passband(center, width, shape, samples=256):
 class Band:
     """band/band.py:89-160 (constructor) and :317-323 (``passband``)."""
 
-    def __init__(self, center=None, width=None, nu=None, tau=None, name=None, shape="gaussian", efficiency=0.5, gain_error=0.0):
+    def __init__(self, center=None, width=None, nu=None, tau=None, name=None, shape="gaussian", efficiency=0.5, gain_error=0.0,
+                 NEP=1e-17, NEP_per_loading=0.0, knee=1.0):
         auto = center is not None and width is not None
         manual = nu is not None and tau is not None
         if not auto ^ manual:
@@ -52,6 +53,7 @@ class Band:
                 raise ValueError(f"'nu' and 'tau' have mismatched shapes ({self.nu.shape} and {self.tau.shape}).")
         self.efficiency = efficiency
         self.gain_error = gain_error
+        self.NEP, self.NEP_per_loading, self.knee = NEP, NEP_per_loading, knee  # W sqrt(s), -, Hz (band.py:103-108)
         self.shape = shape
         self.center = float(np.trapezoid(self.nu * self.tau, self.nu) / np.trapezoid(self.tau, self.nu)) if center is None else float(center)
         self.name = name or f"f{10 ** (np.log10(self.center) % 3):>03.0f}"

@@ -1,0 +1,89 @@
+"""Detector noise: the host side of ``NoiseMixin._simulate_noise`` (sim/noise.py:18-63).
+
+The time-domain synthesis (white + 1/f with correlated modes) runs in ``libmrx``
+(``mrx_noise_generate``); the spatial basis of the correlated modes is a small SVD +
+cubic interpolation on the host, as in the reference (utils/linalg.py:105-126).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import scipy.interpolate
+import scipy.spatial
+import torch
+
+from ._lib import ptr
+
+DEFAULT_NOISE_SIM_KWARGS = {"correlated_noise_proportion": 0.5, "correlated_noise_spatial_scale": 1.0}  # sim/noise.py:11
+
+
+def spatial_basis(offsets, k: int = 5, n_side: int = 16, scale: float = 1.0):
+    """utils/linalg.py:105-126: the k leading modes of a Matern-5/2 kernel on an
+    n_side x n_side grid over the focal plane, cubic-interpolated to the detectors."""
+    offsets = np.asarray(offsets, float)
+    x = np.linspace(offsets[:, 0].min(), offsets[:, 0].max(), n_side)
+    y = np.linspace(offsets[:, 1].min(), offsets[:, 1].max(), n_side)
+    X, Y = np.meshgrid(x, y)
+    pts = np.stack([X.ravel(), Y.ravel()], axis=-1)
+    r = np.sqrt(np.square(pts - pts[:, None]).sum(axis=-1)) / scale
+    cov = (1 + np.sqrt(3) * r + (5.0 / 3.0) * r**2) * np.exp(-np.sqrt(5) * r)
+    u, s, _ = np.linalg.svd(cov)
+    basis = u[:, :k] * np.sqrt(s[:k])
+    B = scipy.interpolate.RegularGridInterpolator((x, y), basis.reshape(n_side, n_side, -1), method="cubic")(offsets)
+    return B * np.sign(B[:, 0].mean())
+
+
+def diameter(offsets):
+    """utils/__init__.py:56-: largest pairwise distance (via the hull)."""
+    pts = np.asarray(offsets, float)
+    if len(pts) < 2:
+        return 0.0
+    try:
+        pts = pts[scipy.spatial.ConvexHull(pts).vertices]
+    except Exception:
+        pass
+    return float(scipy.spatial.distance.pdist(pts).max())
+
+
+def simulate_noise(ctx, dets, T, sample_rate, seed, noise_kwargs=None, device="cuda:0", batch=512, out=None, loading=None):
+    """sim/noise.py:18-63: one band at a time, [ndet, T] float32 in pW on the device.
+    ``dets`` is a ``maria_amd.instrument.Detectors``; bands carry ``NEP`` (W sqrt(s)), ``knee``
+    (Hz) and ``NEP_per_loading``; ``loading`` is the [ndet, T] float32 device tensor of the summed
+    loadings in pW, needed only by bands whose NEP grows with it (noise.py:35-37)."""
+    kw = dict(DEFAULT_NOISE_SIM_KWARGS)
+    kw.update(noise_kwargs or {})
+    dev = torch.device(device)
+    if out is None:
+        out = torch.empty((dets.n, T), dtype=torch.float32, device=dev)
+    for b, band in enumerate(dets.bands):
+        idx = np.nonzero(dets.band_index == b)[0]
+        if len(idx) == 0:
+            continue
+        per_loading = float(getattr(band, "NEP_per_loading", 0.0))
+        if per_loading and loading is None:
+            raise ValueError(f"band {band.name} has NEP_per_loading != 0: pass the summed loading (sim/noise.py:35-37)")
+        if not (np.diff(idx) == 1).all():
+            raise NotImplementedError("detectors of a band must be contiguous rows")
+        offs = dets.offsets[idx]
+        fov = diameter(offs)
+        if fov > 0 and len(idx) > 16:  # sim/noise.py:42-50
+            basis = spatial_basis(offs, k=5, n_side=16, scale=fov * kw.get("correlated_noise_spatial_scale", 0))
+        else:
+            basis = np.ones((len(idx), 1))
+        d_basis = torch.as_tensor(np.ascontiguousarray(basis, np.float32)).to(dev)
+        d_scale = torch.full((len(idx),), float(1e12 * band.NEP), dtype=torch.float32, device=dev)  # noise.py:62
+        n_modes = basis.shape[1]
+        need = C.c_size_t()
+        ctx.lib.mrx_noise_work_floats(int(T), int(n_modes), int(min(batch, len(idx))), C.byref(need))
+        work = torch.empty(need.value, dtype=torch.float32, device=dev)
+        view = out[int(idx[0]) : int(idx[-1]) + 1]
+        ctx.call(
+            "mrx_noise_generate", int(seed) + 7919 * b, len(idx), int(T), float(sample_rate), float(band.knee),
+            float(kw.get("correlated_noise_proportion", 0)), ptr(d_basis), int(n_modes), ptr(d_scale),
+            ptr(loading[int(idx[0]) : int(idx[-1]) + 1]) if per_loading else None, loading.stride(0) if per_loading else 0,
+            1e12 * per_loading, ptr(view), out.stride(0), 0, ptr(work), need.value,
+        )
+        del work
+    return out

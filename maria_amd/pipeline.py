@@ -339,6 +339,17 @@ class DevicePath:
             ptr(c["axis"]), ptr(c["values"]), c["n_el"], c["n_bands"], ptr(out), out.stride(0),
         )
 
+    def to_krj(self, data):
+        """mrx_tod_to_krj: convert a full-rate [D, T] pW field (caller's row order) to K_RJ in
+        place with the calibration of ``set_calibration`` (tod/tod.py:106-142)."""
+        c = self._cal
+        assert tuple(data.shape) == (self.D, self.T) and data.stride(1) == 1
+        self.ctx.call(
+            "mrx_tod_to_krj", ptr(data), data.stride(0), self.D, self.T, None, ptr(self.d_rows), ptr(c["bore_el"]),
+            ptr(c["dx"]), ptr(c["dy"]), ptr(self.d_band), ptr(c["axis"]), ptr(c["values"]), c["n_el"], c["n_bands"],
+        )
+        return data
+
     def check_flags(self):
         """Raise the reference's errors if a sample left a screen or a table."""
         word = C.c_uint32()

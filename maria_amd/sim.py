@@ -183,6 +183,7 @@ class Simulation:
         dtype: type = np.float32,
         *,
         gain_seed: int = None,
+        noise_seed: int = None,
         device_output: bool = False,
     ):
         """sim/simulation.py:76-198.  ``device_output=True`` leaves the TOD on the GPU as
@@ -205,8 +206,10 @@ class Simulation:
         self.disable_progress_bars = not progress_bars
         self.device_output = device_output
         self._gain_rng = np.random.default_rng(gain_seed)
-        if noise:
-            logger.warning("detector noise synthesis is a follow-on row (SURVEY 8(f) rank 2): this run has no noise field")
+        self.noise_kwargs = dict(noise_kwargs)
+        self._noise_seed = int(noise_seed if noise_seed is not None else np.random.SeedSequence().entropy % (1 << 62))
+        self._noise_runs = 0
+        self._noise_ctx = None
         self.obs_list = []
         for plan in self.plans:
             obs = Observation(instrument, plan, site, atmosphere, self.atmosphere_kwargs)
@@ -230,30 +233,57 @@ class Simulation:
     def _simulate_atmosphere(self, obs):
         obs.atmosphere.simulate_pwv(instrument=obs.instrument)
 
+    def _set_calibration(self, obs, metadata):
+        """Host part of ``TOD.to("K_RJ")`` (tod/tod.py:90-97): collapse the bands' transmission
+        tables at the scalars the TOD metadata carries, rounded as run_obs stores them."""
+        atm, dets = obs.atmosphere, obs.instrument.dets
+        sp = atm.spectrum
+        tables = [{"T": sp.side_base_temperature, "pwv": sp.side_zenith_pwv, "el": sp.side_elevation,
+                   "values": band.transmission_table(sp)} for band in dets.bands]
+        polarized = [bool((~np.isnan(dets.gamma[dets.band_index == b])).all()) for b in range(len(dets.bands))]
+        atm._device_path().set_calibration(tables, metadata["base_temperature"], metadata["pwv"], obs.boresight.el,
+                                           obs.coords.offsets, polarized)
+
     def _compute_atmospheric_loading(self, obs, gain=None, units="pW", metadata=None):
         """Spline solve + cubic upsample of the coarse loading the sampling kernel already
         wrote (emission and Mueller weight are fused into it), scaled by ``gain``; with
         ``units="K_RJ"`` the division of ``TOD.to`` (tod/tod.py:90-142) is fused in."""
         import torch
 
-        atm = obs.atmosphere
-        path = atm._device_path()
+        path = obs.atmosphere._device_path()
         path.set_gain(gain)
         out = torch.empty((path.D, path.T), dtype=torch.float32, device=path.device)
         path.prepare()
         if units == "K_RJ":
-            dets = obs.instrument.dets
-            sp = atm.spectrum
-            tables = [{"T": sp.side_base_temperature, "pwv": sp.side_zenith_pwv, "el": sp.side_elevation,
-                       "values": band.transmission_table(sp)} for band in dets.bands]
-            polarized = [bool((~np.isnan(dets.gamma[dets.band_index == b])).all()) for b in range(len(dets.bands))]
-            # the scalars TOD.to reads back from the metadata, rounded as run_obs stores them
-            path.set_calibration(tables, metadata["base_temperature"], metadata["pwv"], obs.boresight.el,
-                                 obs.coords.offsets, polarized)
+            self._set_calibration(obs, metadata)
             path.upsample_krj(out)
         else:
             path.upsample(out)
         return out
+
+    def _simulate_noise(self, obs, loading=None):
+        """sim/noise.py:18-63 on the device, in pW; ``loading`` (pW, [D, T] on the device) only
+        for bands whose NEP grows with the loading.  The gain error does not apply to the
+        noise field (simulation.py:243-245)."""
+        import torch
+
+        from . import noise as mnoise
+        from ._lib import Context
+
+        dets = obs.instrument.dets
+        if hasattr(obs, "atmosphere"):
+            ctx, device = obs.atmosphere._device_path().ctx, obs.atmosphere._device_path().device
+        else:
+            device = torch.device("cuda:0")
+            if self._noise_ctx is None:
+                self._noise_ctx = Context(0)
+            ctx = self._noise_ctx
+            ctx.set_stream(torch.cuda.current_stream(device))
+        t = obs.coords.t
+        fs = 1.0 / np.mean(np.diff(t)) if len(t) > 1 else 1.0
+        self._noise_runs += 1
+        return mnoise.simulate_noise(ctx, dets, len(t), fs, self._noise_seed + 104729 * self._noise_runs,
+                                     self.noise_kwargs, device=device, loading=loading)
 
     def run_obs(self, obs, units: str = "pW") -> TOD:
         """sim/simulation.py:213-272 (followed by ``.to(units)`` of :206)."""
@@ -263,11 +293,34 @@ class Simulation:
         gain_error = np.array([dets.bands[b].gain_error for b in dets.band_index])
         gain = np.exp(gain_error * self._gain_rng.standard_normal(dets.n))
         metadata = {"atmosphere": False, "altitude": float(obs.site.altitude), "region": obs.site.region}
+        # bands whose NEP grows with the loading need the loading in pW before the noise is
+        # drawn (sim/noise.py:35-37); every field is then converted after the fact, as
+        # TOD.to does.  Otherwise the conversion rides on the upsample's store.
+        loading_nep = self.noise and any(getattr(b, "NEP_per_loading", 0.0) for b in dets.bands)
+        deferred = units == "K_RJ" and loading_nep
+        loading = None
         if hasattr(obs, "atmosphere"):
             metadata.update(atmosphere=True, pwv=float(np.round(obs.atmosphere.weather.pwv, 3)),
                             base_temperature=float(np.round(obs.atmosphere.weather.temperature[0], 3)))
             self._simulate_atmosphere(obs)
             loading = self._compute_atmospheric_loading(obs, gain=gain if np.any(gain_error) else None,
-                                                        units=units, metadata=metadata)
+                                                        units="pW" if deferred else units, metadata=metadata)
+        elif units == "K_RJ" and self.noise:
+            raise NotImplementedError("K_RJ needs the atmosphere's calibration tables here: run(units='pW') for a noise-only simulation")
+        noise = None
+        if self.noise:
+            if loading_nep and loading is None:
+                import torch
+
+                loading = torch.zeros((dets.n, len(obs.coords.t)), dtype=torch.float32, device="cuda:0")
+            noise = self._simulate_noise(obs, loading=loading if loading_nep else None)
+            if units == "K_RJ":
+                if deferred:
+                    self._set_calibration(obs, metadata)
+                    obs.atmosphere._device_path().to_krj(loading)
+                obs.atmosphere._device_path().to_krj(noise)
+        if hasattr(obs, "atmosphere"):
             obs.loading["atmosphere"] = loading if self.device_output else loading.cpu().numpy()
+        if noise is not None:
+            obs.loading["noise"] = noise if self.device_output else noise.cpu().numpy()
         return TOD(data=obs.loading, dets=dets, coords=obs.coords, units=units, metadata=metadata)

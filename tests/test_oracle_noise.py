@@ -1,0 +1,54 @@
+"""CPU tier for the noise row: the numpy restatement of noise/generation.py and
+utils/linalg.py behaves as the reference documents, and the product's host-side basis
+equals it (the device synthesis itself is tested in test_gpu_noise.py)."""
+
+import numpy as np
+import scipy.signal
+
+from oracle import noise as onoise
+
+
+def test_oracle_spectrum_white_plus_pink():
+    fs, knee = 100.0, 2.0
+    x = onoise.generate_noise_with_knee((64, 1 << 15), sample_rate=fs, knee=knee, rng=np.random.default_rng(0))
+    f, p = scipy.signal.welch(x, fs=fs, nperseg=4096, detrend=False, axis=-1)
+    p = p.mean(axis=0)
+    for lo, hi in [(0.1, 0.5), (0.5, 2.0), (2.0, 10.0), (10.0, 45.0)]:
+        m = (f >= lo) & (f < hi)
+        assert abs(p[m].mean() / onoise.one_sided_psd_model(f[m], fs, knee).mean() - 1) < 0.1
+    # knee = 0: white only, variance = sample rate (generation.py:25)
+    w = onoise.generate_noise_with_knee((8, 1 << 15), sample_rate=fs, knee=0.0, rng=np.random.default_rng(1))
+    assert abs(w.var() / fs - 1) < 0.02
+
+
+def test_spatial_basis_reproduces_the_matern_kernel():
+    """B B^T approximates the Matern-5/2 covariance between detectors (utils/linalg.py:105-126);
+    the product's host function is the same computation."""
+    from maria_amd import noise as mnoise
+    from maria_amd import synthetic
+
+    off = synthetic.hex_pack(217, np.radians(1.0))
+    scale = mnoise.diameter(off)
+    assert abs(scale - np.sqrt(((off[:, None] - off[None]) ** 2).sum(-1)).max()) < 1e-12
+    B = onoise.generate_spatial_basis(off, k=5, n_side=16, scale=scale)
+    assert B.shape == (217, 5) and B[:, 0].mean() > 0
+    np.testing.assert_allclose(mnoise.spatial_basis(off, k=5, n_side=16, scale=scale), B, atol=1e-12)
+    r = np.sqrt(((off[:, None] - off[None]) ** 2).sum(-1)) / scale
+    # 5 of 256 modes carry most of a kernel as wide as the focal plane
+    assert np.abs(B @ B.T - onoise.matern_five_halves(r)).max() < 0.12
+
+
+def test_correlated_oracle_covariance():
+    """sqrt(c) B modes + sqrt(1-c) pink: low-frequency covariance c B B^T + (1-c) I."""
+    rng = np.random.default_rng(5)
+    D, T, fs, knee, c = 40, 1 << 14, 50.0, 25.0, 0.6
+    B = rng.normal(0, 1, (D, 3)) / np.sqrt(3)
+    x = onoise.generate_noise_with_knee((D, T), fs, knee, basis=B, corr_prop=c, rng=rng)
+    X = np.fft.rfft(x, axis=1)
+    f = np.fft.rfftfreq(T, 1 / fs)
+    m = (f > 0.05) & (f < 1.0)
+    Xw = X[:, m] / np.sqrt(1 + knee / f[m])
+    cov = (Xw @ Xw.conj().T).real / m.sum()
+    model = c * B @ B.T + np.mean(((1 - c) * knee / f[m] + 1) / (1 + knee / f[m])) * np.eye(D)
+    cov *= np.trace(model) / np.trace(cov)
+    assert np.corrcoef(cov.ravel(), model.ravel())[0, 1] > 0.97
