@@ -296,6 +296,13 @@ int mrx_screen_generate(mrx_ctx* ctx, uint64_t seed, uint32_t stream, int ny,
 int mrx_screen_psd_sum(mrx_ctx* ctx, int ny, int nx, double dy, double dx,
                        double r0, double nu, double* host_sum);
 
+/* Test hook for the in-LDS inverse FFT both generators are built on: `rows` independent rows
+ * of n << interleave_log2 complex float32 values, each holding 2^interleave_log2 interleaved
+ * sequences of length n (a power of two >= 4; at most 8192 values per row); unnormalised
+ * (numpy.fft.ifft(x) * n). */
+int mrx_fft_rows(mrx_ctx* ctx, const float* d_in, int rows, int n, int interleave_log2,
+                 float* d_out);
+
 /* ---- detector noise ----------------------------------------- */
 
 /* White + 1/f noise with spatially correlated modes: sim/noise.py:18-63 and
@@ -304,10 +311,14 @@ int mrx_screen_psd_sum(mrx_ctx* ctx, int ny, int nx, double dy, double dx,
  * w white N(0,1); p_d independent pink series with two-sided spectrum (knee/2)/|f| (equal
  * to the white level at f = knee); M_m = sqrt(fs) w'_m + P_m the modes (white + pink, the
  * generator applied to itself, generation.py:41-43); c = corr_prop.  The reference
- * filters white noise with a length-T FFT per detector; here each pink series is
- * synthesised in the frequency domain on a power-of-two period N >= T (a four-step
- * LDS FFT) and cut to T samples: same spectrum, different realisation and period --
- * statistical parity, like the screens.
+ * filters white noise with a length-T FFT per detector; here pink series are synthesised
+ * in the frequency domain on a power-of-two period N >= T (a four-step LDS FFT whose real
+ * and imaginary parts serve two detectors) and cut to T samples: same spectrum, different
+ * realisation and period -- statistical parity, like the screens.  With knee = 0 the
+ * output is white only and neither the basis nor the work buffer is used.
+ *  det_offset   global index of row 0 (even): the draws of detector det_offset + d depend on
+ *               (seed, det_offset + d) only, the modes on the seed only -- shards of one
+ *               band generated on different GPUs share their modes and nothing else
  *  d_basis [D][n_modes] spatial basis (utils/linalg.py:105-126, host), or NULL with n_modes 0
  *  d_scale [D]  1e12 * NEP per detector (noise.py:62), or NULL
  *  d_loading    [D][ld_loading] float32 total optical loading (pW) or NULL: the amplitude of
@@ -315,11 +326,13 @@ int mrx_screen_psd_sum(mrx_ctx* ctx, int ny, int nx, double dy, double dx,
  *               1e12 * NEP_per_loading (noise.py:35-37); must not alias an accumulating d_out
  *  d_out        [D][ld_out] float32, written (accumulate = 0) or added to (accumulate = 1:
  *               noise straight into an existing TOD)
- *  d_work       scratch of work_floats floats; mrx_noise_work_floats(T, n_modes, batch) gives
- *               the size that processes `batch` detectors per pass. */
+ *  d_work       16-byte aligned scratch of work_floats floats; mrx_noise_work_floats(T,
+ *               n_modes, batch) gives the size that processes `batch` detectors per pass
+ *               (4 N bytes per detector).
+ * mrx_noise_period: N = n1 * n2 for T samples (T <= 2^23). */
 int mrx_noise_period(int T, int* n1, int* n2);
 int mrx_noise_work_floats(int T, int n_modes, int batch, size_t* floats);
-int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int T,
+int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T,
                        double sample_rate, double knee, double corr_prop,
                        const float* d_basis, int n_modes, const float* d_scale,
                        const float* d_loading, size_t ld_loading, double per_loading,

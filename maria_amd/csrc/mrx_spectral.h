@@ -105,6 +105,65 @@ __device__ __forceinline__ float2* fft_lds_inverse(float2* a, float2* b,
   return in;
 }
 
+// The same transform on 2^lj interleaved sequences (element i of sequence b at
+// index (i << lj) + b): the Stockham recursion with an initial stride.  n >= 4.
+__device__ __forceinline__ float2* fft_lds_inverse_batched(float2* a, float2* b,
+                                                           const float2* tw, int n,
+                                                           int log2n, int lj) {
+  float2* in = a;
+  float2* out = b;
+  int ns = 1, s = 0;
+  const int q = n >> 2;
+  const int bmask = (1 << lj) - 1;
+  for (; s + 2 <= log2n; s += 2, ns <<= 2) {
+    const int tstride = q / ns;
+    for (int jj = threadIdx.x; jj < (q << lj); jj += kBlock) {
+      const int j = jj >> lj, bb = jj & bmask;
+      const int k = j & (ns - 1);
+      float2 v0 = in[(j << lj) + bb], v1 = in[((j + q) << lj) + bb];
+      float2 v2 = in[((j + 2 * q) << lj) + bb], v3 = in[((j + 3 * q) << lj) + bb];
+      if (ns > 1) {
+        const float2 w1 = tw[k * tstride];
+        const float2 w2 = cmul(w1, w1);
+        const float2 w3 = cmul(w2, w1);
+        v1 = cmul(v1, w1);
+        v2 = cmul(v2, w2);
+        v3 = cmul(v3, w3);
+      }
+      const float2 t0 = make_float2(v0.x + v2.x, v0.y + v2.y);
+      const float2 t1 = make_float2(v0.x - v2.x, v0.y - v2.y);
+      const float2 t2 = make_float2(v1.x + v3.x, v1.y + v3.y);
+      const float2 t3 = make_float2(-(v1.y - v3.y), v1.x - v3.x);
+      const int j0 = ((j - k) << 2) + k;
+      out[(j0 << lj) + bb] = make_float2(t0.x + t2.x, t0.y + t2.y);
+      out[((j0 + ns) << lj) + bb] = make_float2(t1.x + t3.x, t1.y + t3.y);
+      out[((j0 + 2 * ns) << lj) + bb] = make_float2(t0.x - t2.x, t0.y - t2.y);
+      out[((j0 + 3 * ns) << lj) + bb] = make_float2(t1.x - t3.x, t1.y - t3.y);
+    }
+    __syncthreads();
+    float2* t = in;
+    in = out;
+    out = t;
+  }
+  if (s < log2n) {
+    const int h = n >> 1;
+    for (int jj = threadIdx.x; jj < (h << lj); jj += kBlock) {
+      const int j = jj >> lj, bb = jj & bmask;
+      float2 w = tw[j & (q - 1)];
+      if (j >= q) w = make_float2(-w.y, w.x);
+      const float2 v0 = in[(j << lj) + bb];
+      const float2 v1 = cmul(in[((j + h) << lj) + bb], w);
+      out[(j << lj) + bb] = make_float2(v0.x + v1.x, v0.y + v1.y);
+      out[((j + h) << lj) + bb] = make_float2(v0.x - v1.x, v0.y - v1.y);
+    }
+    __syncthreads();
+    float2* t = in;
+    in = out;
+    out = t;
+  }
+  return in;
+}
+
 __device__ __forceinline__ void fill_twiddles(float2* tw, int n) {
   for (int k = threadIdx.x; k < n / 4; k += kBlock) {
     float s, c;

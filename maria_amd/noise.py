@@ -47,42 +47,55 @@ def diameter(offsets):
     return float(scipy.spatial.distance.pdist(pts).max())
 
 
-def simulate_noise(ctx, dets, T, sample_rate, seed, noise_kwargs=None, device="cuda:0", batch=512, out=None, loading=None):
+def simulate_noise(ctx, dets, T, sample_rate, seed, noise_kwargs=None, device="cuda:0", batch=512, out=None, loading=None,
+                   det_slice=None):
     """sim/noise.py:18-63: one band at a time, [ndet, T] float32 in pW on the device.
     ``dets`` is a ``maria_amd.instrument.Detectors``; bands carry ``NEP`` (W sqrt(s)), ``knee``
     (Hz) and ``NEP_per_loading``; ``loading`` is the [ndet, T] float32 device tensor of the summed
-    loadings in pW, needed only by bands whose NEP grows with it (noise.py:35-37)."""
+    loadings in pW, needed only by bands whose NEP grows with it (noise.py:35-37).
+    ``det_slice``: generate only these rows of every band-major table (a detector shard, even
+    start): a shard's rows equal the same rows of the unsharded call, modes included."""
     kw = dict(DEFAULT_NOISE_SIM_KWARGS)
     kw.update(noise_kwargs or {})
     dev = torch.device(device)
+    lo, hi = (0, dets.n) if det_slice is None else (det_slice.start or 0, dets.n if det_slice.stop is None else det_slice.stop)
     if out is None:
-        out = torch.empty((dets.n, T), dtype=torch.float32, device=dev)
+        out = torch.empty((hi - lo, T), dtype=torch.float32, device=dev)
+    assert out.shape[0] == hi - lo and (loading is None or loading.shape[0] == hi - lo)
     for b, band in enumerate(dets.bands):
         idx = np.nonzero(dets.band_index == b)[0]
         if len(idx) == 0:
             continue
+        if not (np.diff(idx) == 1).all():
+            raise NotImplementedError("detectors of a band must be contiguous rows")
+        first, last = max(lo, int(idx[0])), min(hi, int(idx[-1]) + 1)  # this shard's rows of the band
+        if last <= first:
+            continue
+        offset = first - int(idx[0])  # index within the band: what the draws are keyed by
+        if offset % 2:
+            raise ValueError("a detector shard must start at an even row of each band (the pink series come in pairs)")
         per_loading = float(getattr(band, "NEP_per_loading", 0.0))
         if per_loading and loading is None:
             raise ValueError(f"band {band.name} has NEP_per_loading != 0: pass the summed loading (sim/noise.py:35-37)")
-        if not (np.diff(idx) == 1).all():
-            raise NotImplementedError("detectors of a band must be contiguous rows")
         offs = dets.offsets[idx]
         fov = diameter(offs)
         if fov > 0 and len(idx) > 16:  # sim/noise.py:42-50
             basis = spatial_basis(offs, k=5, n_side=16, scale=fov * kw.get("correlated_noise_spatial_scale", 0))
         else:
             basis = np.ones((len(idx), 1))
+        basis = basis[offset : offset + last - first]
+        count = last - first
         d_basis = torch.as_tensor(np.ascontiguousarray(basis, np.float32)).to(dev)
-        d_scale = torch.full((len(idx),), float(1e12 * band.NEP), dtype=torch.float32, device=dev)  # noise.py:62
+        d_scale = torch.full((count,), float(1e12 * band.NEP), dtype=torch.float32, device=dev)  # noise.py:62
         n_modes = basis.shape[1]
         need = C.c_size_t()
-        ctx.lib.mrx_noise_work_floats(int(T), int(n_modes), int(min(batch, len(idx))), C.byref(need))
+        ctx.lib.mrx_noise_work_floats(int(T), int(n_modes), int(min(batch, count)), C.byref(need))
         work = torch.empty(need.value, dtype=torch.float32, device=dev)
-        view = out[int(idx[0]) : int(idx[-1]) + 1]
+        view = out[first - lo : last - lo]
         ctx.call(
-            "mrx_noise_generate", int(seed) + 7919 * b, len(idx), int(T), float(sample_rate), float(band.knee),
+            "mrx_noise_generate", int(seed) + 7919 * b, count, offset, int(T), float(sample_rate), float(band.knee),
             float(kw.get("correlated_noise_proportion", 0)), ptr(d_basis), int(n_modes), ptr(d_scale),
-            ptr(loading[int(idx[0]) : int(idx[-1]) + 1]) if per_loading else None, loading.stride(0) if per_loading else 0,
+            ptr(loading[first - lo : last - lo]) if per_loading else None, loading.stride(0) if per_loading else 0,
             1e12 * per_loading, ptr(view), out.stride(0), 0, ptr(work), need.value,
         )
         del work

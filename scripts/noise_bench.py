@@ -34,7 +34,7 @@ def main():
         ctx.lib.mrx_noise_work_floats(T, 5, batch, C.byref(need))
         work = torch.empty(need.value, dtype=torch.float32, device=dev)
         for knee, modes in ((1.0, 5), (1.0, 0), (0.0, 0)):
-            fn = lambda: ctx.call("mrx_noise_generate", 1, D, T, 400.0, knee, 0.5, ptr(B) if modes else None, modes, ptr(scale),  # noqa: E731
+            fn = lambda: ctx.call("mrx_noise_generate", 1, D, 0, T, 400.0, knee, 0.5, ptr(B) if modes else None, modes, ptr(scale),  # noqa: E731
                                   None, 0, 0.0, ptr(out), out.stride(0), 0, ptr(work), need.value)
             med, mn = timeit(fn, reps)
             print(f"noise D={D} T={T} batch={batch} knee={knee} modes={modes}: median {med:.3f} ms min {mn:.3f} ms "

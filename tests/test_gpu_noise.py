@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _generate(ctx, D, T, fs, knee, corr=0.0, basis=None, scale=None, seed=5, accumulate=0, out=None, batch=64,
-              loading=None, per_loading=0.0):
+              loading=None, per_loading=0.0, det_offset=0):
     import torch
 
     from maria_amd._lib import ptr
@@ -26,7 +26,7 @@ def _generate(ctx, D, T, fs, knee, corr=0.0, basis=None, scale=None, seed=5, acc
     d_scale = None if scale is None else torch.as_tensor(np.asarray(scale, np.float32)).to(dev)
     if out is None:
         out = torch.zeros((D, T), dtype=torch.float32, device=dev)
-    ctx.call("mrx_noise_generate", seed, D, T, float(fs), float(knee), float(corr), ptr(d_basis), n_modes,
+    ctx.call("mrx_noise_generate", seed, D, det_offset, T, float(fs), float(knee), float(corr), ptr(d_basis), n_modes,
              ptr(d_scale), ptr(loading), 0 if loading is None else loading.stride(0), float(per_loading),
              ptr(out), out.stride(0), accumulate, ptr(work), need.value)
     return out
@@ -34,9 +34,10 @@ def _generate(ctx, D, T, fs, knee, corr=0.0, basis=None, scale=None, seed=5, acc
 
 def test_period_helper(gpu_ctx):
     n1, n2 = C.c_int(), C.c_int()
-    for T, want in [(1, 4096), (3000, 4096), (4097, 8192), (240000, 262144), (1440000, 2097152)]:
+    for T, want in [(1, 4096), (3000, 4096), (4097, 8192), (240000, 262144), (1440000, 2097152), (1 << 23, 1 << 23)]:
         assert gpu_ctx.lib.mrx_noise_period(T, C.byref(n1), C.byref(n2)) == 0
-        assert n1.value * n2.value == want and 64 <= n2.value <= n1.value <= 8192 and n1.value in (n2.value, 2 * n2.value)
+        assert n1.value * n2.value == want and 64 <= n1.value <= 1024 and n2.value == min(8192, want // 64)
+    assert gpu_ctx.lib.mrx_noise_period((1 << 23) + 1, C.byref(n1), C.byref(n2)) != 0  # unsupported length
 
 
 def test_white_noise_level_and_independence(gpu_ctx):
@@ -143,6 +144,40 @@ def test_deterministic_batched_and_accumulating(gpu_ctx):
     base = torch.full((D, T + 5), 3.0, dtype=torch.float32, device="cuda:0")
     acc = _generate(gpu_ctx, D, T, fs, knee, seed=9, accumulate=1, out=base)
     assert torch.allclose(acc[:, :T], a + 3.0, atol=1e-5) and bool((acc[:, T:] == 3.0).all())
+
+
+def test_shards_share_modes_and_nothing_else(gpu_ctx):
+    """A detector shard (even det_offset) reproduces exactly its rows of the whole band:
+    the pink pair series and white draws are keyed by the global index, the modes by the seed."""
+    import torch
+
+    from maria_amd import noise as mnoise
+    from maria_amd import synthetic
+
+    D, T, fs, knee = 50, 5000, 80.0, 2.0
+    off = synthetic.hex_pack(D, np.radians(0.5))
+    B = mnoise.spatial_basis(off, k=5, n_side=16, scale=mnoise.diameter(off))
+    scale = np.linspace(1.0, 2.0, D)
+    whole = _generate(gpu_ctx, D, T, fs, knee, corr=0.5, basis=B, scale=scale, seed=21)
+    for lo, hi in [(0, 16), (16, 50), (34, 35)]:
+        part = _generate(gpu_ctx, hi - lo, T, fs, knee, corr=0.5, basis=B[lo:hi], scale=scale[lo:hi], seed=21, det_offset=lo)
+        assert torch.equal(part, whole[lo:hi])
+    with pytest.raises(RuntimeError):
+        _generate(gpu_ctx, 4, T, fs, knee, det_offset=3)  # odd offset would split a pair
+
+
+def test_unaligned_rows_and_short_series(gpu_ctx):
+    """Rows that are not 16-byte aligned take the scalar store path and give the same values;
+    T far below the minimum period (4096) and not a multiple of 4."""
+    import torch
+
+    D, T, fs, knee = 9, 1003, 30.0, 1.5
+    a = _generate(gpu_ctx, D, T, fs, knee, seed=2)
+    buf = torch.full((D, T + 2), -1.0, dtype=torch.float32, device="cuda:0")
+    b = _generate(gpu_ctx, D, T, fs, knee, seed=2, out=buf[:, 1 : T + 1])
+    assert torch.equal(a, b) and bool((buf[:, 0] == -1).all()) and bool((buf[:, T + 1] == -1).all())
+    x = a.cpu().numpy().astype(np.float64)
+    assert np.isfinite(x).all() and abs(x.var() / (fs * (1 + 2 * knee / fs * np.sum(1.0 / np.arange(1, 2049)))) - 1) < 0.5
 
 
 def test_simulation_with_noise(gpu_ctx):

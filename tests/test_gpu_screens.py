@@ -198,3 +198,22 @@ def test_generate_screens_end_to_end(gpu_ctx):
         layer["values"] = s.cpu().numpy()
     ref = hotpath.run_path(p)
     assert rel_err(tod, ref) <= 1e-5
+
+
+@pytest.mark.parametrize("n,lj", [(4, 0), (8, 0), (64, 0), (128, 0), (2048, 0), (4096, 0), (8192, 0), (64, 6), (128, 5), (1024, 2), (4, 3), (32, 4)])
+def test_lds_fft_matches_numpy(gpu_ctx, n, lj):
+    """The in-LDS Stockham transform (and its interleaved-sequences form) against
+    numpy.fft.ifft: the building block of both spectral generators."""
+    import torch
+
+    from maria_amd._lib import ptr
+
+    rng = np.random.default_rng(n + lj)
+    rows, J = 3, 1 << lj
+    x = (rng.normal(size=(rows, n, J)) + 1j * rng.normal(size=(rows, n, J))).astype(np.complex64)
+    d_in = torch.as_tensor(np.ascontiguousarray(x)).to("cuda:0")
+    d_out = torch.empty_like(d_in)
+    gpu_ctx.call("mrx_fft_rows", ptr(d_in), rows, n, lj, ptr(d_out))
+    got = d_out.cpu().numpy()
+    ref = np.fft.ifft(x.astype(np.complex128), axis=1) * n
+    assert np.abs(got - ref).max() <= 1e-6 * np.log2(n) * np.abs(ref).max()
