@@ -83,6 +83,7 @@ enum {
   MRX_OPT_SAMPLE_CHUNK = 3, /* time steps per workgroup (tuning; 0 = automatic) */
   MRX_OPT_UPSAMPLE_GROUPS = 4, /* 16-row detector tiles per workgroup of the TOD
                                   writer (tuning; 0 = automatic) */
+  MRX_OPT_NOISE_GENERIC = 5, /* 1: the LDS second pass even where the register one applies (tests) */
   MRX_OPT_COUNT = 8
 };
 int mrx_set_option(mrx_ctx* ctx, int option, int value);
@@ -299,7 +300,7 @@ int mrx_screen_psd_sum(mrx_ctx* ctx, int ny, int nx, double dy, double dx,
 /* Test hook for the in-LDS inverse FFT both generators are built on: `rows` independent rows
  * of n << interleave_log2 complex float32 values, each holding 2^interleave_log2 interleaved
  * sequences of length n (a power of two >= 4; at most 8192 values per row); unnormalised
- * (numpy.fft.ifft(x) * n). */
+ * (numpy.fft.ifft(x) * n).  interleave_log2 = -1: the 64-point register transform, n = 64. */
 int mrx_fft_rows(mrx_ctx* ctx, const float* d_in, int rows, int n, int interleave_log2,
                  float* d_out);
 
@@ -311,10 +312,11 @@ int mrx_fft_rows(mrx_ctx* ctx, const float* d_in, int rows, int n, int interleav
  * w white N(0,1); p_d independent pink series with two-sided spectrum (knee/2)/|f| (equal
  * to the white level at f = knee); M_m = sqrt(fs) w'_m + P_m the modes (white + pink, the
  * generator applied to itself, generation.py:41-43); c = corr_prop.  The reference
- * filters white noise with a length-T FFT per detector; here pink series are synthesised
- * in the frequency domain on a power-of-two period N >= T (a four-step LDS FFT whose real
- * and imaginary parts serve two detectors) and cut to T samples: same spectrum, different
- * realisation and period -- statistical parity, like the screens.  With knee = 0 the
+ * filters white noise with a length-T FFT per detector; here the pink and correlated parts
+ * are synthesised in the frequency domain on a power-of-two period N >= T (a four-step FFT
+ * whose real and imaginary parts serve two detectors; the modes enter as tabulated
+ * Hermitian spectra) and cut to T samples: same spectrum, different realisation and
+ * period -- statistical parity, like the screens.  With knee = 0 the
  * output is white only and neither the basis nor the work buffer is used.
  *  det_offset   global index of row 0 (even): the draws of detector det_offset + d depend on
  *               (seed, det_offset + d) only, the modes on the seed only -- shards of one
@@ -328,7 +330,7 @@ int mrx_fft_rows(mrx_ctx* ctx, const float* d_in, int rows, int n, int interleav
  *               noise straight into an existing TOD)
  *  d_work       16-byte aligned scratch of work_floats floats; mrx_noise_work_floats(T,
  *               n_modes, batch) gives the size that processes `batch` detectors per pass
- *               (4 N bytes per detector).
+ *               (4 N bytes per detector + 8 N per mode).
  * mrx_noise_period: N = n1 * n2 for T samples (T <= 2^23). */
 int mrx_noise_period(int T, int* n1, int* n2);
 int mrx_noise_work_floats(int T, int n_modes, int batch, size_t* floats);

@@ -16,23 +16,31 @@
 // calling the generator again (generation.py:41-43).
 //
 // The reference shapes white noise with a length-T FFT per detector
-// (generation.py:31-37).  Here pink series are synthesised directly in the
-// frequency domain on a power-of-two period N = N1*N2 >= T, and the first T
-// samples are kept: X_k = sqrt(knee/|k|) (g1 + i g2) with independent normals
-// for every k, so that the variance per frequency bin is the reference's
-// knee/|k|.  Because the amplitude is even in k, the inverse transform is a
-// circular complex Gaussian series: its real and imaginary parts are two
-// independent real series of that spectrum -- one transform serves two
-// detectors.  The length-N transform is a four-step FFT on the in-LDS Stockham
-// passes the screens use, k = k1 + N1 k2, t = j + N2 m:
-//   pass 1  per (series, k1): draw the cells, transform over k2 (length N2),
+// (generation.py:31-37).  Here the pink and the correlated parts are synthesised
+// directly in the frequency domain on a power-of-two period N = N1*N2 >= T, and
+// the first T samples are kept:
+//   * own pink part: X_k = sqrt(knee/|k|) (g1 + i g2), independent normals for
+//     every k, so that the variance per frequency bin is the reference's
+//     knee/|k|.  The amplitude is even in k, so the inverse transform is a
+//     circular complex Gaussian series whose real and imaginary parts are two
+//     independent real series of that spectrum: one transform serves two
+//     detectors (rows a, b).
+//   * modes: each mode is a real series with a Hermitian spectrum F_m[k] of
+//     variance fs/N + knee/|k| per bin (white + pink), tabulated once per call;
+//     the pair's spectrum gets sum_m sqrt(c) (B[a,m] + i B[b,m]) F_m[k], which
+//     puts mode m into the real part with weight B[a,m] and into the imaginary
+//     part with B[b,m].  All of the linear algebra happens before the transform.
+// The length-N transform is a four-step FFT on the in-LDS Stockham passes the
+// screens use, k = k1 + N1 k2, t = j + N2 m:
+//   pass 1  per (series, k1): build the cells, transform over k2 (length N2),
 //           multiply by exp(2 pi i k1 j / N)                   -> A[k1][j]  (HBM)
-//   pass 2  per (series, tile of J = 4096/N1 adjacent j): load A[:, j0:j0+J],
-//           transform over k1 (length N1, J interleaved sequences), and finish
-//           the sample in the epilogue: white draw, mode sum, scale, 16-byte
-//           stores of J consecutive samples per (m, detector).
+//   pass 2  transform over k1 (length N1) and finish the sample: white draw,
+//           scale, store.  N1 = 64 (periods up to 2^19): one thread per j, the
+//           transform in registers.  Otherwise a workgroup takes J = 4096/N1
+//           adjacent j through LDS.
 // HBM traffic per detector: 8 N bytes of scratch (A written and read once, shared
-// by two detectors) + 4 T of TOD.
+// by two detectors) + 4 T of TOD; the arithmetic (Philox, Box-Muller, ~5 log2 N
+// flops per cell) is what bounds the kernels.
 // Normals come from Philox-4x32-10 keyed by (seed, global detector index): every
 // GPU can regenerate any detector's noise independently, and the modes (keyed by
 // the seed alone) are the same on every shard.  Parity with the reference is
@@ -41,16 +49,20 @@
 
 #include "mrx_spectral.h"
 
+#include <set>
+
 namespace {
 
 using namespace mrx_dev;
 
 constexpr uint32_t kTagPink = 0x50494e4bu;   // counter word 3: 'PINK'
 constexpr uint32_t kTagWhite = 0x57484954u;  // 'WHIT'
-constexpr uint32_t kModeId = 0xffff0000u;    // row id of mode m: kModeId + m (detectors: their global index)
-constexpr int kTileCells = 4096;             // complex values per pass-2 workgroup
+constexpr uint32_t kTagMode = 0x4d4f4445u;   // 'MODE'
+constexpr int kTileCells = 4096;             // complex values per workgroup of the LDS pass 2
+constexpr int kMaxModes = 8;
 
 typedef float vfloat4 __attribute__((ext_vector_type(4)));
+typedef float vfloat2 __attribute__((ext_vector_type(2)));
 
 // amplitude of spectrum cell k of a length-n series: sqrt(knee/|k|), 0 at k = 0
 __device__ __forceinline__ float pink_amp(int k, int n, float sqrt_knee) {
@@ -65,44 +77,152 @@ __device__ __forceinline__ vfloat4 white4(uint64_t q, uint32_t id, uint32_t key0
   return vfloat4{a.x, a.y, b.x, b.y};
 }
 
-// pass 1: block (k1, series): spectrum cells k = k1 + N1*k2, FFT over k2, twiddle
+// Spectra of the modes, F[m][k1][k2] (the order pass 1 reads them in), k = k1 + n1 k2:
+// Hermitian, E|F[k]|^2 = fs/N + knee/|k|; the cells k and N - k share one draw.
+__global__ __launch_bounds__(kBlock) void noise_mode_table(float2* __restrict__ F, int n1, int n2,
+                                                           float white_var, float knee,
+                                                           uint32_t key0, uint32_t key1) {
+  const int n = n1 * n2;
+  const int c = blockIdx.x * kBlock + threadIdx.x;  // k1 * n2 + k2
+  if (c >= n) return;
+  const int k1 = c / n2, k2 = c - k1 * n2;
+  const int k = k1 + n1 * k2;
+  const int kk = k < n - k ? k : n - k;
+  const U4 rnd = philox4x32_10(U4{(uint32_t)kk, blockIdx.y, 0u, kTagMode}, key0, key1);
+  const float2 h = box_muller(rnd.x, rnd.y);
+  const float var = white_var + (kk == 0 ? 0.0f : knee / (float)kk);
+  float2 v;
+  if (kk == 0 || 2 * kk == n) {
+    v = make_float2(sqrtf(var) * h.x, 0.0f);  // self-conjugate cells are real
+  } else {
+    const float a = sqrtf(0.5f * var);
+    v = make_float2(a * h.x, k == kk ? a * h.y : -a * h.y);
+  }
+  F[(size_t)blockIdx.y * n + c] = v;
+}
+
+struct SpectrumArgs {
+  const float2* F;     // [n_modes][n] mode spectra, or null
+  const float* basis;  // [rows][n_modes]
+  int n_modes;
+  int row0, rows;      // series s holds rows row0 + 2 s and row0 + 2 s + 1 (< row0 + rows)
+  float w_ind, w_corr;
+  float knee;
+  uint32_t series0;    // Philox id of series 0
+};
+
+// pass 1: block (group of kPairsPerBlock series, k1): spectrum cells k = k1 + N1*k2, FFT over
+// k2, twiddle.  The mode spectra of the block's cells are read once into registers and serve
+// every series of the group (they are the same for all detectors; reading them per series
+// makes the kernel L2-bound).  kIter = max(1, n2 / 512) cell pairs per thread; kModes = the
+// number of modes, or -1 for "any" (read per series, no register copy).
+constexpr int kPairsPerBlock = 4;
+
+template <int kIter, int kModes>
 __global__ __launch_bounds__(kBlock) void noise_spectrum_fft(
-    float2* __restrict__ A, int n1, int n2, int log2n2, float knee,
-    uint32_t key0, uint32_t key1, uint32_t series0) {
+    float2* __restrict__ A, int n1, int n2, int log2n2, SpectrumArgs g, int pairs, uint32_t key0,
+    uint32_t key1) {
   extern __shared__ float2 lds2[];
   float2* data = lds2;
   float2* tw = lds2 + 2 * n2;
-  const int k1 = blockIdx.x;
-  const uint32_t series = series0 + blockIdx.y;
+  const int k1 = blockIdx.y;
   const int n = n1 * n2;  // <= 2^23
-  const float sqrt_knee = sqrtf(knee);
+  const float amp = g.w_ind * sqrtf(g.knee);
+  const float inv_n = 1.0f / (float)n;
   fill_twiddles(tw, n2);
   const int half = n2 >> 1;
-  for (int k2 = threadIdx.x; k2 < half; k2 += kBlock) {
-    const U4 rnd = philox4x32_10(U4{(uint32_t)k1, (uint32_t)k2, series, kTagPink}, key0, key1);
-    const float a0 = pink_amp(k1 + n1 * k2, n, sqrt_knee);
-    const float a1 = pink_amp(k1 + n1 * (k2 + half), n, sqrt_knee);
-    const float2 g0 = box_muller(rnd.x, rnd.y), g1 = box_muller(rnd.z, rnd.w);
-    data[k2] = make_float2(a0 * g0.x, a0 * g0.y);
-    data[k2 + half] = make_float2(a1 * g1.x, a1 * g1.y);
+  constexpr int kRegModes = kModes > 0 ? kModes : 1;
+  float2 f0[kIter][kRegModes], f1[kIter][kRegModes];
+  const float2* F = g.F + (size_t)k1 * n2;
+  if constexpr (kModes > 0) {
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+      const int k2 = threadIdx.x + it * kBlock;
+#pragma unroll
+      for (int m = 0; m < kModes; ++m) {
+        f0[it][m] = k2 < half ? F[(size_t)m * n + k2] : make_float2(0.f, 0.f);
+        f1[it][m] = k2 < half ? F[(size_t)m * n + k2 + half] : make_float2(0.f, 0.f);
+      }
+    }
   }
-  __syncthreads();
-  const float2* res = fft_lds_inverse(data, data + n2, tw, n2, log2n2);
-  float2* dst = A + ((size_t)blockIdx.y * n1 + k1) * n2;
-  const float inv_n = 1.0f / (float)n;
-  for (int j = threadIdx.x; j < n2; j += kBlock) {
-    // exp(2 pi i k1 j / N); k1*j < N <= 2^23 is exact in float32, and so is the fraction
-    // of a revolution the hardware sine and cosine take (absolute error ~1e-6)
-    const float rev = (float)(k1 * j) * inv_n;
-    dst[j] = cmul(res[j], make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)));
+  const int n_modes = kModes >= 0 ? kModes : g.n_modes;
+  for (int p = 0; p < kPairsPerBlock; ++p) {
+    const int pair = blockIdx.x * kPairsPerBlock + p;
+    if (pair >= pairs) break;  // uniform
+    const uint32_t series = g.series0 + pair;
+    // the pair's mode coefficients sqrt(c) (B[a,m] + i B[b,m])
+    float2 coef[kMaxModes];
+    const int row_a = g.row0 + 2 * pair;
+    const bool has_b = row_a + 1 < g.row0 + g.rows;
+#pragma unroll
+    for (int m = 0; m < kMaxModes; ++m)
+      coef[m] = m < n_modes ? make_float2(g.w_corr * g.basis[(size_t)row_a * n_modes + m],
+                                          has_b ? g.w_corr * g.basis[(size_t)(row_a + 1) * n_modes + m] : 0.0f)
+                            : make_float2(0.0f, 0.0f);
+#pragma unroll
+    for (int it = 0; it < kIter; ++it) {
+      const int k2 = threadIdx.x + it * kBlock;
+      if (k2 < half) {
+        const U4 rnd = philox4x32_10(U4{(uint32_t)k1, (uint32_t)k2, series, kTagPink}, key0, key1);
+        const float a0 = pink_amp(k1 + n1 * k2, n, amp);
+        const float a1 = pink_amp(k1 + n1 * (k2 + half), n, amp);
+        const float2 g0 = box_muller(rnd.x, rnd.y), g1 = box_muller(rnd.z, rnd.w);
+        float2 x0 = make_float2(a0 * g0.x, a0 * g0.y), x1 = make_float2(a1 * g1.x, a1 * g1.y);
+        if constexpr (kModes > 0) {
+#pragma unroll
+          for (int m = 0; m < kModes; ++m) {
+            x0 = cadd(x0, cmul(coef[m], f0[it][m]));
+            x1 = cadd(x1, cmul(coef[m], f1[it][m]));
+          }
+        } else if constexpr (kModes < 0) {
+#pragma unroll
+          for (int m = 0; m < kMaxModes; ++m)
+            if (m < n_modes) {
+              x0 = cadd(x0, cmul(coef[m], F[(size_t)m * n + k2]));
+              x1 = cadd(x1, cmul(coef[m], F[(size_t)m * n + k2 + half]));
+            }
+        }
+        data[k2] = x0;
+        data[k2 + half] = x1;
+      }
+    }
+    __syncthreads();
+    const float2* res = fft_lds_inverse<4>(data, data + n2, tw, n2, log2n2);
+    float2* dst = A + ((size_t)pair * n1 + k1) * n2;
+    for (int j = threadIdx.x; j < n2; j += kBlock) {
+      // exp(2 pi i k1 j / N); k1*j < N <= 2^23 is exact in float32, and so is the fraction
+      // of a revolution the hardware sine and cosine take (absolute error ~1e-6)
+      const float rev = (float)(k1 * j) * inv_n;
+      dst[j] = cmul(res[j], make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)));
+    }
+    __syncthreads();  // the next series reuses both LDS images
+  }
+}
+
+typedef void (*SpectrumKernel)(float2*, int, int, int, SpectrumArgs, int, uint32_t, uint32_t);
+
+template <int kIter>
+SpectrumKernel spectrum_kernel_modes(int n_modes) {
+  switch (n_modes) {
+    case 0: return noise_spectrum_fft<kIter, 0>;
+    case 1: return noise_spectrum_fft<kIter, 1>;
+    case 5: return noise_spectrum_fft<kIter, 5>;
+    default: return noise_spectrum_fft<kIter, -1>;
+  }
+}
+
+// the instantiation for a first transform of length n2 (64 .. 8192) and n_modes modes
+SpectrumKernel spectrum_kernel(int n2, int n_modes) {
+  switch (n2 <= 512 ? 1 : n2 / 512) {
+    case 1: return spectrum_kernel_modes<1>(n_modes);
+    case 2: return spectrum_kernel_modes<2>(n_modes);
+    case 4: return spectrum_kernel_modes<4>(n_modes);
+    case 8: return spectrum_kernel_modes<8>(n_modes);
+    default: return spectrum_kernel_modes<16>(n_modes);
   }
 }
 
 struct CombineArgs {
-  const float* P;        // [n_modes][ldp] modes (white + pink), or null
-  size_t ldp;
-  const float* basis;    // [rows][n_modes] or null
-  int n_modes;
   const float* scale;    // [rows] or null
   const float* loading;  // [rows][ld_loading] or null
   size_t ld_loading;
@@ -112,44 +232,24 @@ struct CombineArgs {
   int row0, rows;        // this launch writes rows row0 .. row0 + rows - 1
   uint32_t id0;          // white-noise id of out row 0
   int T;
-  float sqrt_fs, w_corr, w_ind;
+  float sqrt_fs;
   int accumulate, vec_ok;
 };
 
-// one group of 4 consecutive samples of one row: everything but the pink value
-constexpr int kMaxModes = 8;
-
-// the modes' values at samples t0 .. t0 + 3, loaded once for both rows of a pair
-struct Modes4 {
-  vfloat4 p[kMaxModes];
-};
-
-__device__ __forceinline__ void load_modes(const CombineArgs& g, size_t t0, Modes4& M) {
-#pragma unroll
-  for (int m = 0; m < kMaxModes; ++m)
-    if (m < g.n_modes) M.p[m] = *reinterpret_cast<const vfloat4*>(g.P + (size_t)m * g.ldp + t0);
-}
-
+// one group of 4 consecutive samples of one row, given its pink + correlated part
 __device__ __forceinline__ void finish4(const CombineArgs& g, int row, size_t t0, vfloat4 pink,
-                                        const Modes4& M, uint32_t key0, uint32_t key1) {
+                                        uint32_t key0, uint32_t key1) {
   const vfloat4 w = white4(t0 >> 2, g.id0 + (uint32_t)row, key0, key1);
-  vfloat4 v = g.sqrt_fs * w + g.w_ind * pink;
-  if (g.n_modes > 0) {
-    vfloat4 corr = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int m = 0; m < kMaxModes; ++m)
-      if (m < g.n_modes) corr += g.basis[(size_t)row * g.n_modes + m] * M.p[m];
-    v += g.w_corr * corr;
-  }
+  vfloat4 v = g.sqrt_fs * w + pink;
   const float sc = g.scale ? g.scale[row] : 1.0f;
   float* dst = g.out + (size_t)row * g.ld + t0;
   const bool full = g.vec_ok && t0 + 4 <= (size_t)g.T;
   if (g.loading) {
     // total NEP of a sample: NEP + NEP_per_loading x loading (sim/noise.py:35-37)
     const float* L = g.loading + (size_t)row * g.ld_loading + t0;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (t0 + q < (size_t)g.T) v[q] *= sc + g.per_loading * L[q];
+    const float l0 = L[0], l1 = t0 + 1 < (size_t)g.T ? L[1] : 0.f, l2 = t0 + 2 < (size_t)g.T ? L[2] : 0.f,
+                l3 = t0 + 3 < (size_t)g.T ? L[3] : 0.f;
+    v *= sc + g.per_loading * vfloat4{l0, l1, l2, l3};
   } else {
     v *= sc;
   }
@@ -158,14 +258,16 @@ __device__ __forceinline__ void finish4(const CombineArgs& g, int row, size_t t0
     if (g.accumulate) v += *d4;
     __builtin_nontemporal_store(v, d4);
   } else {
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-      if (t0 + q < (size_t)g.T) dst[q] = g.accumulate ? dst[q] + v[q] : v[q];
+    const float v0 = v[0], v1 = v[1], v2 = v[2], v3 = v[3];
+    dst[0] = g.accumulate ? dst[0] + v0 : v0;
+    if (t0 + 1 < (size_t)g.T) dst[1] = g.accumulate ? dst[1] + v1 : v1;
+    if (t0 + 2 < (size_t)g.T) dst[2] = g.accumulate ? dst[2] + v2 : v2;
+    if (t0 + 3 < (size_t)g.T) dst[3] = g.accumulate ? dst[3] + v3 : v3;
   }
 }
 
-// pass 2: block (tile of J adjacent j, series): FFT over k1 for J sequences at once,
-// then the epilogue.  Series s holds rows row0 + 2 s (real part) and row0 + 2 s + 1.
+// pass 2, general: block (tile of J adjacent j, series): FFT over k1 for J sequences at
+// once in LDS, then the epilogue with 16-byte stores of 4 consecutive samples.
 __global__ __launch_bounds__(kBlock) void noise_fft_combine(
     const float2* __restrict__ A, int n1, int n2, int log2n1, int lj, CombineArgs g,
     uint32_t key0, uint32_t key1) {
@@ -183,18 +285,80 @@ __global__ __launch_bounds__(kBlock) void noise_fft_combine(
     data[e] = src[(size_t)k1 * n2 + b];
   }
   __syncthreads();
-  const float2* res = fft_lds_inverse_batched(data, data + kTileCells, tw, n1, log2n1, lj);
+  const float2* res = fft_lds_inverse_batched<8>(data, data + kTileCells, tw, n1, log2n1, lj);
   const int row_a = g.row0 + 2 * blockIdx.y;
   for (int e = threadIdx.x * 4; e < n1 * J; e += kBlock * 4) {
     const int m = e >> lj, b = e & (J - 1);
     const size_t t0 = (size_t)n2 * m + j0 + b;
     if (t0 >= (size_t)g.T) continue;
     const float2 r0 = res[e], r1 = res[e + 1], r2 = res[e + 2], r3 = res[e + 3];
-    Modes4 M;
-    load_modes(g, t0, M);
-    finish4(g, row_a, t0, vfloat4{r0.x, r1.x, r2.x, r3.x}, M, key0, key1);
+    finish4(g, row_a, t0, vfloat4{r0.x, r1.x, r2.x, r3.x}, key0, key1);
     if (row_a + 1 < g.row0 + g.rows)
-      finish4(g, row_a + 1, t0, vfloat4{r0.y, r1.y, r2.y, r3.y}, M, key0, key1);
+      finish4(g, row_a + 1, t0, vfloat4{r0.y, r1.y, r2.y, r3.y}, key0, key1);
+  }
+}
+
+// pass 2 when n1 == 64 (every period up to 2^19 samples): one thread per j, the
+// 64-point transform over k1 in registers -- no LDS, no barrier.  Lane l of a wave
+// holds samples t = j0 + l + n2 m, so each (m, row) is one 256-byte store per wave.
+// The white draws are keyed by (j, m / 4): a Philox call gives the normals of 4
+// values of m at one j.
+template <bool kExtras>
+__global__ __launch_bounds__(kBlock) void noise_fft64_combine(
+    const float2* __restrict__ A, int n2, CombineArgs g, uint32_t key0, uint32_t key1) {
+  const int j = blockIdx.x * kBlock + threadIdx.x;
+  if (j >= n2 || j >= g.T) return;
+  const float2* src = A + (size_t)blockIdx.y * 64 * n2 + j;
+  float re[64], im[64];
+#pragma unroll
+  for (int k = 0; k < 64; ++k) {
+    const vfloat2 v = __builtin_nontemporal_load(reinterpret_cast<const vfloat2*>(src + (size_t)k * n2));
+    re[k] = v[0];
+    im[k] = v[1];
+  }
+  fft64_inverse_reg(re, im);
+  const int row_a = g.row0 + 2 * blockIdx.y;
+  const bool has_b = row_a + 1 < g.row0 + g.rows;
+  const int row_b = has_b ? row_a + 1 : row_a;
+  const float sa = g.scale ? g.scale[row_a] : 1.0f, sb = g.scale ? g.scale[row_b] : 1.0f;
+  float* out_a = g.out + (size_t)row_a * g.ld + j;
+  float* out_b = g.out + (size_t)row_b * g.ld + j;
+  const uint32_t id_a = g.id0 + (uint32_t)row_a, id_b = g.id0 + (uint32_t)row_b;
+#pragma unroll
+  for (int mq = 0; mq < 16; ++mq) {
+    const U4 ra = philox4x32_10(U4{(uint32_t)j, id_a, 0x100u + mq, kTagWhite}, key0, key1);
+    const U4 rb = philox4x32_10(U4{(uint32_t)j, id_b, 0x100u + mq, kTagWhite}, key0, key1);
+    const float2 wa0 = box_muller(ra.x, ra.y), wa1 = box_muller(ra.z, ra.w);
+    const float2 wb0 = box_muller(rb.x, rb.y), wb1 = box_muller(rb.z, rb.w);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int m = 4 * mq + q;
+      const size_t t = (size_t)j + (size_t)n2 * m;
+      if (t >= (size_t)g.T) continue;
+      const float wa = q == 0 ? wa0.x : q == 1 ? wa0.y : q == 2 ? wa1.x : wa1.y;
+      const float wb = q == 0 ? wb0.x : q == 1 ? wb0.y : q == 2 ? wb1.x : wb1.y;
+      float va = g.sqrt_fs * wa + re[fft64_pos(m)];
+      float vb = g.sqrt_fs * wb + im[fft64_pos(m)];
+      const size_t o = (size_t)n2 * m;
+      if (kExtras) {
+        float aa = sa, ab = sb;
+        if (g.loading) {
+          aa += g.per_loading * g.loading[(size_t)row_a * g.ld_loading + t];
+          ab += g.per_loading * g.loading[(size_t)row_b * g.ld_loading + t];
+        }
+        va *= aa;
+        vb *= ab;
+        if (g.accumulate) {
+          va += out_a[o];
+          vb += out_b[o];
+        }
+        out_a[o] = va;
+        if (has_b) out_b[o] = vb;
+      } else {
+        __builtin_nontemporal_store(sa * va, out_a + o);
+        if (has_b) __builtin_nontemporal_store(sb * vb, out_b + o);
+      }
+    }
   }
 }
 
@@ -202,8 +366,7 @@ __global__ __launch_bounds__(kBlock) void noise_fft_combine(
 __global__ __launch_bounds__(kBlock) void noise_white_kernel(CombineArgs g, uint32_t key0, uint32_t key1) {
   const size_t t0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * 4;
   if (t0 >= (size_t)g.T) return;
-  Modes4 M;  // unused: n_modes == 0 without a pink part
-  finish4(g, g.row0 + blockIdx.y, t0, vfloat4{0.f, 0.f, 0.f, 0.f}, M, key0, key1);
+  finish4(g, g.row0 + blockIdx.y, t0, vfloat4{0.f, 0.f, 0.f, 0.f}, key0, key1);
 }
 
 // test hook: the in-LDS transforms on caller data (rows of n complex values;
@@ -223,13 +386,25 @@ __global__ __launch_bounds__(kBlock) void fft_rows_kernel(const float2* __restri
   for (int e = threadIdx.x; e < cells; e += kBlock) out[(size_t)blockIdx.x * cells + e] = res[e];
 }
 
+__global__ __launch_bounds__(64) void fft64_reg_rows_kernel(const float2* __restrict__ in, float2* __restrict__ out, int rows) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  float re[64], im[64];
+#pragma unroll
+  for (int k = 0; k < 64; ++k) {
+    re[k] = in[(size_t)r * 64 + k].x;
+    im[k] = in[(size_t)r * 64 + k].y;
+  }
+  fft64_inverse_reg(re, im);
+#pragma unroll
+  for (int k = 0; k < 64; ++k) out[(size_t)r * 64 + k] = make_float2(re[fft64_pos(k)], im[fft64_pos(k)]);
+}
+
 int ilog2(long long n) {
   int l = 0;
   while ((1LL << l) < n) ++l;
   return (1LL << l) == n ? l : -1;
 }
-
-size_t padded4(size_t n) { return (n + 3) & ~(size_t)3; }
 
 }  // namespace
 
@@ -253,8 +428,8 @@ int mrx_noise_work_floats(int T, int n_modes, int batch, size_t* floats) {
   int rc = mrx_noise_period(T, &n1, &n2);
   if (rc != MRX_OK || !floats || batch < 1 || n_modes < 0) return rc != MRX_OK ? rc : MRX_ERR_INVALID;
   const size_t n = (size_t)n1 * n2;
-  const size_t pairs = (size_t)((batch > n_modes ? batch : n_modes) + 1) / 2;
-  *floats = 2 * n * pairs + (((size_t)n_modes * padded4(T) + 15) & ~(size_t)15) + 16;
+  // mode spectra [n_modes][N] + one complex series [N] per pair of detectors
+  *floats = 2 * n * ((size_t)n_modes + (size_t)(batch + 1) / 2) + 16;
   return MRX_OK;
 }
 
@@ -269,7 +444,7 @@ int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T
   if (D == 0 || T == 0) return MRX_OK;
   MRX_REQUIRE(ctx, d_out, "null pointer");
   MRX_REQUIRE(ctx, ld_out >= (size_t)T, "ld_out smaller than T");
-  MRX_REQUIRE(ctx, det_offset >= 0 && det_offset % 2 == 0 && (long long)det_offset + D < (long long)kModeId,
+  MRX_REQUIRE(ctx, det_offset >= 0 && det_offset % 2 == 0 && (long long)det_offset + D < (1LL << 31),
               "det_offset must be even and non-negative");
   MRX_REQUIRE(ctx, !d_loading || ld_loading >= (size_t)T, "ld_loading smaller than T");
   MRX_REQUIRE(ctx, !d_loading || !accumulate || d_loading != d_out,
@@ -314,73 +489,68 @@ int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T
   if (mrx_noise_period(T, &n1, &n2) != MRX_OK)
     return mrx_fail(ctx, MRX_ERR_UNSUPPORTED, "T = %d exceeds the 2^23-sample noise period", T);
   const size_t n = (size_t)n1 * n2;
-  const size_t ldp = padded4((size_t)T);
-  const size_t fixed = (((size_t)n_modes * ldp + 15) & ~(size_t)15) + 16;
-  const size_t mode_pairs = (size_t)(n_modes + 1) / 2;
-  MRX_REQUIRE(ctx, work_floats >= fixed + 2 * n * (mode_pairs > 1 ? mode_pairs : 1),
+  MRX_REQUIRE(ctx, work_floats >= 2 * n * ((size_t)n_modes + 1),
               "work buffer too small: see mrx_noise_work_floats");
-  const size_t fit = (work_floats - fixed) / (2 * n);
+  const size_t fit = work_floats / (2 * n) - (size_t)n_modes;
   const int pairs_max = (int)(fit < 16384 ? fit : 16384);
   const int l1 = ilog2(n1), l2 = ilog2(n2);
   const int lj = ilog2(kTileCells) - l1;  // J = 4096 / n1 >= 4
-  const float kneef = (float)knee;
 
-  float* P = d_work;  // [n_modes][ldp]
-  float2* A = reinterpret_cast<float2*>(d_work + (((size_t)n_modes * ldp + 15) & ~(size_t)15));
+  float2* F = reinterpret_cast<float2*>(d_work);  // [n_modes][n]
+  float2* A = F + (size_t)n_modes * n;            // [pairs][n]
   const size_t lds1 = (size_t)(2 * n2 + n2 / 4) * sizeof(float2);
   const size_t lds2 = (size_t)(2 * kTileCells + n1 / 4) * sizeof(float2);
-  static size_t cap1 = 0, cap2 = 0;
-  if (lds1 > cap1) {
-    MRX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(noise_spectrum_fft),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-    cap1 = lds1;
-  }
+  const SpectrumKernel pass1 = spectrum_kernel(n2, n_modes);
+  // every instantiation is sized for the longest first transform once
+  static std::set<const void*> sized;
+  if (sized.insert(reinterpret_cast<const void*>(pass1)).second)
+    MRX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pass1),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     (int)((2 * 8192 + 8192 / 4) * sizeof(float2))));
+  static size_t cap2 = 0;
   if (lds2 > cap2) {
     MRX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(noise_fft_combine),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
     cap2 = lds2;
   }
-  // tiles of pass 2 that hold a sample t < T: j0 < min(T, n2)
-  const int tiles = mrx_ceil_div((long long)T < n2 ? T : n2, 1 << lj);
 
-  auto synthesise = [&](uint32_t series0, int pairs, const CombineArgs& h) -> int {
-    hipLaunchKernelGGL(noise_spectrum_fft, dim3(n1, pairs), dim3(kBlock), lds1, ctx->stream,
-                       A, n1, n2, l2, kneef, key0, key1, series0);
-    hipLaunchKernelGGL(noise_fft_combine, dim3(tiles, pairs), dim3(kBlock), lds2, ctx->stream,
-                       A, n1, n2, l1, lj, h, key0, key1);
-    MRX_CHECK_LAUNCH(ctx);
-    return MRX_OK;
-  };
-
-  // pink series ids: mode pair p is series p; detector pair (global rows 2q, 2q+1) is 16 + q
+  SpectrumArgs sp{};
+  sp.knee = (float)knee;
+  sp.w_ind = 1.0f;
   if (n_modes > 0) {
-    CombineArgs h{};
-    h.out = P;
-    h.ld = ldp;
-    h.rows = n_modes;
-    h.id0 = kModeId;
-    h.T = T;
-    h.sqrt_fs = g.sqrt_fs;
-    h.w_ind = 1.0f;
-    h.vec_ok = 1;
-    int rc = synthesise(0u, (int)mode_pairs, h);
-    if (rc != MRX_OK) return rc;
-    g.P = P;
-    g.ldp = ldp;
-    g.basis = d_basis;
-    g.n_modes = n_modes;
-    g.w_corr = (float)sqrt(corr_prop);
-    g.w_ind = (float)sqrt(1.0 - corr_prop);
-  } else {
-    g.w_ind = 1.0f;
+    hipLaunchKernelGGL(noise_mode_table, dim3(mrx_ceil_div((long long)n, kBlock), n_modes), dim3(kBlock),
+                       0, ctx->stream, F, n1, n2, (float)(sample_rate / (double)n), (float)knee, key0, key1);
+    MRX_CHECK_LAUNCH(ctx);
+    sp.F = F;
+    sp.basis = d_basis;
+    sp.n_modes = n_modes;
+    sp.w_corr = (float)sqrt(corr_prop);
+    sp.w_ind = (float)sqrt(1.0 - corr_prop);
   }
+  // tiles of the LDS pass 2 that hold a sample t < T: j0 < min(T, n2)
+  const int j_used = (long long)T < n2 ? T : n2;
   for (int d0 = 0; d0 < D; d0 += 2 * pairs_max) {
     const int count = D - d0 < 2 * pairs_max ? D - d0 : 2 * pairs_max;
+    const int pairs = (count + 1) / 2;
     CombineArgs h = g;
     h.row0 = d0;
     h.rows = count;
-    int rc = synthesise(16u + (uint32_t)((det_offset + d0) / 2), (count + 1) / 2, h);
-    if (rc != MRX_OK) return rc;
+    sp.row0 = d0;
+    sp.rows = count;
+    sp.series0 = 16u + (uint32_t)((det_offset + d0) / 2);  // detector pair (2q, 2q+1) is series 16 + q
+    hipLaunchKernelGGL(pass1, dim3(mrx_ceil_div(pairs, kPairsPerBlock), n1), dim3(kBlock), lds1,
+                       ctx->stream, A, n1, n2, l2, sp, pairs, key0, key1);
+    if (n1 == 64 && !ctx->options[MRX_OPT_NOISE_GENERIC]) {
+      const dim3 grid(mrx_ceil_div(j_used, kBlock), pairs);
+      if (h.loading || h.accumulate)
+        hipLaunchKernelGGL(noise_fft64_combine<true>, grid, dim3(kBlock), 0, ctx->stream, A, n2, h, key0, key1);
+      else
+        hipLaunchKernelGGL(noise_fft64_combine<false>, grid, dim3(kBlock), 0, ctx->stream, A, n2, h, key0, key1);
+    } else {
+      hipLaunchKernelGGL(noise_fft_combine, dim3(mrx_ceil_div(j_used, 1 << lj), pairs), dim3(kBlock), lds2,
+                         ctx->stream, A, n1, n2, l1, lj, h, key0, key1);
+    }
+    MRX_CHECK_LAUNCH(ctx);
   }
   return MRX_OK;
 }
@@ -389,6 +559,13 @@ int mrx_fft_rows(mrx_ctx* ctx, const float* d_in, int rows, int n, int interleav
                  float* d_out) {
   if (!ctx) return MRX_ERR_INVALID;
   const int l = ilog2(n);
+  if (ctx && interleave_log2 == -1) {  // the register transform: n must be 64
+    MRX_REQUIRE(ctx, d_in && d_out && rows >= 1 && n == 64, "bad argument");
+    hipLaunchKernelGGL(fft64_reg_rows_kernel, dim3(mrx_ceil_div(rows, 64)), dim3(64), 0, ctx->stream,
+                       reinterpret_cast<const float2*>(d_in), reinterpret_cast<float2*>(d_out), rows);
+    MRX_CHECK_LAUNCH(ctx);
+    return MRX_OK;
+  }
   MRX_REQUIRE(ctx, d_in && d_out && rows >= 1 && l >= 2 && interleave_log2 >= 0, "bad argument");
   const size_t cells = (size_t)n << interleave_log2;
   MRX_REQUIRE(ctx, cells <= 8192, "at most 8192 complex values per row");

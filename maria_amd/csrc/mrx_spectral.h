@@ -42,126 +42,193 @@ __device__ __forceinline__ float2 box_muller(uint32_t a, uint32_t b) {
   return make_float2(rad * __builtin_amdgcn_cosf(u2), rad * __builtin_amdgcn_sinf(u2));
 }
 
-// ---- in-LDS Stockham inverse FFT, radix 4 (+ one radix-2 stage) ------------
+// ---- in-LDS Stockham inverse FFT, radix 8 (+ one radix-4 or radix-2 pass) ---
 // Autosort (natural order in and out, no bit reversal), ping-pong between two
-// LDS images of n complex values.  tw[m] = exp(+2 pi i m / n) for m < n/4; the
-// other twiddles follow from w^2 = w*w, w^3 = w^2*w and exp(i(a + pi/2)) = i exp(ia).
-// Unnormalised (numpy.fft.ifft * n).  Returns the image that holds the result.
+// LDS images of n complex values.  tw[m] = exp(+2 pi i m / n) for m < n/4; a
+// butterfly looks up w = exp(2 pi i k / (R ns)) and forms its powers by
+// multiplication.  Unnormalised (numpy.fft.ifft * n).  Returns the image that
+// holds the result.
 __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
-__device__ __forceinline__ float2* fft_lds_inverse(float2* a, float2* b,
-                                                   const float2* tw, int n,
-                                                   int log2n) {
-  float2* in = a;
-  float2* out = b;
-  int ns = 1, s = 0;
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul_i(float2 a) { return make_float2(-a.y, a.x); }  // i a
+
+// 8-point inverse DFT in place: v[m] <- sum_r v[r] exp(2 pi i r m / 8)
+__device__ __forceinline__ void dft8(float2 (&v)[8]) {
+  constexpr float h = 0.70710678118654752f;
+  // radix-2 layers on (r = r0 + 2 r1 + 4 r2): first over r2, then r1, then r0
+  const float2 a0 = cadd(v[0], v[4]), a4 = csub(v[0], v[4]);
+  const float2 a1 = cadd(v[1], v[5]), a5 = csub(v[1], v[5]);
+  const float2 a2 = cadd(v[2], v[6]), a6 = csub(v[2], v[6]);
+  const float2 a3 = cadd(v[3], v[7]), a7 = csub(v[3], v[7]);
+  // even outputs from (a0..a3): 4-point DFT; odd outputs from (a4..a7) with exp(2 pi i r / 8)
+  const float2 b0 = cadd(a0, a2), b2 = csub(a0, a2);
+  const float2 b1 = cadd(a1, a3), b3 = cmul_i(csub(a1, a3));
+  const float2 c5 = make_float2(h * (a5.x - a5.y), h * (a5.x + a5.y));    // a5 e^{i pi/4}
+  const float2 c6 = cmul_i(a6);                                            // a6 e^{i pi/2}
+  const float2 c7 = make_float2(-h * (a7.x + a7.y), h * (a7.x - a7.y));   // a7 e^{3 i pi/4}
+  const float2 d4 = cadd(a4, c6), d6 = csub(a4, c6);
+  const float2 d5 = cadd(c5, c7), d7 = cmul_i(csub(c5, c7));
+  v[0] = cadd(b0, b1);
+  v[4] = csub(b0, b1);
+  v[2] = cadd(b2, b3);
+  v[6] = csub(b2, b3);
+  v[1] = cadd(d4, d5);
+  v[5] = csub(d4, d5);
+  v[3] = cadd(d6, d7);
+  v[7] = csub(d6, d7);
+}
+
+// twiddle exp(2 pi i idx / n) for 0 <= idx < n from the quarter table (q = n/4 entries)
+__device__ __forceinline__ float2 tw_at(const float2* tw, int idx, int q) {
+  const float2 w = tw[idx & (q - 1)];
+  const int quad = idx / q;
+  return quad == 0 ? w : quad == 1 ? make_float2(-w.y, w.x) : quad == 2 ? make_float2(-w.x, -w.y) : make_float2(w.y, -w.x);
+}
+
+// One Stockham pass of radix R in {2, 4, 8} over 2^lj interleaved sequences of length n:
+// butterfly j (< n/R) of sequence b reads in[(j + r n/R) << lj | b], multiplies by
+// exp(2 pi i r k / (R ns)), k = j mod ns, and writes out[((j - k) R + k + m ns) << lj | b].
+template <int R>
+__device__ __forceinline__ void stockham_pass(const float2* in, float2* out, const float2* tw, int n,
+                                              int ns, int lj) {
+  const int per = n / R;          // butterflies per sequence
   const int q = n >> 2;
-  for (; s + 2 <= log2n; s += 2, ns <<= 2) {
-    const int tstride = q / ns;  // n / (4 ns)
-    for (int j = threadIdx.x; j < q; j += kBlock) {
-      const int k = j & (ns - 1);
-      float2 v0 = in[j], v1 = in[j + q], v2 = in[j + 2 * q], v3 = in[j + 3 * q];
-      if (ns > 1) {
+  const int bmask = (1 << lj) - 1;
+  const int tstride = per / ns;   // n / (R ns): table index of exp(2 pi i / (R ns))
+  for (int jj = threadIdx.x; jj < (per << lj); jj += kBlock) {
+    const int j = jj >> lj, b = jj & bmask;
+    const int k = j & (ns - 1);
+    float2 v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) v[r] = in[((j + r * per) << lj) + b];
+    if (ns > 1) {
+      if constexpr (R == 2) {
+        v[1] = cmul(v[1], tw_at(tw, k * tstride, q));
+      } else {
+        // k tstride < n / R: first quadrant for R >= 4
         const float2 w1 = tw[k * tstride];
         const float2 w2 = cmul(w1, w1);
         const float2 w3 = cmul(w2, w1);
-        v1 = cmul(v1, w1);
-        v2 = cmul(v2, w2);
-        v3 = cmul(v3, w3);
+        v[1] = cmul(v[1], w1);
+        v[2] = cmul(v[2], w2);
+        v[3] = cmul(v[3], w3);
+        if constexpr (R == 8) {
+          const float2 w4 = cmul(w2, w2);
+          v[4] = cmul(v[4], w4);
+          v[5] = cmul(v[5], cmul(w4, w1));
+          v[6] = cmul(v[6], cmul(w4, w2));
+          v[7] = cmul(v[7], cmul(w4, w3));
+        }
       }
-      const float2 t0 = make_float2(v0.x + v2.x, v0.y + v2.y);
-      const float2 t1 = make_float2(v0.x - v2.x, v0.y - v2.y);
-      const float2 t2 = make_float2(v1.x + v3.x, v1.y + v3.y);
-      const float2 t3 = make_float2(-(v1.y - v3.y), v1.x - v3.x);  // +i (v1 - v3)
-      const int j0 = ((j - k) << 2) + k;
-      out[j0] = make_float2(t0.x + t2.x, t0.y + t2.y);
-      out[j0 + ns] = make_float2(t1.x + t3.x, t1.y + t3.y);
-      out[j0 + 2 * ns] = make_float2(t0.x - t2.x, t0.y - t2.y);
-      out[j0 + 3 * ns] = make_float2(t1.x - t3.x, t1.y - t3.y);
     }
-    __syncthreads();
+    if constexpr (R == 8) {
+      dft8(v);
+    } else if constexpr (R == 4) {
+      const float2 t0 = cadd(v[0], v[2]), t1 = csub(v[0], v[2]);
+      const float2 t2 = cadd(v[1], v[3]), t3 = cmul_i(csub(v[1], v[3]));
+      v[0] = cadd(t0, t2);
+      v[1] = cadd(t1, t3);
+      v[2] = csub(t0, t2);
+      v[3] = csub(t1, t3);
+    } else {
+      const float2 t0 = cadd(v[0], v[1]), t1 = csub(v[0], v[1]);
+      v[0] = t0;
+      v[1] = t1;
+    }
+    const int j0 = (j - k) * R + k;
+#pragma unroll
+    for (int m = 0; m < R; ++m) out[((j0 + m * ns) << lj) + b] = v[m];
+  }
+  __syncthreads();
+}
+
+// Passes of radix kRadix (8 or 4) while enough bits remain, then one smaller pass.  Which
+// radix is faster depends on the caller's mix of VALU and LDS work: measured, radix 8 for the
+// screens (n up to 8192, little else in the kernel) and radix 4 for the noise spectra.
+template <int kRadix = 8>
+__device__ __forceinline__ float2* fft_lds_inverse_batched(float2* a, float2* b,
+                                                           const float2* tw, int n,
+                                                           int log2n, int lj) {
+  constexpr int kBits = kRadix == 8 ? 3 : 2;
+  float2* in = a;
+  float2* out = b;
+  int ns = 1, s = 0;
+  for (; s + kBits <= log2n; s += kBits, ns <<= kBits) {
+    stockham_pass<kRadix>(in, out, tw, n, ns, lj);
     float2* t = in;
     in = out;
     out = t;
   }
-  if (s < log2n) {  // one radix-2 stage left (odd log2 n): ns == n/2
-    const int h = n >> 1;
-    for (int j = threadIdx.x; j < h; j += kBlock) {
-      // twiddle exp(2 pi i j / n), j < n/2
-      float2 w = tw[j & (q - 1)];
-      if (j >= q) w = make_float2(-w.y, w.x);
-      const float2 v0 = in[j];
-      const float2 v1 = cmul(in[j + h], w);
-      out[j] = make_float2(v0.x + v1.x, v0.y + v1.y);
-      out[j + h] = make_float2(v0.x - v1.x, v0.y - v1.y);
-    }
-    __syncthreads();
-    float2* t = in;
-    in = out;
-    out = t;
+  if (log2n - s == 2) {
+    stockham_pass<4>(in, out, tw, n, ns, lj);
+    return out;
+  }
+  if (log2n - s == 1) {
+    stockham_pass<2>(in, out, tw, n, ns, lj);
+    return out;
   }
   return in;
 }
 
-// The same transform on 2^lj interleaved sequences (element i of sequence b at
-// index (i << lj) + b): the Stockham recursion with an initial stride.  n >= 4.
-__device__ __forceinline__ float2* fft_lds_inverse_batched(float2* a, float2* b,
-                                                           const float2* tw, int n,
-                                                           int log2n, int lj) {
-  float2* in = a;
-  float2* out = b;
-  int ns = 1, s = 0;
-  const int q = n >> 2;
-  const int bmask = (1 << lj) - 1;
-  for (; s + 2 <= log2n; s += 2, ns <<= 2) {
-    const int tstride = q / ns;
-    for (int jj = threadIdx.x; jj < (q << lj); jj += kBlock) {
-      const int j = jj >> lj, bb = jj & bmask;
-      const int k = j & (ns - 1);
-      float2 v0 = in[(j << lj) + bb], v1 = in[((j + q) << lj) + bb];
-      float2 v2 = in[((j + 2 * q) << lj) + bb], v3 = in[((j + 3 * q) << lj) + bb];
-      if (ns > 1) {
-        const float2 w1 = tw[k * tstride];
-        const float2 w2 = cmul(w1, w1);
-        const float2 w3 = cmul(w2, w1);
-        v1 = cmul(v1, w1);
-        v2 = cmul(v2, w2);
-        v3 = cmul(v3, w3);
+template <int kRadix = 8>
+__device__ __forceinline__ float2* fft_lds_inverse(float2* a, float2* b, const float2* tw, int n,
+                                                   int log2n) {
+  return fft_lds_inverse_batched<kRadix>(a, b, tw, n, log2n, 0);
+}
+
+// ---- 64-point inverse FFT in registers --------------------------------------
+// Radix-4 decimation in frequency, fully unrolled: every index and twiddle is a
+// compile-time constant, so the arrays live in VGPRs and the trivial twiddles
+// cost nothing.  Output k ends up at position rev4(k) (its three base-4 digits
+// reversed): read x[k] as re[fft64_pos(k)].  Unnormalised, sign +.
+constexpr float kCos64[64] = {1.000000000e+00f, 9.951847267e-01f, 9.807852804e-01f, 9.569403357e-01f, 9.238795325e-01f, 8.819212643e-01f, 8.314696123e-01f, 7.730104534e-01f, 7.071067812e-01f, 6.343932842e-01f, 5.555702330e-01f, 4.713967368e-01f, 3.826834324e-01f, 2.902846773e-01f, 1.950903220e-01f, 9.801714033e-02f, 6.123233996e-17f, -9.801714033e-02f, -1.950903220e-01f, -2.902846773e-01f, -3.826834324e-01f, -4.713967368e-01f, -5.555702330e-01f, -6.343932842e-01f, -7.071067812e-01f, -7.730104534e-01f, -8.314696123e-01f, -8.819212643e-01f, -9.238795325e-01f, -9.569403357e-01f, -9.807852804e-01f, -9.951847267e-01f, -1.000000000e+00f, -9.951847267e-01f, -9.807852804e-01f, -9.569403357e-01f, -9.238795325e-01f, -8.819212643e-01f, -8.314696123e-01f, -7.730104534e-01f, -7.071067812e-01f, -6.343932842e-01f, -5.555702330e-01f, -4.713967368e-01f, -3.826834324e-01f, -2.902846773e-01f, -1.950903220e-01f, -9.801714033e-02f, -1.836970199e-16f, 9.801714033e-02f, 1.950903220e-01f, 2.902846773e-01f, 3.826834324e-01f, 4.713967368e-01f, 5.555702330e-01f, 6.343932842e-01f, 7.071067812e-01f, 7.730104534e-01f, 8.314696123e-01f, 8.819212643e-01f, 9.238795325e-01f, 9.569403357e-01f, 9.807852804e-01f, 9.951847267e-01f};
+constexpr float kSin64[64] = {0.000000000e+00f, 9.801714033e-02f, 1.950903220e-01f, 2.902846773e-01f, 3.826834324e-01f, 4.713967368e-01f, 5.555702330e-01f, 6.343932842e-01f, 7.071067812e-01f, 7.730104534e-01f, 8.314696123e-01f, 8.819212643e-01f, 9.238795325e-01f, 9.569403357e-01f, 9.807852804e-01f, 9.951847267e-01f, 1.000000000e+00f, 9.951847267e-01f, 9.807852804e-01f, 9.569403357e-01f, 9.238795325e-01f, 8.819212643e-01f, 8.314696123e-01f, 7.730104534e-01f, 7.071067812e-01f, 6.343932842e-01f, 5.555702330e-01f, 4.713967368e-01f, 3.826834324e-01f, 2.902846773e-01f, 1.950903220e-01f, 9.801714033e-02f, 1.224646799e-16f, -9.801714033e-02f, -1.950903220e-01f, -2.902846773e-01f, -3.826834324e-01f, -4.713967368e-01f, -5.555702330e-01f, -6.343932842e-01f, -7.071067812e-01f, -7.730104534e-01f, -8.314696123e-01f, -8.819212643e-01f, -9.238795325e-01f, -9.569403357e-01f, -9.807852804e-01f, -9.951847267e-01f, -1.000000000e+00f, -9.951847267e-01f, -9.807852804e-01f, -9.569403357e-01f, -9.238795325e-01f, -8.819212643e-01f, -8.314696123e-01f, -7.730104534e-01f, -7.071067812e-01f, -6.343932842e-01f, -5.555702330e-01f, -4.713967368e-01f, -3.826834324e-01f, -2.902846773e-01f, -1.950903220e-01f, -9.801714033e-02f};
+
+__host__ __device__ constexpr int fft64_pos(int k) {
+  return ((k & 3) << 4) | (k & 12) | ((k >> 4) & 3);
+}
+
+template <int L>
+__device__ __forceinline__ void fft64_stage(float (&re)[64], float (&im)[64]) {
+  constexpr int Q = L / 4;
+#pragma unroll
+  for (int s = 0; s < 64; s += L) {
+#pragma unroll
+    for (int j = 0; j < Q; ++j) {
+      const int i0 = s + j, i1 = i0 + Q, i2 = i0 + 2 * Q, i3 = i0 + 3 * Q;
+      const float ar = re[i0], ai = im[i0], br = re[i1], bi = im[i1];
+      const float cr = re[i2], ci = im[i2], dr = re[i3], di = im[i3];
+      const float t0r = ar + cr, t0i = ai + ci, t1r = ar - cr, t1i = ai - ci;
+      const float t2r = br + dr, t2i = bi + di;
+      const float t3r = -(bi - di), t3i = br - dr;  // +i (b - d)
+      re[i0] = t0r + t2r;
+      im[i0] = t0i + t2i;
+      const float y1r = t1r + t3r, y1i = t1i + t3i;
+      const float y2r = t0r - t2r, y2i = t0i - t2i;
+      const float y3r = t1r - t3r, y3i = t1i - t3i;
+      if (j == 0) {
+        re[i1] = y1r; im[i1] = y1i; re[i2] = y2r; im[i2] = y2i; re[i3] = y3r; im[i3] = y3i;
+      } else {
+        constexpr int step = 64 / L;  // twiddle exp(2 pi i j m / L) = table[j m step]
+        const float c1 = kCos64[(j * step) & 63], s1 = kSin64[(j * step) & 63];
+        const float c2 = kCos64[(2 * j * step) & 63], s2 = kSin64[(2 * j * step) & 63];
+        const float c3 = kCos64[(3 * j * step) & 63], s3 = kSin64[(3 * j * step) & 63];
+        re[i1] = y1r * c1 - y1i * s1; im[i1] = y1r * s1 + y1i * c1;
+        re[i2] = y2r * c2 - y2i * s2; im[i2] = y2r * s2 + y2i * c2;
+        re[i3] = y3r * c3 - y3i * s3; im[i3] = y3r * s3 + y3i * c3;
       }
-      const float2 t0 = make_float2(v0.x + v2.x, v0.y + v2.y);
-      const float2 t1 = make_float2(v0.x - v2.x, v0.y - v2.y);
-      const float2 t2 = make_float2(v1.x + v3.x, v1.y + v3.y);
-      const float2 t3 = make_float2(-(v1.y - v3.y), v1.x - v3.x);
-      const int j0 = ((j - k) << 2) + k;
-      out[(j0 << lj) + bb] = make_float2(t0.x + t2.x, t0.y + t2.y);
-      out[((j0 + ns) << lj) + bb] = make_float2(t1.x + t3.x, t1.y + t3.y);
-      out[((j0 + 2 * ns) << lj) + bb] = make_float2(t0.x - t2.x, t0.y - t2.y);
-      out[((j0 + 3 * ns) << lj) + bb] = make_float2(t1.x - t3.x, t1.y - t3.y);
     }
-    __syncthreads();
-    float2* t = in;
-    in = out;
-    out = t;
   }
-  if (s < log2n) {
-    const int h = n >> 1;
-    for (int jj = threadIdx.x; jj < (h << lj); jj += kBlock) {
-      const int j = jj >> lj, bb = jj & bmask;
-      float2 w = tw[j & (q - 1)];
-      if (j >= q) w = make_float2(-w.y, w.x);
-      const float2 v0 = in[(j << lj) + bb];
-      const float2 v1 = cmul(in[((j + h) << lj) + bb], w);
-      out[(j << lj) + bb] = make_float2(v0.x + v1.x, v0.y + v1.y);
-      out[((j + h) << lj) + bb] = make_float2(v0.x - v1.x, v0.y - v1.y);
-    }
-    __syncthreads();
-    float2* t = in;
-    in = out;
-    out = t;
-  }
-  return in;
+}
+
+__device__ __forceinline__ void fft64_inverse_reg(float (&re)[64], float (&im)[64]) {
+  fft64_stage<64>(re, im);
+  fft64_stage<16>(re, im);
+  fft64_stage<4>(re, im);
 }
 
 __device__ __forceinline__ void fill_twiddles(float2* tw, int n) {
