@@ -30,7 +30,7 @@ def main():
     B = torch.as_tensor(np.ascontiguousarray(mnoise.spatial_basis(off, 5, 16, mnoise.diameter(off)), np.float32)).to(dev)
     scale = torch.full((D,), 1e-5, dtype=torch.float32, device=dev)
     out = torch.empty((D, T), dtype=torch.float32, device=dev)
-    for batch in (256,):
+    for batch in [int(b) for b in os.environ.get("MRX_NOISE_BATCH", "256").split(",")]:
         need = C.c_size_t()
         ctx.lib.mrx_noise_work_floats(T, 5, batch, C.byref(need))
         work = torch.empty(need.value, dtype=torch.float32, device=dev)
