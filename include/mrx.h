@@ -297,6 +297,54 @@ int mrx_screen_generate(mrx_ctx* ctx, uint64_t seed, uint32_t stream, int ny,
 int mrx_screen_psd_sum(mrx_ctx* ctx, int ny, int nx, double dy, double dx,
                        double r0, double nu, double* host_sum);
 
+/* ---- map sampling --------------------------------------------- */
+
+/* A celestial map as MapMixin._sample_maps sees it after smoothing, conversion to K_RJ and
+ * the parity flip (sim/map.py:72-73,104-109): */
+typedef struct mrx_sky_map {
+  const float* d_values;  /* [n_channels][n_stokes][n_eta][n_xi] float32, K_RJ */
+  const double* d_eta;    /* [n_eta] rad, monotonic (descending after the parity flip) */
+  const double* d_xi;     /* [n_xi] rad, monotonic */
+  int n_channels, n_stokes, n_eta, n_xi;
+  double center_phi, center_theta; /* map centre in the map's frame, rad */
+  int bilinear;           /* 1: bilinear sampling, 0: nearest pixel (map_kwargs) */
+  int reserved;
+} mrx_sky_map;
+
+/* K_RJ -> pW of each channel (sim/map.py:117-135, band/band.py:235-255): with an atmosphere
+ * the channel's transmission integral, collapsed by the host at the scalar base temperature
+ * onto (zenith pwv, elevation), is looked up per sample at the detector's elevation and its
+ * zenith-scaled pwv -- the coarse series of mrx_atm_sample, interpolated linearly
+ * (sim/atmosphere.py:30-37); without one, a scalar per channel. */
+typedef struct mrx_map_cal {
+  const float* d_table;    /* [n_channels][n_pwv][n_el] float32, or NULL */
+  const float* d_axis_pwv; /* [n_pwv] */
+  const float* d_axis_el;  /* [n_el] */
+  int n_pwv, n_el;
+  const double* d_pwv;     /* [Ta][D] coarse zenith-scaled pwv, time-major */
+  int Ta, reserved;
+  double ta0, dta;         /* first coarse time and coarse step (s) */
+  const double* d_t;       /* [T] full-rate sample times */
+  const double* d_scalar;  /* [n_channels] Int passband dnu (device), used when d_table is NULL */
+} mrx_map_cal;
+
+/* obs.loading["map"] for the D detectors of one band (sim/map.py:76-172): detector pointing
+ * from the boresight and offsets (float32 chain of coords/transforms.py:10-29), rotation
+ * into the map's frame by the per-sample 3x3 (coords/coordinates.py:184-236; NULL for a map
+ * in the az/el frame), offsets from the map centre (transforms.py:36-53), the pointing-matrix
+ * row of utils/linalg.py:9-58 with the Stokes weights of map/projection.py:134-179, K_RJ -> pW
+ * per channel, float32 accumulation over channels, and the [0.25, 0.5, 0.25] convolution
+ * along time (scipy reflect mode, map.py:170), in one pass.
+ *  d_az, d_el   [T] float32 full-rate boresight
+ *  d_transform  [T][3][3] float64 transform stack (row vector times matrix), or NULL
+ *  d_dx, d_dy   [D] float32 offsets of observation.coords (rolled), radians
+ *  d_stokes_w   [D][n_stokes] float32: Mueller[d, 0, stokes] (array/array.py:204-221)
+ *  d_out        [D][ld_out] float32, pW */
+int mrx_map_sample(mrx_ctx* ctx, const mrx_sky_map* map, const mrx_map_cal* cal,
+                   const float* d_az, const float* d_el, int T, const double* d_transform,
+                   const float* d_dx, const float* d_dy, const float* d_stokes_w, int D,
+                   float* d_out, size_t ld_out);
+
 /* Test hook for the in-LDS inverse FFT both generators are built on: `rows` independent rows
  * of n << interleave_log2 complex float32 values, each holding 2^interleave_log2 interleaved
  * sequences of length n (a power of two >= 4; at most 8192 values per row); unnormalised

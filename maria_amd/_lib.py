@@ -77,6 +77,43 @@ class MrxBandTable(C.Structure):
     ]
 
 
+class MrxSkyMap(C.Structure):
+    """``mrx_sky_map`` (include/mrx.h)."""
+
+    _fields_ = [
+        ("d_values", C.c_void_p),
+        ("d_eta", C.c_void_p),
+        ("d_xi", C.c_void_p),
+        ("n_channels", C.c_int32),
+        ("n_stokes", C.c_int32),
+        ("n_eta", C.c_int32),
+        ("n_xi", C.c_int32),
+        ("center_phi", C.c_double),
+        ("center_theta", C.c_double),
+        ("bilinear", C.c_int32),
+        ("reserved", C.c_int32),
+    ]
+
+
+class MrxMapCal(C.Structure):
+    """``mrx_map_cal`` (include/mrx.h)."""
+
+    _fields_ = [
+        ("d_table", C.c_void_p),
+        ("d_axis_pwv", C.c_void_p),
+        ("d_axis_el", C.c_void_p),
+        ("n_pwv", C.c_int32),
+        ("n_el", C.c_int32),
+        ("d_pwv", C.c_void_p),
+        ("Ta", C.c_int32),
+        ("reserved", C.c_int32),
+        ("ta0", C.c_double),
+        ("dta", C.c_double),
+        ("d_t", C.c_void_p),
+        ("d_scalar", C.c_void_p),
+    ]
+
+
 # name -> (restype, argtypes); the single list the symbol test walks
 _vp, _i, _d, _sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
 SIGNATURES = {
@@ -106,6 +143,7 @@ SIGNATURES = {
     "mrx_map_smooth": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _d]),
     "mrx_screen_generate": (_i, [_vp, C.c_uint64, C.c_uint32, _i, _i, _d, _d, _d, _d, _vp, _vp]),
     "mrx_screen_psd_sum": (_i, [_vp, _i, _i, _d, _d, _d, _d, C.POINTER(_d)]),
+    "mrx_map_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _sz]),
     "mrx_fft_rows": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "mrx_noise_period": (_i, [_i, C.POINTER(_i), C.POINTER(_i)]),
     "mrx_noise_work_floats": (_i, [_i, _i, _i, C.POINTER(_sz)]),

@@ -1,6 +1,9 @@
-"""Beam smoothing of sky maps: ``ProjectionMap.smooth`` (map/projection.py:485-504)."""
+"""Sky maps: beam smoothing (``ProjectionMap.smooth``, map/projection.py:485-504) and sampling
+into the TOD (``MapMixin._sample_maps``, sim/map.py:76-172)."""
 
 from __future__ import annotations
+
+import ctypes as C
 
 import numpy as np
 import torch
@@ -41,3 +44,71 @@ def smooth(data, weight=None, sigma=None, fwhm=None, x_res=1.0, y_res=1.0, devic
     if as_numpy:
         return out.cpu().numpy(), den.cpu().numpy()
     return out, den
+
+
+def mueller_row(gamma):
+    """array/array.py:204-221: row 0 of each detector's Mueller matrix, [D, 4] (I, Q, U, V)."""
+    a = np.asarray(gamma, float)
+    m = np.stack([np.where(np.isnan(a), np.sqrt(2), 1.0), np.where(np.isnan(a), 0.0, np.cos(2 * a)),
+                  np.where(np.isnan(a), 0.0, np.sin(2 * a)), np.zeros_like(a)], axis=1)
+    return 0.5 * m[:, :1] * m
+
+
+def collapse_temperature(table, axis_T, base_temperature):
+    """Host part of the channel calibration (band/band.py:235-255): the (T, pwv, el) grid of a
+    channel's transmission integral collapsed at the scalar base temperature with jax's float32
+    index/weight rule -> [npwv, nel] float32 (NaN when the temperature is off the grid)."""
+    g = np.asarray(axis_T, np.float32)
+    x = np.float32(base_temperature)
+    i = min(max(int(np.searchsorted(g, x, side="left")) - 1, 0), len(g) - 2)
+    w = np.float32((x - g[i]) / (g[i + 1] - g[i]))
+    v = np.asarray(table, np.float32)
+    out = (np.float32(1) - w) * v[i] + w * v[i + 1]
+    if x < g[0] or x > g[-1]:
+        out = np.full_like(out, np.nan)
+    return out.astype(np.float32)
+
+
+def sample_map(ctx, values, eta, xi, center, az, el, offsets, stokes_weights, out=None, transform=None, bilinear=True,
+               cal_tables=None, cal_axis_pwv=None, cal_axis_el=None, coarse_pwv=None, ta0=0.0, dta=1.0, t=None,
+               cal_scalars=None, device="cuda:0"):
+    """``mrx_map_sample`` for the detectors of one band (sim/map.py:76-172).
+
+    values [C, S, n_eta, n_xi] K_RJ (smoothed, parity applied); eta, xi the map axes in radians;
+    center (phi, theta) rad; az, el the full-rate boresight [T]; offsets [D, 2] rad; stokes_weights
+    [D, S]; transform [T, 3, 3] float64 or None (az/el-frame map).  Calibration: either
+    ``cal_tables`` [C, npwv, nel] (collapsed at the base temperature) with the pwv / elevation axes,
+    the coarse zenith-scaled pwv [Ta, D] (device tensor or array), its time grid and the sample
+    times ``t``; or ``cal_scalars`` [C].  Returns the [D, T] float32 device tensor in pW."""
+    from ._lib import MrxMapCal, MrxSkyMap
+
+    dev = torch.device(device)
+    f32 = lambda a: a.to(dev, torch.float32).contiguous() if isinstance(a, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)  # noqa: E731
+    f64 = lambda a: a.to(dev, torch.float64).contiguous() if isinstance(a, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(a, np.float64)).to(dev)  # noqa: E731
+    values = np.asarray(values) if not isinstance(values, torch.Tensor) else values
+    C_, S_, n_eta, n_xi = values.shape
+    offsets = np.asarray(offsets, float)
+    D, T = len(offsets), len(az)
+    keep = dict(values=f32(values), eta=f64(eta), xi=f64(xi), az=f32(az), el=f32(el), dx=f32(offsets[:, 0]), dy=f32(offsets[:, 1]),
+                w=f32(np.asarray(stokes_weights)[:, :S_]))
+    sky = MrxSkyMap(ptr(keep["values"]), ptr(keep["eta"]), ptr(keep["xi"]), C_, S_, n_eta, n_xi, float(center[0]), float(center[1]),
+                    1 if bilinear else 0, 0)
+    cal = MrxMapCal()
+    if cal_tables is not None:
+        keep.update(tab=f32(cal_tables), ap=f32(cal_axis_pwv), ae=f32(cal_axis_el), pwv=f64(coarse_pwv), t=f64(t))
+        assert keep["tab"].shape == (C_, len(cal_axis_pwv), len(cal_axis_el)) and keep["pwv"].shape[1] == D
+        cal.d_table, cal.d_axis_pwv, cal.d_axis_el = ptr(keep["tab"]), ptr(keep["ap"]), ptr(keep["ae"])
+        cal.n_pwv, cal.n_el = len(cal_axis_pwv), len(cal_axis_el)
+        cal.d_pwv, cal.Ta, cal.ta0, cal.dta, cal.d_t = ptr(keep["pwv"]), keep["pwv"].shape[0], float(ta0), float(dta), ptr(keep["t"])
+    else:
+        keep.update(sc=f64(np.atleast_1d(cal_scalars)))
+        assert keep["sc"].shape == (C_,)
+        cal.d_scalar = ptr(keep["sc"])
+    if transform is not None:
+        keep["tr"] = f64(np.asarray(transform).reshape(T, 9) if not isinstance(transform, torch.Tensor) else transform.reshape(T, 9))
+    if out is None:
+        out = torch.empty((D, T), dtype=torch.float32, device=dev)
+    ctx.call("mrx_map_sample", C.byref(sky), C.byref(cal), ptr(keep["az"]), ptr(keep["el"]), T, ptr(keep.get("tr")),
+             ptr(keep["dx"]), ptr(keep["dy"]), ptr(keep["w"]), D, ptr(out), out.stride(0))
+    torch.cuda.current_stream(dev).synchronize()  # the temporaries in `keep` may go once the kernel is done
+    return out

@@ -105,6 +105,28 @@ def main():
     R = rotations.compute_aligning_transform(pts, signature=(True, True, False))
     g["aligning_transform"] = {"points": pts.tolist(), "numpy_seed": 1234, "R": R.tolist()}
 
+    # pointing-matrix ingredients (utils/linalg.py:9-58): the sampling rule of map sampling.
+    # Sides as the map front end hands them over: (t: one node, eta: descending after the
+    # parity flip, xi: ascending); points inside, on nodes, and outside the map.
+    pm_rng = np.random.default_rng(23)
+    eta = np.linspace(0.02, -0.02, 9)
+    xi = np.linspace(-0.03, 0.03, 13)
+    yy = np.concatenate([pm_rng.uniform(-0.025, 0.025, 40), eta[[0, 3, 8]], [0.5, -0.5]]).reshape(5, 9)
+    xx = np.concatenate([pm_rng.uniform(-0.035, 0.035, 40), xi[[0, 5, 12]], [-0.7, 0.7]]).reshape(5, 9)
+    tt = np.zeros((5, 9))
+    g["pointing_matrix"] = {"eta": eta.tolist(), "xi": xi.tolist(), "y": yy.tolist(), "x": xx.tolist(), "cases": []}
+    for bilinear in (True, False):
+        smp, pix, wts, n_pix, n_smp = linalg.compute_pointing_matrix_ingredients(
+            x_list=(tt, yy, xx), side_list=(np.array([0.0]), eta, xi), bilinear=bilinear)
+        g["pointing_matrix"]["cases"].append({"bilinear": bilinear, "samples": smp.tolist(), "pixels": pix.tolist(),
+                                             "weights": wts.tolist(), "n_pixels": int(n_pix), "n_samples": int(n_smp)})
+
+    # spatial basis of the correlated noise modes (utils/linalg.py:105-126)
+    sb_rng = np.random.default_rng(31)
+    offs = sb_rng.uniform(-0.004, 0.004, (25, 2))
+    g["spatial_basis"] = {"offsets": offs.tolist(), "k": 5, "n_side": 16, "scale": 0.01,
+                          "B": linalg.generate_spatial_basis(offs, k=5, n_side=16, scale=0.01).tolist()}
+
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     with open(OUT, "w") as f:
         json.dump(g, f, indent=1)

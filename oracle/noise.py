@@ -5,8 +5,9 @@ maria/utils/linalg.py:105-126 (``generate_spatial_basis``) and the band loop of
 maria/sim/noise.py:18-63.  The reference draws the pink noise's white input from
 ``jax.random.normal(jax.random.key(12345))`` -- the same key on every call; jax is not
 available here, so numpy's generator stands in: the oracle is a statistical target
-(spectrum, variances, cross-detector covariance), not a sample-by-sample one.  Parity
-unpinned (the module cannot be imported: jax).
+(spectrum, variances, cross-detector covariance), not a sample-by-sample one.
+``generate_spatial_basis`` is pinned by tests/golden/leaves.json (utils/linalg.py imports on
+its own); ``generate_noise_with_knee`` is parity unpinned (noise/generation.py needs jax).
 """
 
 from __future__ import annotations

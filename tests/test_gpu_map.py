@@ -1,0 +1,169 @@
+"""GPU parity of map sampling: mrx_map_sample against the numpy
+restatement of sim/map.py:76-172 (oracle/mapsample.py, whose pointing-matrix rule is pinned
+by the reference's own function in tests/golden/leaves.json)."""
+
+import numpy as np
+import pytest
+
+from helpers import rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _scan(D=37, T=3001, fov_deg=0.4, seed=0):
+    from maria_amd import synthetic
+
+    t = 1.7e9 + np.arange(T) / 50.0
+    az, el = synthetic.daisy_scan(t)
+    off = synthetic.hex_pack(D, np.radians(fov_deg))
+    roll = np.radians(11.0)
+    R = np.array([[np.cos(roll), -np.sin(roll)], [np.sin(roll), np.cos(roll)]])
+    return t, az.astype(np.float32), el.astype(np.float32), off @ R.T
+
+
+def _sky_rotation(t):
+    """A smooth stack of orthonormal 3x3 (row vector times matrix), like the fitted
+    az/el -> ra/dec transforms of coords/coordinates.py:205-218: a fixed tilt times a slow
+    rotation about the z axis."""
+    tilt = np.radians(35.0)
+    Rx = np.array([[1, 0, 0], [0, np.cos(tilt), -np.sin(tilt)], [0, np.sin(tilt), np.cos(tilt)]])
+    w = 7.292e-5 * (t - t[0]) + 0.3
+    Rz = np.zeros((len(t), 3, 3))
+    Rz[:, 0, 0], Rz[:, 0, 1], Rz[:, 1, 0], Rz[:, 1, 1], Rz[:, 2, 2] = np.cos(w), -np.sin(w), np.sin(w), np.cos(w), 1
+    return Rx[None] @ Rz
+
+
+def _centre(az, el, transform):
+    """Centre of the scanned patch in the map's frame."""
+    from oracle import mapsample
+
+    phi, theta = mapsample.frame_angles(az[None, :], el[None, :], transform)
+    xyz = mapsample.phi_theta_to_xyz(phi[0], theta[0]).astype(float).mean(axis=0)
+    xyz /= np.linalg.norm(xyz)
+    return float(np.arctan2(xyz[1], xyz[0]) % (2 * np.pi)), float(np.arcsin(xyz[2]))
+
+
+def _rounding_bound(values, eta, xi, stokes_weight_sum, pw_per_k_sum):
+    """Float32 angles carry a few 1e-7 rad of rounding in either implementation (6e-7 is the
+    bound test_offsets_through_ramp_maps holds them to); times the steepest gradient of the
+    sampled field that is the agreement one can ask of two float32 evaluations."""
+    grad = max(np.abs(np.diff(values, axis=-1)).max() / abs(xi[1] - xi[0]), np.abs(np.diff(values, axis=-2)).max() / abs(eta[1] - eta[0]))
+    return 2 * 6e-7 * grad * stokes_weight_sum * pw_per_k_sum
+
+
+def _blob_map(C, S, n_eta, n_xi, eta, xi, rng):
+    X, Y = np.meshgrid(xi, eta)
+    w = 0.25 * (abs(xi[-1] - xi[0]) + abs(eta[-1] - eta[0])) / 2
+    m = np.zeros((C, S, n_eta, n_xi), np.float32)
+    for c in range(C):
+        for s in range(S):
+            x0, y0 = rng.uniform(-0.5, 0.5, 2) * w
+            m[c, s] = (1 + 0.3 * c - 0.2 * s) * np.exp(-((X - x0) ** 2 + (Y - y0) ** 2) / (2 * w * w)) + 0.05 * rng.normal(size=X.shape)
+    return m
+
+
+@pytest.mark.parametrize("frame", ["az/el", "sky"])
+def test_offsets_through_ramp_maps(gpu_ctx, frame):
+    """A map whose value is its own xi (or eta) coordinate returns the sample's offset from
+    the map centre under bilinear sampling: the float32 geometry chain (pointing, frame
+    rotation, phi_theta_to_offsets) agrees with the restatement to a few float32 ulps of angle."""
+    from maria_amd import map as mmap
+    from oracle import hotpath, mapsample
+
+    t, az, el, off = _scan()
+    transform = _sky_rotation(t) if frame == "sky" else None
+    centre = _centre(az, el, transform)
+    n = 64
+    eta = np.linspace(0.02, -0.02, n)   # descending: the parity flip of sim/map.py:72-73
+    xi = np.linspace(-0.02, 0.02, n)
+    X, Y = np.meshgrid(xi, eta)
+    values = np.stack([X, Y])[:, None].astype(np.float32)  # two "channels": xi ramp, eta ramp
+    w = np.ones((len(off), 1))
+    az_d, el_d = hotpath.broadcast(off, az, el)
+    for c in range(2):
+        got = mmap.sample_map(gpu_ctx, values[c : c + 1], eta, xi, centre, az, el, off, w, transform=transform,
+                              cal_scalars=[1.0 / (1e12 * mapsample.K_B)]).cpu().numpy()
+        ref = mapsample.sample_maps(az_d, el_d, t, None, None, eta, xi, centre, values[c : c + 1], w,
+                                    cal_scalars=[1.0 / (1e12 * mapsample.K_B)], transform_stack=transform)
+        assert np.abs(ref).max() > 3e-3  # the scan does cover the map
+        assert np.abs(got - ref).max() <= 6e-7, (c, np.abs(got - ref).max())
+
+
+@pytest.mark.parametrize("bilinear", [True, False])
+def test_map_sampling_matches_oracle(gpu_ctx, bilinear):
+    """Three Stokes planes, two channels, polarised and unpolarised detectors, coarse pixels (so
+    that float32 angle rounding moves no weight by more than 1e-5), samples off the map's edge,
+    a TOD length that is no multiple of the tile, rows that are not 16-byte aligned."""
+    import torch
+
+    from maria_amd import map as mmap
+    from oracle import hotpath, mapsample
+
+    rng = np.random.default_rng(3)
+    t, az, el, off = _scan(D=45, T=2503, fov_deg=0.8)
+    transform = _sky_rotation(t)
+    centre = _centre(az, el, transform)
+    az_d, el_d = hotpath.broadcast(off, az, el)
+    ox = mapsample.phi_theta_to_offsets(*mapsample.frame_angles(az_d, el_d, transform), *centre)
+    # a map smaller than the scanned patch: the samples beyond its edge take the edge pixels
+    n_eta, n_xi = 5, 7
+    half_eta, half_xi = 0.6 * np.abs(ox[..., 1]).max(), 0.6 * np.abs(ox[..., 0]).max()
+    eta = np.linspace(half_eta, -half_eta, n_eta)
+    xi = np.linspace(-half_xi, half_xi, n_xi)
+    values = _blob_map(2, 3, n_eta, n_xi, eta, xi, rng)
+    gamma = np.where(np.arange(len(off)) % 3 == 0, np.nan, rng.uniform(0, np.pi, len(off)))
+    w = mapsample.mueller_row(gamma)[:, :3]
+    np.testing.assert_allclose(mmap.mueller_row(gamma), mapsample.mueller_row(gamma), atol=1e-15)
+    scal = [2.1e10, 0.7e10]
+    ref = mapsample.sample_maps(az_d, el_d, t, None, None, eta, xi, centre, values, w, cal_scalars=scal,
+                                transform_stack=transform, bilinear=bilinear)
+    buf = torch.full((len(off), len(t) + 3), -5.0, dtype=torch.float32, device="cuda:0")
+    out = buf[:, 1 : len(t) + 1]
+    mmap.sample_map(gpu_ctx, values, eta, xi, centre, az, el, off, w, out=out, transform=transform, bilinear=bilinear, cal_scalars=scal)
+    got = out.cpu().numpy()
+    assert bool((buf[:, 0] == -5).all()) and bool((buf[:, len(t) + 1 :] == -5).all())
+    if bilinear:
+        # within 3e-4 of the peak here (measured: 3e-5)
+        bound = _rounding_bound(values, eta, xi, np.abs(w).sum(axis=1).max(), 1e12 * mapsample.K_B * sum(scal))
+        assert np.abs(got - ref).max() <= bound and bound <= 3e-4 * np.abs(ref).max()
+    else:
+        # nearest pixel: a sample within float32 rounding of a pixel boundary may land on
+        # either side; everything else is exact
+        bad = np.abs(got - ref) > 1e-6 * np.abs(ref).max()
+        assert bad.mean() < 2e-3
+
+
+def test_map_sampling_with_atmospheric_transmission(gpu_ctx):
+    """With an atmosphere the K_RJ -> pW factor is looked up per sample at (zenith pwv,
+    elevation) (sim/map.py:117-135): coarse pwv series interpolated linearly, float32
+    trilinear table."""
+    from maria_amd import map as mmap
+    from oracle import hotpath, mapsample
+
+    rng = np.random.default_rng(4)
+    t, az, el, off = _scan(D=20, T=1500)
+    centre = _centre(az, el, None)
+    eta = np.linspace(0.02, -0.02, 9)
+    xi = np.linspace(-0.02, 0.02, 9)
+    values = _blob_map(2, 1, 9, 9, eta, xi, rng)
+    w = np.ones((len(off), 1)) * 0.5
+    axis_T = np.array([250.0, 270.0, 290.0])
+    axis_pwv = np.linspace(0.0, 6.0, 13)
+    axis_el = np.radians(np.linspace(20.0, 90.0, 15))
+    tabs = [(1.5e10 + 4e9 * c) * np.exp(-(0.05 + 0.03 * c + 0.04 * axis_pwv[None, :, None]) / np.sin(axis_el)[None, None, :])
+            * (axis_T[:, None, None] / 270.0) ** 0.2 for c in range(2)]
+    ta = np.arange(t[0], t[-1], 0.5)
+    coarse = 1.2 + 0.3 * np.cumsum(rng.normal(0, 0.05, (len(off), len(ta))), axis=1)
+    T0 = 273.0
+    az_d, el_d = hotpath.broadcast(off, az, el)
+    ref = mapsample.sample_maps(az_d, el_d, t, ta, coarse, eta, xi, centre, values, w, cal_tables=tabs,
+                                cal_axes=(axis_T, axis_pwv, axis_el), base_temperature=T0)
+    collapsed = np.stack([mmap.collapse_temperature(tab, axis_T, T0) for tab in tabs])
+    got = mmap.sample_map(gpu_ctx, values, eta, xi, centre, az, el, off, w, cal_tables=collapsed, cal_axis_pwv=axis_pwv,
+                          cal_axis_el=axis_el, coarse_pwv=coarse.T, ta0=ta[0], dta=0.5, t=t).cpu().numpy()
+    bound = _rounding_bound(values, eta, xi, 0.5, 1e12 * mapsample.K_B * sum(tab.max() for tab in tabs))
+    assert np.isfinite(ref).all() and np.abs(got - ref).max() <= bound + 2e-6 * np.abs(ref).max() and bound <= 3e-4 * np.abs(ref).max()
+    # a pwv beyond the table gives NaN, as jax's interpolator does
+    got2 = mmap.sample_map(gpu_ctx, values, eta, xi, centre, az, el, off, w, cal_tables=collapsed, cal_axis_pwv=axis_pwv,
+                           cal_axis_el=axis_el, coarse_pwv=coarse.T + 10.0, ta0=ta[0], dta=0.5, t=t).cpu().numpy()
+    assert np.isnan(got2).all()

@@ -171,3 +171,32 @@ def test_generate_layers_follows_extrusion_py():
     assert np.sqrt((layers["pwv_rms"] ** 2).sum()) == pytest.approx(0.03 * 2.0)
     assert (layers["res"] >= 2.0).all() and (layers["res"] <= 1e3).all()
     np.testing.assert_allclose(layers["z"], layers["h"] / np.sin(np.radians(45)))
+
+
+def test_pointing_matrix_ingredients_match_reference():
+    """oracle/mapsample.pointing_matrix_ingredients against the reference's own
+    compute_pointing_matrix_ingredients (utils/linalg.py:9-58): bilinear and nearest,
+    descending eta, points on nodes and outside the map."""
+    from oracle import mapsample
+
+    g = GOLD["pointing_matrix"]
+    eta, xi = np.array(g["eta"]), np.array(g["xi"])
+    y, x = np.array(g["y"]), np.array(g["x"])
+    for case in g["cases"]:
+        smp, pix, wts, n_pix, n_smp = mapsample.pointing_matrix_ingredients((np.zeros_like(y), y, x), (np.array([0.0]), eta, xi), case["bilinear"])
+        assert (n_pix, n_smp) == (case["n_pixels"], case["n_samples"])
+        assert np.array_equal(smp, np.array(case["samples"])) and np.array_equal(pix, np.array(case["pixels"]))
+        np.testing.assert_allclose(wts, np.array(case["weights"]), rtol=0, atol=1e-15)
+
+
+def test_spatial_basis_matches_reference():
+    """oracle/noise.generate_spatial_basis and the product's host function against
+    utils/linalg.py:105-126."""
+    from maria_amd import noise as mnoise
+    from oracle import noise as onoise
+
+    g = GOLD["spatial_basis"]
+    off = np.array(g["offsets"])
+    ref = np.array(g["B"])
+    np.testing.assert_allclose(onoise.generate_spatial_basis(off, k=g["k"], n_side=g["n_side"], scale=g["scale"]), ref, rtol=0, atol=1e-11)
+    np.testing.assert_allclose(mnoise.spatial_basis(off, k=g["k"], n_side=g["n_side"], scale=g["scale"]), ref, rtol=0, atol=1e-11)
