@@ -165,6 +165,7 @@ class Instrument:
 
 
 class Site:
-    def __init__(self, altitude=0.0, region="synthetic"):
+    def __init__(self, altitude=0.0, region="synthetic", latitude=-23.0, longitude=-67.8):
         self.altitude = float(altitude)
         self.region = region
+        self.latitude, self.longitude = float(latitude), float(longitude)  # degrees (site/site.py)

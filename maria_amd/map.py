@@ -112,3 +112,65 @@ def sample_map(ctx, values, eta, xi, center, az, el, offsets, stokes_weights, ou
              ptr(keep["dx"]), ptr(keep["dy"]), ptr(keep["w"]), D, ptr(out), out.stride(0))
     torch.cuda.current_stream(dev).synchronize()  # the temporaries in `keep` may go once the kernel is done
     return out
+
+
+class ProjectionMap:
+    """The slice of ``maria.map.ProjectionMap`` map sampling reads (map/projection.py:37-133):
+    ``data`` [stokes, nu, eta, xi] in K_RJ on a uniform tangent-plane grid around ``center``.
+
+    ``data`` may be [n_eta, n_xi], [n_nu, n_eta, n_xi] or [n_stokes, n_nu, n_eta, n_xi]; ``nu``
+    in Hz (one entry per channel), ``stokes`` a string out of "IQUV"; ``width`` / ``height`` /
+    ``resolution`` and ``center`` in degrees (``degrees=True``) or radians; ``frame`` "ra/dec"
+    or "az/el".  Row i of the data sits at eta[i], eta ascending as given -- the reference then
+    flips axis and data together (``apply_parity``), which changes nothing for sampling and is
+    mirrored here so that the device sees the same descending axis.  Units other than K_RJ, the
+    time dimension, FITS/HDF input and plotting stay with maria's front end."""
+
+    def __init__(self, data, nu=None, stokes=None, width=None, height=None, resolution=None, center=(0.0, 0.0),
+                 frame="ra/dec", degrees=True, units="K_RJ"):
+        if units != "K_RJ":
+            raise NotImplementedError("maps are sampled in K_RJ; other map units go through maria's calibration graph")
+        if frame not in ("ra/dec", "az/el"):
+            raise NotImplementedError(f"frame '{frame}': only 'ra/dec' and 'az/el' are built")
+        data = np.asarray(data, np.float32)
+        while data.ndim < 4:
+            data = data[None]
+        if data.ndim != 4:
+            raise ValueError("data must be [eta, xi], [nu, eta, xi] or [stokes, nu, eta, xi]")
+        self.stokes = stokes or "I"
+        self.nu = np.atleast_1d(np.asarray(150e9 if nu is None else nu, float))
+        if data.shape[0] != len(self.stokes) or data.shape[1] != len(self.nu):
+            raise ValueError(f"data of shape {data.shape} does not match stokes '{self.stokes}' and {len(self.nu)} channel(s)")
+        unit = np.pi / 180 if degrees else 1.0
+        n_eta, n_xi = data.shape[-2:]
+        if all(v is None for v in (width, height, resolution)):
+            raise ValueError("You must pass at least one of 'width', 'height', 'resolution'.")
+        xi_res = eta_res = None  # projection.py:104-123
+        if width is not None:
+            xi_res = width / (n_xi - 1)
+            eta_res = xi_res if height is None else None
+        if height is not None:
+            eta_res = height / (n_eta - 1)
+            xi_res = abs(eta_res) if width is None else xi_res
+        if resolution is not None:
+            xi_res = eta_res = resolution
+        self.xi = unit * xi_res * (n_xi - 1) * np.linspace(-0.5, 0.5, n_xi)
+        self.eta = unit * eta_res * (n_eta - 1) * np.linspace(-0.5, 0.5, n_eta)
+        self.x_res, self.y_res = unit * xi_res, unit * eta_res
+        # the parity convention of projection.py:128-130: eta descending
+        self.eta, self.data = self.eta[::-1].copy(), data[:, :, ::-1].copy()
+        self.center = (unit * center[0], unit * center[1])
+        self.frame, self.units = frame, units
+
+    @property
+    def nu_bin_bounds(self):
+        """map/base.py:452-454."""
+        edges = [0.0, *((self.nu[:-1] + self.nu[1:]) / 2), np.inf]
+        return list(zip(edges[:-1], edges[1:]))
+
+    def smooth(self, fwhm, ctx=None, device="cuda:0"):
+        """map/projection.py:485-504 on the device, uniform weights; fwhm in radians."""
+        if fwhm <= 0:
+            return self.data
+        out, _ = smooth(self.data, fwhm=fwhm, x_res=self.x_res, y_res=self.y_res, device=device, ctx=ctx)
+        return out

@@ -83,6 +83,26 @@ class Coordinates:
         return np.stack([np.cos(az) / tan_el, np.sin(az) / tan_el], axis=-1).astype(np.float64)
 
 
+def sky_transform_stack(t, latitude_deg, longitude_deg):
+    """[T, 3, 3] float64 with ``xyz(az, el) @ M[t] = xyz(ra, dec)``: the per-sample transform
+    coords/coordinates.py:184-236 fits to astropy's AltAz -> ICRS at fiducial times and
+    interpolates.  astropy is not available to this package, so the rotation is the
+    textbook one -- horizon to hour angle/declination at the site's latitude, then the local
+    sidereal angle (GMST of IAU 1982 + longitude) -- without precession, nutation, aberration
+    or refraction: coordinates "of date", self-consistent within a simulation.  A caller with
+    astropy hands its own stack to ``mrx_map_sample``."""
+    t = np.asarray(t, float)
+    lat = np.radians(latitude_deg)
+    days = t / 86400.0 + 2440587.5 - 2451545.0
+    lst = np.radians(15.0 * ((18.697374558 + 24.06570982441908 * days) % 24.0) + longitude_deg)
+    A = np.array([[-np.sin(lat), 0.0, np.cos(lat)], [0.0, -1.0, 0.0], [np.cos(lat), 0.0, np.sin(lat)]])  # (N, E, U) -> hour-angle frame
+    B = np.zeros((len(t), 3, 3))
+    B[:, 0, 0], B[:, 0, 1] = np.cos(lst), np.sin(lst)
+    B[:, 1, 0], B[:, 1, 1] = np.sin(lst), -np.cos(lst)
+    B[:, 2, 2] = 1.0
+    return A[None] @ B
+
+
 class Plan:
     """Time-ordered boresight in the az/el frame (``maria.plan.Plan``'s ``time``,
     ``phi``, ``theta``; other frames need astropy and stay with maria's front end)."""
@@ -188,8 +208,9 @@ class Simulation:
     ):
         """sim/simulation.py:76-198.  ``device_output=True`` leaves the TOD on the GPU as
         a torch tensor (a 10 k x 240 k TOD is 9.6 GB; the PCIe copy dwarfs the synthesis)."""
-        if cmb is not None or map is not None:
-            raise NotImplementedError("the CMB and map mixins are follow-on rows (SURVEY 8(f)); only the atmosphere path is built")
+        if cmb is not None:
+            raise NotImplementedError("the CMB mixin is a follow-on row (SURVEY 8(f))")
+        self.map, self.map_kwargs = map, {"bilinear_sampling": True, **dict(map_kwargs)}  # sim/map.py:20
         if np.dtype(dtype) != np.float32:
             raise NotImplementedError("the device path writes float32 TODs (the reference default)")
         if not isinstance(instrument, Instrument):
@@ -261,6 +282,70 @@ class Simulation:
             path.upsample(out)
         return out
 
+    def _sample_maps(self, obs):
+        """sim/map.py:76-172 on the device: one ``mrx_map_sample`` per band, [D, T] pW."""
+        import torch
+
+        from . import map as mmap
+        from ._lib import Context
+        from .instrument import compute_angular_fwhm
+
+        dets = obs.instrument.dets
+        atm = getattr(obs, "atmosphere", None)
+        if atm is not None:
+            path = atm._device_path()
+            ctx, device = path.ctx, path.device
+        else:
+            device = torch.device("cuda:0")
+            self._noise_ctx = self._noise_ctx or Context(0)
+            ctx = self._noise_ctx
+            ctx.set_stream(torch.cuda.current_stream(device))
+        T = len(obs.coords.t)
+        out = torch.zeros((dets.n, T), dtype=torch.float32, device=device)
+        transform = None
+        if self.map.frame == "ra/dec":
+            transform = sky_transform_stack(obs.coords.t, obs.site.latitude, obs.site.longitude)
+        stokes_rows = mmap.mueller_row(dets.gamma)[:, ["IQUV".index(s) for s in self.map.stokes]]
+        for b, band in enumerate(dets.bands):
+            idx = np.nonzero(dets.band_index == b)[0]
+            if len(idx) == 0:
+                continue
+            if not (np.diff(idx) == 1).all():
+                raise NotImplementedError("detectors of a band must be contiguous rows")
+            # ideally one beam per channel; the reference smooths once per band (map.py:101-104)
+            fwhm = float(compute_angular_fwhm(fwhm_0=dets.primary_size.mean(), z=np.inf, nu=band.center))
+            smoothed = self.map.smooth(fwhm, ctx=ctx, device=device)  # [S, C, eta, xi]
+            channels, tables, scalars = [], [], []
+            for c, (nu_min, nu_max) in enumerate(self.map.nu_bin_bounds):
+                if band.nu.max() < nu_min or nu_max < band.nu.min():  # map.py:112-113
+                    continue
+                channels.append(c)
+                if atm is not None:  # band/band.py:250-255
+                    sp = atm.spectrum
+                    mask = (sp.side_nu >= nu_min) & (sp.side_nu < nu_max)
+                    nu = sp.side_nu[mask]
+                    grid = np.trapezoid(band.passband(nu) * np.exp(-sp._opacity[..., mask]), x=nu, axis=-1)
+                    tables.append(mmap.collapse_temperature(grid, sp.side_base_temperature, atm.weather.temperature[0]))
+                else:  # band/band.py:246-248
+                    nu = band.nu[(band.nu >= nu_min) & (band.nu < nu_max)]
+                    scalars.append(float(np.trapezoid(band.passband(nu), x=nu)))
+            if not channels:
+                logger.warning(f"No load from map for band {band.name}")
+                continue
+            values = np.ascontiguousarray(np.swapaxes(np.asarray(smoothed)[:, channels], 0, 1))  # [C, S, eta, xi]
+            kw = {}
+            if atm is not None:
+                sp = atm.spectrum
+                pwv = path.coarse_pwv()[int(idx[0]) : int(idx[-1]) + 1].T.contiguous()  # [Ta, D_band]
+                kw = dict(cal_tables=np.stack(tables), cal_axis_pwv=sp.side_zenith_pwv, cal_axis_el=sp.side_elevation,
+                          coarse_pwv=pwv, ta0=path.ta0, dta=path.dta, t=obs.coords.t)
+            else:
+                kw = dict(cal_scalars=scalars)
+            mmap.sample_map(ctx, values, self.map.eta, self.map.xi, self.map.center, obs.boresight._baz, obs.boresight._bel,
+                            obs.coords.offsets[idx], stokes_rows[idx], out=out[int(idx[0]) : int(idx[-1]) + 1],
+                            transform=transform, bilinear=bool(self.map_kwargs["bilinear_sampling"]), device=device, **kw)
+        return out
+
     def _simulate_noise(self, obs, loading=None):
         """sim/noise.py:18-63 on the device, in pW; ``loading`` (pW, [D, T] on the device) only
         for bands whose NEP grows with the loading.  The gain error does not apply to the
@@ -305,22 +390,39 @@ class Simulation:
             self._simulate_atmosphere(obs)
             loading = self._compute_atmospheric_loading(obs, gain=gain if np.any(gain_error) else None,
                                                         units="pW" if deferred else units, metadata=metadata)
-        elif units == "K_RJ" and self.noise:
-            raise NotImplementedError("K_RJ needs the atmosphere's calibration tables here: run(units='pW') for a noise-only simulation")
-        noise = None
-        if self.noise:
-            if loading_nep and loading is None:
+        elif units == "K_RJ" and (self.noise or self.map is not None):
+            raise NotImplementedError("K_RJ needs the atmosphere's calibration tables here: run(units='pW') without an atmosphere")
+        map_loading = None
+        if self.map is not None:
+            map_loading = self._sample_maps(obs)  # pW; the gain error applies (simulation.py:243-245)
+            if np.any(gain_error):
                 import torch
 
-                loading = torch.zeros((dets.n, len(obs.coords.t)), dtype=torch.float32, device="cuda:0")
-            noise = self._simulate_noise(obs, loading=loading if loading_nep else None)
-            if units == "K_RJ":
-                if deferred:
-                    self._set_calibration(obs, metadata)
-                    obs.atmosphere._device_path().to_krj(loading)
-                obs.atmosphere._device_path().to_krj(noise)
+                map_loading *= torch.as_tensor(gain.astype(np.float32), device=map_loading.device)[:, None]
+        noise = None
+        if self.noise:
+            total = None
+            if loading_nep:  # noise.py:35-37 sums every loading field, in pW
+                fields = [f for f in (loading, map_loading) if f is not None]
+                if fields:
+                    total = fields[0] if len(fields) == 1 else fields[0] + fields[1]
+                else:
+                    import torch
+
+                    total = torch.zeros((dets.n, len(obs.coords.t)), dtype=torch.float32, device="cuda:0")
+            noise = self._simulate_noise(obs, loading=total)
+        if units == "K_RJ":  # TOD.to("K_RJ") of the fields that were not written in K_RJ directly
+            path = obs.atmosphere._device_path()
+            if deferred:
+                self._set_calibration(obs, metadata)
+                path.to_krj(loading)
+            for field in (map_loading, noise):
+                if field is not None:
+                    path.to_krj(field)
         if hasattr(obs, "atmosphere"):
             obs.loading["atmosphere"] = loading if self.device_output else loading.cpu().numpy()
+        if map_loading is not None:
+            obs.loading["map"] = map_loading if self.device_output else map_loading.cpu().numpy()
         if noise is not None:
             obs.loading["noise"] = noise if self.device_output else noise.cpu().numpy()
         return TOD(data=obs.loading, dets=dets, coords=obs.coords, units=units, metadata=metadata)

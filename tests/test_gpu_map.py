@@ -167,3 +167,65 @@ def test_map_sampling_with_atmospheric_transmission(gpu_ctx):
     got2 = mmap.sample_map(gpu_ctx, values, eta, xi, centre, az, el, off, w, cal_tables=collapsed, cal_axis_pwv=axis_pwv,
                            cal_axis_el=axis_el, coarse_pwv=coarse.T + 10.0, ta0=ta[0], dta=0.5, t=t).cpu().numpy()
     assert np.isnan(got2).all()
+
+
+@pytest.mark.parametrize("frame", ["az/el", "ra/dec"])
+def test_simulation_with_map(gpu_ctx, frame):
+    """Simulation(map=...): tod.data["map"] against the oracle chain fed with the same
+    smoothed map, calibration tables and coarse pwv; two bands, one map channel each."""
+    from maria_amd import map as mmap
+    from maria_amd.instrument import Band, Detectors, Instrument, Site, compute_angular_fwhm
+    from maria_amd.sim import Plan, Simulation, sky_transform_stack
+    from oracle import hotpath, mapsample
+
+    rng = np.random.default_rng(8)
+    bands = [Band(center=93e9, width=27e9, shape="top_hat", name="f093"), Band(center=150e9, width=41e9, shape="top_hat", name="f150")]
+    inst = Instrument(Detectors.hexagon(19, 0.25, bands, primary_size=6.0))
+    plan = Plan.daisy(start_time=1.7e9, duration=40.0, sample_rate=50.0, scan_center=(120.0, 50.0), radius=0.3, speed=0.3)
+    site = Site(altitude=1000.0, latitude=-23.0, longitude=-67.8)
+    transform = sky_transform_stack(plan.time, site.latitude, site.longitude) if frame == "ra/dec" else None
+    az32, el32 = plan.phi.astype(np.float32), plan.theta.astype(np.float32)
+    centre = _centre(az32, el32, transform)
+    n = 48
+    X, Y = np.meshgrid(np.linspace(-1, 1, n), np.linspace(-1, 1, n))
+    data = np.stack([np.exp(-((X - 0.2) ** 2 + (Y + 0.1) ** 2) / 0.1), 0.5 * np.exp(-((X + 0.3) ** 2 + Y**2) / 0.2)]).astype(np.float32)
+    data += 0.02 * rng.normal(size=data.shape).astype(np.float32)
+    sky = mmap.ProjectionMap(data, nu=[93e9, 150e9], width=1.2, center=np.degrees(centre), frame=frame, degrees=True)
+    sim = Simulation(inst, plan, site, atmosphere="2d", atmosphere_kwargs={"n_layers": 2, "seed": 5}, map=sky, noise=False)
+    (tod,) = sim.run(units="pW")
+    assert set(tod.fields) == {"atmosphere", "map"}
+    got = tod.data["map"]
+    obs = sim.obs_list[0]
+    atm, dets = obs.atmosphere, inst.dets
+    path = atm._device_path()
+    coarse = path.coarse_pwv().cpu().numpy()  # [D, Ta]
+    ta = path.ta0 + path.dta * np.arange(coarse.shape[1])
+    az_d, el_d = hotpath.broadcast(obs.coords.offsets, az32, el32)
+    ref = np.zeros_like(got)
+    sp = atm.spectrum
+    for b, band in enumerate(bands):
+        rows = np.nonzero(dets.band_index == b)[0]
+        fwhm = float(compute_angular_fwhm(fwhm_0=dets.primary_size.mean(), z=np.inf, nu=band.center))
+        sigma_pix = fwhm / np.sqrt(8 * np.log(2)) / abs(sky.x_res)
+        smoothed = hotpath.map_smooth(sky.data, None, sigma_pix, sigma_pix)
+        smoothed = np.asarray(smoothed[0] if isinstance(smoothed, tuple) else smoothed, np.float32)
+        chans, tabs = [], []
+        for c, (lo, hi) in enumerate(sky.nu_bin_bounds):
+            if band.nu.max() < lo or hi < band.nu.min():
+                continue
+            mask = (sp.side_nu >= lo) & (sp.side_nu < hi)
+            chans.append(c)
+            tabs.append(np.trapezoid(band.passband(sp.side_nu[mask]) * np.exp(-sp._opacity[..., mask]), x=sp.side_nu[mask], axis=-1))
+        values = np.swapaxes(smoothed[:, chans], 0, 1)
+        ref[rows] = mapsample.sample_maps(az_d[rows], el_d[rows], plan.time, ta, coarse[rows], sky.eta, sky.xi, sky.center, values,
+                                          mapsample.mueller_row(dets.gamma[rows])[:, :1], cal_tables=tabs,
+                                          cal_axes=(sp.side_base_temperature, sp.side_zenith_pwv, sp.side_elevation),
+                                          base_temperature=atm.weather.temperature[0], transform_stack=transform)
+    assert np.isfinite(got).all() and np.abs(ref).max() > 0
+    bound = _rounding_bound(sky.data, sky.eta, sky.xi, 1.0, 1e12 * mapsample.K_B * 5e10)
+    assert np.abs(got - ref).max() <= bound + 1e-5 * np.abs(ref).max(), (np.abs(got - ref).max(), bound, np.abs(ref).max())
+    # default units: the same per-sample factor as the atmosphere field (tod/tod.py:130-136)
+    sim2 = Simulation(inst, plan, site, atmosphere="2d", atmosphere_kwargs={"n_layers": 2, "seed": 5}, map=sky, noise=False)
+    (tod2,) = sim2.run()
+    factor = tod2.data["atmosphere"].astype(np.float64) / tod.data["atmosphere"]
+    np.testing.assert_allclose(tod2.data["map"], got * factor, rtol=3e-6, atol=1e-7 * np.abs(got * factor).max())

@@ -52,3 +52,26 @@ def test_correlated_oracle_covariance():
     model = c * B @ B.T + np.mean(((1 - c) * knee / f[m] + 1) / (1 + knee / f[m])) * np.eye(D)
     cov *= np.trace(model) / np.trace(cov)
     assert np.corrcoef(cov.ravel(), model.ravel())[0, 1] > 0.97
+
+
+def test_sky_transform_stack_known_directions():
+    """The host-side horizon -> equatorial rotation (astropy's role in
+    coords/coordinates.py:184-236): orthonormal, zenith at (LST, latitude), the north
+    point at elevation = latitude on the pole, sidereal rate."""
+    from maria_amd.sim import sky_transform_stack
+    from oracle import mapsample
+
+    t = 1.7e9 + np.array([0.0, 3600.0, 86164.0905])
+    lat, lon = 35.0, -110.0
+    M = sky_transform_stack(t, lat, lon)
+    np.testing.assert_allclose(M @ np.swapaxes(M, 1, 2), np.broadcast_to(np.eye(3), M.shape), atol=1e-14)
+    zen = np.array([0.0, 0.0, 1.0]) @ M  # [3 times, 3]
+    np.testing.assert_allclose(np.degrees(np.arcsin(zen[:, 2])), lat, atol=1e-10)
+    ra = np.degrees(np.arctan2(zen[:, 1], zen[:, 0])) % 360
+    assert abs(((ra[1] - ra[0]) % 360) - 15.0410686) < 1e-4  # one hour of sidereal rotation
+    assert abs(((ra[2] - ra[0] + 180) % 360) - 180) < 1e-4     # one sidereal day: back again
+    pole = mapsample.phi_theta_to_xyz(0.0, np.radians(lat)).astype(float) @ M[0]
+    assert abs(pole[2] - 1) < 1e-7
+    # east point on the horizon: declination 0, six hours east of the meridian
+    east = mapsample.phi_theta_to_xyz(np.pi / 2, 0.0).astype(float) @ M[0]
+    assert abs(east[2]) < 1e-7 and abs(((np.degrees(np.arctan2(east[1], east[0])) - ra[0]) % 360) - 90) < 1e-4
