@@ -303,9 +303,10 @@ int mrx_screen_psd_sum(mrx_ctx* ctx, int ny, int nx, double dy, double dx,
  * the parity flip (sim/map.py:72-73,104-109): */
 typedef struct mrx_sky_map {
   const float* d_values;  /* [n_channels][n_stokes][n_eta][n_xi] float32, K_RJ */
-  const double* d_eta;    /* [n_eta] rad, monotonic (descending after the parity flip) */
-  const double* d_xi;     /* [n_xi] rad, monotonic */
   int n_channels, n_stokes, n_eta, n_xi;
+  double eta0, deta;      /* eta[i] = eta0 + i * deta, rad (np.linspace, projection.py:122-123;
+                             deta < 0 after the parity flip) */
+  double xi0, dxi;        /* xi[j] = xi0 + j * dxi */
   double center_phi, center_theta; /* map centre in the map's frame, rad */
   int bilinear;           /* 1: bilinear sampling, 0: nearest pixel (map_kwargs) */
   int reserved;

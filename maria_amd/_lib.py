@@ -82,12 +82,14 @@ class MrxSkyMap(C.Structure):
 
     _fields_ = [
         ("d_values", C.c_void_p),
-        ("d_eta", C.c_void_p),
-        ("d_xi", C.c_void_p),
         ("n_channels", C.c_int32),
         ("n_stokes", C.c_int32),
         ("n_eta", C.c_int32),
         ("n_xi", C.c_int32),
+        ("eta0", C.c_double),
+        ("deta", C.c_double),
+        ("xi0", C.c_double),
+        ("dxi", C.c_double),
         ("center_phi", C.c_double),
         ("center_theta", C.c_double),
         ("bilinear", C.c_int32),

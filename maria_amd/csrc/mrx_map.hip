@@ -15,8 +15,12 @@
 // sample.  Tile = 16 detectors x 1024 samples like the TOD writer; a thread computes 4
 // consecutive raw samples per detector and trades edge values with its neighbours
 // through LDS for the 3-tap kernel (tile edges: one extra evaluation by the first and
-// last thread).  The kernel is bound by the float32 trigonometry of steps 1-3
-// (~15 transcendental calls per sample), not by memory.
+// last thread).  Steps 1-3 are three rotations of a unit vector: by default they are
+// composed once per sample in float64 and applied to the detector's vector with six
+// multiply-adds (the literal float32 chain, ~15 transcendental calls per sample, stays
+// available through MRX_OPT_POINTING_CHAIN and agrees to float32 rounding of the angles).
+// Bound by arithmetic (float64 weights and sums, as the reference's sparse product), not
+// by memory.
 #include "mrx_internal.h"
 
 namespace {
@@ -31,13 +35,20 @@ constexpr float kTwoPiF = 6.283185482025146484375f;
 
 typedef float vfloat4 __attribute__((ext_vector_type(4)));
 
+// One map axis: node i sits at first + i * step (np.linspace, map/projection.py:122-123;
+// step of either sign -- eta is descending after the parity flip).
+struct Axis {
+  int n;
+  double first, inv_step;
+};
+
 struct MapArgs {
   const float* values;  // [C][S][n_eta][n_xi]
-  const double* eta;    // [n_eta]
-  const double* xi;     // [n_xi]
+  Axis eta, xi;
   int C, S, n_eta, n_xi;
   float cphi;           // map centre longitude (float32, as jax demotes it)
   float rot_re, rot_im; // exp(i (pi/2 - ctheta)) in complex64
+  double cos_cphi, sin_cphi, cos_ctheta, sin_ctheta;  // the same centre in float64 (direct mode)
   int bilinear;
   // calibration
   const float* cal;       // [C][n_pwv][n_el] or null
@@ -46,7 +57,7 @@ struct MapArgs {
   int n_pwv, n_el;
   const double* pwv;      // [Ta][D] coarse zenith-scaled pwv
   int Ta;
-  double ta0, dta;
+  double ta0, dta, inv_dta;
   const double* t;        // [T]
   const double* scalar;   // [C] (no atmosphere)
   // pointing
@@ -67,152 +78,227 @@ struct DetConst {
   float w[kMaxStokes];
 };
 
-// np.digitize(x, side) for a monotonic axis (either direction), right = False:
-// ascending: side[b-1] <= x < side[b]; descending: side[b-1] > x >= side[b].
-__device__ __forceinline__ int digitize(const double* side, int n, double x, double first, double inv_step, bool ascending) {
-  int b = (int)fmin(fmax((x - first) * inv_step + 1.0, 0.0), (double)n);
-  if (ascending) {
-    while (b < n && side[b] <= x) ++b;
-    while (b > 0 && side[b - 1] > x) --b;
-  } else {
-    while (b < n && side[b] > x) ++b;
-    while (b > 0 && side[b - 1] <= x) --b;
-  }
-  return b;
-}
+struct SampleConst;
+__device__ __forceinline__ int sc_index(const struct MapArgs& g, const SampleConst& sc);
 
-// one axis of utils/linalg.py:25-41: the two pixels and the weight of the upper one
-__device__ __forceinline__ void axis_weights(const double* side, int n, double x, bool bilinear, int& i0, int& i1, double& p) {
-  const bool ascending = side[n - 1] >= side[0];
+// one axis of utils/linalg.py:25-41: the two pixels and the weight of the upper one.
+// With u = (x - first) / step the reference's np.digitize bin is floor(u) + 1 and its weight
+// (x - side[b-1]) / (side[b] - side[b-1]) is the fractional part of u; at a node the two
+// conventions (bin b with p = 0, bin b - 1 with p = 1) give the same interpolated value, so the
+// nodes themselves need not be read.
+__device__ __forceinline__ void axis_weights(const Axis& a, double x, bool bilinear, int& i0, int& i1, double& p) {
+  const double u = (x - a.first) * a.inv_step;
   if (bilinear) {
-    const double inv = (double)(n - 1) / (side[n - 1] - side[0]);
-    const int b = digitize(side, n, x, side[0], inv, ascending);
-    if (b == 0 || b == n) {
-      p = 0.0;  // (x + inf)/inf = nan -> 0; finite/inf = 0
-    } else {
-      p = (x - side[b - 1]) / (side[b] - side[b - 1]);
-      p = p > 0.0 ? p : 0.0;
-    }
-    i0 = min(max(b - 1, 0), n - 1);
-    i1 = min(b, n - 1);
+    const double fl = floor(u);
+    const int b = (int)fmin(fmax(fl + 1.0, 0.0), (double)a.n);
+    p = (b == 0 || b == a.n) ? 0.0 : u - fl;  // beyond the ends: (x + inf)/inf = nan -> 0; finite/inf = 0
+    i0 = min(max(b - 1, 0), a.n - 1);
+    i1 = min(b, a.n - 1);
   } else {
-    // np.digitize on the midpoints
-    const double inv = (double)(n - 1) / (side[n - 1] - side[0]);
-    int b = (int)fmin(fmax((x - side[0]) * inv + 0.5, 0.0), (double)(n - 1));
-    if (ascending) {
-      while (b < n - 1 && 0.5 * (side[b] + side[b + 1]) <= x) ++b;
-      while (b > 0 && 0.5 * (side[b - 1] + side[b]) > x) --b;
-    } else {
-      while (b < n - 1 && 0.5 * (side[b] + side[b + 1]) > x) ++b;
-      while (b > 0 && 0.5 * (side[b - 1] + side[b]) <= x) --b;
-    }
-    i0 = i1 = b;
+    // np.digitize on the midpoints: the nearest node
+    i0 = i1 = (int)fmin(fmax(floor(u + 0.5), 0.0), (double)(a.n - 1));
     p = 0.0;
   }
 }
 
 // jax RegularGridInterpolator index and weight on a float32 axis (searchsorted left)
 __device__ __forceinline__ void rgi_axis(const float* g, int n, float x, int& i, float& w, bool& oob) {
-  const float inv = (float)(n - 1) / (g[n - 1] - g[0]);
-  int k = min(max((int)fminf(fmaxf((x - g[0]) * inv, -1.0f), 2.0e9f), 0), n - 2);
+  const float g0 = g[0], g1 = g[n - 1];
+  const float inv = (float)(n - 1) / (g1 - g0);
+  int k = min(max((int)fminf(fmaxf((x - g0) * inv, -1.0f), 2.0e9f), 0), n - 2);
   while (k < n - 2 && g[k + 1] < x) ++k;
   while (k > 0 && g[k] >= x) --k;
   i = k;
   w = __fdiv_rn(__fsub_rn(x, g[k]), __fsub_rn(g[k + 1], g[k]));
-  oob = !(x >= g[0] && x <= g[n - 1]);
+  oob = !(x >= g0 && x <= g1);
 }
 
-// raw (unconvolved) map loading of detector `dc` (row d) at sample s, float32
-__device__ __forceinline__ float raw_sample(const MapArgs& g, const DetConst& dc, int d, int s) {
+// What a sample contributes to every detector of the tile.
+struct SampleConst {
+  float ca, sa;   // cos / sin of (el_bore - pi/2), float32 as the chain computes them
+  float az;       // boresight azimuth
+  double G[6];    // direct mode: (dz_re, dz_im) = c @ G, c = (sin r cos p, cos r, sin r sin p)
+  int jj;         // coarse interval of the sample time and the weight within it
+  double u;
+  int s;          // the (clamped) sample index
+};
+
+__device__ __forceinline__ int sc_index(const MapArgs&, const SampleConst& sc) { return sc.s; }
+
+__device__ __forceinline__ void sample_const(const MapArgs& g, int s, bool chain, SampleConst& sc) {
   s = min(max(s, 0), g.T - 1);
-  // 1. detector az/el (transforms.py:10-29)
   const float a = __fsub_rn(g.el[s], kHalfPiF);
-  const float ca = cosf(a), sa = sinf(a);
-  const float re = __fsub_rn(__fmul_rn(dc.c_re, ca), __fmul_rn(dc.c_cr, sa));
-  const float im = __fadd_rn(__fmul_rn(dc.c_re, sa), __fmul_rn(dc.c_cr, ca));
-  const float az_d = __fadd_rn(atan2f(dc.c_im, re), g.az[s]);
-  const float el_d = asinf(im);
-  // 2. frame rotation (coordinates.py:220-230)
-  float phi = az_d, theta = el_d;
-  if (g.transform) {
-    const float ce = cosf(el_d);
-    const double x = (double)__fmul_rn(cosf(az_d), ce), y = (double)__fmul_rn(sinf(az_d), ce), z = (double)sinf(el_d);
-    const double* M = g.transform + (size_t)s * 9;
-    const float vx = (float)(x * M[0] + y * M[3] + z * M[6]);
-    const float vy = (float)(x * M[1] + y * M[4] + z * M[7]);
-    const float vz = (float)(x * M[2] + y * M[5] + z * M[8]);
-    float ph = fmodf(atan2f(vy, vx), kTwoPiF);
-    if (ph < 0.0f) ph = __fadd_rn(ph, kTwoPiF);
-    phi = ph;
-    const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(vx, vx), __fmul_rn(vy, vy)), __fmul_rn(vz, vz)));
-    theta = asinf(__fdiv_rn(vz, nrm));
+  sc.ca = cosf(a);
+  sc.sa = sinf(a);
+  sc.az = g.az[s];
+  if (g.cal) {
+    // zenith-scaled pwv of the sample: linear interpolation of the coarse series
+    // (sim/atmosphere.py:30-37)
+    const double tt = g.t[s];
+    int jj = (int)floor(fmin(fmax((tt - g.ta0) * g.inv_dta, -1.0), 2.0e9));
+    jj = min(max(jj, 0), g.Ta - 2);
+    sc.jj = jj;
+    sc.u = (tt - (g.ta0 + (double)jj * g.dta)) * g.inv_dta;
   }
-  // 3. offsets from the map centre (transforms.py:36-53)
-  const float dphi = __fsub_rn(phi, g.cphi);
-  const float ct = cosf(theta), st = sinf(theta);
-  const float pr = __fmul_rn(cosf(dphi), ct);
-  const float proj_re = __fsub_rn(__fmul_rn(pr, g.rot_re), __fmul_rn(st, g.rot_im));
-  const float dz_re = __fmul_rn(sinf(dphi), ct), dz_im = proj_re;
-  const float r = sqrtf(__fadd_rn(__fmul_rn(dz_re, dz_re), __fmul_rn(dz_im, dz_im)));
-  const float f = __fdiv_rn(asinf(r), r > 0.0f ? r : 1.0f);
-  const float ox = -__fmul_rn(dz_re, f), oy = -__fmul_rn(dz_im, f);
-  // 4. pointing-matrix row
+  if (!chain) {
+    // Steps 1-3 are rotations of the unit vector c: xyz = c @ R(az, el), v = xyz @ M(t),
+    // and phi_theta_to_offsets only needs two components of v in the frame of the map
+    // centre, dz = (sin dphi cos theta, cos dphi cos theta sin ctheta - sin theta cos ctheta).
+    // Composed once per sample in float64.
+    const double ca = (double)sc.ca, sa = (double)sc.sa;
+    const double cb = cos((double)sc.az), sb = sin((double)sc.az);
+    // rows of R: xyz = c_re R[0] + c_cr R[1] + c_im R[2]
+    const double R[3][3] = {{ca * cb, ca * sb, sa}, {-sa * cb, -sa * sb, ca}, {-sb, cb, 0.0}};
+    double P[3][2];  // v -> dz: P = M @ Cmat^T
+    double M[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    if (g.transform) {
+      const double* m = g.transform + (size_t)s * 9;
+#pragma unroll
+      for (int k = 0; k < 9; ++k) M[k] = m[k];
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const double vx = M[j * 3 + 0], vy = M[j * 3 + 1], vz = M[j * 3 + 2];
+      P[j][0] = -vx * g.sin_cphi + vy * g.cos_cphi;
+      P[j][1] = (vx * g.cos_cphi + vy * g.sin_cphi) * g.sin_ctheta - vz * g.cos_ctheta;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int k = 0; k < 2; ++k) sc.G[i * 2 + k] = R[i][0] * P[0][k] + R[i][1] * P[1][k] + R[i][2] * P[2][k];
+  }
+}
+
+// Steps 4-5 for a sample at offsets (ox, oy) from the map centre, detector elevation el_d.
+struct CalLds {
+  const float* pwv;  // [n_pwv] axis
+  const float* el;   // [n_el] axis
+  const float* tab;  // [C][n_pwv][n_el]
+};
+
+template <bool kCal>
+__device__ __forceinline__ float sample_value(const MapArgs& g, const CalLds& cl, const Axis& ax_eta, const Axis& ax_xi,
+                                              const DetConst& dc, int d, const SampleConst& sc, float ox,
+                                              float oy, float el_d) {
   int e0, e1, x0, x1;
   double pe, px;
-  axis_weights(g.eta, g.n_eta, (double)oy, g.bilinear, e0, e1, pe);
-  axis_weights(g.xi, g.n_xi, (double)ox, g.bilinear, x0, x1, px);
-  const double w00 = (1.0 - pe) * (1.0 - px), w10 = pe * (1.0 - px), w01 = (1.0 - pe) * px, w11 = pe * px;
-  // 5. channels
+  axis_weights(ax_eta, (double)oy, g.bilinear, e0, e1, pe);
+  axis_weights(ax_xi, (double)ox, g.bilinear, x0, x1, px);
+  const double qe = 1.0 - pe, qx = 1.0 - px;
+  const double w00 = qe * qx, w10 = pe * qx, w01 = qe * px, w11 = pe * px;
   float cal_w_p = 0.f, cal_w_e = 0.f;
   int ip = 0, ie = 0;
   bool oob = false;
-  if (g.cal) {
-    // zenith-scaled pwv of the sample: linear interpolation of the coarse series
-    // (sim/atmosphere.py:30-37), demoted to float32 by the jax interpolator
-    const double tt = g.t[s];
-    const double inv_dta = 1.0 / g.dta;
-    int jj = (int)floor(fmin(fmax((tt - g.ta0) * inv_dta, -1.0), 2.0e9));
-    jj = min(max(jj, 0), g.Ta - 2);
-    const double u = (tt - (g.ta0 + (double)jj * g.dta)) * inv_dta;
-    const double y0 = g.pwv[(size_t)jj * g.D + d], y1 = g.pwv[(size_t)(jj + 1) * g.D + d];
-    const float pw = (float)(y0 + u * (y1 - y0));
+  if (kCal) {
+    const double y0 = g.pwv[(size_t)sc.jj * g.D + d], y1 = g.pwv[(size_t)(sc.jj + 1) * g.D + d];
+    const float pw = (float)fma(sc.u, y1 - y0, y0);  // demoted to float32 by the jax interpolator
     bool o1, o2;
-    rgi_axis(g.cal_pwv, g.n_pwv, pw, ip, cal_w_p, o1);
-    rgi_axis(g.cal_el, g.n_el, el_d, ie, cal_w_e, o2);
+    rgi_axis(cl.pwv, g.n_pwv, pw, ip, cal_w_p, o1);
+    rgi_axis(cl.el, g.n_el, el_d, ie, cal_w_e, o2);
     oob = o1 || o2;
   }
-  const size_t plane = (size_t)g.n_eta * g.n_xi;
+  const int plane = g.n_eta * g.n_xi;  // < 2^31: checked by the host
+  const int o00 = e0 * g.n_xi + x0, o10 = e1 * g.n_xi + x0, o01 = e0 * g.n_xi + x1, o11 = e1 * g.n_xi + x1;
+  const float* m = g.values;
   float acc = 0.0f;
   for (int c = 0; c < g.C; ++c) {
     double val = 0.0;
-    for (int k = 0; k < g.S; ++k) {
-      const float* m = g.values + ((size_t)c * g.S + k) * plane;
-      const double v = w00 * (double)m[(size_t)e0 * g.n_xi + x0] + w10 * (double)m[(size_t)e1 * g.n_xi + x0] +
-                       w01 * (double)m[(size_t)e0 * g.n_xi + x1] + w11 * (double)m[(size_t)e1 * g.n_xi + x1];
-      val += (double)dc.w[k] * v;
+#pragma unroll
+    for (int k = 0; k < kMaxStokes; ++k) {
+      if (k < g.S) {
+        const double v = fma(w00, (double)m[o00], fma(w10, (double)m[o10], fma(w01, (double)m[o01], w11 * (double)m[o11])));
+        val = fma((double)dc.w[k], v, val);
+        m += plane;
+      }
     }
     double pw_per_k;
-    if (g.cal) {
-      const float* tab = g.cal + (size_t)c * g.n_pwv * g.n_el;
+    if (kCal) {
+      const float* tab = cl.tab + c * g.n_pwv * g.n_el + ip * g.n_el + ie;
       // float32 corner sum in product order, weights built as (1 * w_pwv) * w_el
       const float wp0 = __fsub_rn(1.0f, cal_w_p), we0 = __fsub_rn(1.0f, cal_w_e);
-      float v = __fmul_rn(tab[(size_t)ip * g.n_el + ie], __fmul_rn(wp0, we0));
-      v = __fadd_rn(v, __fmul_rn(tab[(size_t)ip * g.n_el + ie + 1], __fmul_rn(wp0, cal_w_e)));
-      v = __fadd_rn(v, __fmul_rn(tab[(size_t)(ip + 1) * g.n_el + ie], __fmul_rn(cal_w_p, we0)));
-      v = __fadd_rn(v, __fmul_rn(tab[(size_t)(ip + 1) * g.n_el + ie + 1], __fmul_rn(cal_w_p, cal_w_e)));
+      float v = __fmul_rn(tab[0], __fmul_rn(wp0, we0));
+      v = __fadd_rn(v, __fmul_rn(tab[1], __fmul_rn(wp0, cal_w_e)));
+      v = __fadd_rn(v, __fmul_rn(tab[g.n_el], __fmul_rn(cal_w_p, we0)));
+      v = __fadd_rn(v, __fmul_rn(tab[g.n_el + 1], __fmul_rn(cal_w_p, cal_w_e)));
       if (oob) v = __builtin_nanf("");
       pw_per_k = (double)__fmul_rn(1.380649e-11f, v);  // 1e12 k_B as a weak scalar on a float32 array
     } else {
       pw_per_k = 1.380649e-11 * g.scalar[c];
     }
-    acc = (float)((double)acc + pw_per_k * val);  // float32 accumulator (map.py:155)
+    acc = (float)fma(pw_per_k, val, (double)acc);  // float32 accumulator (map.py:155)
   }
   return acc;
 }
 
+__device__ __noinline__ double asin_over_r(double r2) {
+  const double r = sqrt(r2);
+  return asin(fmin(r, 1.0)) / r;
+}
+
+// raw (unconvolved) map loading of one detector at one sample, float32.
+// kChain: steps 1-3 literally as the reference's float32 chain; otherwise the composed
+// rotation of sample_const (same angles to float32 rounding, ~10x less arithmetic).
+template <bool kChain, bool kCal>
+__device__ __forceinline__ float raw_sample(const MapArgs& g, const CalLds& cl, const Axis& ax_eta, const Axis& ax_xi,
+                                            const DetConst& dc, int d, const SampleConst& sc) {
+  const float im = __fadd_rn(__fmul_rn(dc.c_re, sc.sa), __fmul_rn(dc.c_cr, sc.ca));
+  float ox, oy, el_d = 0.0f;
+  if (kChain) {
+    // 1. detector az/el (transforms.py:10-29)
+    const float re = __fsub_rn(__fmul_rn(dc.c_re, sc.ca), __fmul_rn(dc.c_cr, sc.sa));
+    const float az_d = __fadd_rn(atan2f(dc.c_im, re), sc.az);
+    el_d = asinf(im);
+    // 2. frame rotation (coordinates.py:220-230)
+    float phi = az_d, theta = el_d;
+    if (g.transform) {
+      const float ce = cosf(el_d);
+      const double x = (double)__fmul_rn(cosf(az_d), ce), y = (double)__fmul_rn(sinf(az_d), ce), z = (double)sinf(el_d);
+      const double* M = g.transform + (size_t)sc_index(g, sc) * 9;
+      const float vx = (float)(x * M[0] + y * M[3] + z * M[6]);
+      const float vy = (float)(x * M[1] + y * M[4] + z * M[7]);
+      const float vz = (float)(x * M[2] + y * M[5] + z * M[8]);
+      float ph = fmodf(atan2f(vy, vx), kTwoPiF);
+      if (ph < 0.0f) ph = __fadd_rn(ph, kTwoPiF);
+      phi = ph;
+      const float nrm = sqrtf(__fadd_rn(__fadd_rn(__fmul_rn(vx, vx), __fmul_rn(vy, vy)), __fmul_rn(vz, vz)));
+      theta = asinf(__fdiv_rn(vz, nrm));
+    }
+    // 3. offsets from the map centre (transforms.py:36-53)
+    const float dphi = __fsub_rn(phi, g.cphi);
+    const float ct = cosf(theta), st = sinf(theta);
+    const float pr = __fmul_rn(cosf(dphi), ct);
+    const float proj_re = __fsub_rn(__fmul_rn(pr, g.rot_re), __fmul_rn(st, g.rot_im));
+    const float dz_re = __fmul_rn(sinf(dphi), ct), dz_im = proj_re;
+    const float r = sqrtf(__fadd_rn(__fmul_rn(dz_re, dz_re), __fmul_rn(dz_im, dz_im)));
+    const float f = __fdiv_rn(asinf(r), r > 0.0f ? r : 1.0f);
+    ox = -__fmul_rn(dz_re, f);
+    oy = -__fmul_rn(dz_im, f);
+  } else {
+    const double c0 = (double)dc.c_re, c1 = (double)dc.c_cr, c2 = (double)dc.c_im;
+    const double dz_re = fma(c0, sc.G[0], fma(c1, sc.G[2], c2 * sc.G[4]));
+    const double dz_im = fma(c0, sc.G[1], fma(c1, sc.G[3], c2 * sc.G[5]));
+    const double r2 = fma(dz_re, dz_re, dz_im * dz_im);
+    // asin(r)/r: the series to r^12 below 0.3 rad (error < 1e-9), the function beyond
+    double f = fma(r2, fma(r2, fma(r2, fma(r2, fma(r2, fma(r2, 10395.0 / 599040.0, 945.0 / 42240.0), 105.0 / 3456.0), 15.0 / 336.0), 3.0 / 40.0), 1.0 / 6.0), 1.0);
+    if (__builtin_expect(r2 >= 0.09, 0)) f = asin_over_r(r2);
+    ox = (float)(-dz_re * f);
+    oy = (float)(-dz_im * f);
+    if (kCal) el_d = asinf(im);
+  }
+  return sample_value<kCal>(g, cl, ax_eta, ax_xi, dc, d, sc, ox, oy, el_d);
+}
+
+template <bool kChain, bool kCal>
 __global__ __launch_bounds__(kBlock) void map_sample_kernel(MapArgs g) {
   __shared__ DetConst dets[kTileDet];
   __shared__ float2 edge[2][kBlock];  // (first, last) raw value of every thread, double-buffered
+  extern __shared__ float cal_lds[];   // calibration axes and tables (a few KB)
+  CalLds cl{cal_lds, cal_lds + g.n_pwv, cal_lds + g.n_pwv + g.n_el};
+  if (kCal) {
+    for (int i = threadIdx.x; i < g.n_pwv; i += kBlock) cal_lds[i] = g.cal_pwv[i];
+    for (int i = threadIdx.x; i < g.n_el; i += kBlock) cal_lds[g.n_pwv + i] = g.cal_el[i];
+    for (int i = threadIdx.x; i < g.C * g.n_pwv * g.n_el; i += kBlock) cal_lds[g.n_pwv + g.n_el + i] = g.cal[i];
+  }
   const int d0 = blockIdx.y * kTileDet;
   const int s_tile = blockIdx.x * kTileSamples;
   const int sb = s_tile + threadIdx.x * kSamplesPerThread;
@@ -230,6 +316,19 @@ __global__ __launch_bounds__(kBlock) void map_sample_kernel(MapArgs g) {
     for (int k = 0; k < kMaxStokes; ++k) dc.w[k] = k < g.S ? g.stokes_w[(size_t)d * g.S + k] : 0.0f;
     dets[threadIdx.x] = dc;
   }
+  const Axis ax_eta = g.eta, ax_xi = g.xi;
+  SampleConst sc[kSamplesPerThread], sc_halo;
+#pragma unroll
+  for (int q = 0; q < kSamplesPerThread; ++q) {
+    sample_const(g, sb + q, kChain, sc[q]);
+    sc[q].s = min(max(sb + q, 0), g.T - 1);
+  }
+  const bool first = threadIdx.x == 0, last = threadIdx.x == kBlock - 1;
+  if (first || last) {
+    const int sh = first ? s_tile - 1 : s_tile + kTileSamples;
+    sample_const(g, sh, kChain, sc_halo);
+    sc_halo.s = min(max(sh, 0), g.T - 1);
+  }
   __syncthreads();
   const bool full = (sb + kSamplesPerThread <= g.T) && g.vec_ok;
   for (int dl = 0; dl < nd; ++dl) {
@@ -237,14 +336,13 @@ __global__ __launch_bounds__(kBlock) void map_sample_kernel(MapArgs g) {
     const int d = d0 + dl;
     float r[kSamplesPerThread];
 #pragma unroll
-    for (int q = 0; q < kSamplesPerThread; ++q) r[q] = raw_sample(g, dc, d, sb + q);
+    for (int q = 0; q < kSamplesPerThread; ++q) r[q] = raw_sample<kChain, kCal>(g, cl, ax_eta, ax_xi, dc, d, sc[q]);
     float halo = 0.0f;
-    if (threadIdx.x == 0) halo = raw_sample(g, dc, d, s_tile - 1);
-    if (threadIdx.x == kBlock - 1) halo = raw_sample(g, dc, d, s_tile + kTileSamples);
+    if (first || last) halo = raw_sample<kChain, kCal>(g, cl, ax_eta, ax_xi, dc, d, sc_halo);
     edge[dl & 1][threadIdx.x] = make_float2(r[0], r[kSamplesPerThread - 1]);
     __syncthreads();
-    const float left = threadIdx.x == 0 ? halo : edge[dl & 1][threadIdx.x - 1].y;
-    const float right = threadIdx.x == kBlock - 1 ? halo : edge[dl & 1][threadIdx.x + 1].x;
+    const float left = first ? halo : edge[dl & 1][threadIdx.x - 1].y;
+    const float right = last ? halo : edge[dl & 1][threadIdx.x + 1].x;
     // scipy.ndimage.convolve1d, symmetric 3-tap kernel, double accumulation (map.py:170)
     float o[kSamplesPerThread];
 #pragma unroll
@@ -277,7 +375,8 @@ int mrx_map_sample(mrx_ctx* ctx, const mrx_sky_map* map, const mrx_map_cal* cal,
   MRX_REQUIRE(ctx, D >= 0 && T >= 0, "negative size");
   if (D == 0 || T == 0) return MRX_OK;
   MRX_REQUIRE(ctx, map && cal && d_az && d_el && d_dx && d_dy && d_stokes_w && d_out, "null pointer");
-  MRX_REQUIRE(ctx, map->d_values && map->d_eta && map->d_xi, "null map pointer");
+  MRX_REQUIRE(ctx, map->d_values, "null map pointer");
+  MRX_REQUIRE(ctx, map->deta != 0.0 && map->dxi != 0.0, "map axes need a non-zero step");
   MRX_REQUIRE(ctx, map->n_channels >= 1 && map->n_stokes >= 1 && map->n_stokes <= kMaxStokes &&
                        map->n_eta >= 2 && map->n_xi >= 2,
               "need n_channels >= 1, 1 <= n_stokes <= 4, n_eta >= 2, n_xi >= 2");
@@ -291,8 +390,8 @@ int mrx_map_sample(mrx_ctx* ctx, const mrx_sky_map* map, const mrx_map_cal* cal,
   }
   MapArgs g{};
   g.values = map->d_values;
-  g.eta = map->d_eta;
-  g.xi = map->d_xi;
+  g.eta = Axis{map->n_eta, map->eta0, 1.0 / map->deta};
+  g.xi = Axis{map->n_xi, map->xi0, 1.0 / map->dxi};
   g.C = map->n_channels;
   g.S = map->n_stokes;
   g.n_eta = map->n_eta;
@@ -303,6 +402,10 @@ int mrx_map_sample(mrx_ctx* ctx, const mrx_sky_map* map, const mrx_map_cal* cal,
   const float ang = (float)(1.5707963267948966 - map->center_theta);
   g.rot_re = (float)cos((double)ang);
   g.rot_im = (float)sin((double)ang);
+  g.cos_cphi = cos(map->center_phi);
+  g.sin_cphi = sin(map->center_phi);
+  g.cos_ctheta = cos(map->center_theta);
+  g.sin_ctheta = sin(map->center_theta);
   g.bilinear = map->bilinear;
   g.cal = cal->d_table;
   g.cal_pwv = cal->d_axis_pwv;
@@ -313,6 +416,7 @@ int mrx_map_sample(mrx_ctx* ctx, const mrx_sky_map* map, const mrx_map_cal* cal,
   g.Ta = cal->Ta;
   g.ta0 = cal->ta0;
   g.dta = cal->dta;
+  g.inv_dta = cal->dta > 0.0 ? 1.0 / cal->dta : 0.0;
   g.t = cal->d_t;
   g.scalar = cal->d_scalar;
   g.az = d_az;
@@ -328,7 +432,21 @@ int mrx_map_sample(mrx_ctx* ctx, const mrx_sky_map* map, const mrx_map_cal* cal,
   g.vec_ok = (ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15u) == 0);
   dim3 grid(mrx_ceil_div(T, kTileSamples), mrx_ceil_div(D, kTileDet));
   MRX_REQUIRE(ctx, grid.y <= 65535u, "D too large for one launch");
-  hipLaunchKernelGGL(map_sample_kernel, grid, dim3(kBlock), 0, ctx->stream, g);
+  size_t lds = 0;
+  if (cal->d_table) {
+    lds = sizeof(float) * ((size_t)cal->n_pwv + cal->n_el + (size_t)map->n_channels * cal->n_pwv * cal->n_el);
+    MRX_REQUIRE(ctx, lds <= 48 * 1024, "calibration tables of all channels must fit in 48 KiB");
+  }
+  MRX_REQUIRE(ctx, (long long)map->n_eta * map->n_xi < (1LL << 31), "a map plane must hold fewer than 2^31 pixels");
+  const bool chain = ctx->options[MRX_OPT_POINTING_CHAIN] != 0, has_cal = cal->d_table != nullptr;
+#define MRX_LAUNCH_MAP(CH, CA) \
+  hipLaunchKernelGGL((map_sample_kernel<CH, CA>), grid, dim3(kBlock), lds, ctx->stream, g)
+  if (chain) {
+    if (has_cal) MRX_LAUNCH_MAP(true, true); else MRX_LAUNCH_MAP(true, false);
+  } else {
+    if (has_cal) MRX_LAUNCH_MAP(false, true); else MRX_LAUNCH_MAP(false, false);
+  }
+#undef MRX_LAUNCH_MAP
   MRX_CHECK_LAUNCH(ctx);
   return MRX_OK;
 }

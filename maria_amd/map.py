@@ -89,10 +89,14 @@ def sample_map(ctx, values, eta, xi, center, az, el, offsets, stokes_weights, ou
     C_, S_, n_eta, n_xi = values.shape
     offsets = np.asarray(offsets, float)
     D, T = len(offsets), len(az)
-    keep = dict(values=f32(values), eta=f64(eta), xi=f64(xi), az=f32(az), el=f32(el), dx=f32(offsets[:, 0]), dy=f32(offsets[:, 1]),
+    eta, xi = np.asarray(eta, float), np.asarray(xi, float)
+    deta, dxi = (eta[-1] - eta[0]) / (n_eta - 1), (xi[-1] - xi[0]) / (n_xi - 1)
+    if not (np.allclose(np.diff(eta), deta, rtol=1e-6, atol=0) and np.allclose(np.diff(xi), dxi, rtol=1e-6, atol=0)):
+        raise ValueError("map axes must be uniform (np.linspace, map/projection.py:122-123)")
+    keep = dict(values=f32(values), az=f32(az), el=f32(el), dx=f32(offsets[:, 0]), dy=f32(offsets[:, 1]),
                 w=f32(np.asarray(stokes_weights)[:, :S_]))
-    sky = MrxSkyMap(ptr(keep["values"]), ptr(keep["eta"]), ptr(keep["xi"]), C_, S_, n_eta, n_xi, float(center[0]), float(center[1]),
-                    1 if bilinear else 0, 0)
+    sky = MrxSkyMap(ptr(keep["values"]), C_, S_, n_eta, n_xi, float(eta[0]), float(deta), float(xi[0]), float(dxi),
+                    float(center[0]), float(center[1]), 1 if bilinear else 0, 0)
     cal = MrxMapCal()
     if cal_tables is not None:
         keep.update(tab=f32(cal_tables), ap=f32(cal_axis_pwv), ae=f32(cal_axis_el), pwv=f64(coarse_pwv), t=f64(t))

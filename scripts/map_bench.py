@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Timing of mrx_map_sample on one GPU (development aid).
+Usage: python scripts/map_bench.py [n_det] [n_samples] [reps]"""
+
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from maria_amd import map as mmap  # noqa: E402
+from maria_amd import synthetic  # noqa: E402
+from maria_amd._lib import Context  # noqa: E402
+from maria_amd.sim import sky_transform_stack  # noqa: E402
+from scripts.kbench import timeit  # noqa: E402
+
+
+def main():
+    D = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+    T = int(sys.argv[2]) if len(sys.argv) > 2 else 240000
+    reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+    dev = torch.device("cuda:0")
+    ctx = Context(0)
+    ctx.set_stream(torch.cuda.current_stream(dev))
+    t = 1.7e9 + np.arange(T) / 400.0
+    az, el = synthetic.daisy_scan(t)
+    off = synthetic.hex_pack(D, np.radians(1.0))
+    n = 1024
+    xi = np.linspace(-0.03, 0.03, n)
+    eta = xi[::-1].copy()
+    X, Y = np.meshgrid(xi, eta)
+    values = np.exp(-(X**2 + Y**2) / 1e-4).astype(np.float32)[None, None]
+    w = np.ones((D, 1))
+    out = torch.empty((D, T), dtype=torch.float32, device=dev)
+    ta = np.arange(t[0], t[-1], 0.1)
+    for name, transform, cal in (("az/el, scalar cal", None, False), ("ra/dec, scalar cal", sky_transform_stack(t, -23.0, -67.8), False),
+                                 ("ra/dec, atmosphere cal", sky_transform_stack(t, -23.0, -67.8), True)):
+        # stage inputs once: time the kernel alone
+        kw = dict(cal_scalars=[2e10])
+        if cal:
+            kw = dict(cal_tables=np.full((1, 24, 20), 2e10, np.float32), cal_axis_pwv=np.linspace(0, 8, 24), cal_axis_el=np.radians(np.linspace(5, 91, 20)),
+                      coarse_pwv=torch.ones((len(ta), D), dtype=torch.float64, device=dev), ta0=ta[0], dta=0.1, t=t)
+        tr = None if transform is None else torch.as_tensor(transform.reshape(T, 9)).to(dev)
+        centre = (float(np.mean(az)), float(np.mean(el))) if transform is None else None
+        if centre is None:
+            from oracle import mapsample  # geometry helper only (development script)
+
+            phi, theta = mapsample.frame_angles(az[None, ::1000].astype(np.float32), el[None, ::1000].astype(np.float32), transform[::1000])
+            centre = (float(np.median(phi)), float(np.median(theta)))
+        fn = lambda: mmap.sample_map(ctx, values, eta, xi, centre, az, el, off, w, out=out, transform=tr, **kw)  # noqa: E731
+        fn()
+        torch.cuda.synchronize()
+        med, mn = timeit(fn, reps)
+        print(f"map_sample {name}: D={D} T={T}: median {med:.2f} ms (includes host staging of inputs) -> {D*T/med/1e6:.1f} G samples/s; "
+              f"nonzero fraction {float((out != 0).float().mean()):.2f}")
+
+
+if __name__ == "__main__":
+    main()

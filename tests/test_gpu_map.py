@@ -62,8 +62,17 @@ def _blob_map(C, S, n_eta, n_xi, eta, xi, rng):
     return m
 
 
+@pytest.fixture(params=[0, 1], ids=["composed", "chain"])
+def pointing_mode(request, gpu_ctx):
+    """Both forms of steps 1-3: the composed float64 rotation (default) and the reference's
+    float32 chain taken literally (MRX_OPT_POINTING_CHAIN)."""
+    gpu_ctx.set_option(0, request.param)
+    yield request.param
+    gpu_ctx.set_option(0, 0)
+
+
 @pytest.mark.parametrize("frame", ["az/el", "sky"])
-def test_offsets_through_ramp_maps(gpu_ctx, frame):
+def test_offsets_through_ramp_maps(gpu_ctx, frame, pointing_mode):
     """A map whose value is its own xi (or eta) coordinate returns the sample's offset from
     the map centre under bilinear sampling: the float32 geometry chain (pointing, frame
     rotation, phi_theta_to_offsets) agrees with the restatement to a few float32 ulps of angle."""
@@ -90,7 +99,7 @@ def test_offsets_through_ramp_maps(gpu_ctx, frame):
 
 
 @pytest.mark.parametrize("bilinear", [True, False])
-def test_map_sampling_matches_oracle(gpu_ctx, bilinear):
+def test_map_sampling_matches_oracle(gpu_ctx, bilinear, pointing_mode):
     """Three Stokes planes, two channels, polarised and unpolarised detectors, coarse pixels (so
     that float32 angle rounding moves no weight by more than 1e-5), samples off the map's edge,
     a TOD length that is no multiple of the tile, rows that are not 16-byte aligned."""
@@ -107,7 +116,7 @@ def test_map_sampling_matches_oracle(gpu_ctx, bilinear):
     ox = mapsample.phi_theta_to_offsets(*mapsample.frame_angles(az_d, el_d, transform), *centre)
     # a map smaller than the scanned patch: the samples beyond its edge take the edge pixels
     n_eta, n_xi = 5, 7
-    half_eta, half_xi = 0.6 * np.abs(ox[..., 1]).max(), 0.6 * np.abs(ox[..., 0]).max()
+    half_eta, half_xi = 0.6 * float(np.abs(ox[..., 1]).max()), 0.6 * float(np.abs(ox[..., 0]).max())
     eta = np.linspace(half_eta, -half_eta, n_eta)
     xi = np.linspace(-half_xi, half_xi, n_xi)
     values = _blob_map(2, 3, n_eta, n_xi, eta, xi, rng)
@@ -133,7 +142,7 @@ def test_map_sampling_matches_oracle(gpu_ctx, bilinear):
         assert bad.mean() < 2e-3
 
 
-def test_map_sampling_with_atmospheric_transmission(gpu_ctx):
+def test_map_sampling_with_atmospheric_transmission(gpu_ctx, pointing_mode):
     """With an atmosphere the K_RJ -> pW factor is looked up per sample at (zenith pwv,
     elevation) (sim/map.py:117-135): coarse pwv series interpolated linearly, float32
     trilinear table."""
