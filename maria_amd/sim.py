@@ -210,6 +210,13 @@ class Simulation:
         a torch tensor (a 10 k x 240 k TOD is 9.6 GB; the PCIe copy dwarfs the synthesis)."""
         if cmb is not None:
             raise NotImplementedError("the CMB mixin is a follow-on row (SURVEY 8(f))")
+        if isinstance(map, str):
+            raise NotImplementedError("reading a map from a file stays with maria's io; pass a maria_amd.map.ProjectionMap")
+        if map is not None:
+            from .map import ProjectionMap
+
+            if not isinstance(map, ProjectionMap):
+                raise TypeError("'map' must be a maria_amd.map.ProjectionMap")
         self.map, self.map_kwargs = map, {"bilinear_sampling": True, **dict(map_kwargs)}  # sim/map.py:20
         if np.dtype(dtype) != np.float32:
             raise NotImplementedError("the device path writes float32 TODs (the reference default)")

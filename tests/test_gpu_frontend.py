@@ -80,7 +80,9 @@ def test_reference_error_behaviour(gpu_ctx):
     with pytest.raises(TypeError):
         Simulation(inst, "daisy", site)
     with pytest.raises(NotImplementedError):
-        Simulation(inst, plan, site, atmosphere="2d", map="something")
+        Simulation(inst, plan, site, atmosphere="2d", map="some_file.fits")  # map io stays with maria
+    with pytest.raises(NotImplementedError):
+        Simulation(inst, plan, site, atmosphere="2d", cmb="generate")
     sim = Simulation(inst, plan, site, atmosphere="2d", noise=False)
     with pytest.raises(NotImplementedError, match="K_CMB"):
         sim.run(units="K_CMB")  # only the reference's default K_RJ and pW are built
