@@ -339,12 +339,29 @@ typedef struct mrx_map_cal {
  *  d_az, d_el   [T] float32 full-rate boresight
  *  d_transform  [T][3][3] float64 transform stack (row vector times matrix), or NULL
  *  d_dx, d_dy   [D] float32 offsets of observation.coords (rolled), radians
- *  d_stokes_w   [D][n_stokes] float32: Mueller[d, 0, stokes] (array/array.py:204-221)
+ *  d_stokes_w   [D][n_stokes] float64: Mueller[d, 0, stokes] (array/array.py:204-221)
  *  d_out        [D][ld_out] float32, pW */
 int mrx_map_sample(mrx_ctx* ctx, const mrx_sky_map* map, const mrx_map_cal* cal,
                    const float* d_az, const float* d_el, int T, const double* d_transform,
-                   const float* d_dx, const float* d_dy, const float* d_stokes_w, int D,
+                   const float* d_dx, const float* d_dy, const double* d_stokes_w, int D,
                    float* d_out, size_t ld_out);
+
+/* BinMapper.run for one TOD (mappers/bin_mapper.py:84-120): the transpose of the pointing
+ * matrix of mrx_map_sample, map_sum += (W * D) @ P and map_wgt += W @ |P|, as float64 atomic
+ * adds into the caller's (zeroed or running) maps; the map itself is sum / wgt.  `map` gives
+ * the grid (d_values is not read; bilinear = 0 is the mapper's default).
+ *  d_tod     [D][ld_tod] float32 signal (the sum of the TOD's fields)
+ *  d_weight  [D][ld_weight] float32 sample weights, or NULL for ones (tod.weight's default)
+ *  d_channel [D] map channel of each detector (the nu plane whose frequency is the
+ *            detector's band centre, map/projection.py:152-155), or NULL for 0
+ *  d_sum, d_wgt  [n_stokes][n_channels][n_eta][n_xi] float64
+ * Pointing arguments as mrx_map_sample.  Summation order is not fixed (atomics): results
+ * agree with a serial sum to float64 rounding. */
+int mrx_bin_map(mrx_ctx* ctx, const mrx_sky_map* map, const float* d_tod, size_t ld_tod,
+                const float* d_weight, size_t ld_weight, const float* d_az, const float* d_el, int T,
+                const double* d_transform, const float* d_dx, const float* d_dy,
+                const double* d_stokes_w, const int32_t* d_channel, int D, double* d_sum,
+                double* d_wgt);
 
 /* Test hook for the in-LDS inverse FFT both generators are built on: `rows` independent rows
  * of n << interleave_log2 complex float32 values, each holding 2^interleave_log2 interleaved

@@ -146,6 +146,7 @@ SIGNATURES = {
     "mrx_screen_generate": (_i, [_vp, C.c_uint64, C.c_uint32, _i, _i, _d, _d, _d, _d, _vp, _vp]),
     "mrx_screen_psd_sum": (_i, [_vp, _i, _i, _d, _d, _d, _d, C.POINTER(_d)]),
     "mrx_map_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _sz]),
+    "mrx_bin_map": (_i, [_vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "mrx_fft_rows": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "mrx_noise_period": (_i, [_i, C.POINTER(_i), C.POINTER(_i)]),
     "mrx_noise_work_floats": (_i, [_i, _i, _i, C.POINTER(_sz)]),

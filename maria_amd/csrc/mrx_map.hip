@@ -66,7 +66,7 @@ struct MapArgs {
   const double* transform;  // [T][9] or null
   const float* dx;
   const float* dy;
-  const float* stokes_w;  // [D][S]
+  const double* stokes_w;  // [D][S]
   int D, T;
   float* out;
   size_t ld;
@@ -75,7 +75,7 @@ struct MapArgs {
 
 struct DetConst {
   float c_re, c_cr, c_im;  // sin(r)cos(p), cos(r), sin(r)sin(p)
-  float w[kMaxStokes];
+  double w[kMaxStokes];  // Mueller[d, 0, stokes]
 };
 
 struct SampleConst;
@@ -207,7 +207,7 @@ __device__ __forceinline__ float sample_value(const MapArgs& g, const CalLds& cl
     for (int k = 0; k < kMaxStokes; ++k) {
       if (k < g.S) {
         const double v = fma(w00, (double)m[o00], fma(w10, (double)m[o10], fma(w01, (double)m[o01], w11 * (double)m[o11])));
-        val = fma((double)dc.w[k], v, val);
+        val = fma(dc.w[k], v, val);
         m += plane;
       }
     }
@@ -238,11 +238,13 @@ __device__ __noinline__ double asin_over_r(double r2) {
 // raw (unconvolved) map loading of one detector at one sample, float32.
 // kChain: steps 1-3 literally as the reference's float32 chain; otherwise the composed
 // rotation of sample_const (same angles to float32 rounding, ~10x less arithmetic).
-template <bool kChain, bool kCal>
-__device__ __forceinline__ float raw_sample(const MapArgs& g, const CalLds& cl, const Axis& ax_eta, const Axis& ax_xi,
-                                            const DetConst& dc, int d, const SampleConst& sc) {
+// Steps 1-3: offsets (ox, oy) of one detector sample from the map centre, and the
+// detector's elevation when the calibration needs it.
+template <bool kChain, bool kNeedEl>
+__device__ __forceinline__ void sample_offsets(const MapArgs& g, const DetConst& dc, const SampleConst& sc,
+                                               float& ox, float& oy, float& el_d) {
   const float im = __fadd_rn(__fmul_rn(dc.c_re, sc.sa), __fmul_rn(dc.c_cr, sc.ca));
-  float ox, oy, el_d = 0.0f;
+  el_d = 0.0f;
   if (kChain) {
     // 1. detector az/el (transforms.py:10-29)
     const float re = __fsub_rn(__fmul_rn(dc.c_re, sc.ca), __fmul_rn(dc.c_cr, sc.sa));
@@ -283,9 +285,117 @@ __device__ __forceinline__ float raw_sample(const MapArgs& g, const CalLds& cl, 
     if (__builtin_expect(r2 >= 0.09, 0)) f = asin_over_r(r2);
     ox = (float)(-dz_re * f);
     oy = (float)(-dz_im * f);
-    if (kCal) el_d = asinf(im);
+    if (kNeedEl) el_d = asinf(im);
   }
+}
+
+template <bool kChain, bool kCal>
+__device__ __forceinline__ float raw_sample(const MapArgs& g, const CalLds& cl, const Axis& ax_eta, const Axis& ax_xi,
+                                            const DetConst& dc, int d, const SampleConst& sc) {
+  float ox, oy, el_d;
+  sample_offsets<kChain, kCal>(g, dc, sc, ox, oy, el_d);
   return sample_value<kCal>(g, cl, ax_eta, ax_xi, dc, d, sc, ox, oy, el_d);
+}
+
+__device__ __forceinline__ DetConst make_det_const(const MapArgs& g, int d) {
+  const float dx = g.dx[d], dy = g.dy[d];
+  const float r = sqrtf(dx * dx + dy * dy);
+  const float p = atan2f(-dx, -dy);
+  const float sr = sinf(r);
+  DetConst dc;
+  dc.c_re = __fmul_rn(sr, cosf(p));
+  dc.c_cr = cosf(r);
+  dc.c_im = __fmul_rn(sr, sinf(p));
+  for (int k = 0; k < kMaxStokes; ++k) dc.w[k] = k < g.S ? g.stokes_w[(size_t)d * g.S + k] : 0.0;
+  return dc;
+}
+
+// ---- binning: the transpose of the same pointing matrix (mappers/bin_mapper.py:84-120) ----
+struct BinArgs {
+  const float* tod;     // [D][ld_tod] signal
+  size_t ld_tod;
+  const float* weight;  // [D][ld_w] or null (ones)
+  size_t ld_w;
+  const int32_t* channel;  // [D] map channel of each detector, or null (0)
+  double* sum;          // [S][C][n_eta][n_xi]
+  double* wgt;
+};
+
+// One run of consecutive samples that share their pixels: A[c] = sum W D w_c, B[c] = sum W w_c
+// over the 4 corners c (bilinear weights w_c >= 0); flushed with one atomic per corner, Stokes
+// plane and product.
+struct BinRun {
+  int e0, e1, x0, x1;
+  double A[4], B[4];
+};
+
+__device__ __forceinline__ void flush_run(const MapArgs& g, const BinArgs& b, const DetConst& dc, int chan, const BinRun& r) {
+  const int plane = g.n_eta * g.n_xi;
+  const int o[4] = {r.e0 * g.n_xi + r.x0, r.e1 * g.n_xi + r.x0, r.e0 * g.n_xi + r.x1, r.e1 * g.n_xi + r.x1};
+  const int corners = g.bilinear ? 4 : 1;
+  for (int k = 0; k < g.S; ++k) {
+    const size_t base = ((size_t)k * g.C + chan) * plane;
+    const double m = dc.w[k];
+    for (int c = 0; c < corners; ++c) {
+      if (r.B[c] == 0.0) continue;  // zero weight: nothing to add (np.abs(P) entries that are 0)
+      atomicAdd(b.sum + base + o[c], m * r.A[c]);
+      atomicAdd(b.wgt + base + o[c], fabs(m) * r.B[c]);
+    }
+  }
+}
+
+template <bool kChain>
+__global__ __launch_bounds__(kBlock) void bin_map_kernel(MapArgs g, BinArgs b) {
+  __shared__ DetConst dets[kTileDet];
+  const int d0 = blockIdx.y * kTileDet;
+  const int sb = blockIdx.x * kTileSamples + threadIdx.x * kSamplesPerThread;
+  const int nd = min(kTileDet, g.D - d0);
+  if ((int)threadIdx.x < nd) dets[threadIdx.x] = make_det_const(g, d0 + threadIdx.x);
+  const Axis ax_eta = g.eta, ax_xi = g.xi;
+  SampleConst sc[kSamplesPerThread];
+#pragma unroll
+  for (int q = 0; q < kSamplesPerThread; ++q) {
+    sample_const(g, sb + q, kChain, sc[q]);
+    sc[q].s = min(max(sb + q, 0), g.T - 1);
+  }
+  __syncthreads();
+  if (sb >= g.T) return;
+  for (int dl = 0; dl < nd; ++dl) {
+    const DetConst dc = dets[dl];
+    const int d = d0 + dl;
+    const int chan = b.channel ? min(max(b.channel[d], 0), g.C - 1) : 0;
+    BinRun run;
+    bool open = false;
+#pragma unroll
+    for (int q = 0; q < kSamplesPerThread; ++q) {
+      if (sb + q >= g.T) break;
+      float ox, oy, el_d;
+      sample_offsets<kChain, false>(g, dc, sc[q], ox, oy, el_d);
+      int e0, e1, x0, x1;
+      double pe, px;
+      axis_weights(ax_eta, (double)oy, g.bilinear, e0, e1, pe);
+      axis_weights(ax_xi, (double)ox, g.bilinear, x0, x1, px);
+      const double W = b.weight ? (double)b.weight[(size_t)d * b.ld_w + sb + q] : 1.0;
+      const double WD = W * (double)b.tod[(size_t)d * b.ld_tod + sb + q];
+      const double w[4] = {(1.0 - pe) * (1.0 - px), pe * (1.0 - px), (1.0 - pe) * px, pe * px};
+      if (open && (e0 != run.e0 || x0 != run.x0 || e1 != run.e1 || x1 != run.x1)) {
+        flush_run(g, b, dc, chan, run);
+        open = false;
+      }
+      if (!open) {
+        run.e0 = e0; run.e1 = e1; run.x0 = x0; run.x1 = x1;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) run.A[c] = run.B[c] = 0.0;
+        open = true;
+      }
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        run.A[c] = fma(WD, w[c], run.A[c]);
+        run.B[c] = fma(W, w[c], run.B[c]);
+      }
+    }
+    if (open) flush_run(g, b, dc, chan, run);
+  }
 }
 
 template <bool kChain, bool kCal>
@@ -303,19 +413,7 @@ __global__ __launch_bounds__(kBlock) void map_sample_kernel(MapArgs g) {
   const int s_tile = blockIdx.x * kTileSamples;
   const int sb = s_tile + threadIdx.x * kSamplesPerThread;
   const int nd = min(kTileDet, g.D - d0);
-  if ((int)threadIdx.x < nd) {
-    const int d = d0 + threadIdx.x;
-    const float dx = g.dx[d], dy = g.dy[d];
-    const float r = sqrtf(dx * dx + dy * dy);
-    const float p = atan2f(-dx, -dy);
-    const float sr = sinf(r);
-    DetConst dc;
-    dc.c_re = __fmul_rn(sr, cosf(p));
-    dc.c_cr = cosf(r);
-    dc.c_im = __fmul_rn(sr, sinf(p));
-    for (int k = 0; k < kMaxStokes; ++k) dc.w[k] = k < g.S ? g.stokes_w[(size_t)d * g.S + k] : 0.0f;
-    dets[threadIdx.x] = dc;
-  }
+  if ((int)threadIdx.x < nd) dets[threadIdx.x] = make_det_const(g, d0 + threadIdx.x);
   const Axis ax_eta = g.eta, ax_xi = g.xi;
   SampleConst sc[kSamplesPerThread], sc_halo;
 #pragma unroll
@@ -369,7 +467,7 @@ extern "C" {
 
 int mrx_map_sample(mrx_ctx* ctx, const mrx_sky_map* map, const mrx_map_cal* cal,
                    const float* d_az, const float* d_el, int T, const double* d_transform,
-                   const float* d_dx, const float* d_dy, const float* d_stokes_w, int D,
+                   const float* d_dx, const float* d_dy, const double* d_stokes_w, int D,
                    float* d_out, size_t ld_out) {
   if (!ctx) return MRX_ERR_INVALID;
   MRX_REQUIRE(ctx, D >= 0 && T >= 0, "negative size");
@@ -447,6 +545,56 @@ int mrx_map_sample(mrx_ctx* ctx, const mrx_sky_map* map, const mrx_map_cal* cal,
     if (has_cal) MRX_LAUNCH_MAP(false, true); else MRX_LAUNCH_MAP(false, false);
   }
 #undef MRX_LAUNCH_MAP
+  MRX_CHECK_LAUNCH(ctx);
+  return MRX_OK;
+}
+
+int mrx_bin_map(mrx_ctx* ctx, const mrx_sky_map* map, const float* d_tod, size_t ld_tod,
+                const float* d_weight, size_t ld_weight, const float* d_az, const float* d_el, int T,
+                const double* d_transform, const float* d_dx, const float* d_dy,
+                const double* d_stokes_w, const int32_t* d_channel, int D, double* d_sum,
+                double* d_wgt) {
+  if (!ctx) return MRX_ERR_INVALID;
+  MRX_REQUIRE(ctx, D >= 0 && T >= 0, "negative size");
+  if (D == 0 || T == 0) return MRX_OK;
+  MRX_REQUIRE(ctx, map && d_tod && d_az && d_el && d_dx && d_dy && d_stokes_w && d_sum && d_wgt, "null pointer");
+  MRX_REQUIRE(ctx, map->n_channels >= 1 && map->n_stokes >= 1 && map->n_stokes <= kMaxStokes &&
+                       map->n_eta >= 2 && map->n_xi >= 2,
+              "need n_channels >= 1, 1 <= n_stokes <= 4, n_eta >= 2, n_xi >= 2");
+  MRX_REQUIRE(ctx, map->deta != 0.0 && map->dxi != 0.0, "map axes need a non-zero step");
+  MRX_REQUIRE(ctx, (long long)map->n_eta * map->n_xi < (1LL << 31), "a map plane must hold fewer than 2^31 pixels");
+  MRX_REQUIRE(ctx, ld_tod >= (size_t)T && (!d_weight || ld_weight >= (size_t)T), "leading dimension smaller than T");
+  MapArgs g{};
+  g.eta = Axis{map->n_eta, map->eta0, 1.0 / map->deta};
+  g.xi = Axis{map->n_xi, map->xi0, 1.0 / map->dxi};
+  g.C = map->n_channels;
+  g.S = map->n_stokes;
+  g.n_eta = map->n_eta;
+  g.n_xi = map->n_xi;
+  g.cphi = (float)map->center_phi;
+  const float ang = (float)(1.5707963267948966 - map->center_theta);
+  g.rot_re = (float)cos((double)ang);
+  g.rot_im = (float)sin((double)ang);
+  g.cos_cphi = cos(map->center_phi);
+  g.sin_cphi = sin(map->center_phi);
+  g.cos_ctheta = cos(map->center_theta);
+  g.sin_ctheta = sin(map->center_theta);
+  g.bilinear = map->bilinear;
+  g.az = d_az;
+  g.el = d_el;
+  g.transform = d_transform;
+  g.dx = d_dx;
+  g.dy = d_dy;
+  g.stokes_w = d_stokes_w;
+  g.D = D;
+  g.T = T;
+  BinArgs b{d_tod, ld_tod, d_weight, ld_weight, d_channel, d_sum, d_wgt};
+  dim3 grid(mrx_ceil_div(T, kTileSamples), mrx_ceil_div(D, kTileDet));
+  MRX_REQUIRE(ctx, grid.y <= 65535u, "D too large for one launch");
+  if (ctx->options[MRX_OPT_POINTING_CHAIN])
+    hipLaunchKernelGGL(bin_map_kernel<true>, grid, dim3(kBlock), 0, ctx->stream, g, b);
+  else
+    hipLaunchKernelGGL(bin_map_kernel<false>, grid, dim3(kBlock), 0, ctx->stream, g, b);
   MRX_CHECK_LAUNCH(ctx);
   return MRX_OK;
 }

@@ -94,7 +94,7 @@ def sample_map(ctx, values, eta, xi, center, az, el, offsets, stokes_weights, ou
     if not (np.allclose(np.diff(eta), deta, rtol=1e-6, atol=0) and np.allclose(np.diff(xi), dxi, rtol=1e-6, atol=0)):
         raise ValueError("map axes must be uniform (np.linspace, map/projection.py:122-123)")
     keep = dict(values=f32(values), az=f32(az), el=f32(el), dx=f32(offsets[:, 0]), dy=f32(offsets[:, 1]),
-                w=f32(np.asarray(stokes_weights)[:, :S_]))
+                w=f64(np.asarray(stokes_weights)[:, :S_]))
     sky = MrxSkyMap(ptr(keep["values"]), C_, S_, n_eta, n_xi, float(eta[0]), float(deta), float(xi[0]), float(dxi),
                     float(center[0]), float(center[1]), 1 if bilinear else 0, 0)
     cal = MrxMapCal()

@@ -384,7 +384,8 @@ class Simulation:
         # per-detector gain error (simulation.py:239-247), fused into the upsample's store
         gain_error = np.array([dets.bands[b].gain_error for b in dets.band_index])
         gain = np.exp(gain_error * self._gain_rng.standard_normal(dets.n))
-        metadata = {"atmosphere": False, "altitude": float(obs.site.altitude), "region": obs.site.region}
+        metadata = {"atmosphere": False, "altitude": float(obs.site.altitude), "region": obs.site.region,
+                    "latitude": obs.site.latitude, "longitude": obs.site.longitude}
         # bands whose NEP grows with the loading need the loading in pW before the noise is
         # drawn (sim/noise.py:35-37); every field is then converted after the fact, as
         # TOD.to does.  Otherwise the conversion rides on the upsample's store.

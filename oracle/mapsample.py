@@ -145,3 +145,25 @@ def sample_maps(az, el, t, coarse_t, coarse_pwv, map_eta, map_xi, center, channe
         pw = pw_per_k * sample_channel(offsets, map_eta, map_xi, cmap, stokes_weights, bilinear)
         loading += pw  # float32 accumulator (map.py:155)
     return scipy.ndimage.convolve1d(loading, weights=np.array([0.25, 0.5, 0.25]), axis=-1)  # map.py:170
+
+
+def bin_map(az, el, tod, weight, map_eta, map_xi, center, stokes_weights, n_stokes, channel=None, n_channels=1,
+            transform_stack=None, bilinear=False):
+    """mappers/bin_mapper.py:84-120: ``map_sum += (W * D) @ P`` and ``map_wgt += W @ |P|`` with the
+    Stokes-weighted pointing matrix of map/projection.py:134-179.  az/el [D, T] float32 detector
+    pointing; tod, weight [D, T].  Returns (sum, wgt) [n_stokes, n_channels, n_eta, n_xi] float64."""
+    phi, theta = frame_angles(az, el, transform_stack)
+    offsets = phi_theta_to_offsets(phi, theta, center[0], center[1])
+    _, pixels, weights, n_pixels, _ = pointing_matrix_ingredients((offsets[..., 1], offsets[..., 0]), (map_eta, map_xi), bilinear)
+    if channel is not None:
+        pixels = pixels + (np.asarray(channel)[None, :, None] * n_pixels)
+    n_plane = n_pixels * n_channels
+    W = np.ones(np.shape(tod)) if weight is None else np.asarray(weight, float)
+    WD = W * np.asarray(tod, float)
+    msum, mwgt = np.zeros(n_stokes * n_plane), np.zeros(n_stokes * n_plane)
+    for s in range(n_stokes):
+        w = weights * np.asarray(stokes_weights, float)[:, s][None, :, None]
+        np.add.at(msum, (pixels + s * n_plane).ravel(), (w * WD[None]).ravel())
+        np.add.at(mwgt, (pixels + s * n_plane).ravel(), (np.abs(w) * W[None]).ravel())
+    shape = (n_stokes, n_channels, len(map_eta), len(map_xi))
+    return msum.reshape(shape), mwgt.reshape(shape)

@@ -238,3 +238,104 @@ def test_simulation_with_map(gpu_ctx, frame):
     (tod2,) = sim2.run()
     factor = tod2.data["atmosphere"].astype(np.float64) / tod.data["atmosphere"]
     np.testing.assert_allclose(tod2.data["map"], got * factor, rtol=3e-6, atol=1e-7 * np.abs(got * factor).max())
+
+
+@pytest.mark.parametrize("bilinear", [False, True])
+def test_bin_map_matches_oracle(gpu_ctx, bilinear, pointing_mode):
+    """mrx_bin_map (BinMapper.run, mappers/bin_mapper.py:84-120): the transpose of the pointing
+    matrix as float64 atomics.  Random TOD and weights, two Stokes planes, two channels, samples
+    beyond the grid (clamped to the edge pixels, as the reference's clip does)."""
+    import ctypes as C
+
+    import torch
+
+    from maria_amd._lib import MrxSkyMap, ptr
+    from oracle import hotpath, mapsample
+
+    rng = np.random.default_rng(6)
+    t, az, el, off = _scan(D=40, T=2051, fov_deg=0.5)
+    transform = _sky_rotation(t)
+    centre = _centre(az, el, transform)
+    az_d, el_d = hotpath.broadcast(off, az, el)
+    ox = mapsample.phi_theta_to_offsets(*mapsample.frame_angles(az_d, el_d, transform), *centre)
+    n_eta, n_xi = 12, 16
+    half_eta, half_xi = 0.8 * float(np.abs(ox[..., 1]).max()), 0.8 * float(np.abs(ox[..., 0]).max())
+    eta = np.linspace(half_eta, -half_eta, n_eta)
+    xi = np.linspace(-half_xi, half_xi, n_xi)
+    tod = rng.normal(1.0, 0.5, (len(off), len(t))).astype(np.float32)
+    wts = rng.uniform(0.5, 2.0, tod.shape).astype(np.float32)
+    gamma = np.where(np.arange(len(off)) % 2 == 0, np.nan, rng.uniform(0, np.pi, len(off)))
+    sw = mapsample.mueller_row(gamma)[:, :2]
+    chan = (np.arange(len(off)) % 2).astype(np.int32)
+    ref_sum, ref_wgt = mapsample.bin_map(az_d, el_d, tod, wts, eta, xi, centre, sw, 2, channel=chan, n_channels=2,
+                                         transform_stack=transform, bilinear=bilinear)
+    dev = "cuda:0"
+    f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)  # noqa: E731
+    d_tod, d_w, d_az, d_el, d_dx, d_dy = f32(tod), f32(wts), f32(az), f32(el), f32(off[:, 0]), f32(off[:, 1])
+    d_sw = torch.as_tensor(np.ascontiguousarray(sw, np.float64)).to(dev)
+    d_tr = torch.as_tensor(transform.reshape(-1, 9)).to(dev)
+    d_chan = torch.as_tensor(chan).to(dev)
+    msum = torch.zeros((2, 2, n_eta, n_xi), dtype=torch.float64, device=dev)
+    mwgt = torch.zeros_like(msum)
+    sky = MrxSkyMap(None, 2, 2, n_eta, n_xi, float(eta[0]), float(eta[1] - eta[0]), float(xi[0]), float(xi[1] - xi[0]),
+                    centre[0], centre[1], 1 if bilinear else 0, 0)
+    gpu_ctx.call("mrx_bin_map", C.byref(sky), ptr(d_tod), d_tod.stride(0), ptr(d_w), d_w.stride(0), ptr(d_az), ptr(d_el), len(t),
+                 ptr(d_tr), ptr(d_dx), ptr(d_dy), ptr(d_sw), ptr(d_chan), len(off), ptr(msum), ptr(mwgt))
+    got_sum, got_wgt = msum.cpu().numpy(), mwgt.cpu().numpy()
+    assert ref_wgt.sum() > 0 and abs(got_wgt.sum() / ref_wgt.sum() - 1) < 1e-9  # every sample lands somewhere
+    if bilinear:
+        # weights move by the float32 rounding of the offsets (<= 6e-7 rad of a ~1e-3 rad pixel)
+        tol = 6e-7 / abs(xi[1] - xi[0]) * 4
+        assert np.abs(got_sum - ref_sum).max() <= tol * np.abs(ref_sum).max()
+        assert np.abs(got_wgt - ref_wgt).max() <= tol * np.abs(ref_wgt).max()
+    else:
+        # nearest pixel: a handful of samples within float32 rounding of a pixel edge may swap bins
+        moved = np.abs(got_wgt - ref_wgt).sum() / ref_wgt.sum()
+        assert moved < 1e-3, moved
+        # pixels no sample moved into or out of, judged on the I plane (a polarised detector's Q
+        # weight can be arbitrarily small): there the sums agree to float64 rounding
+        ok = np.broadcast_to((np.abs(got_wgt - ref_wgt) <= 1e-9 * ref_wgt.max())[:1], ref_wgt.shape)
+        assert ok.mean() > 0.9 and np.abs(got_sum - ref_sum)[ok].max() <= 1e-9 * np.abs(ref_sum).max()
+
+
+def test_bin_mapper_recovers_the_sampled_map(gpu_ctx):
+    """Simulation(map=...) then BinMapper: binning the noiseless map TOD gives back the
+    beam-smoothed input where the scan covered it (the round trip the reference's
+    tests/mappers exercise), and sum / weight bookkeeping is consistent."""
+    from maria_amd import map as mmap
+    from maria_amd.instrument import Band, Detectors, Instrument, Site
+    from maria_amd.mappers import BinMapper
+    from maria_amd.sim import Plan, Simulation, sky_transform_stack
+
+    bands = [Band(center=150e9, width=30e9, shape="top_hat", name="f150")]
+    inst = Instrument(Detectors.hexagon(61, 0.3, bands, primary_size=30.0))
+    plan = Plan.daisy(start_time=1.7e9, duration=120.0, sample_rate=50.0, scan_center=(100.0, 60.0), radius=0.25, speed=0.5)
+    site = Site(altitude=1000.0)
+    transform = sky_transform_stack(plan.time, site.latitude, site.longitude)
+    centre = _centre(plan.phi.astype(np.float32), plan.theta.astype(np.float32), transform)
+    n = 96
+    X, Y = np.meshgrid(np.linspace(-1, 1, n), np.linspace(-1, 1, n))
+    data = (np.exp(-((X - 0.1) ** 2 + (Y + 0.15) ** 2) / 0.05) + 0.5 * np.exp(-((X + 0.3) ** 2 + (Y - 0.2) ** 2) / 0.02)).astype(np.float32)
+    sky = mmap.ProjectionMap(data, nu=150e9, width=1.0, center=np.degrees(centre), frame="ra/dec")
+    sim = Simulation(inst, plan, site, map=sky, noise=False)
+    (tod,) = sim.run(units="pW")
+    assert set(tod.fields) == {"map"} and np.isfinite(tod.data["map"]).all()
+    mapper = BinMapper([tod], center=np.degrees(centre), width=0.6, resolution=1.0 / 60, stokes="I", nu=150e9, frame="ra/dec", units="pW")
+    with pytest.raises(RuntimeError):
+        _ = mapper.map
+    out = mapper.run()
+    hit = mapper.products["weight"][0, 0] > 20
+    assert hit.mean() > 0.3
+    np.testing.assert_allclose(mapper.products["sum"][0, 0][hit] / mapper.products["weight"][0, 0][hit], out.data[0, 0][hit], rtol=1e-6)
+    # compare with the input map (pW per K_RJ is a constant without an atmosphere) on the hit pixels
+    scale = 1e12 * 1.380649e-23 * float(np.trapezoid(bands[0].passband(bands[0].nu), x=bands[0].nu)) * 0.5 * 2  # mueller I weight = 1
+    from scipy.interpolate import RegularGridInterpolator
+
+    interp = RegularGridInterpolator((sky.eta[::-1], sky.xi), sky.data[0, 0][::-1], bounds_error=False, fill_value=np.nan)
+    E, Xg = np.meshgrid(out.eta, out.xi, indexing="ij")
+    expect = interp(np.stack([E, Xg], axis=-1)) * scale
+    rec = out.data[0, 0]
+    good = hit & np.isfinite(expect)
+    # beam smoothing (a 30 m dish at 150 GHz: ~17 arcsec) and 1-arcmin nearest-pixel binning blur the blobs a little
+    assert np.corrcoef(rec[good], expect[good])[0, 1] > 0.99
+    assert abs(np.sum(rec[good]) / np.sum(expect[good]) - 1) < 0.05
