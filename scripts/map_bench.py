@@ -58,5 +58,40 @@ def main():
               f"nonzero fraction {float((out != 0).float().mean()):.2f}")
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and not os.environ.get("MRX_BENCH_BIN"):
     main()
+
+
+def bench_bin():
+    """mrx_bin_map at the same scale (nearest pixel, the mapper's default)."""
+    import ctypes as C
+
+    from maria_amd._lib import MrxSkyMap, ptr
+
+    D = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
+    T = int(sys.argv[2]) if len(sys.argv) > 2 else 240000
+    dev = torch.device("cuda:0")
+    ctx = Context(0)
+    ctx.set_stream(torch.cuda.current_stream(dev))
+    t = 1.7e9 + np.arange(T) / 400.0
+    az, el = synthetic.daisy_scan(t)
+    off = synthetic.hex_pack(D, np.radians(1.0))
+    f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)  # noqa: E731
+    tod = torch.randn((D, T), dtype=torch.float32, device=dev)
+    d_az, d_el, d_dx, d_dy = f32(az), f32(el), f32(off[:, 0]), f32(off[:, 1])
+    d_sw = torch.ones((D, 1), dtype=torch.float64, device=dev)
+    for n in (256, 1024):
+        for bil in (0, 1):
+            msum = torch.zeros((1, 1, n, n), dtype=torch.float64, device=dev)
+            mwgt = torch.zeros_like(msum)
+            step = 0.05 / n
+            sky = MrxSkyMap(None, 1, 1, n, n, 0.025, -step, -0.025, step, float(np.mean(az)), float(np.mean(el)), bil, 0)
+            fn = lambda: ctx.call("mrx_bin_map", C.byref(sky), ptr(tod), tod.stride(0), None, 0, ptr(d_az), ptr(d_el), T, None,  # noqa: E731
+                                  ptr(d_dx), ptr(d_dy), ptr(d_sw), None, D, ptr(msum), ptr(mwgt))
+            med, mn = timeit(fn, 3)
+            print(f"bin_map {n}x{n} bilinear={bil}: D={D} T={T}: median {med:.2f} ms -> {D*T/med/1e6:.1f} G samples/s "
+                  f"({4.0*D*T/med/1e6:.0f} GB/s of TOD read); hit pixels {int((mwgt > 0).sum())}")
+
+
+if __name__ == "__main__" and os.environ.get("MRX_BENCH_BIN"):
+    bench_bin()
