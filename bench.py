@@ -267,6 +267,20 @@ def main():
     # itself needs no collective).  Reported, never part of `value`; a failure here must not
     # lose the benchmark line.
     if world > 1 and not args.no_allgather:
+        # a collective that never completes must not cost the line either: after 120 s the
+        # watchdog prints it (rank 0) and ends the process
+        import threading
+
+        finished = threading.Event()
+
+        def watchdog():
+            if not finished.wait(120.0):
+                if rank == 0:
+                    result["allgather_epilogue"] = {"error": "no completion within 120 s; skipped"}
+                    print(json.dumps(result), flush=True)
+                os._exit(0)
+
+        threading.Thread(target=watchdog, daemon=True).start()
         try:
             from maria_amd.dist import stream_gathered_tod
 
@@ -288,9 +302,10 @@ def main():
             }
         except Exception as exc:  # pragma: no cover - depends on the node
             result["allgather_epilogue"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        finished.set()
 
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
 
