@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Turn the two rocprofv3 --pmc passes of scripts/profile_round.sh into HBM bytes per launch
+per kernel, with the corrections MI355X_MICROARCH.md prescribes for gfx950: both counters are
+in KB (x 1024), FETCH_SIZE counts a 128-byte read request as 64 bytes (x 2).
+Usage: python scripts/pmc_summary.py gpurun_out/<tag> profiles/<prefix>"""
+
+import collections
+import csv
+import json
+import re
+import sys
+
+
+def per_launch(path, counter):
+    tot, cnt = collections.Counter(), collections.Counter()
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            name = row["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")
+            name = re.split(r"[<(]", name)[0].strip()
+            tot[name] += float(row["Counter_Value"])
+            cnt[name] += 1
+    return {k: tot[k] / cnt[k] for k in tot}, dict(cnt)
+
+
+def main():
+    src, prefix = sys.argv[1], sys.argv[2]
+    fetch, n = per_launch(f"{src}/pmc_fetch/run_counter_collection.csv", "FETCH_SIZE")
+    write, _ = per_launch(f"{src}/pmc_write/run_counter_collection.csv", "WRITE_SIZE")
+    rows = []
+    for k in sorted(set(fetch) | set(write)):
+        fb, wb = 2.0 * 1024.0 * fetch.get(k, 0.0), 1024.0 * write.get(k, 0.0)
+        rows.append((k, n.get(k, 0), fetch.get(k, 0.0), write.get(k, 0.0), fb, wb, fb + wb))
+    with open(f"{prefix}_pmc_hbm_traffic.csv", "w") as f:
+        f.write("kernel,launches,FETCH_SIZE_KB_per_launch,WRITE_SIZE_KB_per_launch,fetch_bytes_corrected,write_bytes,hbm_bytes_per_launch\n")
+        for r in rows:
+            f.write(",".join(str(x) for x in r) + "\n")
+    up = [r for r in rows if r[0] == "spline_upsample_kernel"][0]
+    with open(f"{prefix}_traffic.json", "w") as f:
+        json.dump({"config": "atlast_10k", "kernel": "spline_upsample_kernel", "hbm_bytes_per_launch": up[6], "fetch_bytes_corrected": up[4],
+                   "write_bytes": up[5],
+                   "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes with --kernel-trace only (KB units x1024); "
+                             "FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 counts 128-B read requests as 64 B)",
+                   "source": f"{prefix}_pmc_hbm_traffic.csv"}, f, indent=1)
+    for r in rows:
+        print(f"{r[0]:32s} launches {r[1]:4d}  read {r[4]/1e6:10.2f} MB  written {r[5]/1e6:10.2f} MB")
+
+
+if __name__ == "__main__":
+    main()
