@@ -163,8 +163,9 @@ int get_taps(mrx_ctx* ctx, double sigma, double truncate, int* radius_out,
   auto& slot = ctx->taps[ctx->taps_next];
   ctx->taps_next = (ctx->taps_next + 1) % mrx_ctx::kTapSlots;
   if (slot.d_taps) {
-    // a kernel still in flight may be reading the evicted taps
-    MRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    // a kernel still in flight (on any stream the caller alternates between) may be
+    // reading the evicted taps
+    MRX_HIP(ctx, hipDeviceSynchronize());
     (void)hipFree(slot.d_taps);
     slot.d_taps = nullptr;
   }
