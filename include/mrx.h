@@ -382,7 +382,9 @@ int mrx_fft_rows(mrx_ctx* ctx, const float* d_in, int rows, int n, int interleav
  * are synthesised in the frequency domain on a power-of-two period N >= T (a four-step FFT
  * whose real and imaginary parts serve two detectors; the modes enter as tabulated
  * Hermitian spectra) and cut to T samples: same spectrum, different realisation and
- * period -- statistical parity, like the screens.  With knee = 0 the
+ * period -- statistical parity, like the screens.  As in the reference, whose period is the
+ * TOD itself, the pink and correlated parts carry no power below fs/T and have zero mean over
+ * the T samples (the cells below ceil(N/T) are dropped, the window mean is subtracted).  With knee = 0 the
  * output is white only and neither the basis nor the work buffer is used.
  *  det_offset   global index of row 0 (even): the draws of detector det_offset + d depend on
  *               (seed, det_offset + d) only, the modes on the seed only -- shards of one
@@ -396,7 +398,7 @@ int mrx_fft_rows(mrx_ctx* ctx, const float* d_in, int rows, int n, int interleav
  *               noise straight into an existing TOD)
  *  d_work       16-byte aligned scratch of work_floats floats; mrx_noise_work_floats(T,
  *               n_modes, batch) gives the size that processes `batch` detectors per pass
- *               (4 N bytes per detector + 8 N per mode).
+ *               (4 N + 8 bytes per detector + 8 N per mode).
  * mrx_noise_period: N = n1 * n2 for T samples (T <= 2^23). */
 int mrx_noise_period(int T, int* n1, int* n2);
 int mrx_noise_work_floats(int T, int n_modes, int batch, size_t* floats);

@@ -64,10 +64,10 @@ constexpr int kMaxModes = 8;
 typedef float vfloat4 __attribute__((ext_vector_type(4)));
 typedef float vfloat2 __attribute__((ext_vector_type(2)));
 
-// amplitude of spectrum cell k of a length-n series: sqrt(knee/|k|), 0 at k = 0
-__device__ __forceinline__ float pink_amp(int k, int n, float sqrt_knee) {
+// amplitude of spectrum cell k of a length-n series: sqrt(knee/|k|), 0 below k_min (>= 1)
+__device__ __forceinline__ float pink_amp(int k, int n, float sqrt_knee, int k_min) {
   const int kk = k < n - k ? k : n - k;
-  return kk == 0 ? 0.0f : sqrt_knee * __builtin_amdgcn_rsqf((float)kk);
+  return kk < k_min ? 0.0f : sqrt_knee * __builtin_amdgcn_rsqf((float)kk);
 }
 
 // four white normals for samples 4 q .. 4 q + 3 of row `id`
@@ -77,10 +77,35 @@ __device__ __forceinline__ vfloat4 white4(uint64_t q, uint32_t id, uint32_t key0
   return vfloat4{a.x, a.y, b.x, b.y};
 }
 
+// The reference's pink series has period T (generation.py:31-37): no power below fs/T and a
+// mean of exactly zero over the TOD (tests/noise/test_noise.py:7-31 relies on it: the mean of
+// a detector's noise is white).  On the longer period N the same two properties are restored
+// by (a) dropping the cells below k_min = ceil(N/T) and (b) subtracting the window mean of the
+// pink part, (1/T) sum_k X_k W_k with W_k = sum_{t<T} exp(2 pi i k t / N), which converges
+// like k^-3: the cells below k_cut = 64 k_min carry all of it.
+// W_k / T = exp(i pi k (T-1)/N) sin(pi k T / N) / (T sin(pi k / N)), k != 0.
+__device__ __forceinline__ double2 window_mean_factor(int k, int n, int T) {
+  const long long two_n = 2LL * n;
+  const double a = (double)(((long long)k * (T - 1)) % two_n) / (double)n;  // in units of pi
+  const double b = (double)(((long long)k * T) % two_n) / (double)n;
+  double sa, ca;
+  sincospi(a, &sa, &ca);
+  const double r = sinpi(b) / ((double)T * sinpi((double)k / (double)n));
+  return make_double2(ca * r, sa * r);
+}
+
+struct WindowArgs {
+  int T, k_min, k_cut;
+  double2* mean;  // [pairs]: window mean of each pair's pink part (re: row a, im: row b)
+  double* mu;     // [n_modes]: window mean of each mode's pink part
+};
+
 // Spectra of the modes, F[m][k1][k2] (the order pass 1 reads them in), k = k1 + n1 k2:
-// Hermitian, E|F[k]|^2 = fs/N + knee/|k|; the cells k and N - k share one draw.
+// Hermitian, white part of variance fs/N plus pink part of variance knee/|k| per cell (two
+// independent draws, so that the pink part's window mean can be taken out); the cells k and
+// N - k share their draws.
 __global__ __launch_bounds__(kBlock) void noise_mode_table(float2* __restrict__ F, int n1, int n2,
-                                                           float white_var, float knee,
+                                                           float white_var, float knee, WindowArgs w,
                                                            uint32_t key0, uint32_t key1) {
   const int n = n1 * n2;
   const int c = blockIdx.x * kBlock + threadIdx.x;  // k1 * n2 + k2
@@ -89,16 +114,42 @@ __global__ __launch_bounds__(kBlock) void noise_mode_table(float2* __restrict__ 
   const int k = k1 + n1 * k2;
   const int kk = k < n - k ? k : n - k;
   const U4 rnd = philox4x32_10(U4{(uint32_t)kk, blockIdx.y, 0u, kTagMode}, key0, key1);
-  const float2 h = box_muller(rnd.x, rnd.y);
-  const float var = white_var + (kk == 0 ? 0.0f : knee / (float)kk);
-  float2 v;
-  if (kk == 0 || 2 * kk == n) {
-    v = make_float2(sqrtf(var) * h.x, 0.0f);  // self-conjugate cells are real
-  } else {
-    const float a = sqrtf(0.5f * var);
-    v = make_float2(a * h.x, k == kk ? a * h.y : -a * h.y);
+  const float2 hw = box_muller(rnd.x, rnd.y), hp = box_muller(rnd.z, rnd.w);
+  const float var_p = kk < w.k_min ? 0.0f : knee / (float)kk;
+  const bool self = kk == 0 || 2 * kk == n;  // self-conjugate cells are real
+  const float aw = sqrtf(self ? white_var : 0.5f * white_var), ap = sqrtf(self ? var_p : 0.5f * var_p);
+  const float sgn = k == kk ? 1.0f : -1.0f;
+  const float2 vp = make_float2(ap * hp.x, self ? 0.0f : sgn * ap * hp.y);
+  F[(size_t)blockIdx.y * n + c] = make_float2(aw * hw.x + vp.x, (self ? 0.0f : sgn * aw * hw.y) + vp.y);
+}
+
+// sum of a double over the workgroup (result valid in thread 0)
+__device__ __forceinline__ double block_sum(double v, double* scratch) {
+  scratch[threadIdx.x] = v;
+  __syncthreads();
+  for (int s = kBlock / 2; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) scratch[threadIdx.x] += scratch[threadIdx.x + s];
+    __syncthreads();
   }
-  F[(size_t)blockIdx.y * n + c] = v;
+  return scratch[0];
+}
+
+// mu[m] = window mean of mode m's pink part: the cells k_min <= |k| < k_cut of the table above,
+// redrawn (block m); the pair k, N - k contributes 2 Re(F_k W_k / T).
+__global__ __launch_bounds__(kBlock) void noise_mode_means(int n, float knee, WindowArgs w, uint32_t key0,
+                                                           uint32_t key1) {
+  __shared__ double scratch[kBlock];
+  double acc = 0.0;
+  for (int kk = w.k_min + threadIdx.x; kk < w.k_cut; kk += kBlock) {
+    const U4 rnd = philox4x32_10(U4{(uint32_t)kk, blockIdx.x, 0u, kTagMode}, key0, key1);
+    const float2 hp = box_muller(rnd.z, rnd.w);
+    const bool self = 2 * kk == n;
+    const double ap = sqrt((self ? 1.0 : 0.5) * (double)(knee / (float)kk));
+    const double2 f = window_mean_factor(kk, n, w.T);
+    acc += self ? ap * hp.x * f.x : 2.0 * ap * ((double)hp.x * f.x - (double)hp.y * f.y);
+  }
+  const double total = block_sum(acc, scratch);
+  if (threadIdx.x == 0) w.mu[blockIdx.x] = total;
 }
 
 struct SpectrumArgs {
@@ -109,7 +160,49 @@ struct SpectrumArgs {
   float w_ind, w_corr;
   float knee;
   uint32_t series0;    // Philox id of series 0
+  WindowArgs win;
 };
+
+// mean[pair] = window mean of the pair's pink part (re: row a, im: row b): its own cells
+// k_min <= |k| < k_cut redrawn exactly as pass 1 draws them, plus the modes' means through the
+// pair's coefficients.  One block per pair.
+__global__ __launch_bounds__(kBlock) void noise_pair_means(int n1, int n2, SpectrumArgs g, uint32_t key0,
+                                                           uint32_t key1) {
+  __shared__ double scratch[kBlock];
+  const int n = n1 * n2, half = n2 >> 1;
+  const int pair = blockIdx.x;
+  const uint32_t series = g.series0 + pair;
+  const float amp = g.w_ind * sqrtf(g.knee);
+  double ar = 0.0, ai = 0.0;
+  const int span = g.win.k_cut - g.win.k_min;
+  for (int idx = threadIdx.x; idx < 2 * span; idx += kBlock) {
+    const int kk = g.win.k_min + (idx >> 1);
+    if ((idx & 1) && 2 * kk == n) continue;  // the self-conjugate cell once
+    const int k = (idx & 1) ? n - kk : kk;
+    const int k1 = k & (n1 - 1), k2 = k / n1;
+    const int k2c = k2 < half ? k2 : k2 - half;
+    const U4 rnd = philox4x32_10(U4{(uint32_t)k1, (uint32_t)k2c, series, kTagPink}, key0, key1);
+    const float2 gq = k2 < half ? box_muller(rnd.x, rnd.y) : box_muller(rnd.z, rnd.w);
+    const float a = pink_amp(k, n, amp, g.win.k_min);
+    const double xr = (double)(a * gq.x), xi = (double)(a * gq.y);
+    const double2 f = window_mean_factor(k, n, g.win.T);
+    ar += xr * f.x - xi * f.y;
+    ai += xr * f.y + xi * f.x;
+  }
+  const double sr = block_sum(ar, scratch);
+  __syncthreads();
+  const double si = block_sum(ai, scratch);
+  if (threadIdx.x == 0) {
+    double mr = sr, mi = si;
+    const int row_a = g.row0 + 2 * pair;
+    const bool has_b = row_a + 1 < g.row0 + g.rows;
+    for (int m = 0; m < g.n_modes; ++m) {  // sqrt(c) (B[a,m] + i B[b,m]) mu_m, mu_m real
+      mr += (double)(g.w_corr * g.basis[(size_t)row_a * g.n_modes + m]) * g.win.mu[m];
+      if (has_b) mi += (double)(g.w_corr * g.basis[(size_t)(row_a + 1) * g.n_modes + m]) * g.win.mu[m];
+    }
+    g.win.mean[pair] = make_double2(mr, mi);
+  }
+}
 
 // pass 1: block (group of kPairsPerBlock series, k1): spectrum cells k = k1 + N1*k2, FFT over
 // k2, twiddle.  The mode spectra of the block's cells are read once into registers and serve
@@ -164,8 +257,8 @@ __global__ __launch_bounds__(kBlock) void noise_spectrum_fft(
       const int k2 = threadIdx.x + it * kBlock;
       if (k2 < half) {
         const U4 rnd = philox4x32_10(U4{(uint32_t)k1, (uint32_t)k2, series, kTagPink}, key0, key1);
-        const float a0 = pink_amp(k1 + n1 * k2, n, amp);
-        const float a1 = pink_amp(k1 + n1 * (k2 + half), n, amp);
+        const float a0 = pink_amp(k1 + n1 * k2, n, amp, g.win.k_min);
+        const float a1 = pink_amp(k1 + n1 * (k2 + half), n, amp, g.win.k_min);
         const float2 g0 = box_muller(rnd.x, rnd.y), g1 = box_muller(rnd.z, rnd.w);
         float2 x0 = make_float2(a0 * g0.x, a0 * g0.y), x1 = make_float2(a1 * g1.x, a1 * g1.y);
         if constexpr (kModes > 0) {
@@ -234,6 +327,7 @@ struct CombineArgs {
   int T;
   float sqrt_fs;
   int accumulate, vec_ok;
+  const double2* mean;   // [pairs of this launch] window mean of the pink part, or null
 };
 
 // one group of 4 consecutive samples of one row, given its pink + correlated part
@@ -287,14 +381,15 @@ __global__ __launch_bounds__(kBlock) void noise_fft_combine(
   __syncthreads();
   const float2* res = fft_lds_inverse_batched<8>(data, data + kTileCells, tw, n1, log2n1, lj);
   const int row_a = g.row0 + 2 * blockIdx.y;
+  const float mean_a = g.mean ? (float)g.mean[blockIdx.y].x : 0.0f, mean_b = g.mean ? (float)g.mean[blockIdx.y].y : 0.0f;
   for (int e = threadIdx.x * 4; e < n1 * J; e += kBlock * 4) {
     const int m = e >> lj, b = e & (J - 1);
     const size_t t0 = (size_t)n2 * m + j0 + b;
     if (t0 >= (size_t)g.T) continue;
     const float2 r0 = res[e], r1 = res[e + 1], r2 = res[e + 2], r3 = res[e + 3];
-    finish4(g, row_a, t0, vfloat4{r0.x, r1.x, r2.x, r3.x}, key0, key1);
+    finish4(g, row_a, t0, vfloat4{r0.x, r1.x, r2.x, r3.x} - mean_a, key0, key1);
     if (row_a + 1 < g.row0 + g.rows)
-      finish4(g, row_a + 1, t0, vfloat4{r0.y, r1.y, r2.y, r3.y}, key0, key1);
+      finish4(g, row_a + 1, t0, vfloat4{r0.y, r1.y, r2.y, r3.y} - mean_b, key0, key1);
   }
 }
 
@@ -324,6 +419,7 @@ __global__ __launch_bounds__(kBlock) void noise_fft64_combine(
   float* out_a = g.out + (size_t)row_a * g.ld + j;
   float* out_b = g.out + (size_t)row_b * g.ld + j;
   const uint32_t id_a = g.id0 + (uint32_t)row_a, id_b = g.id0 + (uint32_t)row_b;
+  const float mean_a = g.mean ? (float)g.mean[blockIdx.y].x : 0.0f, mean_b = g.mean ? (float)g.mean[blockIdx.y].y : 0.0f;
 #pragma unroll
   for (int mq = 0; mq < 16; ++mq) {
     const U4 ra = philox4x32_10(U4{(uint32_t)j, id_a, 0x100u + mq, kTagWhite}, key0, key1);
@@ -337,8 +433,8 @@ __global__ __launch_bounds__(kBlock) void noise_fft64_combine(
       if (t >= (size_t)g.T) continue;
       const float wa = q == 0 ? wa0.x : q == 1 ? wa0.y : q == 2 ? wa1.x : wa1.y;
       const float wb = q == 0 ? wb0.x : q == 1 ? wb0.y : q == 2 ? wb1.x : wb1.y;
-      float va = g.sqrt_fs * wa + re[fft64_pos(m)];
-      float vb = g.sqrt_fs * wb + im[fft64_pos(m)];
+      float va = g.sqrt_fs * wa + (re[fft64_pos(m)] - mean_a);
+      float vb = g.sqrt_fs * wb + (im[fft64_pos(m)] - mean_b);
       const size_t o = (size_t)n2 * m;
       if (kExtras) {
         float aa = sa, ab = sb;
@@ -429,7 +525,9 @@ int mrx_noise_work_floats(int T, int n_modes, int batch, size_t* floats) {
   if (rc != MRX_OK || !floats || batch < 1 || n_modes < 0) return rc != MRX_OK ? rc : MRX_ERR_INVALID;
   const size_t n = (size_t)n1 * n2;
   // mode spectra [n_modes][N] + one complex series [N] per pair of detectors
-  *floats = 2 * n * ((size_t)n_modes + (size_t)(batch + 1) / 2) + 16;
+  // window means (8 doubles for the modes, a double2 per pair), mode spectra [n_modes][N], one
+  // complex series [N] per pair of detectors
+  *floats = 16 + (2 * n + 4) * ((size_t)(batch + 1) / 2) + 2 * n * (size_t)n_modes + 16;
   return MRX_OK;
 }
 
@@ -489,15 +587,17 @@ int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T
   if (mrx_noise_period(T, &n1, &n2) != MRX_OK)
     return mrx_fail(ctx, MRX_ERR_UNSUPPORTED, "T = %d exceeds the 2^23-sample noise period", T);
   const size_t n = (size_t)n1 * n2;
-  MRX_REQUIRE(ctx, work_floats >= 2 * n * ((size_t)n_modes + 1),
+  MRX_REQUIRE(ctx, work_floats >= 16 + 2 * n * (size_t)n_modes + (2 * n + 4) + 16,
               "work buffer too small: see mrx_noise_work_floats");
-  const size_t fit = work_floats / (2 * n) - (size_t)n_modes;
+  const size_t fit = (work_floats - 32 - 2 * n * (size_t)n_modes) / (2 * n + 4);
   const int pairs_max = (int)(fit < 16384 ? fit : 16384);
   const int l1 = ilog2(n1), l2 = ilog2(n2);
   const int lj = ilog2(kTileCells) - l1;  // J = 4096 / n1 >= 4
 
-  float2* F = reinterpret_cast<float2*>(d_work);  // [n_modes][n]
-  float2* A = F + (size_t)n_modes * n;            // [pairs][n]
+  double* mu = reinterpret_cast<double*>(d_work);                  // [8] modes' pink window means
+  double2* mean = reinterpret_cast<double2*>(d_work + 16);         // [pairs_max] pairs' pink window means
+  float2* F = reinterpret_cast<float2*>(d_work + 16 + 4 * (size_t)pairs_max);  // [n_modes][n]
+  float2* A = F + (size_t)n_modes * n;                             // [pairs][n]
   const size_t lds1 = (size_t)(2 * n2 + n2 / 4) * sizeof(float2);
   const size_t lds2 = (size_t)(2 * kTileCells + n1 / 4) * sizeof(float2);
   const SpectrumKernel pass1 = spectrum_kernel(n2, n_modes);
@@ -517,9 +617,16 @@ int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T
   SpectrumArgs sp{};
   sp.knee = (float)knee;
   sp.w_ind = 1.0f;
+  sp.win.T = T;
+  sp.win.k_min = (int)((n + (size_t)T - 1) / (size_t)T);  // ceil(N / T): nothing slower than the TOD
+  sp.win.k_cut = (int)(64LL * sp.win.k_min < (long long)(n / 2) ? 64 * sp.win.k_min : n / 2);
+  sp.win.mean = mean;
+  sp.win.mu = mu;
   if (n_modes > 0) {
+    hipLaunchKernelGGL(noise_mode_means, dim3(n_modes), dim3(kBlock), 0, ctx->stream, (int)n, (float)knee,
+                       sp.win, key0, key1);
     hipLaunchKernelGGL(noise_mode_table, dim3(mrx_ceil_div((long long)n, kBlock), n_modes), dim3(kBlock),
-                       0, ctx->stream, F, n1, n2, (float)(sample_rate / (double)n), (float)knee, key0, key1);
+                       0, ctx->stream, F, n1, n2, (float)(sample_rate / (double)n), (float)knee, sp.win, key0, key1);
     MRX_CHECK_LAUNCH(ctx);
     sp.F = F;
     sp.basis = d_basis;
@@ -538,6 +645,8 @@ int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T
     sp.row0 = d0;
     sp.rows = count;
     sp.series0 = 16u + (uint32_t)((det_offset + d0) / 2);  // detector pair (2q, 2q+1) is series 16 + q
+    h.mean = mean;
+    hipLaunchKernelGGL(noise_pair_means, dim3(pairs), dim3(kBlock), 0, ctx->stream, n1, n2, sp, key0, key1);
     hipLaunchKernelGGL(pass1, dim3(mrx_ceil_div(pairs, kPairsPerBlock), n1), dim3(kBlock), lds1,
                        ctx->stream, A, n1, n2, l2, sp, pairs, key0, key1);
     if (n1 == 64 && !ctx->options[MRX_OPT_NOISE_GENERIC]) {

@@ -211,3 +211,42 @@ def test_simulation_with_noise(gpu_ctx):
     # band 0: white + pink: more variance than its white level, and positively correlated rows
     assert n[:40].var(axis=1).mean() > 1.5 * 100.0 * (1e12 * 2e-17) ** 2
     assert np.corrcoef(n[:40])[~np.eye(40, dtype=bool)].mean() > 0.02
+
+
+def test_reference_white_noise_levels_test_case(gpu_ctx):
+    """maria/tests/noise/test_noise.py:7-31: MUSTANG-2 (217 detectors, NEP 1.5e-17, knee 5 Hz,
+    band/configs/m2.yml) on the ten-second zenith stare at 50 Hz: the per-detector mean of the
+    noise over the TOD, in units of NEP / sqrt(duration), must have a standard deviation in
+    [0.7, 1.3] -- i.e. the 1/f part averages to zero over the TOD, as it does in the reference
+    whose pink series has the TOD's own period."""
+    from maria_amd.instrument import Band, Detectors, Instrument, Site
+    from maria_amd.sim import Plan, Simulation
+
+    m2 = Band(nu=np.linspace(74e9, 105e9, 31), tau=np.r_[0.0, np.linspace(1.0, 0.3, 29), 0.0], name="m2/f093", efficiency=0.1,
+              NEP=1.5e-17, knee=5.0)
+    inst = Instrument(Detectors.hexagon(217, 0.07, [m2], primary_size=100.0), name="MUSTANG-2")
+    t = 1.7e9 + np.arange(0, 10, 1 / 50.0)
+    plan = Plan(t, np.zeros_like(t), np.full_like(t, np.pi / 2))
+    for seed in (1, 2, 3):
+        sim = Simulation(inst, plan, Site(altitude=825.0, region="green_bank"), noise=True, noise_seed=seed)
+        (tod,) = sim.run(units="pW")
+        target_error = 1e12 * 1.5e-17 / np.sqrt(plan.duration + 1 / 50.0)
+        scaled = tod.data["noise"].astype(np.float64).mean(axis=1) / target_error
+        assert 0.7 < scaled.std() < 1.3, scaled.std()
+
+
+@pytest.mark.parametrize("T,fs,knee", [(500, 50.0, 5.0), (5000, 100.0, 20.0), (100000, 400.0, 2.0)])
+def test_pink_part_has_zero_mean_and_no_power_below_the_tod(gpu_ctx, T, fs, knee):
+    """The mean of a detector's noise over the TOD is the mean of its white part: variance
+    fs / T (generation.py:27-37 zeroes the f = 0 cell and the period is the TOD).  A pink
+    part that kept periods longer than the TOD would add several times that."""
+    D = 256
+    x = _generate(gpu_ctx, D, T, fs, knee, seed=12).cpu().numpy().astype(np.float64)
+    m = x.mean(axis=1)
+    assert abs(m.var() / (fs / T) - 1) < 0.25, m.var() / (fs / T)
+    # and the spectrum still follows 2 (1 + knee / f) from the second harmonic of the TOD on
+    X = np.abs(np.fft.rfft(x, axis=1)) ** 2
+    psd = 2 * X.mean(axis=0) / (fs * T)  # one-sided, per Hz: the white level is 2
+    f = np.fft.rfftfreq(T, 1 / fs)
+    for j in (2, 3, 5, 8):
+        assert abs(psd[j] / (2 * (1 + knee / f[j])) - 1) < 0.35, (j, psd[j], 2 * (1 + knee / f[j]))

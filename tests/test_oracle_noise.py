@@ -75,3 +75,19 @@ def test_sky_transform_stack_known_directions():
     # east point on the horizon: declination 0, six hours east of the meridian
     east = mapsample.phi_theta_to_xyz(np.pi / 2, 0.0).astype(float) @ M[0]
     assert abs(east[2]) < 1e-7 and abs(((np.degrees(np.arctan2(east[1], east[0])) - ra[0]) % 360) - 90) < 1e-4
+
+
+def test_offsets_round_trip_like_the_reference_test():
+    """maria/tests/coordinates/test_coordinates.py:7-19 on the restated float32 transforms:
+    offsets -> (phi, theta) -> offsets for random centres, mean square error < 1e-5 (here the
+    round trip is good to float32 rounding)."""
+    from oracle import hotpath, mapsample
+
+    rng = np.random.default_rng(0)
+    for cphi in rng.uniform(0, 2 * np.pi, 5):
+        for ctheta in rng.uniform(-np.pi / 2, np.pi / 2, 5):
+            offsets = np.radians(rng.uniform(-0.5, 0.5, (256, 2)))
+            phi, theta = hotpath.offsets_to_phi_theta(offsets[:, 0], offsets[:, 1], cphi, ctheta)
+            back = mapsample.phi_theta_to_offsets(phi, theta, cphi, ctheta)
+            assert np.mean(np.square(offsets - back)) < 1e-5
+            assert np.abs(offsets - back).max() < 5e-6
