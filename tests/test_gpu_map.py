@@ -339,3 +339,44 @@ def test_bin_mapper_recovers_the_sampled_map(gpu_ctx):
     # beam smoothing (a 30 m dish at 150 GHz: ~17 arcsec) and 1-arcmin nearest-pixel binning blur the blobs a little
     assert np.corrcoef(rec[good], expect[good])[0, 1] > 0.99
     assert abs(np.sum(rec[good]) / np.sum(expect[good]) - 1) < 0.05
+
+
+def test_end_to_end_polarised_multifrequency_pipeline(gpu_ctx):
+    """The shape of the reference's end-to-end tests (tests/sim/test_pipeline.py:21-54,
+    test_polarization.py, test_multifrequency.py): atmosphere + map + noise in the default
+    units, polarised detectors on an IQU map with one plane per band, then a BinMapper; their
+    assertions: no NaN anywhere, and the mapper's weight sums to something positive."""
+    from maria_amd import map as mmap
+    from maria_amd import synthetic
+    from maria_amd.instrument import Band, Detectors, Instrument, Site
+    from maria_amd.mappers import BinMapper
+    from maria_amd.sim import Plan, Simulation, sky_transform_stack
+
+    rng = np.random.default_rng(11)
+    bands = [Band(center=90e9, width=30e9, name="f090", NEP=3e-17, knee=1.0, gain_error=0.02),
+             Band(center=150e9, width=40e9, name="f150", NEP=4e-17, knee=1.0, gain_error=0.02)]
+    pos = synthetic.hex_pack(30, np.radians(0.3))
+    gamma = np.tile(np.where(np.arange(30) % 3 == 0, np.nan, rng.uniform(0, np.pi, 30)), 2)  # some unpolarised
+    dets = Detectors(np.tile(pos, (2, 1)), bands, np.repeat([0, 1], 30), primary_size=12.0, gamma=gamma)
+    inst = Instrument(dets)
+    plan = Plan.daisy(start_time=1.71e9, duration=60.0, sample_rate=50.0, scan_center=(200.0, 55.0), radius=0.25, speed=0.4)
+    site = Site(altitude=5000.0, latitude=-23.0, longitude=-67.8)
+    centre = _centre(plan.phi.astype(np.float32), plan.theta.astype(np.float32), sky_transform_stack(plan.time, site.latitude, site.longitude))
+    n = 64
+    X, Y = np.meshgrid(np.linspace(-1, 1, n), np.linspace(-1, 1, n))
+    blob = np.exp(-(X**2 + Y**2) / 0.1).astype(np.float32)
+    data = np.stack([np.stack([(1 + c) * s * blob for c in range(2)]) for s in (1.0, 0.1, -0.05)])  # [IQU, nu, eta, xi]
+    sky = mmap.ProjectionMap(data * 1e-3, nu=[90e9, 150e9], stokes="IQU", width=1.0, center=np.degrees(centre), frame="ra/dec")
+    sim = Simulation(inst, plan, site, atmosphere="2d", atmosphere_kwargs={"n_layers": 3, "seed": 1}, map=sky, noise=True, noise_seed=2)
+    (tod,) = sim.run()
+    assert tod.units == "K_RJ" and set(tod.fields) == {"atmosphere", "map", "noise"}
+    for field in tod.fields:
+        assert np.isfinite(tod.data[field]).all(), field
+    assert tod.data["map"].std() > 0 and tod.data["noise"].std() > 0
+    # polarised detectors see Q and U: their map signal differs from the unpolarised neighbour's
+    assert not np.allclose(tod.data["map"][1], tod.data["map"][0] * tod.data["map"][1].mean() / tod.data["map"][0].mean(), rtol=1e-3)
+    mapper = BinMapper([tod], center=np.degrees(centre), width=0.8, resolution=1.0 / 30, stokes="IQU", nu=[90e9, 150e9], frame="ra/dec", units="K_RJ")
+    out = mapper.run()
+    w = mapper.products["weight"]
+    assert w.shape == (3, 2, 24, 24) and w.sum() > 0 and (w[0] > 0).mean() > 0.3
+    assert np.isfinite(out.data[w > 0]).all()
