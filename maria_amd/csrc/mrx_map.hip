@@ -102,15 +102,35 @@ __device__ __forceinline__ void axis_weights(const Axis& a, double x, bool bilin
 }
 
 // jax RegularGridInterpolator index and weight on a float32 axis (searchsorted left)
-__device__ __forceinline__ void rgi_axis(const float* g, int n, float x, int& i, float& w, bool& oob) {
-  const float g0 = g[0], g1 = g[n - 1];
-  const float inv = (float)(n - 1) / (g1 - g0);
-  int k = min(max((int)fminf(fmaxf((x - g0) * inv, -1.0f), 2.0e9f), 0), n - 2);
-  while (k < n - 2 && g[k + 1] < x) ++k;
-  while (k > 0 && g[k] >= x) --k;
+struct RgiAxis {
+  const float* g;  // nodes (LDS)
+  int n;
+  float first, last, inv;  // inv: (n - 1) / (last - first), the arithmetic first guess
+};
+
+__device__ __forceinline__ RgiAxis make_rgi_axis(const float* g, int n) {
+  RgiAxis a{g, n, g[0], g[n - 1], 0.0f};
+  a.inv = (float)(n - 1) / (a.last - a.first);
+  return a;
+}
+
+__device__ __forceinline__ void rgi_axis(const RgiAxis& a, float x, int& i, float& w, bool& oob) {
+  const float* g = a.g;
+  int k = min(max((int)fminf(fmaxf((x - a.first) * a.inv, -1.0f), 2.0e9f), 0), a.n - 2);
+  float lo = g[k], hi = g[k + 1];
+  while (k < a.n - 2 && hi < x) {
+    ++k;
+    lo = hi;
+    hi = g[k + 1];
+  }
+  while (k > 0 && lo >= x) {
+    --k;
+    hi = lo;
+    lo = g[k];
+  }
   i = k;
-  w = __fdiv_rn(__fsub_rn(x, g[k]), __fsub_rn(g[k + 1], g[k]));
-  oob = !(x >= g0 && x <= g1);
+  w = (x - lo) * __builtin_amdgcn_rcpf(hi - lo);  // 1 ulp from the reference's division
+  oob = !(x >= a.first && x <= a.last);
 }
 
 // What a sample contributes to every detector of the tile.
@@ -171,15 +191,14 @@ __device__ __forceinline__ void sample_const(const MapArgs& g, int s, bool chain
 
 // Steps 4-5 for a sample at offsets (ox, oy) from the map centre, detector elevation el_d.
 struct CalLds {
-  const float* pwv;  // [n_pwv] axis
-  const float* el;   // [n_el] axis
-  const float* tab;  // [C][n_pwv][n_el]
+  RgiAxis pwv, el;   // axes (nodes in LDS)
+  const float* tab;  // [C][n_pwv][n_el] (LDS)
 };
 
-template <bool kCal>
+template <bool kCal, int kS>
 __device__ __forceinline__ float sample_value(const MapArgs& g, const CalLds& cl, const Axis& ax_eta, const Axis& ax_xi,
                                               const DetConst& dc, int d, const SampleConst& sc, float ox,
-                                              float oy, float el_d) {
+                                              float oy, float el_d, double y0, double y1) {
   int e0, e1, x0, x1;
   double pe, px;
   axis_weights(ax_eta, (double)oy, g.bilinear, e0, e1, pe);
@@ -190,11 +209,10 @@ __device__ __forceinline__ float sample_value(const MapArgs& g, const CalLds& cl
   int ip = 0, ie = 0;
   bool oob = false;
   if (kCal) {
-    const double y0 = g.pwv[(size_t)sc.jj * g.D + d], y1 = g.pwv[(size_t)(sc.jj + 1) * g.D + d];
     const float pw = (float)fma(sc.u, y1 - y0, y0);  // demoted to float32 by the jax interpolator
     bool o1, o2;
-    rgi_axis(cl.pwv, g.n_pwv, pw, ip, cal_w_p, o1);
-    rgi_axis(cl.el, g.n_el, el_d, ie, cal_w_e, o2);
+    rgi_axis(cl.pwv, pw, ip, cal_w_p, o1);
+    rgi_axis(cl.el, el_d, ie, cal_w_e, o2);
     oob = o1 || o2;
   }
   const int plane = g.n_eta * g.n_xi;  // < 2^31: checked by the host
@@ -204,12 +222,10 @@ __device__ __forceinline__ float sample_value(const MapArgs& g, const CalLds& cl
   for (int c = 0; c < g.C; ++c) {
     double val = 0.0;
 #pragma unroll
-    for (int k = 0; k < kMaxStokes; ++k) {
-      if (k < g.S) {
-        const double v = fma(w00, (double)m[o00], fma(w10, (double)m[o10], fma(w01, (double)m[o01], w11 * (double)m[o11])));
-        val = fma(dc.w[k], v, val);
-        m += plane;
-      }
+    for (int k = 0; k < kS; ++k) {
+      const double v = fma(w00, (double)m[o00], fma(w10, (double)m[o10], fma(w01, (double)m[o01], w11 * (double)m[o11])));
+      val = fma(dc.w[k], v, val);
+      m += plane;
     }
     double pw_per_k;
     if (kCal) {
@@ -228,6 +244,22 @@ __device__ __forceinline__ float sample_value(const MapArgs& g, const CalLds& cl
     acc = (float)fma(pw_per_k, val, (double)acc);  // float32 accumulator (map.py:155)
   }
   return acc;
+}
+
+// asin on [-1, 1] by Abramowitz & Stegun 4.4.46 (|error| <= 2e-8, below the float32 spacing of
+// an elevation): pi/2 - sqrt(1 - |x|) P7(|x|).  Only the composed path's table lookup uses it.
+__device__ __forceinline__ float asin_poly(float x) {
+  const float a = fabsf(x);
+  float p = -0.0012624911f;
+  p = fmaf(p, a, 0.0066700901f);
+  p = fmaf(p, a, -0.0170881256f);
+  p = fmaf(p, a, 0.0308918810f);
+  p = fmaf(p, a, -0.0501743046f);
+  p = fmaf(p, a, 0.0889789874f);
+  p = fmaf(p, a, -0.2145988016f);
+  p = fmaf(p, a, 1.5707963050f);
+  const float r = 1.57079632679f - sqrtf(fmaxf(1.0f - a, 0.0f)) * p;
+  return copysignf(r, x);
 }
 
 __device__ __noinline__ double asin_over_r(double r2) {
@@ -285,16 +317,23 @@ __device__ __forceinline__ void sample_offsets(const MapArgs& g, const DetConst&
     if (__builtin_expect(r2 >= 0.09, 0)) f = asin_over_r(r2);
     ox = (float)(-dz_re * f);
     oy = (float)(-dz_im * f);
-    if (kNeedEl) el_d = asinf(im);
+    if (kNeedEl) el_d = asin_poly(im);
   }
 }
 
-template <bool kChain, bool kCal>
+// (jj0, y0, y1): the coarse pwv pair the caller already holds for this detector (the samples
+// of a thread nearly always share their coarse interval); reloaded when the sample's differs.
+template <bool kChain, bool kCal, int kS>
 __device__ __forceinline__ float raw_sample(const MapArgs& g, const CalLds& cl, const Axis& ax_eta, const Axis& ax_xi,
-                                            const DetConst& dc, int d, const SampleConst& sc) {
+                                            const DetConst& dc, int d, const SampleConst& sc, int jj0, double y0,
+                                            double y1) {
   float ox, oy, el_d;
   sample_offsets<kChain, kCal>(g, dc, sc, ox, oy, el_d);
-  return sample_value<kCal>(g, cl, ax_eta, ax_xi, dc, d, sc, ox, oy, el_d);
+  if (kCal && sc.jj != jj0) {
+    y0 = g.pwv[(size_t)sc.jj * g.D + d];
+    y1 = g.pwv[(size_t)(sc.jj + 1) * g.D + d];
+  }
+  return sample_value<kCal, kS>(g, cl, ax_eta, ax_xi, dc, d, sc, ox, oy, el_d, y0, y1);
 }
 
 __device__ __forceinline__ DetConst make_det_const(const MapArgs& g, int d) {
@@ -398,12 +437,12 @@ __global__ __launch_bounds__(kBlock) void bin_map_kernel(MapArgs g, BinArgs b) {
   }
 }
 
-template <bool kChain, bool kCal>
+template <bool kChain, bool kCal, int kS>
 __global__ __launch_bounds__(kBlock) void map_sample_kernel(MapArgs g) {
   __shared__ DetConst dets[kTileDet];
   __shared__ float2 edge[2][kBlock];  // (first, last) raw value of every thread, double-buffered
   extern __shared__ float cal_lds[];   // calibration axes and tables (a few KB)
-  CalLds cl{cal_lds, cal_lds + g.n_pwv, cal_lds + g.n_pwv + g.n_el};
+  CalLds cl{};
   if (kCal) {
     for (int i = threadIdx.x; i < g.n_pwv; i += kBlock) cal_lds[i] = g.cal_pwv[i];
     for (int i = threadIdx.x; i < g.n_el; i += kBlock) cal_lds[g.n_pwv + i] = g.cal_el[i];
@@ -428,15 +467,27 @@ __global__ __launch_bounds__(kBlock) void map_sample_kernel(MapArgs g) {
     sc_halo.s = min(max(sh, 0), g.T - 1);
   }
   __syncthreads();
+  if (kCal) {
+    cl.pwv = make_rgi_axis(cal_lds, g.n_pwv);
+    cl.el = make_rgi_axis(cal_lds + g.n_pwv, g.n_el);
+    cl.tab = cal_lds + g.n_pwv + g.n_el;
+  }
   const bool full = (sb + kSamplesPerThread <= g.T) && g.vec_ok;
   for (int dl = 0; dl < nd; ++dl) {
     const DetConst dc = dets[dl];
     const int d = d0 + dl;
     float r[kSamplesPerThread];
+    const int jj0 = kCal ? sc[0].jj : 0;
+    double y0 = 0.0, y1 = 0.0;
+    if (kCal) {
+      y0 = g.pwv[(size_t)jj0 * g.D + d];
+      y1 = g.pwv[(size_t)(jj0 + 1) * g.D + d];
+    }
 #pragma unroll
-    for (int q = 0; q < kSamplesPerThread; ++q) r[q] = raw_sample<kChain, kCal>(g, cl, ax_eta, ax_xi, dc, d, sc[q]);
+    for (int q = 0; q < kSamplesPerThread; ++q)
+      r[q] = raw_sample<kChain, kCal, kS>(g, cl, ax_eta, ax_xi, dc, d, sc[q], jj0, y0, y1);
     float halo = 0.0f;
-    if (first || last) halo = raw_sample<kChain, kCal>(g, cl, ax_eta, ax_xi, dc, d, sc_halo);
+    if (first || last) halo = raw_sample<kChain, kCal, kS>(g, cl, ax_eta, ax_xi, dc, d, sc_halo, jj0, y0, y1);
     edge[dl & 1][threadIdx.x] = make_float2(r[0], r[kSamplesPerThread - 1]);
     __syncthreads();
     const float left = first ? halo : edge[dl & 1][threadIdx.x - 1].y;
@@ -537,13 +588,21 @@ int mrx_map_sample(mrx_ctx* ctx, const mrx_sky_map* map, const mrx_map_cal* cal,
   }
   MRX_REQUIRE(ctx, (long long)map->n_eta * map->n_xi < (1LL << 31), "a map plane must hold fewer than 2^31 pixels");
   const bool chain = ctx->options[MRX_OPT_POINTING_CHAIN] != 0, has_cal = cal->d_table != nullptr;
-#define MRX_LAUNCH_MAP(CH, CA) \
-  hipLaunchKernelGGL((map_sample_kernel<CH, CA>), grid, dim3(kBlock), lds, ctx->stream, g)
-  if (chain) {
-    if (has_cal) MRX_LAUNCH_MAP(true, true); else MRX_LAUNCH_MAP(true, false);
-  } else {
-    if (has_cal) MRX_LAUNCH_MAP(false, true); else MRX_LAUNCH_MAP(false, false);
+#define MRX_LAUNCH_MAP(CH, CA, S) \
+  hipLaunchKernelGGL((map_sample_kernel<CH, CA, S>), grid, dim3(kBlock), lds, ctx->stream, g)
+#define MRX_LAUNCH_MAP_S(CH, CA)                    \
+  switch (map->n_stokes) {                          \
+    case 1: MRX_LAUNCH_MAP(CH, CA, 1); break;       \
+    case 2: MRX_LAUNCH_MAP(CH, CA, 2); break;       \
+    case 3: MRX_LAUNCH_MAP(CH, CA, 3); break;       \
+    default: MRX_LAUNCH_MAP(CH, CA, 4); break;      \
   }
+  if (chain) {
+    if (has_cal) { MRX_LAUNCH_MAP_S(true, true); } else { MRX_LAUNCH_MAP_S(true, false); }
+  } else {
+    if (has_cal) { MRX_LAUNCH_MAP_S(false, true); } else { MRX_LAUNCH_MAP_S(false, false); }
+  }
+#undef MRX_LAUNCH_MAP_S
 #undef MRX_LAUNCH_MAP
   MRX_CHECK_LAUNCH(ctx);
   return MRX_OK;
