@@ -1,0 +1,65 @@
+"""CPU tier for the host logic of the map rows: grid construction, channel bounds,
+Stokes weights, the temperature collapse of the calibration tables, the mapper's grid."""
+
+import numpy as np
+import pytest
+
+from maria_amd import map as mmap
+from oracle import hotpath, mapsample
+
+
+def test_projection_map_axes_follow_the_reference_constructor():
+    """map/projection.py:104-130: xi = xi_res (n-1) linspace(-1/2, 1/2, n), likewise eta, then the
+    parity flip (eta descending) applied to axis and data together."""
+    data = np.arange(2 * 3 * 4 * 6, dtype=np.float32).reshape(2, 3, 4, 6)
+    m = mmap.ProjectionMap(data, nu=[90e9, 150e9, 220e9], stokes="IQ", width=2.0, center=(10.0, -5.0), frame="ra/dec", degrees=True)
+    res = np.radians(2.0 / 5)
+    np.testing.assert_allclose(m.xi, res * 5 * np.linspace(-0.5, 0.5, 6), rtol=1e-15)
+    np.testing.assert_allclose(m.eta, (res * 3 * np.linspace(-0.5, 0.5, 4))[::-1], rtol=1e-15)
+    assert np.array_equal(m.data, data[:, :, ::-1])  # row i still sits at its own eta
+    np.testing.assert_allclose(m.center, np.radians([10.0, -5.0]))
+    assert m.nu_bin_bounds == [(0.0, 120e9), (120e9, 185e9), (185e9, np.inf)]  # map/base.py:452-454
+    one = mmap.ProjectionMap(data[0, 0], resolution=0.01, degrees=False)
+    assert one.data.shape == (1, 1, 4, 6) and one.stokes == "I" and one.nu_bin_bounds == [(0.0, np.inf)]
+    assert abs(one.xi[1] - one.xi[0] - 0.01) < 1e-15
+    with pytest.raises(NotImplementedError):
+        mmap.ProjectionMap(data[0, 0], width=1.0, units="Jy/pixel")
+    with pytest.raises(ValueError):
+        mmap.ProjectionMap(data, nu=[90e9], stokes="IQ", width=1.0)
+    with pytest.raises(ValueError):
+        mmap.ProjectionMap(data[0, 0])
+
+
+def test_mueller_row_and_temperature_collapse():
+    gamma = np.array([np.nan, 0.0, np.pi / 4, 1.0])
+    got = mmap.mueller_row(gamma)
+    np.testing.assert_allclose(got, mapsample.mueller_row(gamma), atol=1e-16)
+    np.testing.assert_allclose(got[0], [1.0, 0, 0, 0], atol=1e-16)         # unpolarised: sqrt(2)^2 / 2
+    np.testing.assert_allclose(got[1], [0.5, 0.5, 0.0, 0.0], atol=1e-16)   # horizontal
+    np.testing.assert_allclose(got[2], [0.5, 0.0, 0.5, 0.0], atol=1e-16)
+    # collapsing the table at T0 then interpolating (pwv, el) = the 3-D float32 interpolator at (T0, pwv, el)
+    rng = np.random.default_rng(0)
+    aT, ap, ae = np.array([250.0, 270.0, 290.0]), np.linspace(0, 5, 6), np.linspace(0.3, 1.6, 7)
+    tab = rng.uniform(1, 2, (3, 6, 7))
+    T0 = 263.7
+    col = mmap.collapse_temperature(tab, aT, T0)
+    pw, el = rng.uniform(0, 5, 50), rng.uniform(0.3, 1.6, 50)
+    ref = hotpath.rgi_linear_f32((aT, ap, ae), tab, (np.full(50, T0), pw, el))
+    two = hotpath.rgi_linear_f32((ap, ae), col, (pw, el))
+    np.testing.assert_allclose(two, ref, rtol=3e-7)
+    assert np.isnan(mmap.collapse_temperature(tab, aT, 300.0)).all()  # off the grid: jax's fill value
+
+
+def test_bin_mapper_grid_and_argument_checks():
+    """mappers/base.py:295-309: n = int(max(1, width / resolution)) pixels of `resolution`."""
+    from maria_amd.mappers import BinMapper
+
+    m = BinMapper([], center=(30.0, 10.0), width=1.0, height=0.5, resolution=0.1, degrees=True)
+    assert (m.n_xi, m.n_eta) == (10, 5)
+    assert abs((m.xi[1] - m.xi[0]) - np.radians(0.1)) < 1e-15 and m.eta[0] > m.eta[-1]
+    with pytest.raises(RuntimeError, match="not been run"):
+        _ = m.map
+    with pytest.raises(NotImplementedError):
+        BinMapper([], center=(0, 0), width=1.0, resolution=0.1, tod_preprocessing={"remove_modes": {"modes_to_remove": 1}})
+    with pytest.raises(ValueError):
+        BinMapper([], center=(0, 0), width=1.0)
