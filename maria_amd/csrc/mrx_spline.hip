@@ -432,6 +432,49 @@ __device__ __forceinline__ float krj_lookup(float s, float el, const float2* G, 
   return krj_value(s, el, G[i], G[i + 1], el_first, el_last);
 }
 
+// The K_RJ values of a thread's 4 consecutive samples of one detector.  den is piecewise
+// linear in the elevation and the elevation is linear in the sample index to ~5e-8 rad over
+// 4 samples (10 ms of scanning), so when the first and last sample share a cell of the axis
+// the two inner dens are interpolated between the outer ones (float32 rounding apart, the
+// value jax computes); otherwise -- a node between them, a guess that missed, an elevation
+// off the axis -- every sample is looked up on its own at the interpolated elevation.
+__device__ __forceinline__ void krj_row(const CalDet& c, const float2* G, int n_el, float el_first,
+                                        float el_last, float el_inv, const float (&eb)[kSamplesPerThread],
+                                        const float (&ca)[kSamplesPerThread], const float (&sa)[kSamplesPerThread],
+                                        const float (&sv)[kSamplesPerThread], float (&o)[kSamplesPerThread]) {
+  constexpr int kL = kSamplesPerThread - 1;
+  const float e0 = det_elevation(c, eb[0], ca[0], sa[0]), e3 = det_elevation(c, eb[kL], ca[kL], sa[kL]);
+  const int i0 = min(max((int)fminf(fmaxf((e0 - el_first) * el_inv, -1.0f), 2.0e9f), 0), n_el - 2);
+  const int i3 = min(max((int)fminf(fmaxf((e3 - el_first) * el_inv, -1.0f), 2.0e9f), 0), n_el - 2);
+  const float2 lo = G[i0], hi = G[i0 + 1];
+  const float emin = fminf(e0, e3), emax = fmaxf(e0, e3);
+  // both ends in cell i0 by jax's rule (lo < x <= hi, the first cell closed below), on the axis
+  const bool slow = i0 != i3 || (i0 < n_el - 2 && hi.x < emax) || (i0 > 0 && lo.x >= emin) ||
+                    !(emin >= el_first && emax <= el_last);
+  {
+    const float inv = __builtin_amdgcn_rcpf(hi.x - lo.x);
+    const float w0 = (e0 - lo.x) * inv, w3 = (e3 - lo.x) * inv;
+    float d0 = 0.0f + lo.y * (1.0f - w0);
+    d0 = d0 + hi.y * w0;
+    float d3 = 0.0f + lo.y * (1.0f - w3);
+    d3 = d3 + hi.y * w3;
+    const float step = (d3 - d0) * (1.0f / (float)kL);
+#pragma unroll
+    for (int q = 0; q < kSamplesPerThread; ++q)
+      o[q] = sv[q] * __builtin_amdgcn_rcpf(q == 0 ? d0 : q == kL ? d3 : d0 + (float)q * step);
+  }
+  // lanes that cross a node (or left the axis) look every sample up, at the elevation
+  // interpolated between the outer two
+  if (slow) {
+    const float de = (e3 - e0) * (1.0f / (float)kL);
+#pragma unroll 1
+    for (int q = 0; q < kSamplesPerThread; ++q) {
+      const float el = q == 0 ? e0 : q == kL ? e3 : e0 + (float)q * de;
+      o[q] = krj_lookup(sv[q], el, G, n_el, el_first, el_last, el_inv);
+    }
+  }
+}
+
 __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
     const float2* __restrict__ ym, int D, int n, double ta0, double inv_dta,
     const double* __restrict__ t, int T, const float* __restrict__ scale,
@@ -497,8 +540,7 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
   for (int dl = 0; dl < nd; ++dl) {
     const CalDet c = cdet[dl];
     const float2* G = cal_lds + c.band * n_el;  // (axis node, den)
-    float o[kSamplesPerThread], sv[kSamplesPerThread], ev[kSamplesPerThread];
-    bool miss = false;
+    float o[kSamplesPerThread], sv[kSamplesPerThread];
 #pragma unroll
     for (int q = 0; q < kSamplesPerThread; ++q) {
       float2 k0, k1;
@@ -511,28 +553,8 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
         k1 = ym[(size_t)(w.j[q] + 1) * D + d0 + dl];
       }
       sv[q] = c.scale * spline_eval(w, q, k0, k1);
-      const float el = det_elevation(c, eb[q], ca[q], sa[q]);
-      ev[q] = el;
-      // jax _find_indices on the elevation axis: arithmetic guess from the first
-      // interval's step (am's axis is uniform but for its last node, which the clamp
-      // absorbs); a sample within rounding of a node, or a non-uniform axis, is
-      // redone by the full search below
-      const int i = min(max((int)fminf(fmaxf((el - el_first) * el_inv, -1.0f), 2.0e9f), 0), n_el - 2);
-      const float2 lo = G[i], hi = G[i + 1];
-      miss |= (i < n_el - 2 && hi.x < el) || (i > 0 && lo.x >= el);
-      o[q] = krj_value(sv[q], el, lo, hi, el_first, el_last);
     }
-    if (__builtin_amdgcn_ballot_w64(miss) != 0) {
-      // full search for this detector row's 4 samples (rare)
-#pragma unroll 1
-      for (int q = 0; q < kSamplesPerThread; ++q) {
-        const float el = ev[q];
-        int i = min(max((int)fminf(fmaxf((el - el_first) * el_inv, -1.0f), 2.0e9f), 0), n_el - 2);
-        while (i < n_el - 2 && G[i + 1].x < el) ++i;
-        while (i > 0 && G[i].x >= el) --i;
-        o[q] = krj_value(sv[q], el, G[i], G[i + 1], el_first, el_last);
-      }
-    }
+    krj_row(c, G, n_el, el_first, el_last, el_inv, eb, ca, sa, sv, o);
     float* dst = out + row_of(d0 + dl) * ld + sb;
     if (full) {
       const vfloat4 v = {o[0], o[1], o[2], o[3]};
@@ -594,11 +616,10 @@ __global__ __launch_bounds__(kBlock) void tod_krj_kernel(
 #pragma unroll
       for (int q = 0; q < kSamplesPerThread; ++q) v[q] = sb + q < T ? row[q] : 0.0f;
     }
+    float sv[kSamplesPerThread];
 #pragma unroll
-    for (int q = 0; q < kSamplesPerThread; ++q) {
-      const float el = det_elevation(c, eb[q], ca[q], sa[q]);
-      v[q] = krj_lookup(c.scale * v[q], el, G, n_el, el_first, el_last, el_inv);
-    }
+    for (int q = 0; q < kSamplesPerThread; ++q) sv[q] = c.scale * v[q];
+    krj_row(c, G, n_el, el_first, el_last, el_inv, eb, ca, sa, sv, v);
     if (full) {
       const vfloat4 x = {v[0], v[1], v[2], v[3]};
       __builtin_nontemporal_store(x, reinterpret_cast<vfloat4*>(row));

@@ -53,6 +53,19 @@ def main():
         total += med
         print(f"{name:22s} median {med:8.3f} ms  min {mn:8.3f} ms  alg {nbytes/1e9:7.3f} GB -> {nbytes/med/1e6:8.1f} GB/s")
     print(f"sum of medians {total:.3f} ms -> {D*T/total/1e6:.1f} G det-samples/s; point-layers/s in sample: {D*Ta*L/1e6:.1f} M")
+    # the default-units writer (K_RJ fused) and the in-place conversion of a pW field
+    Tg = np.array([250.0, 270.0, 290.0])
+    pw = np.linspace(0.0, 10.0, 21)
+    elg = np.radians(np.linspace(float(os.environ.get("MRX_EL0", "10.0")), 90.0, 33))
+    elg[-1] = np.radians(90.1)
+    tabs = [{"T": Tg, "pwv": pw, "el": elg, "values": 2e10 * np.exp(-(0.03 + 0.01 * pw[None, :, None]) / np.sin(np.minimum(elg, np.pi / 2))[None, None, :])
+             * np.ones((3, 1, 1))} for _ in p["tables"]]
+    az_full, el_full = synthetic.daisy_scan(p["t"])
+    path.set_calibration(tabs, 273.0, 1.0, el_full, p["offsets"])
+    med, mn = timeit(lambda: path.upsample_krj(tod), reps)
+    print(f"upsample_krj (fused)   median {med:8.3f} ms  min {mn:8.3f} ms")
+    med, mn = timeit(lambda: path.to_krj(tod), reps)
+    print(f"tod_to_krj (in place)  median {med:8.3f} ms  min {mn:8.3f} ms")
     for g in (1, 2, 4, 8, 16):
         path.ctx.set_option(4, g)
         med, mn = timeit(lambda: path.upsample(tod), reps)
