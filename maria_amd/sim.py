@@ -398,8 +398,6 @@ class Simulation:
             self._simulate_atmosphere(obs)
             loading = self._compute_atmospheric_loading(obs, gain=gain if np.any(gain_error) else None,
                                                         units="pW" if deferred else units, metadata=metadata)
-        elif units == "K_RJ" and (self.noise or self.map is not None):
-            raise NotImplementedError("K_RJ needs the atmosphere's calibration tables here: run(units='pW') without an atmosphere")
         map_loading = None
         if self.map is not None:
             map_loading = self._sample_maps(obs)  # pW; the gain error applies (simulation.py:243-245)
@@ -419,7 +417,8 @@ class Simulation:
 
                     total = torch.zeros((dets.n, len(obs.coords.t)), dtype=torch.float32, device="cuda:0")
             noise = self._simulate_noise(obs, loading=total)
-        if units == "K_RJ":  # TOD.to("K_RJ") of the fields that were not written in K_RJ directly
+        if units == "K_RJ" and hasattr(obs, "atmosphere"):
+            # TOD.to("K_RJ") of the fields that were not written in K_RJ directly
             path = obs.atmosphere._device_path()
             if deferred:
                 self._set_calibration(obs, metadata)
@@ -427,6 +426,19 @@ class Simulation:
             for field in (map_loading, noise):
                 if field is not None:
                     path.to_krj(field)
+        elif units == "K_RJ":
+            # no atmosphere: the transmission integral is the band's own Int passband dnu, one
+            # number per band (band/band.py:246-248, calibration/functions.py:73-90)
+            import torch
+
+            den = np.empty(dets.n)
+            for b, band in enumerate(dets.bands):
+                rows = dets.band_index == b
+                polarized = bool((~np.isnan(dets.gamma[rows])).all()) if rows.any() else False
+                den[rows] = (0.5 if polarized else 1.0) * 1e12 * 1.380649e-23 * float(np.trapezoid(band.passband(band.nu), x=band.nu))
+            for field in (map_loading, noise):
+                if field is not None:
+                    field /= torch.as_tensor(den.astype(np.float32), device=field.device)[:, None]
         if hasattr(obs, "atmosphere"):
             obs.loading["atmosphere"] = loading if self.device_output else loading.cpu().numpy()
         if map_loading is not None:

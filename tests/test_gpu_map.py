@@ -380,3 +380,62 @@ def test_end_to_end_polarised_multifrequency_pipeline(gpu_ctx):
     w = mapper.products["weight"]
     assert w.shape == (3, 2, 24, 24) and w.sum() > 0 and (w[0] > 0).mean() > 0.3
     assert np.isfinite(out.data[w > 0]).all()
+
+
+def test_default_units_without_an_atmosphere(gpu_ctx):
+    """TOD.to("K_RJ") with spectrum = None (tod/tod.py:98-100): one transmission integral per
+    band, Int passband dnu; the map-only run in K_RJ is the pW run divided by it."""
+    from maria_amd import map as mmap
+    from maria_amd.instrument import Band, Detectors, Instrument, Site
+    from maria_amd.sim import Plan, Simulation
+
+    band = Band(center=150e9, width=30e9, shape="top_hat", name="f150", NEP=2e-17, knee=0.0)
+    inst = Instrument(Detectors.hexagon(19, 0.2, [band], primary_size=20.0))
+    plan = Plan.daisy(start_time=1.7e9, duration=20.0, sample_rate=50.0, scan_center=(100.0, 60.0), radius=0.2, speed=0.4)
+    n = 32
+    X, Y = np.meshgrid(np.linspace(-1, 1, n), np.linspace(-1, 1, n))
+    sky = mmap.ProjectionMap(np.exp(-(X**2 + Y**2) / 0.2).astype(np.float32), nu=150e9, width=1.0, center=(100.0, 60.0), frame="az/el")
+    runs = {}
+    for units in ("pW", "K_RJ"):
+        sim = Simulation(inst, plan, Site(altitude=1000.0), map=sky, noise=True, noise_seed=5)
+        (runs[units],) = sim.run(units=units)
+    den = 1e12 * 1.380649e-23 * float(np.trapezoid(band.passband(band.nu), x=band.nu))  # unpolarised
+    for field in ("map", "noise"):
+        np.testing.assert_allclose(runs["K_RJ"].data[field], runs["pW"].data[field] / np.float32(den), rtol=2e-6)
+    # a 1 K_RJ source comes back as ~1 K_RJ in the TOD (peak of the smoothed blob below 1)
+    assert 0.5 < runs["K_RJ"].data["map"].max() <= 1.0
+
+
+def test_map_entry_points_reject_bad_arguments(gpu_ctx):
+    """Negative status and a message instead of a launch: the error behaviour of the map rows'
+    entry points."""
+    import ctypes as C
+
+    import torch
+
+    from maria_amd._lib import MrxError, MrxMapCal, MrxSkyMap, ptr
+
+    dev = "cuda:0"
+    vals = torch.zeros((1, 1, 4, 4), dtype=torch.float32, device=dev)
+    one = torch.zeros(8, dtype=torch.float32, device=dev)
+    one64 = torch.ones(8, dtype=torch.float64, device=dev)
+    out = torch.zeros((2, 8), dtype=torch.float32, device=dev)
+    cal = MrxMapCal()
+    cal.d_scalar = ptr(one64)
+
+    def call(sky, ld=8):
+        gpu_ctx.call("mrx_map_sample", C.byref(sky), C.byref(cal), ptr(one), ptr(one), 8, None, ptr(one), ptr(one), ptr(one64), 2,
+                     ptr(out), ld)
+
+    good = MrxSkyMap(ptr(vals), 1, 1, 4, 4, 0.1, -0.05, -0.1, 0.05, 0.0, 1.0, 1, 0)
+    call(good)
+    for bad, msg in [(MrxSkyMap(ptr(vals), 1, 5, 4, 4, 0.1, -0.05, -0.1, 0.05, 0.0, 1.0, 1, 0), "n_stokes"),
+                     (MrxSkyMap(ptr(vals), 1, 1, 4, 4, 0.1, 0.0, -0.1, 0.05, 0.0, 1.0, 1, 0), "non-zero step"),
+                     (MrxSkyMap(None, 1, 1, 4, 4, 0.1, -0.05, -0.1, 0.05, 0.0, 1.0, 1, 0), "null")]:
+        with pytest.raises(MrxError, match=msg):
+            call(bad)
+    with pytest.raises(MrxError, match="ld_out"):
+        call(good, ld=4)
+    with pytest.raises(MrxError, match="leading dimension"):
+        gpu_ctx.call("mrx_bin_map", C.byref(good), ptr(out), 4, None, 0, ptr(one), ptr(one), 8, None, ptr(one), ptr(one), ptr(one64),
+                     None, 2, ptr(one64), ptr(one64))
