@@ -439,3 +439,43 @@ def test_map_entry_points_reject_bad_arguments(gpu_ctx):
     with pytest.raises(MrxError, match="leading dimension"):
         gpu_ctx.call("mrx_bin_map", C.byref(good), ptr(out), 4, None, 0, ptr(one), ptr(one), 8, None, ptr(one), ptr(one), ptr(one64),
                      None, 2, ptr(one64), ptr(one64))
+
+
+@pytest.mark.parametrize("D,T", [(1, 1), (1, 3), (3, 5), (17, 1025)])
+def test_tiny_and_ragged_sizes(gpu_ctx, D, T):
+    """One detector, one sample, lengths below the 4-sample group and one past the tile:
+    map sampling and binning agree with the restatement (the 3-tap kernel reflects at both
+    ends, as scipy does for a length-1 series too)."""
+    import ctypes as C
+
+    import torch
+
+    from maria_amd import map as mmap
+    from maria_amd import synthetic
+    from maria_amd._lib import MrxSkyMap, ptr
+    from oracle import hotpath, mapsample
+
+    t = 1.7e9 + np.arange(T) / 50.0
+    az, el = synthetic.daisy_scan(t)
+    az, el = az.astype(np.float32), el.astype(np.float32)
+    off = synthetic.hex_pack(max(D, 2), np.radians(0.2))[:D]
+    centre = (float(az.mean()), float(el.mean()))
+    eta, xi = np.linspace(0.01, -0.01, 8), np.linspace(-0.01, 0.01, 8)
+    X, Y = np.meshgrid(xi, eta)
+    values = (1.0 + 30 * X - 20 * Y).astype(np.float32)[None, None]
+    w = np.ones((D, 1))
+    az_d, el_d = hotpath.broadcast(off, az, el)
+    ref = mapsample.sample_maps(az_d, el_d, t, None, None, eta, xi, centre, values, w, cal_scalars=[1e10])
+    got = mmap.sample_map(gpu_ctx, values, eta, xi, centre, az, el, off, w, cal_scalars=[1e10]).cpu().numpy()
+    assert got.shape == (D, T) and np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
+    tod = np.random.default_rng(D + T).normal(size=(D, T)).astype(np.float32)
+    rs, rw = mapsample.bin_map(az_d, el_d, tod, None, eta, xi, centre, w, 1)
+    dev = "cuda:0"
+    f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)  # noqa: E731
+    d_tod, d_az, d_el, d_dx, d_dy = f32(tod), f32(az), f32(el), f32(off[:, 0]), f32(off[:, 1])
+    d_sw = torch.ones((D, 1), dtype=torch.float64, device=dev)
+    ms, mw = torch.zeros((1, 1, 8, 8), dtype=torch.float64, device=dev), torch.zeros((1, 1, 8, 8), dtype=torch.float64, device=dev)
+    sky = MrxSkyMap(None, 1, 1, 8, 8, float(eta[0]), float(eta[1] - eta[0]), float(xi[0]), float(xi[1] - xi[0]), centre[0], centre[1], 0, 0)
+    gpu_ctx.call("mrx_bin_map", C.byref(sky), ptr(d_tod), d_tod.stride(0), None, 0, ptr(d_az), ptr(d_el), T, None, ptr(d_dx), ptr(d_dy),
+                 ptr(d_sw), None, D, ptr(ms), ptr(mw))
+    assert abs(mw.sum().item() - D * T) < 1e-9 and abs(mw.cpu().numpy() - rw).sum() <= 2  # at most a boundary sample moved

@@ -250,3 +250,20 @@ def test_pink_part_has_zero_mean_and_no_power_below_the_tod(gpu_ctx, T, fs, knee
     f = np.fft.rfftfreq(T, 1 / fs)
     for j in (2, 3, 5, 8):
         assert abs(psd[j] / (2 * (1 + knee / f[j])) - 1) < 0.35, (j, psd[j], 2 * (1 + knee / f[j]))
+
+
+@pytest.mark.parametrize("D,T", [(1, 1), (1, 2), (2, 3), (3, 7), (5, 4097)])
+def test_tiny_and_odd_sizes(gpu_ctx, D, T):
+    """One detector (a pair with no partner), a single sample, lengths below the 4-sample
+    group, one past the minimum period: finite output of the right size, nothing written
+    beyond it, with and without modes."""
+    import torch
+
+    for modes in (0, 2):
+        basis = None if modes == 0 else np.ones((D, modes)) / np.sqrt(modes)
+        buf = torch.full((D, T + 4), 9.0, dtype=torch.float32, device="cuda:0")
+        out = _generate(gpu_ctx, D, T, 50.0, 2.0, corr=0.5, basis=basis, seed=3, out=buf[:, :T])
+        x = out.cpu().numpy()
+        assert x.shape == (D, T) and np.isfinite(x).all() and bool((buf[:, T:] == 9.0).all())
+        if T > 1000:
+            assert 0.5 < x.std() / np.sqrt(50.0 * (1 + 2 * 2.0 / 50.0 * np.log(T / 2))) < 2.0
