@@ -363,6 +363,33 @@ int mrx_bin_map(mrx_ctx* ctx, const mrx_sky_map* map, const float* d_tod, size_t
                 const double* d_stokes_w, const int32_t* d_channel, int D, double* d_sum,
                 double* d_wgt);
 
+/* ---- TOD pre-processing for the mappers (tod/processing.py:91-204) --------------------- */
+
+/* remove_slope (D -= linspace(D[:, 0], D[:, -1], T), processing.py:99-105) and / or window
+ * (D *= w, processing.py:139-146) on a [D][ld] float32 TOD in place, each step rounded to
+ * float32 as the reference's in-place numpy operations do.
+ *  d_window [T] float64 window (scipy.signal.windows.*, host) or NULL
+ *  d_work   2 * D doubles of scratch (only read when remove_slope is set) */
+int mrx_tod_detrend_window(mrx_ctx* ctx, float* d_data, size_t ld, int D, int T, int remove_slope,
+                           const double* d_window, double* d_work);
+
+/* scipy.signal.sosfilt along time (utils/signal/filters.py:46-69; zero initial state,
+ * transposed direct form II, float64) of every row, optionally after remove_slope
+ * (processing.py:151): the low-pass and the high-pass of process_tod are one cascade.  The
+ * recursion is time-parallel: chunks of mrx_sosfilt_chunk() samples are run from a zero state,
+ * chained through the chunk transition matrix and run again from their true initial state; the
+ * result equals the serial loop up to float64 rounding.
+ *  sos            [n_sections][6] host array (b0 b1 b2 a0 a1 a2), n_sections <= 8
+ *  d_chunk_matrix [2 n][2 n] float64, device: the state transition of the cascade over one
+ *                 chunk, state order (z0, z1) per section (maria_amd/tod_processing.py builds it)
+ *  d_in, d_out    [D][ld] float32; may be the same buffer
+ *  d_work         mrx_sosfilt_work_doubles(D, T, n_sections) doubles */
+int mrx_sosfilt_chunk(void);
+int mrx_sosfilt_work_doubles(int D, int T, int n_sections, size_t* doubles);
+int mrx_sosfilt(mrx_ctx* ctx, const double* sos, int n_sections, const double* d_chunk_matrix,
+                const float* d_in, size_t ld_in, int D, int T, int remove_slope, float* d_out,
+                size_t ld_out, double* d_work);
+
 /* Test hook for the in-LDS inverse FFT both generators are built on: `rows` independent rows
  * of n << interleave_log2 complex float32 values, each holding 2^interleave_log2 interleaved
  * sequences of length n (a power of two >= 4; at most 8192 values per row); unnormalised

@@ -147,6 +147,10 @@ SIGNATURES = {
     "mrx_screen_psd_sum": (_i, [_vp, _i, _i, _d, _d, _d, _d, C.POINTER(_d)]),
     "mrx_map_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _sz]),
     "mrx_bin_map": (_i, [_vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "mrx_tod_detrend_window": (_i, [_vp, _vp, _sz, _i, _i, _i, _vp, _vp]),
+    "mrx_sosfilt_chunk": (_i, []),
+    "mrx_sosfilt_work_doubles": (_i, [_i, _i, _i, C.POINTER(_sz)]),
+    "mrx_sosfilt": (_i, [_vp, C.POINTER(_d), _i, _vp, _vp, _sz, _i, _i, _i, _vp, _sz, _vp]),
     "mrx_fft_rows": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "mrx_noise_period": (_i, [_i, C.POINTER(_i), C.POINTER(_i)]),
     "mrx_noise_work_floats": (_i, [_i, _i, _i, C.POINTER(_sz)]),

@@ -1,8 +1,8 @@
 """``BinMapper`` (maria/mappers/bin_mapper.py): the TODs binned back onto a tangent-plane grid,
 ``map = ((W * D) @ P) / (W @ |P|)`` with the Stokes-weighted pointing matrix of
 map/projection.py:134-179 -- on the device as float64 atomic adds (``mrx_bin_map``), never
-materialising P.  The TOD pre-processing and map post-processing pipelines of
-mappers/base.py stay with maria's front end."""
+materialising P.  ``tod_preprocessing`` runs ``maria_amd.tod_processing.process_tod`` first, as
+mappers/base.py:138 does; the map post-processing pipeline stays with maria's front end."""
 
 from __future__ import annotations
 
@@ -18,8 +18,9 @@ from .map import ProjectionMap, mueller_row
 class BinMapper:
     def __init__(self, tods, center, width=None, height=None, resolution=None, stokes="I", nu=None, frame="ra/dec",
                  units="K_RJ", degrees=True, bilinear=False, tod_preprocessing=None, map_postprocessing=None, device="cuda:0"):
-        if tod_preprocessing or map_postprocessing:
-            raise NotImplementedError("TOD pre-processing and map post-processing stay with maria's mappers/base.py")
+        if map_postprocessing:
+            raise NotImplementedError("map post-processing stays with maria's mappers/base.py")
+        self.tod_preprocessing = dict(tod_preprocessing or {})  # mappers/base.py:138: tod.process(config=...)
         if frame not in ("ra/dec", "az/el"):
             raise NotImplementedError(f"frame '{frame}': only 'ra/dec' and 'az/el' are built")
         self.tods = list(tods)
@@ -58,12 +59,21 @@ class BinMapper:
             dets, coords = tod.dets, tod.coords
             if dets.n == 0:
                 continue
-            signal = None
-            for field in tod.data.values():  # tod.signal: the sum of the fields
-                f = field if isinstance(field, torch.Tensor) else torch.as_tensor(field)
-                f = f.to(dev, torch.float32)
-                signal = f.clone() if signal is None else signal.add_(f)
-            signal = signal.contiguous()
+            weight = None
+            if self.tod_preprocessing:
+                from .tod_processing import process_tod
+
+                done = process_tod(tod, config={k: dict(v) for k, v in self.tod_preprocessing.items()}, ctx=ctx, device=dev)
+                signal = done.data["total"]
+                if not np.all(done.weight == 1.0):  # the window is the processed TOD's weight (processing.py:193)
+                    weight = torch.as_tensor(np.ascontiguousarray(done.weight, np.float32)).to(dev).expand(signal.shape[0], -1).contiguous()
+            else:
+                signal = None
+                for field in tod.data.values():  # tod.signal: the sum of the fields
+                    f = field if isinstance(field, torch.Tensor) else torch.as_tensor(field)
+                    f = f.to(dev, torch.float32)
+                    signal = f.clone() if signal is None else signal.add_(f)
+                signal = signal.contiguous()
             transform = None
             if self.frame == "ra/dec":
                 transform = torch.as_tensor(sky_transform_stack(coords.t, tod.metadata["latitude"], tod.metadata["longitude"]).reshape(-1, 9)).to(dev)
@@ -75,7 +85,8 @@ class BinMapper:
             d_chan = torch.as_tensor(chan).to(dev)
             az, el = f32(coords._baz), f32(coords._bel)
             dx, dy = f32(coords.offsets[:, 0]), f32(coords.offsets[:, 1])
-            ctx.call("mrx_bin_map", C.byref(sky), ptr(signal), signal.stride(0), None, 0, ptr(az), ptr(el), signal.shape[1],
+            ctx.call("mrx_bin_map", C.byref(sky), ptr(signal), signal.stride(0), ptr(weight), 0 if weight is None else weight.stride(0),
+                     ptr(az), ptr(el), signal.shape[1],
                      ptr(transform), ptr(dx), ptr(dy), ptr(stokes_w), ptr(d_chan), dets.n, ptr(msum), ptr(mwgt))
             torch.cuda.current_stream(dev).synchronize()
         data = (msum / mwgt).cpu().numpy()  # 0/0 = nan where nothing was observed, as numpy gives the reference

@@ -10,7 +10,7 @@ exist on the GPU box):
 astropy, h5py ... are not installed).  Registering bare parent
 packages lets the leaf modules that only need numpy/scipy load unmodified:
 ``maria.constants``, ``maria.functions``, ``maria.beam``, ``maria.utils.linalg``,
-``maria.utils.rotations``.  No third-party library is stubbed.  The outputs below
+``maria.utils.rotations``, ``maria.utils.signal``.  No third-party library is stubbed.  The outputs below
 are data (inputs and the reference's answers); no reference source is copied.
 """
 
@@ -37,12 +37,13 @@ def _load_reference_leaves():
     import maria.functions as functions
     import maria.utils.linalg as linalg
     import maria.utils.rotations as rotations
+    import maria.utils.signal as signal
 
-    return constants, functions, beam, linalg, rotations
+    return constants, functions, beam, linalg, rotations, signal
 
 
 def main():
-    constants, functions, beam, linalg, rotations = _load_reference_leaves()
+    constants, functions, beam, linalg, rotations, signal = _load_reference_leaves()
     g = {"_generator": "oracle/gen_golden.py", "_reference": "thomaswmorris/maria @ /root/reference"}
 
     g["constants"] = {"k_B": constants.k_B, "c": constants.c}
@@ -126,6 +127,23 @@ def main():
     offs = sb_rng.uniform(-0.004, 0.004, (25, 2))
     g["spatial_basis"] = {"offsets": offs.tolist(), "k": 5, "n_side": 16, "scale": 0.01,
                           "B": linalg.generate_spatial_basis(offs, k=5, n_side=16, scale=0.01).tolist()}
+
+    # TOD pre-processing leaves (utils/signal/__init__.py, utils/signal/filters.py)
+    sg_rng = np.random.default_rng(41)
+    tt = 100.0 + np.arange(400) / 20.0  # 20 s at 20 Hz
+    Dm = np.cumsum(sg_rng.normal(size=(6, 400)), axis=1) + 3.0 * sg_rng.normal(size=(6, 1))
+    common = np.sin(2 * np.pi * (tt - tt[0]) / 7.0)
+    Dm += np.outer(sg_rng.uniform(2, 5, 6), common) * 10
+    A, Bm = signal.decompose(Dm, k=3)
+    g["signal"] = {
+        "t": tt.tolist(), "D": Dm.tolist(),
+        "bspline_basis_spacing_3_order_3": signal.bspline_basis(tt, spacing=3.0, order=3).tolist(),
+        "remove_slope": signal.remove_slope(Dm).tolist(),
+        "lowpass_fc1.5_order1": signal.lowpass(Dm, fc=1.5, sample_rate=20.0, order=1).tolist(),
+        "highpass_fc0.2_order1": signal.highpass(Dm, fc=0.2, sample_rate=20.0, order=1).tolist(),
+        "lowpass_fc2.5_order2": signal.lowpass(Dm, fc=2.5, sample_rate=20.0, order=2).tolist(),
+        "decompose_k3_first2_modes": (A[:, :2] @ Bm[:2]).tolist(),
+    }
 
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     with open(OUT, "w") as f:

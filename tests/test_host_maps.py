@@ -60,6 +60,7 @@ def test_bin_mapper_grid_and_argument_checks():
     with pytest.raises(RuntimeError, match="not been run"):
         _ = m.map
     with pytest.raises(NotImplementedError):
-        BinMapper([], center=(0, 0), width=1.0, resolution=0.1, tod_preprocessing={"remove_modes": {"modes_to_remove": 1}})
+        BinMapper([], center=(0, 0), width=1.0, resolution=0.1, map_postprocessing={"gaussian_filter": {"sigma": 1}})
+    assert BinMapper([], center=(0, 0), width=1.0, resolution=0.1, tod_preprocessing={"remove_modes": {"modes_to_remove": 1}}).tod_preprocessing
     with pytest.raises(ValueError):
         BinMapper([], center=(0, 0), width=1.0)
