@@ -54,38 +54,91 @@ __global__ __launch_bounds__(kBlock) void anchors_kernel(const float* __restrict
   anchors[2 * d + 1] = (double)data[(size_t)d * ld + T - 1];
 }
 
+// One workgroup = 256 consecutive chunks of one detector (65536 samples), one thread per chunk.
+// A thread walks its chunk sequentially, but the workgroup moves the data 32 samples of every
+// chunk at a time through LDS: global loads and stores are whole 128-byte lines (8 lanes x 16
+// bytes per chunk), and a thread reads its own LDS row (pitch 33 words: conflict-free).
+constexpr int kSub = 32;            // samples of every chunk per stage
+constexpr int kPitch = kSub + 1;
+
 template <int S, bool kWrite>
 __global__ __launch_bounds__(kBlock) void sos_chunk_kernel(SosArgs g) {
-  const int c = blockIdx.x * kBlock + threadIdx.x;  // chunk
+  __shared__ float stage[kBlock * kPitch];
+  const int c0 = blockIdx.x * kBlock;              // first chunk of the workgroup
+  const int c = c0 + threadIdx.x;                  // this thread's chunk
   const int d = blockIdx.y;
-  if (c >= g.n_chunks) return;
   const float* row = g.in + (size_t)d * g.ld_in;
+  float* orow = g.out + (size_t)d * g.ld_out;
   const double first = g.anchors[2 * d], last = g.anchors[2 * d + 1];
   const double step = g.T > 1 ? (last - first) / (double)(g.T - 1) : 0.0;
+  const bool live = c < g.n_chunks;
   double z0[S], z1[S];
-  double* st = g.states + ((size_t)d * g.n_chunks + c) * (2 * S);
+  double* st = g.states + ((size_t)d * g.n_chunks + (live ? c : 0)) * (2 * S);
 #pragma unroll
   for (int s = 0; s < S; ++s) {
-    z0[s] = kWrite ? st[2 * s] : 0.0;
-    z1[s] = kWrite ? st[2 * s + 1] : 0.0;
+    z0[s] = (kWrite && live) ? st[2 * s] : 0.0;
+    z1[s] = (kWrite && live) ? st[2 * s + 1] : 0.0;
   }
-  const int t0 = c * kChunk;
-  const int t1 = min(t0 + kChunk, g.T);
-  float* orow = g.out + (size_t)d * g.ld_out;
-  for (int t = t0; t < t1; ++t) {
-    double x = (double)row[t];
-    if (g.remove_slope) x -= line_at(first, last, step, t, g.T);  // utils/signal/__init__.py:151-152
+  // cooperative tile moves: lane group of 8 handles one chunk's 32 samples (4 per lane)
+  const int part = threadIdx.x & 7, rowgrp = threadIdx.x >> 3;  // 32 chunks per pass of the block
+  const bool vec_in = (g.ld_in % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.in) & 15u) == 0);
+  const bool vec_out = (g.ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(g.out) & 15u) == 0);
+  for (int j = 0; j < kChunk / kSub; ++j) {
+    // ---- load stage j of all 256 chunks
+    for (int cc = rowgrp; cc < kBlock; cc += kBlock / 8) {
+      const long long t = (long long)(c0 + cc) * kChunk + j * kSub + part * 4;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (t + 4 <= g.T && vec_in) {
+        const vfloat4 q = *reinterpret_cast<const vfloat4*>(row + t);
+        v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+      } else {
 #pragma unroll
-    for (int s = 0; s < S; ++s) {
-      // scipy/signal/_sosfilt.pyx: transposed direct form II
-      const double y = g.b0[s] * x + z0[s];
-      z0[s] = g.b1[s] * x - g.a1[s] * y + z1[s];
-      z1[s] = g.b2[s] * x - g.a2[s] * y;
-      x = y;
+        for (int k = 0; k < 4; ++k)
+          if (t + k < g.T) v[k] = row[t + k];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) stage[cc * kPitch + part * 4 + k] = v[k];
     }
-    if (kWrite) orow[t] = (float)x;
+    __syncthreads();
+    // ---- every thread: 32 steps of its own chunk
+    const int tb = c * kChunk + j * kSub;
+    if (live) {
+#pragma unroll 4
+      for (int i = 0; i < kSub; ++i) {
+        const int t = tb + i;
+        if (t >= g.T) break;
+        double x = (double)stage[threadIdx.x * kPitch + i];
+        if (g.remove_slope) x -= line_at(first, last, step, t, g.T);  // utils/signal/__init__.py:151-152
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+          // scipy/signal/_sosfilt.pyx: transposed direct form II
+          const double y = g.b0[s] * x + z0[s];
+          z0[s] = g.b1[s] * x - g.a1[s] * y + z1[s];
+          z1[s] = g.b2[s] * x - g.a2[s] * y;
+          x = y;
+        }
+        if (kWrite) stage[threadIdx.x * kPitch + i] = (float)x;
+      }
+    }
+    __syncthreads();
+    if (kWrite) {
+      // ---- store stage j
+      for (int cc = rowgrp; cc < kBlock; cc += kBlock / 8) {
+        const long long t = (long long)(c0 + cc) * kChunk + j * kSub + part * 4;
+        if (t >= g.T) continue;
+        const float* v = stage + cc * kPitch + part * 4;
+        if (t + 4 <= g.T && vec_out) {
+          *reinterpret_cast<vfloat4*>(orow + t) = vfloat4{v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if (t + k < g.T) orow[t + k] = v[k];
+        }
+      }
+      __syncthreads();
+    }
   }
-  if (!kWrite) {
+  if (!kWrite && live) {
 #pragma unroll
     for (int s = 0; s < S; ++s) {
       st[2 * s] = z0[s];
