@@ -7,6 +7,7 @@ mappers/base.py:138 does; the map post-processing pipeline stays with maria's fr
 from __future__ import annotations
 
 import ctypes as C
+import logging
 
 import numpy as np
 import torch
@@ -14,12 +15,16 @@ import torch
 from ._lib import Context, MrxSkyMap, ptr
 from .map import ProjectionMap, mueller_row
 
+logger = logging.getLogger("maria")
+
 
 class BinMapper:
     def __init__(self, tods, center, width=None, height=None, resolution=None, stokes="I", nu=None, frame="ra/dec",
                  units="K_RJ", degrees=True, bilinear=False, tod_preprocessing=None, map_postprocessing=None, device="cuda:0"):
         if map_postprocessing:
-            raise NotImplementedError("map post-processing stays with maria's mappers/base.py")
+            # BinMapper.run overrides BaseMapper.run (mappers/bin_mapper.py:84 vs base.py:162-198):
+            # the reference accepts the argument and never applies it
+            logger.warning("BinMapper does not apply 'map_postprocessing' (neither does the reference's)")
         self.tod_preprocessing = dict(tod_preprocessing or {})  # mappers/base.py:138: tod.process(config=...)
         if frame not in ("ra/dec", "az/el"):
             raise NotImplementedError(f"frame '{frame}': only 'ra/dec' and 'az/el' are built")

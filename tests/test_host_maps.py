@@ -59,8 +59,7 @@ def test_bin_mapper_grid_and_argument_checks():
     assert abs((m.xi[1] - m.xi[0]) - np.radians(0.1)) < 1e-15 and m.eta[0] > m.eta[-1]
     with pytest.raises(RuntimeError, match="not been run"):
         _ = m.map
-    with pytest.raises(NotImplementedError):
-        BinMapper([], center=(0, 0), width=1.0, resolution=0.1, map_postprocessing={"gaussian_filter": {"sigma": 1}})
+    BinMapper([], center=(0, 0), width=1.0, resolution=0.1, map_postprocessing={"gaussian_filter": {"sigma": 1}})  # accepted, unused
     assert BinMapper([], center=(0, 0), width=1.0, resolution=0.1, tod_preprocessing={"remove_modes": {"modes_to_remove": 1}}).tod_preprocessing
     with pytest.raises(ValueError):
         BinMapper([], center=(0, 0), width=1.0)
