@@ -244,6 +244,14 @@ int mrx_tod_to_krj(mrx_ctx* ctx, float* d_data, size_t ld, int D, int T,
                    const int32_t* d_band, const float* d_cal_axis_el,
                    const float* d_cal_values, int n_el, int n_bands);
 
+/* The way back, TOD.to("pW") of a K_RJ field in place: d_data *= d_scale[d] * den(el(d, s));
+ * same arguments.  (tests/noise/test_noise.py:14 converts the default-unit TOD this way.) */
+int mrx_tod_from_krj(mrx_ctx* ctx, float* d_data, size_t ld, int D, int T,
+                     const float* d_scale, const int32_t* d_rows,
+                     const float* d_bore_el, const float* d_dx, const float* d_dy,
+                     const int32_t* d_band, const float* d_cal_axis_el,
+                     const float* d_cal_values, int n_el, int n_bands);
+
 /* Full-rate detector pointing: Coordinates.broadcast at the sample rate
  * (coords/coordinates.py:378-386 via transforms.py:10-29, float32;
  * sim/observation.py:55-58).  d_az, d_el [T] float32 boresight; d_dx, d_dy [D];

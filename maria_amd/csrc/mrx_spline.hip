@@ -376,6 +376,8 @@ struct CalDet {
 
 // K_RJ of one sample: s / lerp(den) with jax's weight (x - lo)/(hi - lo); NaN
 // outside the axis (jax fill value).
+// kInverse: the way back, K_RJ -> pW (s * den).
+template <bool kInverse = false>
 __device__ __forceinline__ float krj_value(float s, float el, float2 lo,
                                            float2 hi, float el_first,
                                            float el_last) {
@@ -383,7 +385,7 @@ __device__ __forceinline__ float krj_value(float s, float el, float2 lo,
   float den = 0.0f + lo.y * (1.0f - wt);
   den = den + hi.y * wt;
   if (!(el >= el_first && el <= el_last)) den = __builtin_nanf("");
-  return s * __builtin_amdgcn_rcpf(den);
+  return kInverse ? s * den : s * __builtin_amdgcn_rcpf(den);
 }
 
 // detector elevation (transforms.py:20-28): im = sin(el) as the chain computes
@@ -424,12 +426,13 @@ __device__ __forceinline__ CalDet make_cal_det(float dx, float dy, int band, flo
 // first interval's step (am's axis is uniform but for its last node, which the clamp
 // absorbs), corrected by a short walk when the guess is off (non-uniform axis, a sample
 // within rounding of a node)
+template <bool kInverse = false>
 __device__ __forceinline__ float krj_lookup(float s, float el, const float2* G, int n_el,
                                             float el_first, float el_last, float el_inv) {
   int i = min(max((int)fminf(fmaxf((el - el_first) * el_inv, -1.0f), 2.0e9f), 0), n_el - 2);
   while (i < n_el - 2 && G[i + 1].x < el) ++i;
   while (i > 0 && G[i].x >= el) --i;
-  return krj_value(s, el, G[i], G[i + 1], el_first, el_last);
+  return krj_value<kInverse>(s, el, G[i], G[i + 1], el_first, el_last);
 }
 
 // The K_RJ values of a thread's 4 consecutive samples of one detector.  den is piecewise
@@ -438,6 +441,7 @@ __device__ __forceinline__ float krj_lookup(float s, float el, const float2* G, 
 // the two inner dens are interpolated between the outer ones (float32 rounding apart, the
 // value jax computes); otherwise -- a node between them, a guess that missed, an elevation
 // off the axis -- every sample is looked up on its own at the interpolated elevation.
+template <bool kInverse = false>
 __device__ __forceinline__ void krj_row(const CalDet& c, const float2* G, int n_el, float el_first,
                                         float el_last, float el_inv, const float (&eb)[kSamplesPerThread],
                                         const float (&ca)[kSamplesPerThread], const float (&sa)[kSamplesPerThread],
@@ -461,7 +465,10 @@ __device__ __forceinline__ void krj_row(const CalDet& c, const float2* G, int n_
     const float step = (d3 - d0) * (1.0f / (float)kL);
 #pragma unroll
     for (int q = 0; q < kSamplesPerThread; ++q)
-      o[q] = sv[q] * __builtin_amdgcn_rcpf(q == 0 ? d0 : q == kL ? d3 : d0 + (float)q * step);
+    {
+      const float den = q == 0 ? d0 : q == kL ? d3 : d0 + (float)q * step;
+      o[q] = kInverse ? sv[q] * den : sv[q] * __builtin_amdgcn_rcpf(den);
+    }
   }
   // lanes that cross a node (or left the axis) look every sample up, at the elevation
   // interpolated between the outer two
@@ -470,7 +477,7 @@ __device__ __forceinline__ void krj_row(const CalDet& c, const float2* G, int n_
 #pragma unroll 1
     for (int q = 0; q < kSamplesPerThread; ++q) {
       const float el = q == 0 ? e0 : q == kL ? e3 : e0 + (float)q * de;
-      o[q] = krj_lookup(sv[q], el, G, n_el, el_first, el_last, el_inv);
+      o[q] = krj_lookup<kInverse>(sv[q], el, G, n_el, el_first, el_last, el_inv);
     }
   }
 }
@@ -573,6 +580,7 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
 // tod/tod.py:106-142), in place: data[row(d)][s] *= scale_d / den_band(d)(el(d, s)).
 // Same tile as the fused writer: 16 detectors x 1024 samples per workgroup, 16-byte
 // loads and non-temporal stores; 8 B of HBM traffic per sample.
+template <bool kInverse>
 __global__ __launch_bounds__(kBlock) void tod_krj_kernel(
     float* __restrict__ data, size_t ld, int D, int T, const float* __restrict__ scale,
     const int32_t* __restrict__ rows, const float* __restrict__ bore_el,
@@ -619,7 +627,7 @@ __global__ __launch_bounds__(kBlock) void tod_krj_kernel(
     float sv[kSamplesPerThread];
 #pragma unroll
     for (int q = 0; q < kSamplesPerThread; ++q) sv[q] = c.scale * v[q];
-    krj_row(c, G, n_el, el_first, el_last, el_inv, eb, ca, sa, sv, v);
+    krj_row<kInverse>(c, G, n_el, el_first, el_last, el_inv, eb, ca, sa, sv, v);
     if (full) {
       const vfloat4 x = {v[0], v[1], v[2], v[3]};
       __builtin_nontemporal_store(x, reinterpret_cast<vfloat4*>(row));
@@ -817,11 +825,11 @@ int mrx_spline_upsample_krj(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
   return MRX_OK;
 }
 
-int mrx_tod_to_krj(mrx_ctx* ctx, float* d_data, size_t ld, int D, int T,
-                   const float* d_scale, const int32_t* d_rows,
-                   const float* d_bore_el, const float* d_dx, const float* d_dy,
-                   const int32_t* d_band, const float* d_cal_axis_el,
-                   const float* d_cal_values, int n_el, int n_bands) {
+static int tod_convert(mrx_ctx* ctx, bool inverse, float* d_data, size_t ld, int D, int T,
+                       const float* d_scale, const int32_t* d_rows,
+                       const float* d_bore_el, const float* d_dx, const float* d_dy,
+                       const int32_t* d_band, const float* d_cal_axis_el,
+                       const float* d_cal_values, int n_el, int n_bands) {
   if (!ctx) return MRX_ERR_INVALID;
   MRX_REQUIRE(ctx, D >= 0 && T >= 0, "negative size");
   if (D == 0 || T == 0) return MRX_OK;
@@ -834,11 +842,34 @@ int mrx_tod_to_krj(mrx_ctx* ctx, float* d_data, size_t ld, int D, int T,
   MRX_REQUIRE(ctx, grid.y <= 65535u, "D too large for one launch");
   const int vec_ok = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_data) & 15u) == 0);
   const size_t lds = sizeof(float2) * (size_t)n_el * n_bands;
-  hipLaunchKernelGGL(tod_krj_kernel, grid, dim3(kBlock), lds, ctx->stream, d_data, ld, D, T,
-                     d_scale, d_rows, d_bore_el, d_dx, d_dy, d_band, d_cal_axis_el,
-                     d_cal_values, n_el, n_bands, vec_ok);
+  if (inverse)
+    hipLaunchKernelGGL(tod_krj_kernel<true>, grid, dim3(kBlock), lds, ctx->stream, d_data, ld, D, T,
+                       d_scale, d_rows, d_bore_el, d_dx, d_dy, d_band, d_cal_axis_el,
+                       d_cal_values, n_el, n_bands, vec_ok);
+  else
+    hipLaunchKernelGGL(tod_krj_kernel<false>, grid, dim3(kBlock), lds, ctx->stream, d_data, ld, D, T,
+                       d_scale, d_rows, d_bore_el, d_dx, d_dy, d_band, d_cal_axis_el,
+                       d_cal_values, n_el, n_bands, vec_ok);
   MRX_CHECK_LAUNCH(ctx);
   return MRX_OK;
+}
+
+int mrx_tod_to_krj(mrx_ctx* ctx, float* d_data, size_t ld, int D, int T,
+                   const float* d_scale, const int32_t* d_rows,
+                   const float* d_bore_el, const float* d_dx, const float* d_dy,
+                   const int32_t* d_band, const float* d_cal_axis_el,
+                   const float* d_cal_values, int n_el, int n_bands) {
+  return tod_convert(ctx, false, d_data, ld, D, T, d_scale, d_rows, d_bore_el, d_dx, d_dy, d_band,
+                     d_cal_axis_el, d_cal_values, n_el, n_bands);
+}
+
+int mrx_tod_from_krj(mrx_ctx* ctx, float* d_data, size_t ld, int D, int T,
+                     const float* d_scale, const int32_t* d_rows,
+                     const float* d_bore_el, const float* d_dx, const float* d_dy,
+                     const int32_t* d_band, const float* d_cal_axis_el,
+                     const float* d_cal_values, int n_el, int n_bands) {
+  return tod_convert(ctx, true, d_data, ld, D, T, d_scale, d_rows, d_bore_el, d_dx, d_dy, d_band,
+                     d_cal_axis_el, d_cal_values, n_el, n_bands);
 }
 
 int mrx_pointing_broadcast(mrx_ctx* ctx, const float* d_az, const float* d_el,

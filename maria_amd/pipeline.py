@@ -350,6 +350,16 @@ class DevicePath:
         )
         return data
 
+    def from_krj(self, data):
+        """mrx_tod_from_krj: the way back, a [D, T] K_RJ field to pW in place."""
+        c = self._cal
+        assert tuple(data.shape) == (self.D, self.T) and data.stride(1) == 1
+        self.ctx.call(
+            "mrx_tod_from_krj", ptr(data), data.stride(0), self.D, self.T, None, ptr(self.d_rows), ptr(c["bore_el"]),
+            ptr(c["dx"]), ptr(c["dy"]), ptr(self.d_band), ptr(c["axis"]), ptr(c["values"]), c["n_el"], c["n_bands"],
+        )
+        return data
+
     def check_flags(self):
         """Raise the reference's errors if a sample left a screen or a table."""
         word = C.c_uint32()

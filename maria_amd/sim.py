@@ -173,15 +173,19 @@ class TOD:
         return self.coords.t
 
     def to(self, units):
-        """tod/tod.py:106-142.  ``Simulation.run(units=...)`` writes pW or K_RJ directly (the
-        K_RJ division is fused into the kernel that writes the TOD); other conversions of an
-        existing TOD stay with maria's calibration graph."""
+        """tod/tod.py:106-142 between "pW" and "K_RJ" (``mrx_tod_to_krj`` / ``mrx_tod_from_krj`` on
+        every field), for a TOD that came out of ``Simulation.run``; other units stay with maria's
+        calibration graph."""
         if units == self.units:
             return self
-        raise NotImplementedError(
-            f"conversion {self.units} -> {units} of an existing TOD is not built; ask Simulation.run() "
-            "for units='K_RJ' or 'pW'"
-        )
+        if {units, self.units} != {"pW", "K_RJ"} or getattr(self, "_calibrator", None) is None:
+            raise NotImplementedError(
+                f"conversion {self.units} -> {units}: only pW <-> K_RJ of a TOD made by Simulation.run() is built"
+            )
+        out = TOD(data=self._calibrator(self.data, to_krj=(units == "K_RJ")), dets=self.dets, coords=self.coords, units=units,
+                  metadata=self.metadata)
+        out._calibrator = self._calibrator
+        return out
 
 
 class Simulation:
@@ -445,4 +449,37 @@ class Simulation:
             obs.loading["map"] = map_loading if self.device_output else map_loading.cpu().numpy()
         if noise is not None:
             obs.loading["noise"] = noise if self.device_output else noise.cpu().numpy()
-        return TOD(data=obs.loading, dets=dets, coords=obs.coords, units=units, metadata=metadata)
+        tod = TOD(data=obs.loading, dets=dets, coords=obs.coords, units=units, metadata=metadata)
+        tod._calibrator = self._make_calibrator(obs, metadata)
+        return tod
+
+    def _make_calibrator(self, obs, metadata):
+        """What ``TOD.to`` needs to move a finished TOD between pW and K_RJ: the observation's
+        calibration on the device (atmosphere) or one number per band (none)."""
+        dets = obs.instrument.dets
+
+        def convert(data, to_krj):
+            import torch
+
+            out = {}
+            if hasattr(obs, "atmosphere"):
+                path = obs.atmosphere._device_path()
+                self._set_calibration(obs, metadata)
+            else:
+                den = np.empty(dets.n)
+                for b, band in enumerate(dets.bands):
+                    rows = dets.band_index == b
+                    polarized = bool((~np.isnan(dets.gamma[rows])).all()) if rows.any() else False
+                    den[rows] = (0.5 if polarized else 1.0) * 1e12 * 1.380649e-23 * float(np.trapezoid(band.passband(band.nu), x=band.nu))
+            for name, field in data.items():
+                on_device = isinstance(field, torch.Tensor)
+                f = (field.clone() if on_device else torch.as_tensor(np.ascontiguousarray(field, np.float32)).to("cuda:0")).contiguous()
+                if hasattr(obs, "atmosphere"):
+                    path.to_krj(f) if to_krj else path.from_krj(f)
+                else:
+                    d = torch.as_tensor(den.astype(np.float32), device=f.device)[:, None]
+                    f = f / d if to_krj else f * d
+                out[name] = f if on_device else f.cpu().numpy()
+            return out
+
+        return convert

@@ -182,3 +182,28 @@ def test_noise_field_in_krj_and_loading_dependent_nep(gpu_ctx):
     # deferred conversion (pW first, then both fields in place) equals the fused one
     np.testing.assert_allclose(krj2.data["atmosphere"], krj.data["atmosphere"], rtol=5e-7)
     np.testing.assert_allclose(krj2.data["noise"], pw2.data["noise"] * factor, rtol=2e-6)
+
+
+def test_tod_to_round_trip_like_the_reference_noise_test(gpu_ctx):
+    """tests/noise/test_noise.py:14: ``sim.run()[0].to("pW")`` -- the default-unit TOD converted
+    back to pW (mrx_tod_from_krj) equals the pW run of the same realisation; and forth again."""
+    from maria_amd.instrument import Band, Detectors, Instrument, Site
+    from maria_amd.sim import Plan, Simulation
+
+    bands = [Band(center=93e9, width=27e9, shape="top_hat", name="f093", knee=0.0), Band(center=150e9, width=41e9, shape="top_hat", name="f150", knee=0.0)]
+    inst = Instrument(Detectors.hexagon(19, 0.3, bands, primary_size=6.0))
+    plan = Plan.daisy(start_time=1.7e9, duration=20.0, sample_rate=50.0, scan_center=(45.0, 55.0), radius=0.4, speed=0.4)
+
+    def run(units):
+        sim = Simulation(inst, plan, Site(altitude=1000.0), atmosphere="2d", atmosphere_kwargs={"n_layers": 2, "seed": 9}, noise=True, noise_seed=3)
+        return sim.run(units=units)[0]
+
+    k, p = run("K_RJ"), run("pW")
+    back = k.to("pW")
+    assert back.units == "pW" and set(back.fields) == {"atmosphere", "noise"} and k.units == "K_RJ"
+    for f in back.fields:
+        np.testing.assert_allclose(back.data[f], p.data[f], rtol=3e-6, atol=1e-6 * np.abs(p.data[f]).max())
+    again = back.to("K_RJ")
+    for f in again.fields:
+        np.testing.assert_allclose(again.data[f], k.data[f], rtol=3e-6, atol=1e-6 * np.abs(k.data[f]).max())
+    assert k.to("K_RJ") is k

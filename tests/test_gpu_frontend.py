@@ -88,7 +88,7 @@ def test_reference_error_behaviour(gpu_ctx):
         sim.run(units="K_CMB")  # only the reference's default K_RJ and pW are built
     (tod,) = sim.run(units="pW")
     with pytest.raises(NotImplementedError):
-        tod.to("K_RJ")  # converting an existing TOD stays with maria's calibration graph
+        tod.to("K_CMB")  # only pW <-> K_RJ of an existing TOD is built
 
 
 def test_screen_statistics_through_the_front_end(gpu_ctx):

@@ -229,7 +229,7 @@ def test_reference_white_noise_levels_test_case(gpu_ctx):
     plan = Plan(t, np.zeros_like(t), np.full_like(t, np.pi / 2))
     for seed in (1, 2, 3):
         sim = Simulation(inst, plan, Site(altitude=825.0, region="green_bank"), noise=True, noise_seed=seed)
-        (tod,) = sim.run(units="pW")
+        tod = sim.run()[0].to("pW")  # as the reference's test: default units, then TOD.to
         target_error = 1e12 * 1.5e-17 / np.sqrt(plan.duration + 1 / 50.0)
         scaled = tod.data["noise"].astype(np.float64).mean(axis=1) / target_error
         assert 0.7 < scaled.std() < 1.3, scaled.std()
