@@ -31,10 +31,28 @@ def test_header_symbols_are_exported_and_bound():
     assert maria_amd.load().mrx_version() == 100
 
 
-def test_struct_layouts_match_the_header():
-    # sizes the C compiler gives mrx_layer / mrx_band_table (8-byte aligned members)
-    assert ctypes.sizeof(_lib.MrxLayer) == 5 * 8 + 2 * 4 + 9 * 8 + 2 * 4
-    assert ctypes.sizeof(_lib.MrxBandTable) == 3 * 8 + 4 * 4
+def test_struct_layouts_match_the_header(tmp_path):
+    """Size and every field offset of the four boundary structs, as gcc lays out include/mrx.h,
+    against the ctypes mirrors."""
+    import subprocess
+
+    pairs = [("mrx_layer", _lib.MrxLayer), ("mrx_band_table", _lib.MrxBandTable), ("mrx_sky_map", _lib.MrxSkyMap), ("mrx_map_cal", _lib.MrxMapCal)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "mrx.h"', "int main(void) {"]
+    for cname, cls in pairs:
+        lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
+        for field, _ in cls._fields_:
+            lines.append(f'  printf("{cname} {field} %zu\\n", offsetof({cname}, {field}));')
+    lines += ["  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split("\n")
+    got = {tuple(l.split()[:2]): int(l.split()[2]) for l in out if l.strip()}
+    for cname, cls in pairs:
+        assert got[(cname, "size")] == ctypes.sizeof(cls), cname
+        for field, _ in cls._fields_:
+            assert got[(cname, field)] == getattr(cls, field).offset, (cname, field)
 
 
 # Random123 known-answer vectors for philox4x32-10 (kat_vectors): counter, key -> output
