@@ -372,6 +372,12 @@ struct CalDet {
   int band;
   float scale;
   float dy, sdy, cdy;  // vertical offset and its sine / cosine
+  // el_det - el_bore as a linear function of el_bore around the tile's middle boresight
+  // elevation (it does not depend on the azimuth): el_det(s) = eb + dm + slope (eb - ebm).
+  // Curvature over a tile's elevation range (~0.02 rad) is below 1e-7 rad.  exact = 1 near the
+  // zenith, where the detector elevation is not smooth in eb: every sample takes the full formula.
+  float dm, slope, ebm;
+  int exact;
 };
 
 // K_RJ of one sample: s / lerp(den) with jax's weight (x - lo)/(hi - lo); NaN
@@ -406,6 +412,25 @@ __device__ __forceinline__ float det_elevation(const CalDet& c, float eb, float 
   if (__builtin_amdgcn_ballot_w64(steep) != 0)
     if (steep) el = asinf(im);
   return el;
+}
+
+// the linear model of CalDet around the boresight elevation ebm (see CalDet)
+__device__ __forceinline__ void set_elevation_model(CalDet& c, float ebm) {
+  constexpr float h = 2.0e-2f;  // wide enough that float32 rounding of the differences stays below 1e-7 rad over a tile
+  float e[3];
+  bool steep = false;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float eb = ebm + (float)(k - 1) * h;
+    const float a = eb - 1.57079637050628662109375f;
+    const float ca = cosf(a), sa = sinf(a);
+    steep |= !(-sa * c.cdy - ca * c.sdy > 0.3f);  // cos(el_bore + dy): within ~17 deg of the zenith
+    e[k] = det_elevation(c, eb, ca, sa) - eb;
+  }
+  c.ebm = ebm;
+  c.dm = e[1];
+  c.slope = (e[2] - e[0]) * (0.5f / h);
+  c.exact = steep ? 1 : 0;
 }
 
 __device__ __forceinline__ CalDet make_cal_det(float dx, float dy, int band, float scale) {
@@ -447,7 +472,14 @@ __device__ __forceinline__ void krj_row(const CalDet& c, const float2* G, int n_
                                         const float (&ca)[kSamplesPerThread], const float (&sa)[kSamplesPerThread],
                                         const float (&sv)[kSamplesPerThread], float (&o)[kSamplesPerThread]) {
   constexpr int kL = kSamplesPerThread - 1;
-  const float e0 = det_elevation(c, eb[0], ca[0], sa[0]), e3 = det_elevation(c, eb[kL], ca[kL], sa[kL]);
+  float e0, e3;
+  if (c.exact) {  // uniform over the workgroup: one detector row at a time
+    e0 = det_elevation(c, eb[0], ca[0], sa[0]);
+    e3 = det_elevation(c, eb[kL], ca[kL], sa[kL]);
+  } else {
+    e0 = fmaf(c.slope, eb[0] - c.ebm, eb[0] + c.dm);
+    e3 = fmaf(c.slope, eb[kL] - c.ebm, eb[kL] + c.dm);
+  }
   const int i0 = min(max((int)fminf(fmaxf((e0 - el_first) * el_inv, -1.0f), 2.0e9f), 0), n_el - 2);
   const int i3 = min(max((int)fminf(fmaxf((e3 - el_first) * el_inv, -1.0f), 2.0e9f), 0), n_el - 2);
   const float2 lo = G[i0], hi = G[i0 + 1];
@@ -518,7 +550,8 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
     cal_lds[i] = make_float2(cal_axis[i % n_el], cal_values[i]);
   if ((int)threadIdx.x < nd) {
     const int d = d0 + threadIdx.x;
-    const CalDet c = make_cal_det(dxs[d], dys[d], min(max(band[d], 0), n_bands - 1), scale ? scale[d] : 1.0f);
+    CalDet c = make_cal_det(dxs[d], dys[d], min(max(band[d], 0), n_bands - 1), scale ? scale[d] : 1.0f);
+    set_elevation_model(c, bore_el[min(s_tile + kTileSamples / 2, T - 1)]);
     cdet[threadIdx.x] = c;
   }
 
@@ -605,7 +638,9 @@ __global__ __launch_bounds__(kBlock) void tod_krj_kernel(
     cal_lds[i] = make_float2(cal_axis[i % n_el], cal_values[i]);
   if ((int)threadIdx.x < nd) {
     const int d = d0 + threadIdx.x;
-    cdet[threadIdx.x] = make_cal_det(dxs[d], dys[d], min(max(band[d], 0), n_bands - 1), scale ? scale[d] : 1.0f);
+    CalDet c = make_cal_det(dxs[d], dys[d], min(max(band[d], 0), n_bands - 1), scale ? scale[d] : 1.0f);
+    set_elevation_model(c, bore_el[min(s_tile + kTileSamples / 2, T - 1)]);
+    cdet[threadIdx.x] = c;
   }
   __syncthreads();
   if (sb >= T) return;
