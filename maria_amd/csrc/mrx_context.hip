@@ -64,6 +64,7 @@ int mrx_set_option(mrx_ctx* ctx, int option, int value) {
 }
 
 int mrx_synchronize(mrx_ctx* ctx) {
+  MRX_ENTER(ctx);
   if (!ctx) return MRX_ERR_INVALID;
   MRX_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return MRX_OK;
@@ -87,12 +88,14 @@ int mrx_device_info(const mrx_ctx* ctx, int* n_cu, int* lds_bytes_per_cu,
 }
 
 int mrx_timer_start(mrx_ctx* ctx) {
+  MRX_ENTER(ctx);
   if (!ctx) return MRX_ERR_INVALID;
   MRX_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
   return MRX_OK;
 }
 
 int mrx_timer_stop(mrx_ctx* ctx, float* elapsed_ms) {
+  MRX_ENTER(ctx);
   if (!ctx || !elapsed_ms) return MRX_ERR_INVALID;
   MRX_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
   MRX_HIP(ctx, hipEventSynchronize(ctx->ev_stop));
@@ -101,6 +104,7 @@ int mrx_timer_stop(mrx_ctx* ctx, float* elapsed_ms) {
 }
 
 int mrx_clear_flags(mrx_ctx* ctx, uint32_t* d_flags) {
+  MRX_ENTER(ctx);
   if (!ctx || !d_flags) return MRX_ERR_INVALID;
   MRX_HIP(ctx, hipMemsetAsync(d_flags, 0, sizeof(uint32_t), ctx->stream));
   return MRX_OK;
@@ -108,6 +112,7 @@ int mrx_clear_flags(mrx_ctx* ctx, uint32_t* d_flags) {
 
 int mrx_read_flags(mrx_ctx* ctx, const uint32_t* d_flags,
                    uint32_t* host_flags) {
+  MRX_ENTER(ctx);
   if (!ctx || !d_flags || !host_flags) return MRX_ERR_INVALID;
   MRX_HIP(ctx, hipMemcpyAsync(host_flags, d_flags, sizeof(uint32_t),
                               hipMemcpyDeviceToHost, ctx->stream));

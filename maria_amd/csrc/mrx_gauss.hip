@@ -184,16 +184,8 @@ int get_taps(mrx_ctx* ctx, double sigma, double truncate, int* radius_out,
 constexpr size_t kMaxLds = 128 * 1024;  // of the CU's 160 KiB
 
 int raise_lds_cap(mrx_ctx* ctx) {
-  static bool done = false;
-  if (!done) {
-    MRX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_x_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)kMaxLds));
-    MRX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(gauss_y_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)kMaxLds));
-    done = true;
-  }
+  MRX_LDS_CAP(ctx, gauss_x_kernel, kMaxLds);
+  MRX_LDS_CAP(ctx, gauss_y_kernel, kMaxLds);
   return MRX_OK;
 }
 
@@ -248,6 +240,7 @@ extern "C" {
 int mrx_gauss_smooth2d(mrx_ctx* ctx, const float* d_in, float* d_out,
                        float* d_tmp, int ny, int nx, double sigma_y,
                        double sigma_x, double truncate) {
+  MRX_ENTER(ctx);
   if (!ctx) return MRX_ERR_INVALID;
   MRX_REQUIRE(ctx, d_in && d_out && d_tmp, "null pointer");
   MRX_REQUIRE(ctx, ny >= 0 && nx >= 0, "negative size");
@@ -280,6 +273,7 @@ int mrx_gauss_smooth2d(mrx_ctx* ctx, const float* d_in, float* d_out,
 int mrx_map_smooth(mrx_ctx* ctx, const float* d_data, const float* d_weight,
                    float* d_out, float* d_denom_out, float* d_tmp, int ny,
                    int nx, double sigma_y, double sigma_x) {
+  MRX_ENTER(ctx);
   if (!ctx) return MRX_ERR_INVALID;
   MRX_REQUIRE(ctx, d_data && d_out && d_tmp, "null pointer");
   MRX_REQUIRE(ctx, ny >= 0 && nx >= 0, "negative size");

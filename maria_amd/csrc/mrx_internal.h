@@ -41,6 +41,17 @@ struct mrx_ctx {
   int psd_next = 0;
   double* d_reduce = nullptr;  // kPsdSlots doubles
   size_t reduce_cap = 0;
+  // dynamic-LDS caps already raised on THIS context's device: the attribute is per
+  // device, so the bookkeeping lives here and not in process-wide statics
+  static constexpr int kLdsSlots = 48;
+  struct LdsCap {
+    const void* fn = nullptr;
+    size_t bytes = 0;
+  } lds_caps[kLdsSlots];
+  // second stream + events of the block-pipelined TOD synthesis (mrx_atm_tod), made on demand
+  hipStream_t side_stream = nullptr;
+  static constexpr int kPipeEvents = 34;
+  hipEvent_t pipe_ev[kPipeEvents] = {nullptr};
 };
 
 inline int mrx_fail(mrx_ctx* ctx, int code, const char* fmt, ...) {
@@ -73,6 +84,44 @@ inline int mrx_fail(mrx_ctx* ctx, int code, const char* fmt, ...) {
     if (e__ != hipSuccess)                                                   \
       return mrx_fail((ctx), MRX_ERR_HIP, "kernel launch failed: %s (%s:%d)", \
                       hipGetErrorString(e__), __FILE__, __LINE__);           \
+  } while (0)
+
+// Entry points that launch or allocate run on the context's own device, whatever the
+// calling thread's current device is; the caller's device is restored on return.
+struct mrx_device_guard {
+  int prev = -1;
+  explicit mrx_device_guard(const mrx_ctx* ctx) {
+    if (ctx && hipGetDevice(&prev) == hipSuccess && prev != ctx->device)
+      (void)hipSetDevice(ctx->device);
+    else
+      prev = -1;
+  }
+  ~mrx_device_guard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+#define MRX_ENTER(ctx) mrx_device_guard mrx_guard__(ctx)
+
+// Raise kernel `fn`'s dynamic-LDS cap to at least `bytes` on the context's device, once.
+inline int mrx_lds_cap(mrx_ctx* ctx, const void* fn, size_t bytes) {
+  if (bytes <= 64 * 1024) return MRX_OK;  // the default cap
+  mrx_ctx::LdsCap* slot = nullptr;
+  for (auto& c : ctx->lds_caps) {
+    if (c.fn == fn) { slot = &c; break; }
+    if (!c.fn && !slot) slot = &c;
+  }
+  if (slot && slot->fn == fn && slot->bytes >= bytes) return MRX_OK;
+  MRX_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  if (slot) {
+    slot->fn = fn;
+    slot->bytes = bytes;
+  }
+  return MRX_OK;
+}
+#define MRX_LDS_CAP(ctx, kernel, bytes)                                                    \
+  do {                                                                                     \
+    int rc__ = mrx_lds_cap((ctx), reinterpret_cast<const void*>(kernel), (size_t)(bytes)); \
+    if (rc__ != MRX_OK) return rc__;                                                       \
   } while (0)
 
 static inline int mrx_ceil_div(long long a, long long b) {

@@ -520,6 +520,7 @@ int mrx_map_sample(mrx_ctx* ctx, const mrx_sky_map* map, const mrx_map_cal* cal,
                    const float* d_az, const float* d_el, int T, const double* d_transform,
                    const float* d_dx, const float* d_dy, const double* d_stokes_w, int D,
                    float* d_out, size_t ld_out) {
+  MRX_ENTER(ctx);
   if (!ctx) return MRX_ERR_INVALID;
   MRX_REQUIRE(ctx, D >= 0 && T >= 0, "negative size");
   if (D == 0 || T == 0) return MRX_OK;
@@ -613,6 +614,7 @@ int mrx_bin_map(mrx_ctx* ctx, const mrx_sky_map* map, const float* d_tod, size_t
                 const double* d_transform, const float* d_dx, const float* d_dy,
                 const double* d_stokes_w, const int32_t* d_channel, int D, double* d_sum,
                 double* d_wgt) {
+  MRX_ENTER(ctx);
   if (!ctx) return MRX_ERR_INVALID;
   MRX_REQUIRE(ctx, D >= 0 && T >= 0, "negative size");
   if (D == 0 || T == 0) return MRX_OK;

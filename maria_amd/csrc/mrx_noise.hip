@@ -49,7 +49,6 @@
 
 #include "mrx_spectral.h"
 
-#include <set>
 
 namespace {
 
@@ -537,6 +536,7 @@ int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T
                        const float* d_loading, size_t ld_loading, double per_loading,
                        float* d_out, size_t ld_out, int accumulate,
                        float* d_work, size_t work_floats) {
+  MRX_ENTER(ctx);
   if (!ctx) return MRX_ERR_INVALID;
   MRX_REQUIRE(ctx, D >= 0 && T >= 0, "negative size");
   if (D == 0 || T == 0) return MRX_OK;
@@ -601,18 +601,10 @@ int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T
   const size_t lds1 = (size_t)(2 * n2 + n2 / 4) * sizeof(float2);
   const size_t lds2 = (size_t)(2 * kTileCells + n1 / 4) * sizeof(float2);
   const SpectrumKernel pass1 = spectrum_kernel(n2, n_modes);
-  // every instantiation is sized for the longest first transform once
-  static std::set<const void*> sized;
-  if (sized.insert(reinterpret_cast<const void*>(pass1)).second)
-    MRX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(pass1),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize,
-                                     (int)((2 * 8192 + 8192 / 4) * sizeof(float2))));
-  static size_t cap2 = 0;
-  if (lds2 > cap2) {
-    MRX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(noise_fft_combine),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
-    cap2 = lds2;
-  }
+  // every instantiation is sized for the longest first transform once (per context: the
+  // attribute belongs to the device)
+  MRX_LDS_CAP(ctx, pass1, (2 * 8192 + 8192 / 4) * sizeof(float2));
+  MRX_LDS_CAP(ctx, noise_fft_combine, lds2);
 
   SpectrumArgs sp{};
   sp.knee = (float)knee;
@@ -666,6 +658,7 @@ int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T
 
 int mrx_fft_rows(mrx_ctx* ctx, const float* d_in, int rows, int n, int interleave_log2,
                  float* d_out) {
+  MRX_ENTER(ctx);
   if (!ctx) return MRX_ERR_INVALID;
   const int l = ilog2(n);
   if (ctx && interleave_log2 == -1) {  // the register transform: n must be 64
@@ -679,12 +672,7 @@ int mrx_fft_rows(mrx_ctx* ctx, const float* d_in, int rows, int n, int interleav
   const size_t cells = (size_t)n << interleave_log2;
   MRX_REQUIRE(ctx, cells <= 8192, "at most 8192 complex values per row");
   const size_t lds = (2 * cells + n / 4) * sizeof(float2);
-  static size_t cap = 0;
-  if (lds > cap) {
-    MRX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(fft_rows_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    cap = lds;
-  }
+  MRX_LDS_CAP(ctx, fft_rows_kernel, lds);
   hipLaunchKernelGGL(fft_rows_kernel, dim3(rows), dim3(kBlock), lds, ctx->stream,
                      reinterpret_cast<const float2*>(d_in), reinterpret_cast<float2*>(d_out), n, l,
                      interleave_log2);

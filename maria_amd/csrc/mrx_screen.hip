@@ -179,6 +179,7 @@ extern "C" {
 
 int mrx_screen_psd_sum(mrx_ctx* ctx, int ny, int nx, double dy, double dx,
                        double r0, double nu, double* host_sum) {
+  MRX_ENTER(ctx);
   if (!ctx || !host_sum) return MRX_ERR_INVALID;
   MRX_REQUIRE(ctx, ny > 0 && nx > 0 && dy > 0 && dx > 0 && r0 > 0 && nu > 0,
               "sizes, steps, r0 and nu must be positive");
@@ -194,6 +195,7 @@ int mrx_screen_psd_sum(mrx_ctx* ctx, int ny, int nx, double dy, double dx,
 int mrx_screen_generate(mrx_ctx* ctx, uint64_t seed, uint32_t stream, int ny,
                         int nx, double dy, double dx, double r0, double nu,
                         float* d_out, float* d_work) {
+  MRX_ENTER(ctx);
   if (!ctx) return MRX_ERR_INVALID;
   MRX_REQUIRE(ctx, d_out && d_work, "null pointer");
   MRX_REQUIRE(ctx, dy > 0 && dx > 0 && r0 > 0 && nu > 0,
@@ -246,6 +248,7 @@ int mrx_screen_generate(mrx_ctx* ctx, uint64_t seed, uint32_t stream, int ny,
 
 int mrx_philox_normal(mrx_ctx* ctx, uint64_t seed, uint32_t stream, size_t n,
                       float* d_out) {
+  MRX_ENTER(ctx);
   if (!ctx) return MRX_ERR_INVALID;
   MRX_REQUIRE(ctx, d_out != nullptr || n == 0, "null pointer");
   if (n == 0) return MRX_OK;

@@ -271,7 +271,6 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_kernel(
   // detectors in a locality order and still get the TOD in its own row order
   auto row_of = [&](int d) -> size_t { return rows ? (size_t)rows[d] : (size_t)d; };
   __shared__ float2 tile[kTileDet * kPitch];
-
   const int s_tile = blockIdx.x * kTileSamples;
   const int sb = s_tile + threadIdx.x * kSamplesPerThread;
 
@@ -763,6 +762,7 @@ extern "C" {
 
 int mrx_spline_prepare(mrx_ctx* ctx, const float* d_y, int D, int Ta,
                        float* d_ym) {
+  MRX_ENTER(ctx);
   if (!ctx) return MRX_ERR_INVALID;
   MRX_REQUIRE(ctx, D >= 0, "negative D");
   if (D == 0) return MRX_OK;
@@ -783,6 +783,7 @@ int mrx_spline_upsample(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
                         double ta0, double dta, const double* d_t, int T,
                         const float* d_scale, const int32_t* d_rows,
                         float* d_out, size_t ld_out) {
+  MRX_ENTER(ctx);
   if (!ctx) return MRX_ERR_INVALID;
   MRX_REQUIRE(ctx, D >= 0 && T >= 0, "negative size");
   if (D == 0 || T == 0) return MRX_OK;
@@ -832,6 +833,7 @@ int mrx_spline_upsample_krj(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
                             const float* d_cal_axis_el,
                             const float* d_cal_values, int n_el, int n_bands,
                             float* d_out, size_t ld_out) {
+  MRX_ENTER(ctx);
   if (!ctx) return MRX_ERR_INVALID;
   MRX_REQUIRE(ctx, D >= 0 && T >= 0, "negative size");
   if (D == 0 || T == 0) return MRX_OK;
@@ -894,6 +896,7 @@ int mrx_tod_to_krj(mrx_ctx* ctx, float* d_data, size_t ld, int D, int T,
                    const float* d_bore_el, const float* d_dx, const float* d_dy,
                    const int32_t* d_band, const float* d_cal_axis_el,
                    const float* d_cal_values, int n_el, int n_bands) {
+  MRX_ENTER(ctx);
   return tod_convert(ctx, false, d_data, ld, D, T, d_scale, d_rows, d_bore_el, d_dx, d_dy, d_band,
                      d_cal_axis_el, d_cal_values, n_el, n_bands);
 }
@@ -903,6 +906,7 @@ int mrx_tod_from_krj(mrx_ctx* ctx, float* d_data, size_t ld, int D, int T,
                      const float* d_bore_el, const float* d_dx, const float* d_dy,
                      const int32_t* d_band, const float* d_cal_axis_el,
                      const float* d_cal_values, int n_el, int n_bands) {
+  MRX_ENTER(ctx);
   return tod_convert(ctx, true, d_data, ld, D, T, d_scale, d_rows, d_bore_el, d_dx, d_dy, d_band,
                      d_cal_axis_el, d_cal_values, n_el, n_bands);
 }
@@ -910,6 +914,7 @@ int mrx_tod_from_krj(mrx_ctx* ctx, float* d_data, size_t ld, int D, int T,
 int mrx_pointing_broadcast(mrx_ctx* ctx, const float* d_az, const float* d_el,
                            int T, const float* d_dx, const float* d_dy, int D,
                            float* d_az_out, float* d_el_out, size_t ld_out) {
+  MRX_ENTER(ctx);
   if (!ctx) return MRX_ERR_INVALID;
   MRX_REQUIRE(ctx, D >= 0 && T >= 0, "negative size");
   if (D == 0 || T == 0) return MRX_OK;
@@ -931,6 +936,7 @@ int mrx_pointing_broadcast(mrx_ctx* ctx, const float* d_az, const float* d_el,
 int mrx_linear_upsample(mrx_ctx* ctx, const double* d_pwv, int D, int Ta,
                         double ta0, double dta, const double* d_t, int T,
                         float* d_out, size_t ld_out) {
+  MRX_ENTER(ctx);
   if (!ctx) return MRX_ERR_INVALID;
   MRX_REQUIRE(ctx, D >= 0 && T >= 0, "negative size");
   if (D == 0 || T == 0) return MRX_OK;

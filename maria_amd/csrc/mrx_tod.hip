@@ -218,6 +218,7 @@ extern "C" {
 
 int mrx_tod_detrend_window(mrx_ctx* ctx, float* d_data, size_t ld, int D, int T, int remove_slope,
                            const double* d_window, double* d_work) {
+  MRX_ENTER(ctx);
   if (!ctx) return MRX_ERR_INVALID;
   MRX_REQUIRE(ctx, D >= 0 && T >= 0, "negative size");
   if (D == 0 || T == 0 || (!remove_slope && !d_window)) return MRX_OK;
@@ -243,6 +244,7 @@ int mrx_sosfilt_work_doubles(int D, int T, int n_sections, size_t* doubles) {
 int mrx_sosfilt(mrx_ctx* ctx, const double* sos, int n_sections, const double* d_chunk_matrix,
                 const float* d_in, size_t ld_in, int D, int T, int remove_slope, float* d_out,
                 size_t ld_out, double* d_work) {
+  MRX_ENTER(ctx);
   if (!ctx) return MRX_ERR_INVALID;
   MRX_REQUIRE(ctx, D >= 0 && T >= 0, "negative size");
   if (D == 0 || T == 0) return MRX_OK;
