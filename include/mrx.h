@@ -289,15 +289,44 @@ int mrx_map_smooth(mrx_ctx* ctx, const float* d_data, const float* d_weight,
                    float* d_out, float* d_denom_out, float* d_tmp, int ny,
                    int nx, double sigma_y, double sigma_x);
 
-/* Turbulent screen generator: Philox-4x32-10 normals in k space, times the
- * square root of the Matern / von Karman spectrum
+/* Turbulent screen generator: Philox-4x32-10 normals on the Hermitian half of k
+ * space, times the square root of the Matern / von Karman spectrum
  *     PSD(k) ~ (k0^2 + |k|^2)^-(nu + 1),  k0 = sqrt(2 nu)/r0
  * (functions/__init__.py:30-39 is the covariance this is the transform of),
- * then a 2-D inverse FFT; the real part, scaled to unit variance, is the
- * screen.  Replaces the autoregressive generator (atmosphere/process.py:191-209)
- * with a different algorithm of the same target covariance; parity is
- * statistical.  ny, nx powers of two in [64, 8192].
- *  d_work: 2*ny*nx float2 of scratch.  d_out [ny][nx] f32. */
+ * then a 2-D complex-to-real inverse FFT scaled to unit variance.  Replaces the
+ * autoregressive generator (atmosphere/process.py:191-209) with a different
+ * algorithm of the same target covariance; parity is statistical.
+ * Spectrum cell (ky, kx), 0 <= kx <= nx/2, is amp(k) (a + i b)/sqrt 2 with (a, b) the
+ * Box-Muller pair of Philox words (0,1) [ky < ny/2] or (2,3) [ky >= ny/2] of
+ * counter (kx, ky mod ny/2, stream, 0), key = seed; the columns kx = 0 and nx/2 are
+ * made Hermitian in ky from their cells ky < ny/2 (cells ky = 0, ny/2: amp a).
+ * ny, nx powers of two in [64, 8192].
+ *
+ * mrx_screen_generate_batch makes n_screens screens that share one FFT domain (the
+ * layers of an atmosphere) in two launches, with the beam smoothing of
+ * atmosphere/atmosphere.py:341-344 (scipy.ndimage.gaussian_filter: reflect, truncate 4)
+ * folded in: along y on the half spectra between the two FFT passes, along x on the
+ * finished row; float32 accumulation (equal to mrx_gauss_smooth2d of the unsmoothed
+ * screen to ~1e-6 of its rms).  Only the top-left out_ny x out_nx block of the
+ * periodic domain is smoothed and written (reflection at ITS edges): a layer may use a
+ * larger FFT domain than its grid so that opposite edges decorrelate. */
+typedef struct mrx_screen_desc {
+  float* d_out;            /* [out_ny][ld_out] f32                                  */
+  uint32_t stream;         /* Philox stream of this screen (the layer index)        */
+  int32_t out_ny, out_nx;  /* written block; 0 = the whole domain                   */
+  int32_t reserved;
+  size_t ld_out;           /* row pitch in floats; 0 = out_nx                        */
+  double dy, dx;           /* grid steps (m)                                         */
+  double r0, nu;           /* outer scale (m), Matern smoothness                     */
+  double sigma_y, sigma_x; /* beam sigma in pixels along y / x; 0 = no smoothing     */
+} mrx_screen_desc;
+/* floats of scratch for n_screens screens: 2 * n_screens * (nx/2 + 1) * (ny + 16) */
+int mrx_screen_work_floats(int ny, int nx, int n_screens, size_t* floats);
+int mrx_screen_generate_batch(mrx_ctx* ctx, uint64_t seed, int ny, int nx,
+                              const mrx_screen_desc* screens, int n_screens,
+                              float* d_work, size_t work_floats);
+/* One unsmoothed screen over the whole domain.  d_work: mrx_screen_work_floats(ny, nx, 1)
+ * floats (a buffer of 2*ny*nx float2, the size earlier versions asked for, is ample). */
 int mrx_screen_generate(mrx_ctx* ctx, uint64_t seed, uint32_t stream, int ny,
                         int nx, double dy, double dx, double r0, double nu,
                         float* d_out, float* d_work);

@@ -77,6 +77,25 @@ class MrxBandTable(C.Structure):
     ]
 
 
+class MrxScreenDesc(C.Structure):
+    """``mrx_screen_desc`` (include/mrx.h)."""
+
+    _fields_ = [
+        ("d_out", C.c_void_p),
+        ("stream", C.c_uint32),
+        ("out_ny", C.c_int32),
+        ("out_nx", C.c_int32),
+        ("reserved", C.c_int32),
+        ("ld_out", C.c_size_t),
+        ("dy", C.c_double),
+        ("dx", C.c_double),
+        ("r0", C.c_double),
+        ("nu", C.c_double),
+        ("sigma_y", C.c_double),
+        ("sigma_x", C.c_double),
+    ]
+
+
 class MrxSkyMap(C.Structure):
     """``mrx_sky_map`` (include/mrx.h)."""
 
@@ -145,6 +164,8 @@ SIGNATURES = {
     "mrx_gauss_smooth2d": (_i, [_vp, _vp, _vp, _vp, _i, _i, _d, _d, _d]),
     "mrx_map_smooth": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _d]),
     "mrx_screen_generate": (_i, [_vp, C.c_uint64, C.c_uint32, _i, _i, _d, _d, _d, _d, _vp, _vp]),
+    "mrx_screen_work_floats": (_i, [_i, _i, _i, C.POINTER(_sz)]),
+    "mrx_screen_generate_batch": (_i, [_vp, C.c_uint64, _i, _i, C.POINTER(MrxScreenDesc), _i, _vp, _sz]),
     "mrx_screen_psd_sum": (_i, [_vp, _i, _i, _d, _d, _d, _d, C.POINTER(_d)]),
     "mrx_map_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _sz]),
     "mrx_bin_map": (_i, [_vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),

@@ -43,6 +43,8 @@ int mrx_destroy(mrx_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   for (auto& slot : ctx->taps)
     if (slot.d_taps) (void)hipFree(slot.d_taps);
+  for (auto& slot : ctx->ftaps)
+    if (slot.d_taps) (void)hipFree(slot.d_taps);
   if (ctx->d_reduce) (void)hipFree(ctx->d_reduce);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);

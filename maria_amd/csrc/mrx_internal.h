@@ -29,6 +29,13 @@ struct mrx_ctx {
     double* d_taps = nullptr;
   } taps[kTapSlots];
   int taps_next = 0;
+  // float32 taps of the fused screen smoothing, zero-padded to a fixed length
+  struct FTapSlot {
+    double sigma = -1.0;
+    int radius = 0;
+    float* d_taps = nullptr;
+  } ftaps[kTapSlots];
+  int ftaps_next = 0;
   int options[MRX_OPT_COUNT] = {0};
   // screen normalisations (sum of the PSD over the FFT grid), one device double
   // per distinct (grid, spectrum)

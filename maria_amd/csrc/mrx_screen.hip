@@ -1,19 +1,30 @@
-// Turbulent screen generator for gfx950: Philox-4x32-10 complex normals in
-// k space x sqrt(von Karman / Matern PSD) -> 2-D inverse FFT -> real part.
+// Turbulent screen generator for gfx950: Philox-4x32-10 normals on the Hermitian
+// half of k space x sqrt(von Karman / Matern PSD) -> 2-D complex-to-real inverse FFT,
+// with the Gaussian beam smoothing folded into the two FFT passes.
 //
 // Replaces the reference's autoregressive generator
 // (atmosphere/process.py:111-209) by a spectral one with the same target
 // covariance, Matern(nu, r0) (functions/__init__.py:30-39): in two dimensions
 // its spectrum is PSD(k) ~ (k0^2 + |k|^2)^-(nu+1), k0 = sqrt(2 nu)/r0.
 //
-// Passes (ny rows, nx columns, both powers of two):
-//   1. one workgroup per kx: draw S[ky][kx] for all ky straight into LDS,
-//      inverse FFT along y                       -> work1[kx][y]
-//   2. LDS-tiled transpose                        -> work2[y][kx]
-//   3. one workgroup per y: inverse FFT along x, keep the real part, scale to
-//      unit variance                              -> out[y][x]
+// A real field needs only the columns kx = 0 .. nx/2 of its spectrum H
+// (H[-ky][-kx] = conj H[ky][kx]); the two passes (ny rows, nx columns, powers of two):
+//   1. one workgroup per (kx, layer): draw H[.][kx] straight into LDS (interior
+//      columns: independent complex normals / sqrt 2; the columns kx = 0 and nx/2 are
+//      Hermitian in ky), inverse FFT along y, optional Gaussian along y (linear in y,
+//      so it commutes with the x transform still to come)   -> G[kx][y]
+//   2. one workgroup per (block of 2^LJ rows, layer): gathers the rows' half spectra
+//      (the only transposed access: 8 << LJ bytes per kx, neighbouring row blocks on the
+//      same XCD so that they share the fetched lines in its L2), folds them into an
+//      nx/2-point complex sequence, one batched inverse FFT gives (even, odd) samples,
+//      optional Gaussian along x on the real row in LDS, scale to unit variance
+//                                                           -> out[y][x]
+// Per pixel: 4 B written + 4 B read (G) + 4 B written (screen) against 53 B for the
+// full-spectrum form with its transpose and the two separate stencil passes.
 // The random number of spectrum cell (kx, ky) depends only on (seed, stream,
 // kx, ky), so every GPU regenerates bit-identical screens with no broadcast.
+#include <cmath>
+
 #include "mrx_internal.h"
 
 #include "mrx_spectral.h"
@@ -21,6 +32,12 @@
 namespace {
 
 using namespace mrx_dev;
+
+constexpr int kMaxBatch = 16;         // layers per launch
+// G[kx][.] rows are ny + kPitchPad complex apart: pass 2 walks kx at fixed y, and a power-of-two
+// stride of 8 ny bytes would put every access of that walk on the same memory channel
+constexpr int kPitchPad = 16;
+constexpr int kMaxFusedRadius = 128;  // Gaussian taps kept in LDS by the fused passes
 
 // sqrt of the von Karman / Matern spectrum: (k0^2 + |k|^2)^expo via exp2/log2
 __device__ __forceinline__ float spectrum_amp(double k2, float expo) {
@@ -32,70 +49,269 @@ __device__ __forceinline__ double wavenumber(int i, int n, double d) {
   return 6.283185307179586476925 * (double)s / ((double)n * d);
 }
 
+struct ScreenLayerArgs {
+  float2* work;           // [nx/2 + 1][ny]
+  float* out;             // [out_ny][ld_out]
+  const double* psd_sum;  // device scalar: sum of the PSD over the grid
+  const float* taps_y;    // [kMaxFusedRadius + 1] normalised Gaussian taps, zero beyond the radius
+  const float* taps_x;
+  double dy, dx, k0sq;
+  unsigned long long ld_out;
+  float expo;
+  int ry, rx;                    // stencil radii, 0 = no smoothing along that axis
+  int out_ny, out_nx;            // the written top-left block of the periodic domain
+  uint32_t stream;
+};
 
-// pass 1: spectrum column kx, all ky; FFT along y
-__global__ __launch_bounds__(kBlock) void screen_spectrum_fft_y(
-    float2* __restrict__ work1, int ny, int nx, int log2ny, double dy,
-    double dx, double k0sq, float expo, uint32_t key0, uint32_t key1,
-    uint32_t stream) {
-  extern __shared__ float2 lds2[];
+struct ScreenBatchArgs {
+  ScreenLayerArgs l[kMaxBatch];
+};
+
+// scipy.ndimage "reflect" (d c b a | a b c d | d c b a), any distance
+__device__ __forceinline__ int reflect_index(int i, int n) {
+  if (i < 0) i = -i - 1;
+  if (i >= n) i = 2 * n - 1 - i;
+  if ((unsigned)i >= (unsigned)n) {  // a radius beyond the line's length: several reflections
+    const int period = 2 * n;
+    i %= period;
+    if (i < 0) i += period;
+    i = i < n ? i : period - 1 - i;
+  }
+  return i;
+}
+
+// Gaussian stencil along a line held in LDS, scipy.ndimage semantics (reflect at the ends of
+// the n written samples).  Radii up to kFastRadius (every beam the reference's grid rule allows:
+// res >= fwhm/10, atmosphere/extrusion.py:56-60, gives sigma <= 4.25 pixels, radius 17) take
+// the register-window form: a thread owns a few consecutive outputs, pulls their whole
+// neighbourhood with 16-byte LDS reads and runs the symmetric taps (wave-uniform, from
+// scalar loads) over registers -- 3x fewer LDS bytes than one read per tap.  Threads whose
+// window would cross an end, and wider beams, take the plain loop.
+constexpr int kFastRadius = 20;
+
+// the first kFastRadius + 1 taps as wave-uniform values (SGPRs)
+__device__ __forceinline__ void uniform_taps(const float* __restrict__ taps, float (&tp)[kFastRadius + 1]) {
+#pragma unroll
+  for (int k = 0; k <= kFastRadius; ++k)
+    tp[k] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, taps[k])));
+}
+
+__device__ __forceinline__ float smooth_real_at(const float* row, int x, int n, int r,
+                                                const float* __restrict__ taps) {
+  float acc = taps[0] * row[x];
+  for (int k = 1; k <= r; ++k)
+    acc = fmaf(taps[k], row[reflect_index(x - k, n)] + row[reflect_index(x + k, n)], acc);
+  return acc;
+}
+
+__device__ __forceinline__ float2 smooth_complex_at(const float2* col, int y, int n, int r,
+                                                    const float* __restrict__ taps) {
+  float2 acc = col[y];
+  acc.x *= taps[0];
+  acc.y *= taps[0];
+  for (int k = 1; k <= r; ++k) {
+    const float2 a = col[reflect_index(y - k, n)], b = col[reflect_index(y + k, n)];
+    acc.x = fmaf(taps[k], a.x + b.x, acc.x);
+    acc.y = fmaf(taps[k], a.y + b.y, acc.y);
+  }
+  return acc;
+}
+
+// pass 1: spectrum column kx of one layer, all ky; inverse FFT along y; Gaussian along y
+__global__ __launch_bounds__(kBlock) void screen_half_spectrum_fft_y(
+    const ScreenBatchArgs args, int ny, int nx, int log2ny, uint32_t key0, uint32_t key1) {
+  extern __shared__ __align__(16) float2 lds2[];
+  const ScreenLayerArgs& L = args.l[blockIdx.y];
   float2* data = lds2;
   float2* tw = lds2 + 2 * ny;
-  const int ix = blockIdx.x;
-  const double kx = wavenumber(ix, nx, dx);
+  const int ix = blockIdx.x;  // 0 .. nx/2
+  const double kx = wavenumber(ix, nx, L.dx);
+  const bool edge = ix == 0 || 2 * ix == nx;
   fill_twiddles(tw, ny);
   // one Philox call feeds two cells: words (x, y) -> ky index iy, (z, w) -> iy + ny/2
   const int half = ny >> 1;
+  constexpr float kRoot = 0.70710678118654752f;
   for (int iy = threadIdx.x; iy < half; iy += kBlock) {
-    const U4 rnd = philox4x32_10(U4{(uint32_t)ix, (uint32_t)iy, stream, 0u},
-                                 key0, key1);
-    const double ky0 = wavenumber(iy, ny, dy), ky1 = wavenumber(iy + half, ny, dy);
-    const float amp0 = spectrum_amp(k0sq + kx * kx + ky0 * ky0, expo);
-    const float amp1 = spectrum_amp(k0sq + kx * kx + ky1 * ky1, expo);
+    const U4 rnd = philox4x32_10(U4{(uint32_t)ix, (uint32_t)iy, L.stream, 0u}, key0, key1);
+    const double ky0 = wavenumber(iy, ny, L.dy), ky1 = wavenumber(iy + half, ny, L.dy);
+    const float amp0 = spectrum_amp(L.k0sq + kx * kx + ky0 * ky0, L.expo);
+    const float amp1 = spectrum_amp(L.k0sq + kx * kx + ky1 * ky1, L.expo);
     const float2 g0 = box_muller(rnd.x, rnd.y), g1 = box_muller(rnd.z, rnd.w);
-    data[iy] = make_float2(amp0 * g0.x, amp0 * g0.y);
-    data[iy + half] = make_float2(amp1 * g1.x, amp1 * g1.y);
+    if (!edge) {
+      data[iy] = make_float2(kRoot * amp0 * g0.x, kRoot * amp0 * g0.y);
+      data[iy + half] = make_float2(kRoot * amp1 * g1.x, kRoot * amp1 * g1.y);
+    } else if (iy == 0) {
+      // the four self-conjugate cells are real
+      data[0] = make_float2(amp0 * g0.x, 0.0f);
+      data[half] = make_float2(amp1 * g1.x, 0.0f);
+    } else {
+      // kx = 0 and kx = nx/2 are their own mirror columns: Hermitian in ky
+      const float2 h = make_float2(kRoot * amp0 * g0.x, kRoot * amp0 * g0.y);
+      data[iy] = h;
+      data[ny - iy] = make_float2(h.x, -h.y);
+    }
   }
   __syncthreads();
   const float2* res = fft_lds_inverse(data, data + ny, tw, ny, log2ny);
-  float2* dst = work1 + (size_t)ix * ny;
-  for (int y = threadIdx.x; y < ny; y += kBlock) dst[y] = res[y];
+  float2* dst = L.work + (size_t)ix * (ny + kPitchPad);
+  if (L.ry > 0) {
+    // scipy.ndimage.gaussian_filter along axis 0 of the written block (reflect at its edges)
+    const int r = L.ry, n = L.out_ny;
+    const float* __restrict__ taps = L.taps_y;
+    if (r <= kFastRadius) {
+      constexpr int R = kFastRadius;
+      float tp[R + 1];
+      uniform_taps(taps, tp);
+      for (int y0 = 2 * threadIdx.x; y0 < n; y0 += 2 * kBlock) {
+        float2 win[2 + 2 * R];
+        if (y0 >= R && y0 + 2 + R <= n) {
+          const float4* wp = reinterpret_cast<const float4*>(res + (y0 - R));
+#pragma unroll
+          for (int j = 0; j < 1 + R; ++j) {
+            const float4 q = wp[j];
+            win[2 * j] = make_float2(q.x, q.y);
+            win[2 * j + 1] = make_float2(q.z, q.w);
+          }
+        } else {  // the window crosses an end of the column: gather it through the reflection
+#pragma unroll
+          for (int j = 0; j < 2 + 2 * R; ++j) win[j] = res[reflect_index(y0 - R + j, n)];
+        }
+        float2 acc[2];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) acc[v] = make_float2(tp[0] * win[R + v].x, tp[0] * win[R + v].y);
+#pragma unroll
+        for (int k = 1; k <= R; ++k) {
+          const float w = tp[k];
+#pragma unroll
+          for (int v = 0; v < 2; ++v) {
+            acc[v].x = fmaf(w, win[R + v - k].x + win[R + v + k].x, acc[v].x);
+            acc[v].y = fmaf(w, win[R + v - k].y + win[R + v + k].y, acc[v].y);
+          }
+        }
+        if (y0 + 2 <= n) {
+          *reinterpret_cast<float4*>(dst + y0) = make_float4(acc[0].x, acc[0].y, acc[1].x, acc[1].y);
+        } else {
+          dst[y0] = acc[0];
+        }
+      }
+    } else {
+      for (int y = threadIdx.x; y < n; y += kBlock) dst[y] = smooth_complex_at(res, y, n, r, taps);
+    }
+  } else {
+    for (int y = threadIdx.x; y < L.out_ny; y += kBlock) dst[y] = res[y];
+  }
 }
 
-// pass 2: transpose [rows][cols] -> [cols][rows], 32x32 tiles, padded LDS
-__global__ __launch_bounds__(kBlock) void transpose_c32(
-    const float2* __restrict__ in, float2* __restrict__ out, int rows,
-    int cols) {
-  __shared__ float2 tile[32][33];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
-  const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
-  for (int k = ty; k < 32; k += 8) {
-    const int r = r0 + k, c = c0 + tx;
-    if (r < rows && c < cols) tile[k][tx] = in[(size_t)r * cols + c];
-  }
-  __syncthreads();
-  for (int k = ty; k < 32; k += 8) {
-    const int c = c0 + k, r = r0 + tx;
-    if (r < rows && c < cols) out[(size_t)c * rows + r] = tile[tx][k];
-  }
-}
+// pass 2: 2^LJ rows of one layer: fold the half spectra, batched inverse FFT of length
+// nx/2, Gaussian along x, unit-variance scale
+template <int LJ>
+__global__ __launch_bounds__(kBlock) void screen_c2r_x(const ScreenBatchArgs args, int ny, int nx,
+                                                       int log2n2) {
+  extern __shared__ __align__(16) float2 lds2[];
+  constexpr int B = 1 << LJ;
+  const ScreenLayerArgs& L = args.l[blockIdx.y];
+  const int n2 = nx >> 1;
+  const int cells = n2 << LJ;
+  float2* imgA = lds2;
+  float2* imgB = lds2 + cells;
+  float2* tw_full = lds2 + 2 * cells;  // exp(2 pi i m / nx), m < nx/4
+  float2* tw_half = tw_full + nx / 4;  // exp(2 pi i m / n2), m < n2/4
+  float2* nyq = tw_half + n2 / 4;      // [B]
 
-// pass 3: FFT along x of row y; real part * norm
-__global__ __launch_bounds__(kBlock) void screen_fft_x_real(
-    const float2* __restrict__ work2, float* __restrict__ out, int ny, int nx,
-    int log2nx, const double* __restrict__ psd_sum) {
-  extern __shared__ float2 lds2[];
-  float2* data = lds2;
-  float2* tw = lds2 + 2 * nx;
-  const int y = blockIdx.x;
-  fill_twiddles(tw, nx);
-  const float2* src = work2 + (size_t)y * nx;
-  for (int x = threadIdx.x; x < nx; x += kBlock) data[x] = src[x];
+  // row blocks that share the 128-byte lines of G (16 consecutive y) run on one XCD:
+  // workgroups b and b + 8 share an XCD, so XCD x takes a contiguous range of blocks
+  const int nblocks = gridDim.x;
+  int yb = blockIdx.x;
+  if ((nblocks & 7) == 0) yb = (blockIdx.x & 7) * (nblocks >> 3) + (blockIdx.x >> 3);
+  const int y0 = yb << LJ;
+  const size_t pitch = (size_t)ny + kPitchPad;
+
+  fill_twiddles(tw_full, nx);
+  fill_twiddles(tw_half, n2);
+  for (int idx = threadIdx.x; idx < cells; idx += kBlock) {
+    const int k = idx >> LJ, y = y0 + (idx & (B - 1));
+    imgA[idx] = y < L.out_ny ? L.work[(size_t)k * pitch + y] : make_float2(0.f, 0.f);
+  }
+  if ((int)threadIdx.x < B) {
+    const int y = y0 + threadIdx.x;
+    nyq[threadIdx.x] = y < L.out_ny ? L.work[(size_t)n2 * pitch + y] : make_float2(0.f, 0.f);
+  }
   __syncthreads();
-  const float2* res = fft_lds_inverse(data, data + nx, tw, nx, log2nx);
-  const float norm = (float)(1.0 / sqrt(*psd_sum));
-  float* dst = out + (size_t)y * nx;
-  for (int x = threadIdx.x; x < nx; x += kBlock) dst[x] = res[x].x * norm;
+  // x[2n] + i x[2n+1] = IFFT_{n2}(Z),  Z[k] = (X[k] + conj X[n2-k]) + i w^k (X[k] - conj X[n2-k])
+  for (int idx = threadIdx.x; idx < cells; idx += kBlock) {
+    const int k = idx >> LJ, b = idx & (B - 1);
+    float2 xk = imgA[idx], xm;
+    if (k == 0) {
+      xk.y = 0.0f;  // G[0][y] and G[nx/2][y] are real up to rounding
+      xm = make_float2(nyq[b].x, 0.0f);
+    } else {
+      xm = imgA[((n2 - k) << LJ) | b];
+    }
+    const float2 e = make_float2(xk.x + xm.x, xk.y - xm.y);
+    const float2 o = cmul(make_float2(xk.x - xm.x, xk.y + xm.y), tw_at(tw_full, k, nx >> 2));
+    imgB[idx] = make_float2(e.x - o.y, e.y + o.x);
+  }
+  __syncthreads();
+  float2* res = fft_lds_inverse_batched(imgB, imgA, tw_half, n2, log2n2, LJ);
+  // de-interleave into contiguous real rows in the other image (pitch nx floats)
+  float* rows = reinterpret_cast<float*>(res == imgA ? imgB : imgA);
+  for (int idx = threadIdx.x; idx < cells; idx += kBlock) {
+    const int n = idx >> LJ, b = idx & (B - 1);
+    *reinterpret_cast<float2*>(rows + (size_t)b * nx + 2 * n) = res[idx];
+  }
+  __syncthreads();
+  const float norm = (float)(1.0 / sqrt(*L.psd_sum));
+  const int r = L.rx, nxo = L.out_nx;
+  const float* __restrict__ taps = L.taps_x;
+  const bool vec_ok = (L.ld_out & 3) == 0 && (reinterpret_cast<uintptr_t>(L.out) & 15) == 0;
+  float tp[kFastRadius + 1] = {0.0f};
+  if (r > 0 && r <= kFastRadius) uniform_taps(taps, tp);
+  for (int b = 0; b < B; ++b) {
+    const int y = y0 + b;
+    if (y >= L.out_ny) break;
+    const float* row = rows + (size_t)b * nx;
+    float* dst = L.out + (size_t)y * L.ld_out;
+    if (r > kFastRadius) {
+      for (int x = threadIdx.x; x < nxo; x += kBlock) dst[x] = norm * smooth_real_at(row, x, nxo, r, taps);
+      continue;
+    }
+    for (int x0 = 4 * threadIdx.x; x0 < nxo; x0 += 4 * kBlock) {
+      float o[4];
+      constexpr int R = kFastRadius;
+      if (r == 0) {
+        const float4 q = *reinterpret_cast<const float4*>(row + x0);
+        o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w;
+      } else {
+        float win[4 + 2 * R];
+        if (x0 >= R && x0 + 4 + R <= nxo) {
+          const float4* wp = reinterpret_cast<const float4*>(row + (x0 - R));
+#pragma unroll
+          for (int j = 0; j < 1 + R / 2; ++j) {
+            const float4 q = wp[j];
+            win[4 * j] = q.x; win[4 * j + 1] = q.y; win[4 * j + 2] = q.z; win[4 * j + 3] = q.w;
+          }
+        } else {  // the window crosses an end of the row: gather it through the reflection
+#pragma unroll
+          for (int j = 0; j < 4 + 2 * R; ++j) win[j] = row[reflect_index(x0 - R + j, nxo)];
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) o[v] = tp[0] * win[R + v];
+#pragma unroll
+        for (int k = 1; k <= R; ++k) {
+          const float w = tp[k];
+#pragma unroll
+          for (int v = 0; v < 4; ++v) o[v] = fmaf(w, win[R + v - k] + win[R + v + k], o[v]);
+        }
+      }
+      if (vec_ok && x0 + 4 <= nxo) {
+        *reinterpret_cast<float4*>(dst + x0) = make_float4(o[0] * norm, o[1] * norm, o[2] * norm, o[3] * norm);
+      } else {
+#pragma unroll
+        for (int v = 0; v < 4; ++v)
+          if (x0 + v < nxo) dst[x0 + v] = o[v] * norm;
+      }
+    }
+  }
 }
 
 // sum over the grid of amp^2 (what Var[real part] equals), float64
@@ -131,6 +347,35 @@ __global__ void philox_normal_kernel(float* __restrict__ out, size_t n,
   const U4 rnd = philox4x32_10(
       U4{(uint32_t)i, (uint32_t)(i >> 32), stream, 0u}, key0, key1);
   out[i] = box_muller(rnd.x, rnd.y).x;
+}
+
+// float32 Gaussian taps of scipy.ndimage._filters._gaussian_kernel1d (order 0, truncate 4),
+// normalised in float64, zero-padded to kMaxFusedRadius + 1 entries; cached per sigma
+int get_ftaps(mrx_ctx* ctx, double sigma, int radius, const float** d_out) {
+  for (auto& slot : ctx->ftaps)
+    if (slot.d_taps && slot.sigma == sigma && slot.radius == radius) {
+      *d_out = slot.d_taps;
+      return MRX_OK;
+    }
+  float w[kMaxFusedRadius + 1] = {0.0f};
+  double e[kMaxFusedRadius + 1], sum = 0.0;
+  for (int k = 0; k <= radius; ++k) {
+    e[k] = std::exp(-0.5 / (sigma * sigma) * (double)k * (double)k);
+    sum += k ? 2.0 * e[k] : e[k];
+  }
+  for (int k = 0; k <= radius; ++k) w[k] = (float)(e[k] / sum);
+  auto& slot = ctx->ftaps[ctx->ftaps_next];
+  ctx->ftaps_next = (ctx->ftaps_next + 1) % mrx_ctx::kTapSlots;
+  if (slot.d_taps)  // a kernel in flight may still read the evicted taps
+    MRX_HIP(ctx, hipDeviceSynchronize());
+  else
+    MRX_HIP(ctx, hipMalloc(&slot.d_taps, sizeof(w)));
+  MRX_HIP(ctx, hipMemcpyAsync(slot.d_taps, w, sizeof(w), hipMemcpyHostToDevice, ctx->stream));
+  MRX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // w goes out of scope
+  slot.sigma = sigma;
+  slot.radius = radius;
+  *d_out = slot.d_taps;
+  return MRX_OK;
 }
 
 int ilog2_exact(int n) {
@@ -192,58 +437,126 @@ int mrx_screen_psd_sum(mrx_ctx* ctx, int ny, int nx, double dy, double dx,
   return MRX_OK;
 }
 
-int mrx_screen_generate(mrx_ctx* ctx, uint64_t seed, uint32_t stream, int ny,
-                        int nx, double dy, double dx, double r0, double nu,
-                        float* d_out, float* d_work) {
+int mrx_screen_work_floats(int ny, int nx, int n_screens, size_t* floats) {
+  if (!floats || ny <= 0 || nx <= 0 || n_screens < 0) return MRX_ERR_INVALID;
+  *floats = 2 * (size_t)n_screens * ((size_t)nx / 2 + 1) * ((size_t)ny + kPitchPad);
+  return MRX_OK;
+}
+
+int mrx_screen_generate_batch(mrx_ctx* ctx, uint64_t seed, int ny, int nx,
+                              const mrx_screen_desc* screens, int n_screens, float* d_work,
+                              size_t work_floats) {
   MRX_ENTER(ctx);
   if (!ctx) return MRX_ERR_INVALID;
-  MRX_REQUIRE(ctx, d_out && d_work, "null pointer");
-  MRX_REQUIRE(ctx, dy > 0 && dx > 0 && r0 > 0 && nu > 0,
-              "steps, r0 and nu must be positive");
+  MRX_REQUIRE(ctx, n_screens >= 0, "negative count");
+  if (n_screens == 0) return MRX_OK;
+  MRX_REQUIRE(ctx, screens && d_work, "null pointer");
   const int ly = ilog2_exact(ny), lx = ilog2_exact(nx);
   if (ly < 0 || lx < 0 || ny < 64 || nx < 64 || ny > 8192 || nx > 8192)
     return mrx_fail(ctx, MRX_ERR_UNSUPPORTED,
-                    "screen sides must be powers of two in [64, 8192] "
-                    "(got %d x %d)", ny, nx);
-  const double* d_sum = nullptr;
-  int rc = psd_sum_slot(ctx, ny, nx, dy, dx, r0, nu, &d_sum);
-  if (rc != MRX_OK) return rc;
-
-  const double k0sq = 2.0 * nu / (r0 * r0);
-  const float expo = (float)(-(nu + 1.0) / 2.0);
-  float2* work1 = reinterpret_cast<float2*>(d_work);
-  float2* work2 = work1 + (size_t)ny * nx;
+                    "screen sides must be powers of two in [64, 8192] (got %d x %d)", ny, nx);
+  size_t need = 0;
+  mrx_screen_work_floats(ny, nx, n_screens, &need);
+  MRX_REQUIRE(ctx, work_floats >= need, "work buffer smaller than mrx_screen_work_floats()");
+  MRX_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(d_work) & 15u) == 0, "d_work must be 16-byte aligned");
+  const size_t per_screen = need / (size_t)n_screens;
   const uint32_t key0 = (uint32_t)seed, key1 = (uint32_t)(seed >> 32);
+  const int n2 = nx / 2;
 
-  // two ping-pong images + n/4 twiddles
-  const size_t lds_y = (size_t)(2 * ny + ny / 4) * sizeof(float2);
-  const size_t lds_x = (size_t)(2 * nx + nx / 4) * sizeof(float2);
-  static size_t lds_set_y = 0, lds_set_x = 0;  // raise the dynamic-LDS cap once
-  if (lds_y > lds_set_y) {
-    MRX_HIP(ctx, hipFuncSetAttribute(
-                     reinterpret_cast<const void*>(screen_spectrum_fft_y),
-                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_y));
-    lds_set_y = lds_y;
-  }
-  if (lds_x > lds_set_x) {
-    MRX_HIP(ctx, hipFuncSetAttribute(
-                     reinterpret_cast<const void*>(screen_fft_x_real),
-                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_x));
-    lds_set_x = lds_x;
-  }
+  // rows per workgroup of the second pass: as many as the two LDS images allow
+  const size_t fixed2 = (size_t)(nx / 4 + n2 / 4 + 4) * sizeof(float2);
+  int lj = 2;
+  while (lj > 0 && 2 * ((size_t)n2 << lj) * sizeof(float2) + fixed2 > 150 * 1024) --lj;
+  const size_t lds2 = 2 * ((size_t)n2 << lj) * sizeof(float2) + fixed2;
+  const size_t lds1 = (size_t)(2 * ny + ny / 4) * sizeof(float2);
+  MRX_LDS_CAP(ctx, screen_half_spectrum_fft_y, lds1);
+  if (lj == 2) MRX_LDS_CAP(ctx, screen_c2r_x<2>, lds2);
+  else if (lj == 1) MRX_LDS_CAP(ctx, screen_c2r_x<1>, lds2);
+  else MRX_LDS_CAP(ctx, screen_c2r_x<0>, lds2);
 
-  hipLaunchKernelGGL(screen_spectrum_fft_y, dim3(nx), dim3(kBlock), lds_y,
-                     ctx->stream, work1, ny, nx, ly, dy, dx, k0sq, expo, key0,
-                     key1, stream);
-  MRX_CHECK_LAUNCH(ctx);
-  // work1 is [nx rows][ny cols] -> work2 [ny][nx]
-  hipLaunchKernelGGL(transpose_c32, dim3(ny / 32, nx / 32), dim3(kBlock), 0,
-                     ctx->stream, work1, work2, nx, ny);
-  MRX_CHECK_LAUNCH(ctx);
-  hipLaunchKernelGGL(screen_fft_x_real, dim3(ny), dim3(kBlock), lds_x,
-                     ctx->stream, work2, d_out, ny, nx, lx, d_sum);
-  MRX_CHECK_LAUNCH(ctx);
+  for (int first = 0; first < n_screens; first += kMaxBatch) {
+    const int nb = n_screens - first < kMaxBatch ? n_screens - first : kMaxBatch;
+    ScreenBatchArgs args{};
+    int max_out_ny = 0;
+    bool late_smooth[kMaxBatch] = {false};
+    for (int i = 0; i < nb; ++i) {
+      const mrx_screen_desc& d = screens[first + i];
+      MRX_REQUIRE(ctx, d.d_out != nullptr, "null output pointer");
+      MRX_REQUIRE(ctx, d.dy > 0 && d.dx > 0 && d.r0 > 0 && d.nu > 0,
+                  "steps, r0 and nu must be positive");
+      const int out_ny = d.out_ny > 0 ? d.out_ny : ny, out_nx = d.out_nx > 0 ? d.out_nx : nx;
+      MRX_REQUIRE(ctx, out_ny <= ny && out_nx <= nx, "written block larger than the FFT domain");
+      const size_t ld = d.ld_out ? d.ld_out : (size_t)out_nx;
+      MRX_REQUIRE(ctx, ld >= (size_t)out_nx, "ld_out smaller than the row");
+      MRX_REQUIRE(ctx, d.sigma_y >= 0.0 && d.sigma_x >= 0.0, "sigma must be >= 0");
+      ScreenLayerArgs& L = args.l[i];
+      const double* d_sum = nullptr;
+      int rc = psd_sum_slot(ctx, ny, nx, d.dy, d.dx, d.r0, d.nu, &d_sum);
+      if (rc != MRX_OK) return rc;
+      L.work = reinterpret_cast<float2*>(d_work) + (size_t)(first + i) * (per_screen / 2);
+      L.out = d.d_out;
+      L.psd_sum = d_sum;
+      L.dy = d.dy;
+      L.dx = d.dx;
+      L.k0sq = 2.0 * d.nu / (d.r0 * d.r0);
+      L.ld_out = ld;
+      L.expo = (float)(-(d.nu + 1.0) / 2.0);
+      // scipy: radius = int(truncate * sigma + 0.5), truncate = 4; a sigma <= 1e-15 skips the axis
+      const int ry = d.sigma_y > 1e-15 ? (int)(4.0 * d.sigma_y + 0.5) : 0;
+      const int rx = d.sigma_x > 1e-15 ? (int)(4.0 * d.sigma_x + 0.5) : 0;
+      // radii beyond the LDS tap table (beams of > 32 pixels) take the separate stencil kernels
+      late_smooth[i] = ry > kMaxFusedRadius || rx > kMaxFusedRadius;
+      L.ry = late_smooth[i] ? 0 : ry;
+      L.rx = late_smooth[i] ? 0 : rx;
+      L.taps_y = L.taps_x = nullptr;
+      if (L.ry > 0 && (rc = get_ftaps(ctx, d.sigma_y, L.ry, &L.taps_y)) != MRX_OK) return rc;
+      if (L.rx > 0 && (rc = get_ftaps(ctx, d.sigma_x, L.rx, &L.taps_x)) != MRX_OK) return rc;
+      L.out_ny = out_ny;
+      L.out_nx = out_nx;
+      L.stream = d.stream;
+      if (out_ny > max_out_ny) max_out_ny = out_ny;
+    }
+    hipLaunchKernelGGL(screen_half_spectrum_fft_y, dim3(n2 + 1, nb), dim3(kBlock), lds1, ctx->stream,
+                       args, ny, nx, ly, key0, key1);
+    MRX_CHECK_LAUNCH(ctx);
+    const dim3 grid2(mrx_ceil_div(max_out_ny, 1 << lj), nb);
+    if (lj == 2)
+      hipLaunchKernelGGL(screen_c2r_x<2>, grid2, dim3(kBlock), lds2, ctx->stream, args, ny, nx, lx - 1);
+    else if (lj == 1)
+      hipLaunchKernelGGL(screen_c2r_x<1>, grid2, dim3(kBlock), lds2, ctx->stream, args, ny, nx, lx - 1);
+    else
+      hipLaunchKernelGGL(screen_c2r_x<0>, grid2, dim3(kBlock), lds2, ctx->stream, args, ny, nx, lx - 1);
+    MRX_CHECK_LAUNCH(ctx);
+    for (int i = 0; i < nb; ++i) {
+      if (!late_smooth[i]) continue;
+      const mrx_screen_desc& d = screens[first + i];
+      const ScreenLayerArgs& L = args.l[i];
+      MRX_REQUIRE(ctx, L.ld_out == (unsigned long long)L.out_nx,
+                  "a beam wider than 32 pixels needs a contiguous output (ld_out == out_nx)");
+      // the half spectra are consumed: the work buffer is free scratch now
+      int rc = mrx_gauss_smooth2d(ctx, L.out, L.out, d_work, L.out_ny, L.out_nx, d.sigma_y, d.sigma_x, 4.0);
+      if (rc != MRX_OK) return rc;
+    }
+  }
   return MRX_OK;
+}
+
+int mrx_screen_generate(mrx_ctx* ctx, uint64_t seed, uint32_t stream, int ny,
+                        int nx, double dy, double dx, double r0, double nu,
+                        float* d_out, float* d_work) {
+  if (!ctx) return MRX_ERR_INVALID;
+  MRX_REQUIRE(ctx, d_out && d_work, "null pointer");
+  mrx_screen_desc d{};
+  d.d_out = d_out;
+  d.stream = stream;
+  d.dy = dy;
+  d.dx = dx;
+  d.r0 = r0;
+  d.nu = nu;
+  size_t need = 0;
+  if (mrx_screen_work_floats(ny, nx, 1, &need) != MRX_OK)
+    return mrx_fail(ctx, MRX_ERR_INVALID, "mrx_screen_generate: sizes must be positive");
+  return mrx_screen_generate_batch(ctx, seed, ny, nx, &d, 1, d_work, need);
 }
 
 int mrx_philox_normal(mrx_ctx* ctx, uint64_t seed, uint32_t stream, size_t n,

@@ -204,13 +204,13 @@ class DevicePath:
         return ua.value, bool(tl.value)
 
     def generate_screens(self, smooth=True):
-        """Philox + k-space filter + iFFT on the device, then the beam smoothing
-        (atmosphere/atmosphere.py:328-344), into persistent screen buffers.  The
-        first call allocates the buffers and binds them; later calls only launch
-        kernels.  Returns the device tensors."""
+        """Philox + k-space filter + complex-to-real iFFT on the device with the beam
+        smoothing (atmosphere/atmosphere.py:328-344) folded into the two FFT passes
+        (mrx_screen_generate_batch), into persistent screen buffers.  The first call
+        allocates the buffers and binds them; later calls only launch kernels: two per
+        group of layers that share an FFT domain.  Returns the device tensors."""
         dev = self.device
         layers = self.problem["layers"]
-        torch.cuda.nvtx.range_push("Generating turbulence") if hasattr(torch.cuda, "nvtx") else None
         shapes = [(len(l["extrusion"]), len(l["cross_section"])) for l in layers]
         # a layer may ask for a larger periodic FFT domain ("fft_shape") than its grid:
         # the screen is then the top-left block of it (atmosphere.py ribbons are not
@@ -218,30 +218,32 @@ class DevicePath:
         fft_shapes = [tuple(l.get("fft_shape") or sh) for l, sh in zip(layers, shapes)]
         if getattr(self, "_gen_screens", None) is None:
             self._gen_screens = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in shapes]
-            biggest = max(a * b for a, b in fft_shapes)
-            self._gen_work = torch.empty(4 * biggest, dtype=torch.float32, device=dev)
-            self._gen_big = None
-            if any(f != s for f, s in zip(fft_shapes, shapes)):
-                self._gen_big = torch.empty(biggest, dtype=torch.float32, device=dev)
+            self._gen_groups = {}
+            for l, f in enumerate(fft_shapes):
+                self._gen_groups.setdefault(f, []).append(l)
+            need = 0
+            for (fe, fc), members in self._gen_groups.items():
+                n = C.c_size_t()
+                _lib.load().mrx_screen_work_floats(fe, fc, len(members), C.byref(n))
+                need = max(need, n.value)
+            self._gen_work = torch.empty(need, dtype=torch.float32, device=dev)
             self.set_screens(self._gen_screens)
-        for l, (layer, out) in enumerate(zip(layers, self._gen_screens)):
-            ne, nc = shapes[l]
-            fe, fc = fft_shapes[l]
-            de = float(layer["extrusion"][1] - layer["extrusion"][0])
-            dc = float(layer["cross_section"][1] - layer["cross_section"][0])
-            target = out if (fe, fc) == (ne, nc) else self._gen_big[: fe * fc].view(fe, fc)
-            self.ctx.call(
-                "mrx_screen_generate", self.problem["seed"], l, fe, fc, de, dc,
-                float(layer["r0"]), float(layer["nu"]), ptr(target), ptr(self._gen_work),
-            )
-            if target is not out:
-                out.copy_(target[:ne, :nc])  # crop (a strided device copy; plumbing)
-            if smooth and layer.get("beam_sigma", 0) > 0:
+        with _range("Generating turbulence"):
+            for (fe, fc), members in self._gen_groups.items():
+                descs = (_lib.MrxScreenDesc * len(members))()
+                for d, l in zip(descs, members):
+                    layer, out = layers[l], self._gen_screens[l]
+                    de = float(layer["extrusion"][1] - layer["extrusion"][0])
+                    dc = float(layer["cross_section"][1] - layer["cross_section"][0])
+                    sigma = float(layer.get("beam_sigma", 0) or 0) if smooth else 0.0
+                    d.d_out, d.stream = out.data_ptr(), l
+                    d.out_ny, d.out_nx, d.ld_out = out.shape[0], out.shape[1], out.stride(0)
+                    d.dy, d.dx, d.r0, d.nu = de, dc, float(layer["r0"]), float(layer["nu"])
+                    d.sigma_y, d.sigma_x = sigma / de, sigma / dc
                 self.ctx.call(
-                    "mrx_gauss_smooth2d", ptr(out), ptr(out), ptr(self._gen_work), ne, nc,
-                    layer["beam_sigma"] / de, layer["beam_sigma"] / dc, 4.0,
+                    "mrx_screen_generate_batch", self.problem["seed"], fe, fc, descs, len(members),
+                    ptr(self._gen_work), self._gen_work.numel(),
                 )
-        torch.cuda.nvtx.range_pop() if hasattr(torch.cuda, "nvtx") else None
         return self._gen_screens
 
     # -- hot path ------------------------------------------------------------

@@ -28,6 +28,37 @@ def numpy_screen(ny, nx, dy, dx, r0, nu, rng):
     return (field / np.sqrt((amp**2).sum())).astype(np.float32)
 
 
+def hermitian_philox_screen(philox4x32, seed, stream, ny, nx, dy, dx, r0, nu):
+    """The screen mrx_screen_generate defines (include/mrx.h): the Hermitian half spectrum
+    rebuilt cell by cell from the library's own Philox routine, then numpy's irfft2.
+    ``philox4x32(seed, counter) -> 4 words`` (maria_amd._lib.philox4x32, host-evaluated)."""
+    amp = psd_amplitude(ny, nx, dy, dx, r0, nu)
+    half = ny // 2
+    H = np.zeros((ny, nx // 2 + 1), complex)
+
+    def normal_pair(a, b):
+        u1 = ((a >> 8) + 0.5) / 16777216.0
+        u2 = (b >> 8) / 16777216.0
+        rad = np.sqrt(-2 * np.log(u1))
+        return rad * np.cos(2 * np.pi * u2), rad * np.sin(2 * np.pi * u2)
+
+    for ix in range(nx // 2 + 1):
+        edge = ix == 0 or ix == nx // 2
+        for iy in range(half):
+            w = philox4x32(seed, (ix, iy, stream, 0))
+            g0, g1 = normal_pair(w[0], w[1]), normal_pair(w[2], w[3])
+            if not edge:
+                H[iy, ix] = amp[iy, ix] * complex(*g0) / np.sqrt(2)
+                H[iy + half, ix] = amp[iy + half, ix] * complex(*g1) / np.sqrt(2)
+            elif iy == 0:
+                H[0, ix] = amp[0, ix] * g0[0]
+                H[half, ix] = amp[half, ix] * g1[0]
+            else:
+                H[iy, ix] = amp[iy, ix] * complex(*g0) / np.sqrt(2)
+                H[ny - iy, ix] = np.conj(H[iy, ix])
+    return np.fft.irfft2(H, s=(ny, nx)) * (ny * nx) / np.sqrt((amp**2).sum())
+
+
 def radial_covariance(screen, dy, dx, lags_px):
     """Empirical covariance of a periodic screen at integer-pixel lags along both
     axes (FFT autocorrelation); returns (r_metres, cov) for each axis."""

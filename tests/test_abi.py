@@ -32,11 +32,11 @@ def test_header_symbols_are_exported_and_bound():
 
 
 def test_struct_layouts_match_the_header(tmp_path):
-    """Size and every field offset of the four boundary structs, as gcc lays out include/mrx.h,
+    """Size and every field offset of the boundary structs, as gcc lays out include/mrx.h,
     against the ctypes mirrors."""
     import subprocess
 
-    pairs = [("mrx_layer", _lib.MrxLayer), ("mrx_band_table", _lib.MrxBandTable), ("mrx_sky_map", _lib.MrxSkyMap), ("mrx_map_cal", _lib.MrxMapCal)]
+    pairs = [("mrx_layer", _lib.MrxLayer), ("mrx_band_table", _lib.MrxBandTable), ("mrx_sky_map", _lib.MrxSkyMap), ("mrx_map_cal", _lib.MrxMapCal), ("mrx_screen_desc", _lib.MrxScreenDesc)]
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "mrx.h"', "int main(void) {"]
     for cname, cls in pairs:
         lines.append(f'  printf("{cname} size %zu\\n", sizeof({cname}));')
