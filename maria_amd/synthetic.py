@@ -53,16 +53,61 @@ def hex_pack(n: int, fov_rad: float) -> np.ndarray:
     return pts * scale
 
 
+def _daisy_curve(phase, a, b, petals, miss_freq):
+    """The daisy's closed form (plan/patterns.py:108-113): a rose of ``petals`` lobes of
+    amplitude ``a`` plus a slow ``b`` term that makes successive petals miss the centre,
+    rescaled so that the farthest point lies at ``a + b``."""
+    lobe, swing = np.cos(petals * phase), np.sin(petals * phase)
+    x = a * lobe * np.sin(phase) + b * swing * np.cos(miss_freq * phase)
+    y = a * lobe * np.cos(phase) + b * swing * np.sin(miss_freq * phase)
+    return (a + b) * np.stack([x, y]) / np.sqrt((x * x + y * y).max())
+
+
+def daisy_offsets(time, x_throw, y_throw=None, speed=0.5, petals=np.sqrt(np.e), miss_factor=0.2, miss_freq=0.1):
+    """Boresight offsets [2, T] of the reference's ``daisy`` scan pattern (plan/patterns.py:116-155),
+    in the units of ``x_throw``: the phase advances at ``speed / radius``, then up to four passes
+    rescale the phase rate until the fastest sample moves at ``speed`` (within 1 %)."""
+    time = np.asarray(time, float)
+    y_throw = x_throw if y_throw is None else y_throw
+    radius = x_throw
+    if not radius > 0:
+        return np.zeros((2, len(time)))
+    a = radius / (1 + miss_factor)
+    b = a * miss_factor
+    dt = np.gradient(time)
+    dphase = (speed / radius) * dt
+    for _ in range(4):
+        phase = np.cumsum(dphase)
+        tx, ty = _daisy_curve(phase, a, b, petals, miss_freq)
+        fastest = np.sqrt((np.gradient(tx) / dt) ** 2 + (np.gradient(ty) / dt) ** 2).max()
+        if abs(np.log(fastest / speed)) <= 0.01:
+            break
+        dphase = dphase * (speed / fastest)
+    x, y = _daisy_curve(phase, a, b, petals, miss_freq)
+    return np.stack([x, (y_throw / x_throw) * y])
+
+
+def offsets_to_phi_theta(dx, dy, c_phi, c_theta):
+    """coords/transforms.py:10-29 in float32 (jax's default precision): the direction at
+    offset (dx, dy) radians from the centre (c_phi, c_theta).  Host-side set-up only; the
+    kernels carry their own copy of this chain (csrc/mrx_sample.hip)."""
+    f32 = np.float32
+    dx, dy = np.asarray(dx, f32), np.asarray(dy, f32)
+    r = np.sqrt(dx * dx + dy * dy)
+    p = np.arctan2(-dx, -dy)
+    a = np.asarray(c_theta, f32) - f32(np.pi / 2)
+    a_re, a_im = np.sin(r) * np.cos(p), np.cos(r)
+    re = a_re * np.cos(a) - a_im * np.sin(a)
+    im = a_re * np.sin(a) + a_im * np.cos(a)
+    return np.arctan2(np.sin(r) * np.sin(p), re) + np.asarray(c_phi, f32), np.arcsin(im)
+
+
 def daisy_scan(t, radius_deg=0.5, speed_deg_s=0.5, az_deg=45.0, el_deg=60.0, petals=np.sqrt(np.e)):
-    """A daisy-like boresight track (az, el in radians) of the shape produced by
-    plan/patterns.py:108-155: petals swept at roughly constant speed."""
-    t = np.asarray(t, float)
-    phase = (t - t[0]) * speed_deg_s / radius_deg
-    x = radius_deg * np.cos(petals * phase) * np.sin(phase)
-    y = radius_deg * np.cos(petals * phase) * np.cos(phase)
-    el = np.radians(el_deg + y)
-    az = np.radians(az_deg) + np.radians(x) / np.cos(np.radians(el_deg))
-    return az, el
+    """Boresight (az, el in radians) of ``Plan.generate(scan_pattern="daisy", frame="az/el")``:
+    the daisy offsets about the scan centre (plan/plan.py:90-140)."""
+    off = np.radians(daisy_offsets(t, radius_deg, radius_deg, speed_deg_s, petals=petals))
+    az, el = offsets_to_phi_theta(off[0], off[1], np.radians(az_deg), np.radians(el_deg))
+    return az.astype(np.float64), el.astype(np.float64)
 
 
 def coarse_grid(t, az, el, timestep):

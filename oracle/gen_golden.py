@@ -10,7 +10,7 @@ exist on the GPU box):
 astropy, h5py ... are not installed).  Registering bare parent
 packages lets the leaf modules that only need numpy/scipy load unmodified:
 ``maria.constants``, ``maria.functions``, ``maria.beam``, ``maria.utils.linalg``,
-``maria.utils.rotations``, ``maria.utils.signal``.  No third-party library is stubbed.  The outputs below
+``maria.utils.rotations``, ``maria.utils.signal``, ``maria.plan.patterns``.  No third-party library is stubbed.  The outputs below
 are data (inputs and the reference's answers); no reference source is copied.
 """
 
@@ -28,7 +28,7 @@ OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 
 
 def _load_reference_leaves():
-    for pk in ("maria", "maria.utils"):
+    for pk in ("maria", "maria.utils", "maria.plan"):
         m = types.ModuleType(pk)
         m.__path__ = [os.path.join(REF, *pk.split("."))]
         sys.modules[pk] = m
@@ -39,11 +39,16 @@ def _load_reference_leaves():
     import maria.utils.rotations as rotations
     import maria.utils.signal as signal
 
-    return constants, functions, beam, linalg, rotations, signal
+    # maria/utils/__init__.py re-exports its rotations module; the bare parent package
+    # gets the reference's own function under the name plan/patterns.py imports
+    sys.modules["maria.utils"].get_rotation_matrix_2d = rotations.get_rotation_matrix_2d
+    import maria.plan.patterns as patterns
+
+    return constants, functions, beam, linalg, rotations, signal, patterns
 
 
 def main():
-    constants, functions, beam, linalg, rotations, signal = _load_reference_leaves()
+    constants, functions, beam, linalg, rotations, signal, patterns = _load_reference_leaves()
     g = {"_generator": "oracle/gen_golden.py", "_reference": "thomaswmorris/maria @ /root/reference"}
 
     g["constants"] = {"k_B": constants.k_B, "c": constants.c}
@@ -144,6 +149,16 @@ def main():
         "lowpass_fc2.5_order2": signal.lowpass(Dm, fc=2.5, sample_rate=20.0, order=2).tolist(),
         "decompose_k3_first2_modes": (A[:, :2] @ Bm[:2]).tolist(),
     }
+
+    # the daisy scan pattern every BASELINE config names (plan/patterns.py:108-155)
+    g["daisy"] = []
+    for kw in (
+        dict(n=600, fs=10.0, x_throw=0.5, y_throw=0.5, speed=0.5),
+        dict(n=900, fs=20.0, x_throw=0.25, y_throw=0.4, speed=0.3, petals=2.0, miss_factor=0.35, miss_freq=0.17),
+    ):
+        tt = 1.7e9 + np.arange(kw["n"]) / kw["fs"]
+        args = {k: v for k, v in kw.items() if k not in ("n", "fs")}
+        g["daisy"].append({"n": kw["n"], "fs": kw["fs"], "t0": 1.7e9, "kwargs": args, "offsets": patterns.daisy(tt, **args).tolist()})
 
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     with open(OUT, "w") as f:

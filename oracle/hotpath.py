@@ -61,6 +61,18 @@ def offsets_to_phi_theta(dx, dy, cphi, ctheta):
     return phi.astype(f32), theta.astype(f32)
 
 
+def phi_theta_to_offsets(phi, theta, cphi, ctheta):
+    """coords/transforms.py:36-53, the inverse of ``offsets_to_phi_theta`` (float64 here: it
+    only closes the reference's own round-trip test, tests/coordinates/test_coordinates.py:7-19)."""
+    phi, theta = np.asarray(phi, np.float64), np.asarray(theta, np.float64)
+    dphi = phi - cphi
+    proj_from_east = (np.cos(dphi) * np.cos(theta) + 1j * np.sin(theta)) * np.exp(1j * (np.pi / 2 - ctheta))
+    dz = np.sin(dphi) * np.cos(theta) + 1j * np.real(proj_from_east)
+    r = np.abs(dz)
+    dz = dz * np.arcsin(r) / np.where(r > 0, r, 1.0)
+    return np.stack([-np.real(dz), -np.imag(dz)], axis=-1)
+
+
 def broadcast(offsets, az, el):
     """coords/coordinates.py:378-386: boresight [Ta] x offsets [D,2] -> [D,Ta] float32."""
     offsets = np.asarray(offsets)

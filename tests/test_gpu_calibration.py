@@ -35,6 +35,38 @@ def test_full_rate_pointing_matches_oracle(gpu_ctx):
     assert np.abs(ga[:, :T] - ref_az).max() <= 6e-7 and np.abs(ge[:, :T] - ref_el).max() <= 6e-7
 
 
+def test_pointing_round_trip_like_the_reference_test(gpu_ctx):
+    """The reference's own numeric test of this transform (tests/coordinates/test_coordinates.py:
+    7-19), on the HIP path: offsets -> (phi, theta) by mrx_pointing_broadcast about random centres
+    over the whole sphere, back through phi_theta_to_offsets; mean squared error < 1e-5 (the
+    reference's bound; float32 gives ~1e-13 away from the poles)."""
+    import torch
+
+    from maria_amd._lib import ptr
+    from oracle import hotpath
+
+    rng = np.random.default_rng(123)
+    n = 256
+    cphi = rng.uniform(0, 2 * np.pi, 5)
+    ctheta = rng.uniform(-np.pi / 2, np.pi / 2, 5)
+    az, el = np.repeat(cphi, 5), np.tile(ctheta, 5)  # the 25 centres as 25 "samples"
+    offsets = np.radians(rng.uniform(-0.5, 0.5, (n, 2)))
+    dev = "cuda:0"
+    t = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)  # noqa: E731
+    d_az, d_el, d_dx, d_dy = t(az), t(el), t(offsets[:, 0]), t(offsets[:, 1])
+    out_az = torch.empty((n, 25), dtype=torch.float32, device=dev)
+    out_el = torch.empty((n, 25), dtype=torch.float32, device=dev)
+    gpu_ctx.call("mrx_pointing_broadcast", ptr(d_az), ptr(d_el), 25, ptr(d_dx), ptr(d_dy), n, ptr(out_az), ptr(out_el), 25)
+    phi, theta = out_az.cpu().numpy(), out_el.cpu().numpy()
+    worst = 0.0
+    for k in range(25):
+        back = hotpath.phi_theta_to_offsets(phi[:, k], theta[:, k], np.float32(az[k]), np.float32(el[k]))
+        mse = float(np.mean(np.square(offsets.astype(np.float32) - back)))
+        worst = max(worst, mse)
+        assert mse < 1e-5, (k, az[k], el[k], mse)
+    assert worst < 1e-9  # what float32 actually delivers for centres at least ~1 deg from a pole
+
+
 def _cal_tables(n_bands):
     """Synthetic transmission-integral tables on a (T, pwv, el) grid (band.py:248-252 shape)."""
     T = np.array([250.0, 270.0, 290.0])
