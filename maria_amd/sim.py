@@ -209,9 +209,15 @@ class Simulation:
         gain_seed: int = None,
         noise_seed: int = None,
         device_output: bool = False,
+        shard=None,
     ):
         """sim/simulation.py:76-198.  ``device_output=True`` leaves the TOD on the GPU as
-        a torch tensor (a 10 k x 240 k TOD is 9.6 GB; the PCIe copy dwarfs the synthesis)."""
+        a torch tensor (a 10 k x 240 k TOD is 9.6 GB; the PCIe copy dwarfs the synthesis).
+        ``shard``: ``(rank, world_size)`` -- this process simulates its contiguous block of
+        detector rows (maria_amd.dist.shard_slice) of every observation, ``"auto"`` takes both
+        from an initialised ``torch.distributed`` group, ``None`` simulates every row.  Every
+        detector row is independent given the shared geometry (atmosphere.py:346-373 has no
+        cross-detector term), so a shard's TOD equals the same rows of the unsharded run."""
         if cmb is not None:
             raise NotImplementedError("the CMB mixin is a follow-on row (SURVEY 8(f))")
         if isinstance(map, str):
@@ -237,6 +243,22 @@ class Simulation:
         self.noise, self.dtype = noise, dtype
         self.disable_progress_bars = not progress_bars
         self.device_output = device_output
+        if shard == "auto":
+            import torch.distributed as dist
+
+            shard = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else None
+        if shard is not None:
+            rank, world = (int(v) for v in shard)
+            if not 0 <= rank < world:
+                raise ValueError(f"shard rank {rank} outside [0, {world})")
+            shard = (rank, world)
+        self.shard = shard
+        if shard is not None and shard[1] > 1:
+            bands = instrument.dets.bands if isinstance(instrument, Instrument) else []
+            if noise and noise_seed is None:
+                raise ValueError("a sharded run needs an explicit noise_seed: the correlated noise modes are common to all shards")
+            if gain_seed is None and any(getattr(b, "gain_error", 0.0) for b in bands):
+                raise ValueError("a sharded run needs an explicit gain_seed: every rank draws the whole gain vector and keeps its rows")
         self._gain_rng = np.random.default_rng(gain_seed)
         self.noise_kwargs = dict(noise_kwargs)
         self._noise_seed = int(noise_seed if noise_seed is not None else np.random.SeedSequence().entropy % (1 << 62))
@@ -249,21 +271,51 @@ class Simulation:
                 obs.atmosphere.initialize(obs)
             self.obs_list.append(obs)
 
-    def run(self, units: str = "K_RJ"):
+    def _rows(self, n_det):
+        """[lo, hi) of this process's detector rows (all of them without a shard)."""
+        if self.shard is None:
+            return 0, n_det
+        from .dist import shard_bounds
+
+        return shard_bounds(n_det, self.shard[1], self.shard[0])
+
+    def run(self, units: str = "K_RJ", gather: bool = False):
         """sim/simulation.py:201-211: one TOD per plan, in ``units`` ("K_RJ", the reference
-        default, or "pW")."""
+        default, or "pW").  With a shard each TOD holds this rank's rows; ``gather=True``
+        all-gathers every field over the initialised ``torch.distributed`` group (RCCL over
+        xGMI for device tensors) into the whole [ndet, nt] arrays on every rank."""
         if units not in ("K_RJ", "pW"):
             raise NotImplementedError(f"units '{units}': only 'K_RJ' and 'pW' are built (tod/tod.py:106-142)")
         tods = []
         for k, obs in enumerate(self.obs_list):
             t0 = ttime.monotonic()
-            tods.append(self.run_obs(obs, units=units))
+            tod = self.run_obs(obs, units=units)
+            if gather and self.shard is not None and self.shard[1] > 1:
+                tod = self._gather(obs, tod)
+            tods.append(tod)
             logger.info(f"Simulated observation {k + 1} of {len(self.obs_list)} in {ttime.monotonic() - t0:.2f} s")
         return tods
 
     # -- sim/atmosphere.py:24-84 -------------------------------------------------------
     def _simulate_atmosphere(self, obs):
-        obs.atmosphere.simulate_pwv(instrument=obs.instrument)
+        lo, hi = self._rows(obs.instrument.dets.n)
+        obs.atmosphere.simulate_pwv(instrument=obs.instrument, det_slice=None if self.shard is None else slice(lo, hi))
+
+    def _gather(self, obs, tod):
+        """All-gather a shard's TOD along the detector axis (equal row blocks, so the gathered
+        array is the concatenation: dist.all_gather_tod)."""
+        import torch
+
+        from .dist import all_gather_tod
+
+        dets = obs.instrument.dets
+        data = {}
+        for name, field in tod.data.items():
+            on_device = isinstance(field, torch.Tensor)
+            full = all_gather_tod(field if on_device else torch.as_tensor(field), dets.n)
+            data[name] = full if on_device else full.numpy()
+        out = TOD(data=data, dets=dets, coords=obs.coords, units=tod.units, metadata=dict(tod.metadata, shard=None))
+        return out
 
     def _set_calibration(self, obs, metadata):
         """Host part of ``TOD.to("K_RJ")`` (tod/tod.py:90-97): collapse the bands' transmission
@@ -293,15 +345,18 @@ class Simulation:
             path.upsample(out)
         return out
 
-    def _sample_maps(self, obs):
-        """sim/map.py:76-172 on the device: one ``mrx_map_sample`` per band, [D, T] pW."""
+    def _sample_maps(self, obs, rows=None):
+        """sim/map.py:76-172 on the device: one ``mrx_map_sample`` per band, [D, T] pW
+        (``rows = (lo, hi)``: only this shard's detector rows)."""
         import torch
 
         from . import map as mmap
         from ._lib import Context
         from .instrument import compute_angular_fwhm
 
-        dets = obs.instrument.dets
+        lo, hi = rows or (0, obs.instrument.dets.n)
+        dets = obs.instrument.dets.subset(np.arange(lo, hi))
+        offsets = obs.coords.offsets[lo:hi]
         atm = getattr(obs, "atmosphere", None)
         if atm is not None:
             path = atm._device_path()
@@ -353,11 +408,11 @@ class Simulation:
             else:
                 kw = dict(cal_scalars=scalars)
             mmap.sample_map(ctx, values, self.map.eta, self.map.xi, self.map.center, obs.boresight._baz, obs.boresight._bel,
-                            obs.coords.offsets[idx], stokes_rows[idx], out=out[int(idx[0]) : int(idx[-1]) + 1],
+                            offsets[idx], stokes_rows[idx], out=out[int(idx[0]) : int(idx[-1]) + 1],
                             transform=transform, bilinear=bool(self.map_kwargs["bilinear_sampling"]), device=device, **kw)
         return out
 
-    def _simulate_noise(self, obs, loading=None):
+    def _simulate_noise(self, obs, loading=None, rows=None):
         """sim/noise.py:18-63 on the device, in pW; ``loading`` (pW, [D, T] on the device) only
         for bands whose NEP grows with the loading.  The gain error does not apply to the
         noise field (simulation.py:243-245)."""
@@ -379,36 +434,43 @@ class Simulation:
         fs = 1.0 / np.mean(np.diff(t)) if len(t) > 1 else 1.0
         self._noise_runs += 1
         return mnoise.simulate_noise(ctx, dets, len(t), fs, self._noise_seed + 104729 * self._noise_runs,
-                                     self.noise_kwargs, device=device, loading=loading)
+                                     self.noise_kwargs, device=device, loading=loading,
+                                     det_slice=None if rows is None else slice(*rows))
 
     def run_obs(self, obs, units: str = "pW") -> TOD:
-        """sim/simulation.py:213-272 (followed by ``.to(units)`` of :206)."""
+        """sim/simulation.py:213-272 (followed by ``.to(units)`` of :206), for this process's
+        detector rows."""
+        import torch
+
         obs.loading = {}
-        dets = obs.instrument.dets
-        # per-detector gain error (simulation.py:239-247), fused into the upsample's store
-        gain_error = np.array([dets.bands[b].gain_error for b in dets.band_index])
-        gain = np.exp(gain_error * self._gain_rng.standard_normal(dets.n))
+        all_dets = obs.instrument.dets
+        lo, hi = self._rows(all_dets.n)
+        rows = None if self.shard is None else (lo, hi)
+        dets = all_dets if rows is None else all_dets.subset(np.arange(lo, hi))
+        # per-detector gain error (simulation.py:239-247): every rank draws the whole vector
+        # and keeps its rows
+        gain_error = np.array([all_dets.bands[b].gain_error for b in all_dets.band_index])
+        gain = np.exp(gain_error * self._gain_rng.standard_normal(all_dets.n))[lo:hi]
+        has_gain = bool(np.any(gain_error[lo:hi]))
         metadata = {"atmosphere": False, "altitude": float(obs.site.altitude), "region": obs.site.region,
-                    "latitude": obs.site.latitude, "longitude": obs.site.longitude}
-        # bands whose NEP grows with the loading need the loading in pW before the noise is
-        # drawn (sim/noise.py:35-37); every field is then converted after the fact, as
-        # TOD.to does.  Otherwise the conversion rides on the upsample's store.
+                    "latitude": obs.site.latitude, "longitude": obs.site.longitude,
+                    "shard": None if rows is None else {"rank": self.shard[0], "world": self.shard[1], "rows": [lo, hi]}}
+        has_atm = hasattr(obs, "atmosphere")
+        device = torch.device(obs.atmosphere.device) if has_atm else torch.device("cuda:0")
+        # Bands whose NEP grows with the loading need the loadings in pW, WITHOUT the gain
+        # error, before the noise is drawn (sim/noise.py:35-37 runs before simulation.py:239-247
+        # multiplies the gain into the non-noise fields); gain and the K_RJ conversion are then
+        # applied after the fact.  Otherwise both ride on the upsample's store.
         loading_nep = self.noise and any(getattr(b, "NEP_per_loading", 0.0) for b in dets.bands)
-        deferred = units == "K_RJ" and loading_nep
         loading = None
-        if hasattr(obs, "atmosphere"):
+        if has_atm:
             metadata.update(atmosphere=True, pwv=float(np.round(obs.atmosphere.weather.pwv, 3)),
                             base_temperature=float(np.round(obs.atmosphere.weather.temperature[0], 3)))
             self._simulate_atmosphere(obs)
-            loading = self._compute_atmospheric_loading(obs, gain=gain if np.any(gain_error) else None,
-                                                        units="pW" if deferred else units, metadata=metadata)
-        map_loading = None
-        if self.map is not None:
-            map_loading = self._sample_maps(obs)  # pW; the gain error applies (simulation.py:243-245)
-            if np.any(gain_error):
-                import torch
-
-                map_loading *= torch.as_tensor(gain.astype(np.float32), device=map_loading.device)[:, None]
+            loading = self._compute_atmospheric_loading(
+                obs, gain=gain if has_gain and not loading_nep else None,
+                units="pW" if loading_nep else units, metadata=metadata)
+        map_loading = self._sample_maps(obs, rows) if self.map is not None else None  # pW
         noise = None
         if self.noise:
             total = None
@@ -417,64 +479,69 @@ class Simulation:
                 if fields:
                     total = fields[0] if len(fields) == 1 else fields[0] + fields[1]
                 else:
-                    import torch
-
-                    total = torch.zeros((dets.n, len(obs.coords.t)), dtype=torch.float32, device="cuda:0")
-            noise = self._simulate_noise(obs, loading=total)
-        if units == "K_RJ" and hasattr(obs, "atmosphere"):
+                    total = torch.zeros((dets.n, len(obs.coords.t)), dtype=torch.float32, device=device)
+            noise = self._simulate_noise(obs, loading=total, rows=rows)
+        if has_gain:  # the gain error applies to every field but the noise (simulation.py:243-245)
+            d_gain = torch.as_tensor(gain.astype(np.float32), device=device)[:, None]
+            if map_loading is not None:
+                map_loading *= d_gain
+            if loading is not None and loading_nep:
+                loading *= d_gain
+        if units == "K_RJ" and has_atm:
             # TOD.to("K_RJ") of the fields that were not written in K_RJ directly
             path = obs.atmosphere._device_path()
-            if deferred:
+            if loading_nep:
                 self._set_calibration(obs, metadata)
                 path.to_krj(loading)
             for field in (map_loading, noise):
                 if field is not None:
                     path.to_krj(field)
         elif units == "K_RJ":
-            # no atmosphere: the transmission integral is the band's own Int passband dnu, one
-            # number per band (band/band.py:246-248, calibration/functions.py:73-90)
-            import torch
-
-            den = np.empty(dets.n)
-            for b, band in enumerate(dets.bands):
-                rows = dets.band_index == b
-                polarized = bool((~np.isnan(dets.gamma[rows])).all()) if rows.any() else False
-                den[rows] = (0.5 if polarized else 1.0) * 1e12 * 1.380649e-23 * float(np.trapezoid(band.passband(band.nu), x=band.nu))
+            den = torch.as_tensor(self._band_denominators(all_dets)[lo:hi].astype(np.float32), device=device)[:, None]
             for field in (map_loading, noise):
                 if field is not None:
-                    field /= torch.as_tensor(den.astype(np.float32), device=field.device)[:, None]
-        if hasattr(obs, "atmosphere"):
-            obs.loading["atmosphere"] = loading if self.device_output else loading.cpu().numpy()
-        if map_loading is not None:
-            obs.loading["map"] = map_loading if self.device_output else map_loading.cpu().numpy()
-        if noise is not None:
-            obs.loading["noise"] = noise if self.device_output else noise.cpu().numpy()
-        tod = TOD(data=obs.loading, dets=dets, coords=obs.coords, units=units, metadata=metadata)
-        tod._calibrator = self._make_calibrator(obs, metadata)
+                    field /= den
+        for name, field in (("atmosphere", loading), ("map", map_loading), ("noise", noise)):
+            if field is not None:
+                obs.loading[name] = field if self.device_output else field.cpu().numpy()
+        coords = obs.coords if rows is None else obs.boresight.broadcast(obs.coords.offsets[lo:hi])
+        tod = TOD(data=obs.loading, dets=dets, coords=coords, units=units, metadata=metadata)
+        tod._calibrator = self._make_calibrator(obs, metadata, (lo, hi))
         return tod
 
-    def _make_calibrator(self, obs, metadata):
+    @staticmethod
+    def _band_denominators(dets):
+        """Without an atmosphere the transmission integral of ``TOD.to("K_RJ")`` is the band's own
+        Int passband dnu, one number per band (band/band.py:246-248, calibration/functions.py:73-90):
+        pW per K_RJ for every detector row."""
+        den = np.empty(dets.n)
+        for b, band in enumerate(dets.bands):
+            rows = dets.band_index == b
+            polarized = bool((~np.isnan(dets.gamma[rows])).all()) if rows.any() else False
+            den[rows] = (0.5 if polarized else 1.0) * 1e12 * 1.380649e-23 * float(np.trapezoid(band.passband(band.nu), x=band.nu))
+        return den
+
+    def _make_calibrator(self, obs, metadata, rows):
         """What ``TOD.to`` needs to move a finished TOD between pW and K_RJ: the observation's
         calibration on the device (atmosphere) or one number per band (none)."""
-        dets = obs.instrument.dets
+        lo, hi = rows
+        has_atm = hasattr(obs, "atmosphere")
 
         def convert(data, to_krj):
             import torch
 
             out = {}
-            if hasattr(obs, "atmosphere"):
+            if has_atm:
                 path = obs.atmosphere._device_path()
                 self._set_calibration(obs, metadata)
+                device = path.device
             else:
-                den = np.empty(dets.n)
-                for b, band in enumerate(dets.bands):
-                    rows = dets.band_index == b
-                    polarized = bool((~np.isnan(dets.gamma[rows])).all()) if rows.any() else False
-                    den[rows] = (0.5 if polarized else 1.0) * 1e12 * 1.380649e-23 * float(np.trapezoid(band.passband(band.nu), x=band.nu))
+                device = torch.device("cuda:0")
+                den = self._band_denominators(obs.instrument.dets)[lo:hi]
             for name, field in data.items():
                 on_device = isinstance(field, torch.Tensor)
-                f = (field.clone() if on_device else torch.as_tensor(np.ascontiguousarray(field, np.float32)).to("cuda:0")).contiguous()
-                if hasattr(obs, "atmosphere"):
+                f = (field.clone() if on_device else torch.as_tensor(np.ascontiguousarray(field, np.float32)).to(device)).contiguous()
+                if has_atm:
                     path.to_krj(f) if to_krj else path.from_krj(f)
                 else:
                     d = torch.as_tensor(den.astype(np.float32), device=f.device)[:, None]

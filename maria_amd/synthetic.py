@@ -70,10 +70,12 @@ def daisy_offsets(time, x_throw, y_throw=None, speed=0.5, petals=np.sqrt(np.e), 
     time = np.asarray(time, float)
     y_throw = x_throw if y_throw is None else y_throw
     radius = x_throw
-    if not radius > 0:
+    if not radius > 0 or len(time) == 0:
         return np.zeros((2, len(time)))
     a = radius / (1 + miss_factor)
     b = a * miss_factor
+    if len(time) < 2:  # a single sample has no speed to normalise (the reference's np.gradient raises)
+        return _daisy_curve(np.zeros(len(time)), a, b, petals, miss_freq) * np.array([[1.0], [y_throw / x_throw]])
     dt = np.gradient(time)
     dphase = (speed / radius) * dt
     for _ in range(4):
