@@ -52,6 +52,7 @@ typedef enum mrx_status {
 
 typedef struct mrx_ctx mrx_ctx;
 typedef struct mrx_atm_plan mrx_atm_plan;
+typedef struct mrx_comm mrx_comm;
 
 /* ---- context ------------------------------------------------------------ */
 
@@ -335,6 +336,30 @@ int mrx_screen_generate(mrx_ctx* ctx, uint64_t seed, uint32_t stream, int ny,
  * (float64); mrx_screen_generate uses it internally, exposed for tests. */
 int mrx_screen_psd_sum(mrx_ctx* ctx, int ny, int nx, double dy, double dx,
                        double r0, double nu, double* host_sum);
+
+/* ---- multi-GPU --------------------------------------------------------- */
+
+/* Detectors shard across the GPUs of a node in equal blocks of contiguous rows (the last may
+ * be short); the data path itself needs no collective.  The epilogue the reference's seam
+ * implies -- one [ndet, nt] array per observation, sim/simulation.py:266-272 -- is ONE RCCL
+ * all-gather over xGMI: the TOD is detector-major, so the gathered array is the concatenation
+ * of the shards and nothing is packed or staged.
+ *
+ * mrx_comm_unique_id (rank 0; the caller hands the MRX_COMM_ID_BYTES bytes to every rank by
+ * whatever channel it has: torch.distributed, MPI, a file) + mrx_comm_create = ncclGetUniqueId +
+ * ncclCommInitRank on the context's device; mrx_comm_wrap adopts an ncclComm_t the caller
+ * already owns.  RCCL is loaded at first use (dlopen), not at library load. */
+#define MRX_COMM_ID_BYTES 128
+int mrx_comm_unique_id(mrx_ctx* ctx, void* id_out);
+int mrx_comm_create(mrx_ctx* ctx, const void* id, int world, int rank, mrx_comm** comm);
+int mrx_comm_wrap(mrx_ctx* ctx, void* nccl_comm, int world, int rank, mrx_comm** comm);
+int mrx_comm_destroy(mrx_ctx* ctx, mrx_comm* comm);
+/* d_full[r * count + i] = rank r's d_shard[i], for every rank, enqueued on the context's
+ * stream.  count = rows_per_rank * ld floats: every rank passes the same count (pad the last
+ * shard's rows).  In place when d_shard == d_full + rank * count, i.e. when the writer put the
+ * shard straight into its slot of the full TOD (mrx_spline_upsample's d_out / ld_out). */
+int mrx_allgather_tod(mrx_ctx* ctx, mrx_comm* comm, const float* d_shard, float* d_full,
+                      size_t count);
 
 /* ---- map sampling --------------------------------------------- */
 

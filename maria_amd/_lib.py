@@ -164,6 +164,11 @@ SIGNATURES = {
     "mrx_gauss_smooth2d": (_i, [_vp, _vp, _vp, _vp, _i, _i, _d, _d, _d]),
     "mrx_map_smooth": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _d]),
     "mrx_screen_generate": (_i, [_vp, C.c_uint64, C.c_uint32, _i, _i, _d, _d, _d, _d, _vp, _vp]),
+    "mrx_comm_unique_id": (_i, [_vp, _vp]),
+    "mrx_comm_create": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
+    "mrx_comm_wrap": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
+    "mrx_comm_destroy": (_i, [_vp, _vp]),
+    "mrx_allgather_tod": (_i, [_vp, _vp, _vp, _vp, _sz]),
     "mrx_screen_work_floats": (_i, [_i, _i, _i, C.POINTER(_sz)]),
     "mrx_screen_generate_batch": (_i, [_vp, C.c_uint64, _i, _i, C.POINTER(MrxScreenDesc), _i, _vp, _sz]),
     "mrx_screen_psd_sum": (_i, [_vp, _i, _i, _d, _d, _d, _d, C.POINTER(_d)]),

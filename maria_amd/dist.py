@@ -54,6 +54,87 @@ def all_gather_tod(local: torch.Tensor, n_det: int, align: int = 16, time_chunk:
     return out
 
 
+class TodGather:
+    """The all-gather of the north star through the C ABI: ``mrx_comm_create`` +
+    ``mrx_allgather_tod`` (RCCL over xGMI, loaded by libmrx itself).  The unique id travels
+    from rank 0 over the already-initialised ``torch.distributed`` group (any backend) -- the
+    only thing torch does here.  ``world == 1`` needs no group at all.
+
+    The TOD is detector-major and shards are equal row blocks, so every rank allocates the
+    whole ``[world * rows_per_rank, T]`` array once, the writer puts the shard straight into
+    this rank's rows (``my_rows``) and ``gather()`` completes the array in place: no staging."""
+
+    def __init__(self, ctx, n_det: int, world: int = None, rank: int = None, align: int = 16):
+        import ctypes as C
+
+        if world is None:
+            world = dist.get_world_size() if dist.is_initialized() else 1
+        if rank is None:
+            rank = dist.get_rank() if dist.is_initialized() else 0
+        self.ctx, self.world, self.rank, self.n_det = ctx, int(world), int(rank), int(n_det)
+        self.rows_per_rank = shard_bounds(n_det, world, 0, align)[1] if world > 1 else n_det
+        self.lo, self.hi = shard_bounds(n_det, world, rank, align)
+        ident = C.create_string_buffer(128)
+        if self.rank == 0:
+            ctx.call("mrx_comm_unique_id", ident)
+        if self.world > 1:
+            box = [ident.raw]
+            dist.broadcast_object_list(box, src=0)
+            ident = C.create_string_buffer(box[0], 128)
+        comm = C.c_void_p()
+        ctx.call("mrx_comm_create", ident, self.world, self.rank, C.byref(comm))
+        self.comm = comm
+
+    def full_buffer(self, T: int, device) -> torch.Tensor:
+        """[world * rows_per_rank, T] float32; rows >= n_det (padding of the last shard) are scratch."""
+        return torch.empty((self.world * self.rows_per_rank, T), dtype=torch.float32, device=device)
+
+    def my_rows(self, full: torch.Tensor) -> torch.Tensor:
+        return full[self.lo : self.hi]
+
+    def gather(self, full: torch.Tensor, shard: torch.Tensor = None):
+        """Complete ``full`` on every rank (enqueued on the context's stream).  ``shard``: a
+        separate contiguous [rows_per_rank, T] buffer to gather from; default in place."""
+        from ._lib import ptr
+
+        assert full.is_contiguous() and full.shape[0] == self.world * self.rows_per_rank
+        count = self.rows_per_rank * full.shape[1]
+        src = full[self.rank * self.rows_per_rank :] if shard is None else shard
+        assert src.is_contiguous() and src.numel() >= count
+        self.ctx.call("mrx_allgather_tod", self.comm, ptr(src), ptr(full), count)
+        return full[: self.n_det]
+
+    def bytes_received(self, T: int) -> int:
+        return (self.world - 1) * self.rows_per_rank * T * 4
+
+    def close(self):
+        if getattr(self, "comm", None):
+            self.ctx.call("mrx_comm_destroy", self.comm)
+            self.comm = None
+
+
+def layers_of_rank(n_layers: int, world_size: int = None, rank: int = None):
+    """Round-robin ownership of the turbulent layers for sharded screen generation."""
+    if world_size is None:
+        world_size = dist.get_world_size() if dist.is_initialized() else 1
+    if rank is None:
+        rank = dist.get_rank() if dist.is_initialized() else 0
+    return list(range(rank, n_layers, world_size))
+
+
+def exchange_layer_screens(screens):
+    """Strong-scaling option: each rank generated only ``layers_of_rank`` into its (persistent,
+    plan-bound) screen buffers; one broadcast per layer from its owner fills the rest in
+    place.  Screens are functions of (seed, layer) only, so the result is bit for bit what every
+    rank would have generated itself.  Layers may differ in shape, hence per-layer broadcasts."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return screens
+    world = dist.get_world_size()
+    for l, t in enumerate(screens):
+        dist.broadcast(t, src=l % world)
+    return screens
+
+
 def stream_gathered_tod(local: torch.Tensor, n_det: int, time_chunk: int, consume=None, align: int = 16) -> int:
     """All-gather the TOD one time chunk at a time into a reusable staging buffer and
     hand each gathered [n_det, chunk] block to ``consume`` (the full gather of a large

@@ -203,12 +203,14 @@ class DevicePath:
         self.ctx.call("mrx_atm_plan_info", self.plan, C.byref(ua), C.byref(tl))
         return ua.value, bool(tl.value)
 
-    def generate_screens(self, smooth=True):
+    def generate_screens(self, smooth=True, only=None):
         """Philox + k-space filter + complex-to-real iFFT on the device with the beam
         smoothing (atmosphere/atmosphere.py:328-344) folded into the two FFT passes
         (mrx_screen_generate_batch), into persistent screen buffers.  The first call
         allocates the buffers and binds them; later calls only launch kernels: two per
-        group of layers that share an FFT domain.  Returns the device tensors."""
+        group of layers that share an FFT domain.  ``only``: generate just these layer indices
+        (sharded generation, maria_amd.dist.exchange_layer_screens fills in the rest).
+        Returns the device tensors."""
         dev = self.device
         layers = self.problem["layers"]
         shapes = [(len(l["extrusion"]), len(l["cross_section"])) for l in layers]
@@ -230,6 +232,10 @@ class DevicePath:
             self.set_screens(self._gen_screens)
         with _range("Generating turbulence"):
             for (fe, fc), members in self._gen_groups.items():
+                if only is not None:
+                    members = [l for l in members if l in only]
+                    if not members:
+                        continue
                 descs = (_lib.MrxScreenDesc * len(members))()
                 for d, l in zip(descs, members):
                     layer, out = layers[l], self._gen_screens[l]

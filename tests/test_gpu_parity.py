@@ -268,3 +268,29 @@ def test_shard_rows_are_bit_identical(gpu_ctx):
     for sl in [slice(0, 100), slice(100, 117), slice(117, 301)]:
         part = _device_path(p, ctx=gpu_ctx, det_slice=sl).run().cpu().numpy()
         assert np.array_equal(part, whole[sl])
+
+
+def test_allgather_through_the_c_abi_single_rank(gpu_ctx):
+    """mrx_comm_create + mrx_allgather_tod (RCCL loaded by libmrx) with a communicator of one
+    rank: in place it leaves the buffer as the writer filled it, out of place it copies the shard
+    into slot 0.  The multi-rank path is the same call with world > 1 (bench.py --gpus N)."""
+    import torch
+
+    from maria_amd.dist import TodGather
+
+    n_det, T = 37, 1000
+    g = TodGather(gpu_ctx, n_det, world=1, rank=0)
+    assert (g.lo, g.hi, g.rows_per_rank) == (0, n_det, n_det)
+    full = g.full_buffer(T, "cuda:0")
+    rows = g.my_rows(full)
+    rows.copy_(torch.arange(n_det * T, dtype=torch.float32, device="cuda:0").reshape(n_det, T))
+    want = rows.clone()
+    out = g.gather(full)
+    torch.cuda.synchronize()
+    assert torch.equal(out, want)
+    shard = torch.rand((n_det, T), dtype=torch.float32, device="cuda:0")
+    out = g.gather(full, shard=shard)
+    torch.cuda.synchronize()
+    assert torch.equal(out, shard)
+    assert g.bytes_received(T) == 0
+    g.close()
