@@ -12,7 +12,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmrx.so")
+# MRX_LIB_PATH: another build of the same sources (kernel A/B timing on one box, scripts/ab.sh)
+LIB_PATH = os.environ.get("MRX_LIB_PATH") or os.path.join(_HERE, "libmrx.so")
 
 MRX_OK = 0
 FLAG_SCREEN_OOB = 1

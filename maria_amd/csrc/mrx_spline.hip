@@ -379,20 +379,6 @@ struct CalDet {
   int exact;
 };
 
-// K_RJ of one sample: s / lerp(den) with jax's weight (x - lo)/(hi - lo); NaN
-// outside the axis (jax fill value).
-// kInverse: the way back, K_RJ -> pW (s * den).
-template <bool kInverse = false>
-__device__ __forceinline__ float krj_value(float s, float el, float2 lo,
-                                           float2 hi, float el_first,
-                                           float el_last) {
-  const float wt = (el - lo.x) * __builtin_amdgcn_rcpf(hi.x - lo.x);
-  float den = 0.0f + lo.y * (1.0f - wt);
-  den = den + hi.y * wt;
-  if (!(el >= el_first && el <= el_last)) den = __builtin_nanf("");
-  return kInverse ? s * den : s * __builtin_amdgcn_rcpf(den);
-}
-
 // detector elevation (transforms.py:20-28): im = sin(el) as the chain computes
 // it, then el = asin(im) by one Newton step from el0 = el_bore + dy, whose
 // sine and cosine follow from the angle-addition formulas (no inverse
@@ -414,8 +400,10 @@ __device__ __forceinline__ float det_elevation(const CalDet& c, float eb, float 
 }
 
 // the linear model of CalDet around the boresight elevation ebm (see CalDet)
+constexpr float kModelHalfRange = 2.0e-2f;  // wide enough that float32 rounding of the differences stays below 1e-7 rad over a tile
+
 __device__ __forceinline__ void set_elevation_model(CalDet& c, float ebm) {
-  constexpr float h = 2.0e-2f;  // wide enough that float32 rounding of the differences stays below 1e-7 rad over a tile
+  constexpr float h = kModelHalfRange;
   float e[3];
   bool steep = false;
 #pragma unroll
@@ -446,71 +434,143 @@ __device__ __forceinline__ CalDet make_cal_det(float dx, float dy, int band, flo
   return c;
 }
 
-// den lookup with jax's _find_indices on the elevation axis: arithmetic guess from the
-// first interval's step (am's axis is uniform but for its last node, which the clamp
-// absorbs), corrected by a short walk when the guess is off (non-uniform axis, a sample
-// within rounding of a node)
-template <bool kInverse = false>
-__device__ __forceinline__ float krj_lookup(float s, float el, const float2* G, int n_el,
-                                            float el_first, float el_last, float el_inv) {
-  int i = min(max((int)fminf(fmaxf((el - el_first) * el_inv, -1.0f), 2.0e9f), 0), n_el - 2);
-  while (i < n_el - 2 && G[i + 1].x < el) ++i;
-  while (i > 0 && G[i].x >= el) --i;
-  return krj_value<kInverse>(s, el, G[i], G[i + 1], el_first, el_last);
+// The calibration table as the kernels hold it in LDS: per band, per cell i of the elevation
+// axis one float4 (x_i, den_i, 1/(x_{i+1} - x_i), den_{i+1}), so that one 16-byte LDS read
+// serves a lookup.  n_el - 1 cells per band.
+__device__ __forceinline__ void stage_cal_cells(float4* cells, const float* __restrict__ axis,
+                                                const float* __restrict__ values, int n_el, int n_bands) {
+  const int nc = n_el - 1;
+  for (int i = threadIdx.x; i < nc * n_bands; i += kBlock) {
+    const int b = i / nc, k = i - b * nc;
+    const float x0 = axis[k], x1 = axis[k + 1];
+    cells[i] = make_float4(x0, values[b * n_el + k], 1.0f / (x1 - x0), values[b * n_el + k + 1]);
+  }
 }
 
+// den at elevation el with jax's _find_indices / linear weights on the elevation axis
+// (NaN off the axis): arithmetic guess from the first cell's step (am's axis is uniform but
+// for its last node, which the clamp absorbs), corrected by a short walk when the guess is off
+// (non-uniform axis, a sample within rounding of a node)
+__device__ __forceinline__ float den_lookup(float el, const float4* C, int n_el, float el_first,
+                                            float el_last, float el_inv) {
+  const int nc = n_el - 1;
+  int i = min(max((int)fminf(fmaxf((el - el_first) * el_inv, -1.0f), 2.0e9f), 0), nc - 1);
+  while (i < nc - 1 && C[i + 1].x < el) ++i;  // searchsorted(side="left") - 1: x_i < el <= x_{i+1}
+  while (i > 0 && C[i].x >= el) --i;
+  const float4 c = C[i];
+  const float wt = (el - c.x) * c.z;
+  float den = 0.0f + c.y * (1.0f - wt);
+  den = den + c.w * wt;
+  return (el >= el_first && el <= el_last) ? den : __builtin_nanf("");
+}
+
+// Per-thread part of the K_RJ conversion that does not depend on the detector row.
+struct KrjSamples {
+  float eb0, eb3;  // boresight elevation of the thread's first and last sample
+  float x0, x3;    // the same minus the tile's reference elevation (CalDet::ebm)
+};
+
 // The K_RJ values of a thread's 4 consecutive samples of one detector.  den is piecewise
-// linear in the elevation and the elevation is linear in the sample index to ~5e-8 rad over
-// 4 samples (10 ms of scanning), so when the first and last sample share a cell of the axis
-// the two inner dens are interpolated between the outer ones (float32 rounding apart, the
-// value jax computes); otherwise -- a node between them, a guess that missed, an elevation
-// off the axis -- every sample is looked up on its own at the interpolated elevation.
+// linear in the elevation, and the elevation is linear in the sample index to ~5e-8 rad over 4
+// samples (10 ms of scanning, over which den itself moves by ~3e-6 of its value): when the
+// first and last sample share a cell of the axis, den -- or its reciprocal, equal to second
+// order, 1e-11 -- of the inner two is interpolated between the outer ones (float32 rounding
+// apart, the value jax computes); otherwise -- a node between them, a guess that missed, an
+// elevation off the axis -- every sample is looked up on its own at the interpolated
+// elevation.  `sv` already carries the detector's scale.
 template <bool kInverse = false>
-__device__ __forceinline__ void krj_row(const CalDet& c, const float2* G, int n_el, float el_first,
-                                        float el_last, float el_inv, const float (&eb)[kSamplesPerThread],
-                                        const float (&ca)[kSamplesPerThread], const float (&sa)[kSamplesPerThread],
+__device__ __forceinline__ void krj_row(const CalDet& c, const float4* C, int n_el, float el_first,
+                                        float el_last, float el_inv, const KrjSamples& k,
                                         const float (&sv)[kSamplesPerThread], float (&o)[kSamplesPerThread]) {
   constexpr int kL = kSamplesPerThread - 1;
   float e0, e3;
-  if (c.exact) {  // uniform over the workgroup: one detector row at a time
-    e0 = det_elevation(c, eb[0], ca[0], sa[0]);
-    e3 = det_elevation(c, eb[kL], ca[kL], sa[kL]);
+  if (c.exact) {  // uniform over the workgroup (one detector row at a time), and rare
+    const float a0 = k.eb0 - 1.57079637050628662109375f, a3 = k.eb3 - 1.57079637050628662109375f;
+    // cos / sin of (el_bore - pi/2) = sin / -cos of el_bore up to the rounding of float32(pi/2)
+    e0 = det_elevation(c, k.eb0, cosf(a0), sinf(a0));
+    e3 = det_elevation(c, k.eb3, cosf(a3), sinf(a3));
   } else {
-    e0 = fmaf(c.slope, eb[0] - c.ebm, eb[0] + c.dm);
-    e3 = fmaf(c.slope, eb[kL] - c.ebm, eb[kL] + c.dm);
+    e0 = fmaf(c.slope, k.x0, k.eb0 + c.dm);
+    e3 = fmaf(c.slope, k.x3, k.eb3 + c.dm);
   }
   const int i0 = min(max((int)fminf(fmaxf((e0 - el_first) * el_inv, -1.0f), 2.0e9f), 0), n_el - 2);
-  const int i3 = min(max((int)fminf(fmaxf((e3 - el_first) * el_inv, -1.0f), 2.0e9f), 0), n_el - 2);
-  const float2 lo = G[i0], hi = G[i0 + 1];
-  const float emin = fminf(e0, e3), emax = fmaxf(e0, e3);
-  // both ends in cell i0 by jax's rule (lo < x <= hi, the first cell closed below), on the axis
-  const bool slow = i0 != i3 || (i0 < n_el - 2 && hi.x < emax) || (i0 > 0 && lo.x >= emin) ||
-                    !(emin >= el_first && emax <= el_last);
-  {
-    const float inv = __builtin_amdgcn_rcpf(hi.x - lo.x);
-    const float w0 = (e0 - lo.x) * inv, w3 = (e3 - lo.x) * inv;
-    float d0 = 0.0f + lo.y * (1.0f - w0);
-    d0 = d0 + hi.y * w0;
-    float d3 = 0.0f + lo.y * (1.0f - w3);
-    d3 = d3 + hi.y * w3;
+  const float4 cell = C[i0];
+  const float w0 = (e0 - cell.x) * cell.z, w3 = (e3 - cell.x) * cell.z;
+  // both ends inside cell i0 (0 < w <= 1; the first cell closed below) and on the axis.  A
+  // sample within rounding of a node may be taken for either neighbour: den is continuous there.
+  const float wmin = fminf(w0, w3), wmax = fmaxf(w0, w3);
+  const bool fast = (wmin > 0.0f || (i0 == 0 && wmin >= 0.0f)) && wmax <= 1.0f &&
+                    fminf(e0, e3) >= el_first && fmaxf(e0, e3) <= el_last;
+  float d0 = 0.0f + cell.y * (1.0f - w0);
+  d0 = d0 + cell.w * w0;
+  float d3 = 0.0f + cell.y * (1.0f - w3);
+  d3 = d3 + cell.w * w3;
+  if (kInverse) {
     const float step = (d3 - d0) * (1.0f / (float)kL);
 #pragma unroll
-    for (int q = 0; q < kSamplesPerThread; ++q)
-    {
-      const float den = q == 0 ? d0 : q == kL ? d3 : d0 + (float)q * step;
-      o[q] = kInverse ? sv[q] * den : sv[q] * __builtin_amdgcn_rcpf(den);
-    }
+    for (int q = 0; q < kSamplesPerThread; ++q) o[q] = sv[q] * (q == 0 ? d0 : q == kL ? d3 : fmaf((float)q, step, d0));
+  } else {
+    const float r0 = __builtin_amdgcn_rcpf(d0), r3 = __builtin_amdgcn_rcpf(d3);
+    const float step = (r3 - r0) * (1.0f / (float)kL);
+#pragma unroll
+    for (int q = 0; q < kSamplesPerThread; ++q) o[q] = sv[q] * (q == 0 ? r0 : q == kL ? r3 : fmaf((float)q, step, r0));
   }
-  // lanes that cross a node (or left the axis) look every sample up, at the elevation
-  // interpolated between the outer two
-  if (slow) {
-    const float de = (e3 - e0) * (1.0f / (float)kL);
+  if (__builtin_amdgcn_ballot_w64(!fast) != 0) {
+    if (!fast) {
+      const float de = (e3 - e0) * (1.0f / (float)kL);
 #pragma unroll 1
-    for (int q = 0; q < kSamplesPerThread; ++q) {
-      const float el = q == 0 ? e0 : q == kL ? e3 : e0 + (float)q * de;
-      o[q] = krj_lookup<kInverse>(sv[q], el, G, n_el, el_first, el_last, el_inv);
+      for (int q = 0; q < kSamplesPerThread; ++q) {
+        const float el = q == 0 ? e0 : q == kL ? e3 : e0 + (float)q * de;
+        const float den = den_lookup(el, C, n_el, el_first, el_last, el_inv);
+        o[q] = kInverse ? sv[q] * den : sv[q] * __builtin_amdgcn_rcpf(den);
+      }
     }
   }
+}
+
+// Shared prologue of the two K_RJ kernels: stage the cell table and the tile's detector
+// constants, fit the tile's elevation model, and return this thread's sample constants.
+// Ends with a barrier.
+__device__ __forceinline__ KrjSamples krj_prologue(float4* cells, CalDet* cdet, float* red,
+                                                   const float* __restrict__ bore_el, int T, int sb, int s_tile,
+                                                   const float* __restrict__ dxs, const float* __restrict__ dys,
+                                                   const int32_t* __restrict__ band, const float* __restrict__ scale,
+                                                   const float* __restrict__ cal_axis,
+                                                   const float* __restrict__ cal_values, int n_el, int n_bands,
+                                                   int d0, int nd) {
+  KrjSamples k;
+  k.eb0 = bore_el[min(sb, T - 1)];
+  k.eb3 = bore_el[min(sb + kSamplesPerThread - 1, T - 1)];
+  // boresight elevation range of the tile (its samples are monotone enough that the ends of
+  // the threads' 4-sample runs bound it to ~1e-7 rad): lanes -> waves -> workgroup
+  float lo = fminf(k.eb0, k.eb3), hi = fmaxf(k.eb0, k.eb3);
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, m, 64));
+    hi = fmaxf(hi, __shfl_xor(hi, m, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[2 * (threadIdx.x >> 6)] = lo;
+    red[2 * (threadIdx.x >> 6) + 1] = hi;
+  }
+  stage_cal_cells(cells, cal_axis, cal_values, n_el, n_bands);
+  __syncthreads();
+  lo = fminf(fminf(red[0], red[2]), fminf(red[4], red[6]));
+  hi = fmaxf(fmaxf(red[1], red[3]), fmaxf(red[5], red[7]));
+  const float ebm = 0.5f * (lo + hi);
+  if ((int)threadIdx.x < nd) {
+    const int d = d0 + threadIdx.x;
+    CalDet c = make_cal_det(dxs[d], dys[d], min(max(band[d], 0), n_bands - 1), scale ? scale[d] : 1.0f);
+    set_elevation_model(c, ebm);
+    // the model is a finite difference over ebm +- 0.02 rad: a tile whose boresight sweeps
+    // farther (slow sample rates, fast elevation slews) takes the full formula per sample
+    if (!(hi - lo <= 2.0f * kModelHalfRange)) c.exact = 1;
+    cdet[threadIdx.x] = c;
+  }
+  k.x0 = k.eb0 - ebm;
+  k.x3 = k.eb3 - ebm;
+  __syncthreads();
+  return k;
 }
 
 __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
@@ -521,11 +581,12 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
     const int32_t* __restrict__ band, const float* __restrict__ cal_axis,
     const float* __restrict__ cal_values, int n_el, int n_bands,
     float* __restrict__ out, size_t ld, int vec_ok) {
-  constexpr int kMaxKnots = 256;
+  constexpr int kMaxKnots = 64;  // 8 KiB image: the arithmetic of this writer wants the occupancy
   constexpr int kPitch = kMaxKnots + 1;
-  extern __shared__ float2 cal_lds[];  // [n_bands][n_el] pairs (axis node, den value)
+  extern __shared__ __align__(16) float4 cal_cells[];  // [n_bands][n_el - 1], see stage_cal_cells
   __shared__ float2 tile[kTileDet * kPitch];
   __shared__ CalDet cdet[kTileDet];
+  __shared__ float red[8];
   auto row_of = [&](int d) -> size_t { return rows ? (size_t)rows[d] : (size_t)d; };
 
   const int s_tile = blockIdx.x * kTileSamples;
@@ -535,24 +596,6 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
 
   SampleWeights w;
   sample_weights(t, sb, T, n, ta0, inv_dta, w);
-  // boresight tilt of this thread's samples: cos/sin of (el - pi/2), float32
-  float ca[kSamplesPerThread], sa[kSamplesPerThread], eb[kSamplesPerThread];
-#pragma unroll
-  for (int q = 0; q < kSamplesPerThread; ++q) {
-    eb[q] = bore_el[min(sb + q, T - 1)];
-    const float a = eb[q] - 1.57079637050628662109375f;
-    ca[q] = cosf(a);  // = sin(el_bore) up to the rounding of float32(pi/2)
-    sa[q] = sinf(a);  // = -cos(el_bore)
-  }
-
-  for (int i = threadIdx.x; i < n_el * n_bands; i += kBlock)
-    cal_lds[i] = make_float2(cal_axis[i % n_el], cal_values[i]);
-  if ((int)threadIdx.x < nd) {
-    const int d = d0 + threadIdx.x;
-    CalDet c = make_cal_det(dxs[d], dys[d], min(max(band[d], 0), n_bands - 1), scale ? scale[d] : 1.0f);
-    set_elevation_model(c, bore_el[min(s_tile + kTileSamples / 2, T - 1)]);
-    cdet[threadIdx.x] = c;
-  }
 
   const int s_last = min(s_tile + kTileSamples, T) - 1;
   const int jmin = interval_of((t[s_tile] - ta0) * inv_dta, n);
@@ -568,32 +611,35 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
       tile[dl * kPitch + r] = v;
     }
   }
-  __syncthreads();
+  const KrjSamples ks = krj_prologue(cal_cells, cdet, red, bore_el, T, sb, s_tile, dxs, dys, band, scale, cal_axis,
+                                     cal_values, n_el, n_bands, d0, nd);  // ends with a barrier
 
-  const float el_first = cal_lds[0].x, el_last = cal_lds[n_el - 1].x;
-  const float el_inv = 1.0f / (cal_lds[1].x - el_first);
+  const float el_first = cal_cells[0].x, el_last = cal_axis[n_el - 1];
+  const float el_inv = cal_cells[0].z;
   const bool full = (sb + kSamplesPerThread <= T) && vec_ok;
+  int r[kSamplesPerThread];
+#pragma unroll
+  for (int q = 0; q < kSamplesPerThread; ++q) r[q] = min(max(w.j[q] - jmin, 0), max(K - 2, 0));
   // the loop body is instantiated once per knot source so that each instance
   // addresses one memory space (a runtime select would force flat loads)
   auto body = [&](auto from_lds) {
   for (int dl = 0; dl < nd; ++dl) {
     const CalDet c = cdet[dl];
-    const float2* G = cal_lds + c.band * n_el;  // (axis node, den)
+    const float4* C = cal_cells + c.band * (n_el - 1);
     float o[kSamplesPerThread], sv[kSamplesPerThread];
 #pragma unroll
     for (int q = 0; q < kSamplesPerThread; ++q) {
       float2 k0, k1;
       if constexpr (decltype(from_lds)::value) {
-        const int r = min(max(w.j[q] - jmin, 0), K - 2);
-        k0 = tile[dl * kPitch + r];
-        k1 = tile[dl * kPitch + r + 1];
+        k0 = tile[dl * kPitch + r[q]];
+        k1 = tile[dl * kPitch + r[q] + 1];
       } else {
         k0 = ym[(size_t)w.j[q] * D + d0 + dl];
         k1 = ym[(size_t)(w.j[q] + 1) * D + d0 + dl];
       }
       sv[q] = c.scale * spline_eval(w, q, k0, k1);
     }
-    krj_row(c, G, n_el, el_first, el_last, el_inv, eb, ca, sa, sv, o);
+    krj_row(c, C, n_el, el_first, el_last, el_inv, ks, sv, o);
     float* dst = out + row_of(d0 + dl) * ld + sb;
     if (full) {
       const vfloat4 v = {o[0], o[1], o[2], o[3]};
@@ -619,36 +665,22 @@ __global__ __launch_bounds__(kBlock) void tod_krj_kernel(
     const float* __restrict__ dxs, const float* __restrict__ dys,
     const int32_t* __restrict__ band, const float* __restrict__ cal_axis,
     const float* __restrict__ cal_values, int n_el, int n_bands, int vec_ok) {
-  extern __shared__ float2 cal_lds[];
+  extern __shared__ __align__(16) float4 cal_cells[];
   __shared__ CalDet cdet[kTileDet];
+  __shared__ float red[8];
   const int s_tile = blockIdx.x * kTileSamples;
   const int d0 = blockIdx.y * kTileDet;
   const int sb = s_tile + threadIdx.x * kSamplesPerThread;
   const int nd = min(kTileDet, D - d0);
-  float ca[kSamplesPerThread], sa[kSamplesPerThread], eb[kSamplesPerThread];
-#pragma unroll
-  for (int q = 0; q < kSamplesPerThread; ++q) {
-    eb[q] = bore_el[min(sb + q, T - 1)];
-    const float a = eb[q] - 1.57079637050628662109375f;
-    ca[q] = cosf(a);
-    sa[q] = sinf(a);
-  }
-  for (int i = threadIdx.x; i < n_el * n_bands; i += kBlock)
-    cal_lds[i] = make_float2(cal_axis[i % n_el], cal_values[i]);
-  if ((int)threadIdx.x < nd) {
-    const int d = d0 + threadIdx.x;
-    CalDet c = make_cal_det(dxs[d], dys[d], min(max(band[d], 0), n_bands - 1), scale ? scale[d] : 1.0f);
-    set_elevation_model(c, bore_el[min(s_tile + kTileSamples / 2, T - 1)]);
-    cdet[threadIdx.x] = c;
-  }
-  __syncthreads();
+  const KrjSamples ks = krj_prologue(cal_cells, cdet, red, bore_el, T, sb, s_tile, dxs, dys, band, scale, cal_axis,
+                                     cal_values, n_el, n_bands, d0, nd);  // ends with a barrier
   if (sb >= T) return;
-  const float el_first = cal_lds[0].x, el_last = cal_lds[n_el - 1].x;
-  const float el_inv = 1.0f / (cal_lds[1].x - el_first);
+  const float el_first = cal_cells[0].x, el_last = cal_axis[n_el - 1];
+  const float el_inv = cal_cells[0].z;
   const bool full = (sb + kSamplesPerThread <= T) && vec_ok;
   for (int dl = 0; dl < nd; ++dl) {
     const CalDet c = cdet[dl];
-    const float2* G = cal_lds + c.band * n_el;
+    const float4* C = cal_cells + c.band * (n_el - 1);
     float* row = data + (rows ? (size_t)rows[d0 + dl] : (size_t)(d0 + dl)) * ld + sb;
     float v[kSamplesPerThread];
     if (full) {
@@ -661,7 +693,7 @@ __global__ __launch_bounds__(kBlock) void tod_krj_kernel(
     float sv[kSamplesPerThread];
 #pragma unroll
     for (int q = 0; q < kSamplesPerThread; ++q) sv[q] = c.scale * v[q];
-    krj_row<kInverse>(c, G, n_el, el_first, el_last, el_inv, eb, ca, sa, sv, v);
+    krj_row<kInverse>(c, C, n_el, el_first, el_last, el_inv, ks, sv, v);
     if (full) {
       const vfloat4 x = {v[0], v[1], v[2], v[3]};
       __builtin_nontemporal_store(x, reinterpret_cast<vfloat4*>(row));
@@ -852,7 +884,7 @@ int mrx_spline_upsample_krj(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
   MRX_REQUIRE(ctx, grid.y <= 65535u, "D too large for one launch");
   const int vec_ok =
       (ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15u) == 0);
-  const size_t lds = sizeof(float2) * (size_t)n_el * n_bands;
+  const size_t lds = sizeof(float4) * (size_t)(n_el - 1) * n_bands;  // the cell table
   hipLaunchKernelGGL(spline_upsample_krj_kernel, grid, dim3(kBlock), lds,
                      ctx->stream, reinterpret_cast<const float2*>(d_ym), D, Ta,
                      ta0, 1.0 / dta, d_t, T, d_scale, d_rows, d_bore_el, d_dx,
@@ -878,7 +910,7 @@ static int tod_convert(mrx_ctx* ctx, bool inverse, float* d_data, size_t ld, int
   dim3 grid(mrx_ceil_div(T, kTileSamples), mrx_ceil_div(D, kTileDet));
   MRX_REQUIRE(ctx, grid.y <= 65535u, "D too large for one launch");
   const int vec_ok = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_data) & 15u) == 0);
-  const size_t lds = sizeof(float2) * (size_t)n_el * n_bands;
+  const size_t lds = sizeof(float4) * (size_t)(n_el - 1) * n_bands;  // the cell table
   if (inverse)
     hipLaunchKernelGGL(tod_krj_kernel<true>, grid, dim3(kBlock), lds, ctx->stream, d_data, ld, D, T,
                        d_scale, d_rows, d_bore_el, d_dx, d_dy, d_band, d_cal_axis_el,

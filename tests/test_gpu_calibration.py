@@ -121,6 +121,39 @@ def test_krj_upsample_matches_oracle(gpu_ctx):
     assert np.array_equal(got[b1], 2.0 * got2[b1]) and np.array_equal(got[~b1], got2[~b1])
 
 
+@pytest.mark.parametrize("el_range_deg", [(25.0, 80.0), (50.0, 52.2), (50.0, 51.5), (84.0, 89.5)])
+def test_krj_conversion_under_an_elevation_slew(gpu_ctx, el_range_deg):
+    """The K_RJ kernels model a detector's elevation per 1024-sample tile as linear in the
+    boresight elevation (fitted over +-0.02 rad); a tile whose boresight sweeps farther -- a fast
+    elevation slew at a low sample rate -- must take the full formula per sample, and so must
+    one that ends near the zenith.  One tile of 1000 samples over 55 deg, over 2.2 deg (just past
+    the model's range), over 1.5 deg (inside it) and up to 89.5 deg, wide focal plane."""
+    import torch
+
+    from maria_amd.pipeline import DevicePath
+    from oracle import hotpath
+
+    p = small_problem(n_det=45, n_bands=2, n_layers=1)
+    T = len(p["t"])
+    rng = np.random.default_rng(3)
+    coords_offsets = np.radians(rng.uniform(-1.0, 1.0, (45, 2)))  # a 2 deg focal plane
+    el_slew = np.radians(np.linspace(el_range_deg[0], el_range_deg[1], T))
+    tables = _cal_tables(2)
+    T0r, pwvr = 273.15, 1.0
+    path = DevicePath(p, device="cuda:0", ctx=gpu_ctx)
+    path.set_calibration(tables, T0r, pwvr, el_slew, coords_offsets, [False, True])
+    data = torch.ones((path.D, path.T), dtype=torch.float32, device="cuda:0")
+    path.to_krj(data)
+    got = data.cpu().numpy()
+    _, el_det = hotpath.broadcast(coords_offsets, np.zeros(T), el_slew)
+    ref = hotpath.calibrate_to_krj(np.ones((45, T), np.float32), p["band_index"], tables, T0r, pwvr, el_det, [False, True])
+    ok = np.isfinite(ref)  # beyond the table's last node (90.1 deg) both give NaN
+    assert np.array_equal(np.isfinite(got), ok)
+    assert np.abs(got[ok] / ref[ok] - 1).max() <= 1e-5
+    back = path.from_krj(data).cpu().numpy()
+    assert np.abs(back[ok] - 1).max() <= 2e-6
+
+
 def test_run_default_units_are_krj(gpu_ctx):
     """Simulation.run() with the reference's default units against the oracle chain."""
     from maria_amd.instrument import Band, Detectors, Instrument, Site
