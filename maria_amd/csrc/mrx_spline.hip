@@ -468,6 +468,7 @@ __device__ __forceinline__ float den_lookup(float el, const float4* C, int n_el,
 struct KrjSamples {
   float eb0, eb3;  // boresight elevation of the thread's first and last sample
   float x0, x3;    // the same minus the tile's reference elevation (CalDet::ebm)
+  float ca0, sa0, ca3, sa3;
 };
 
 // The K_RJ values of a thread's 4 consecutive samples of one detector.  den is piecewise
@@ -485,10 +486,8 @@ __device__ __forceinline__ void krj_row(const CalDet& c, const float4* C, int n_
   constexpr int kL = kSamplesPerThread - 1;
   float e0, e3;
   if (c.exact) {  // uniform over the workgroup (one detector row at a time), and rare
-    const float a0 = k.eb0 - 1.57079637050628662109375f, a3 = k.eb3 - 1.57079637050628662109375f;
-    // cos / sin of (el_bore - pi/2) = sin / -cos of el_bore up to the rounding of float32(pi/2)
-    e0 = det_elevation(c, k.eb0, cosf(a0), sinf(a0));
-    e3 = det_elevation(c, k.eb3, cosf(a3), sinf(a3));
+    e0 = det_elevation(c, k.eb0, k.ca0, k.sa0);
+    e3 = det_elevation(c, k.eb3, k.ca3, k.sa3);
   } else {
     e0 = fmaf(c.slope, k.x0, k.eb0 + c.dm);
     e3 = fmaf(c.slope, k.x3, k.eb3 + c.dm);
@@ -528,21 +527,26 @@ __device__ __forceinline__ void krj_row(const CalDet& c, const float4* C, int n_
   }
 }
 
-// Shared prologue of the two K_RJ kernels: stage the cell table and the tile's detector
-// constants, fit the tile's elevation model, and return this thread's sample constants.
-// Ends with a barrier.
-__device__ __forceinline__ KrjSamples krj_prologue(float4* cells, CalDet* cdet, float* red,
-                                                   const float* __restrict__ bore_el, int T, int sb, int s_tile,
-                                                   const float* __restrict__ dxs, const float* __restrict__ dys,
-                                                   const int32_t* __restrict__ band, const float* __restrict__ scale,
-                                                   const float* __restrict__ cal_axis,
-                                                   const float* __restrict__ cal_values, int n_el, int n_bands,
-                                                   int d0, int nd) {
+// the trigonometry the exact path needs
+__device__ __forceinline__ void krj_exact_trig(KrjSamples& k) {
+  const float a0 = k.eb0 - 1.57079637050628662109375f, a3 = k.eb3 - 1.57079637050628662109375f;
+  k.ca0 = cosf(a0);  // = sin(el_bore) up to the rounding of float32(pi/2)
+  k.sa0 = sinf(a0);  // = -cos(el_bore)
+  k.ca3 = cosf(a3);
+  k.sa3 = sinf(a3);
+}
+
+// Shared prologue of the two K_RJ kernels, per workgroup: stage the cell table, reduce the
+// boresight elevation range of the tile's 1024 samples (red[8] = lo, red[9] = hi) and return
+// this thread's sample constants.  Ends with a barrier.
+__device__ __forceinline__ KrjSamples krj_prologue(float4* cells, float* red, const float* __restrict__ bore_el,
+                                                   int T, int sb, const float* __restrict__ cal_axis,
+                                                   const float* __restrict__ cal_values, int n_el, int n_bands) {
   KrjSamples k;
   k.eb0 = bore_el[min(sb, T - 1)];
   k.eb3 = bore_el[min(sb + kSamplesPerThread - 1, T - 1)];
-  // boresight elevation range of the tile (its samples are monotone enough that the ends of
-  // the threads' 4-sample runs bound it to ~1e-7 rad): lanes -> waves -> workgroup
+  // (the samples are monotone enough that the ends of the threads' 4-sample runs bound the
+  // range to ~1e-7 rad): lanes -> waves -> workgroup
   float lo = fminf(k.eb0, k.eb3), hi = fmaxf(k.eb0, k.eb3);
 #pragma unroll
   for (int m = 32; m > 0; m >>= 1) {
@@ -558,19 +562,39 @@ __device__ __forceinline__ KrjSamples krj_prologue(float4* cells, CalDet* cdet, 
   lo = fminf(fminf(red[0], red[2]), fminf(red[4], red[6]));
   hi = fmaxf(fmaxf(red[1], red[3]), fmaxf(red[5], red[7]));
   const float ebm = 0.5f * (lo + hi);
-  if ((int)threadIdx.x < nd) {
-    const int d = d0 + threadIdx.x;
-    CalDet c = make_cal_det(dxs[d], dys[d], min(max(band[d], 0), n_bands - 1), scale ? scale[d] : 1.0f);
-    set_elevation_model(c, ebm);
-    // the model is a finite difference over ebm +- 0.02 rad: a tile whose boresight sweeps
-    // farther (slow sample rates, fast elevation slews) takes the full formula per sample
-    if (!(hi - lo <= 2.0f * kModelHalfRange)) c.exact = 1;
-    cdet[threadIdx.x] = c;
-  }
   k.x0 = k.eb0 - ebm;
   k.x3 = k.eb3 - ebm;
+  krj_exact_trig(k);  // few tiles need it, but computing it under a (uniform) branch costs more than it saves
+  if (threadIdx.x == 0) {
+    red[8] = lo;
+    red[9] = hi;
+  }
   __syncthreads();
   return k;
+}
+
+// Per group of 16 detector rows: their constants and the tile's elevation model.  The caller
+// puts a barrier between this and the rows' use of cdet[].  Returns nothing; cdet[16].exact
+// of the LAST entry's neighbour slot red[10] is set when any row needs the full formula.
+__device__ __forceinline__ void krj_stage_rows(CalDet* cdet, float* red, const float* __restrict__ dxs,
+                                               const float* __restrict__ dys, const int32_t* __restrict__ band,
+                                               const float* __restrict__ scale, int n_bands, int d0, int nd) {
+  if ((int)threadIdx.x < kTileDet) {
+    const float lo = red[8], hi = red[9];
+    bool exact = false;
+    if ((int)threadIdx.x < nd) {
+      const int d = d0 + threadIdx.x;
+      CalDet c = make_cal_det(dxs[d], dys[d], min(max(band[d], 0), n_bands - 1), scale ? scale[d] : 1.0f);
+      set_elevation_model(c, 0.5f * (lo + hi));
+      // the model is a finite difference over ebm +- 0.02 rad: a tile whose boresight sweeps
+      // farther (slow sample rates, fast elevation slews) takes the full formula per sample
+      if (!(hi - lo <= 2.0f * kModelHalfRange)) c.exact = 1;
+      cdet[threadIdx.x] = c;
+      exact = c.exact != 0;
+    }
+    const bool any = __builtin_amdgcn_ballot_w64(exact) != 0;  // the 16 lanes sit in wave 0
+    if (threadIdx.x == 0) red[10] = any ? 1.0f : 0.0f;
+  }
 }
 
 __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
@@ -580,78 +604,85 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
     const float* __restrict__ dxs, const float* __restrict__ dys,
     const int32_t* __restrict__ band, const float* __restrict__ cal_axis,
     const float* __restrict__ cal_values, int n_el, int n_bands,
-    float* __restrict__ out, size_t ld, int vec_ok) {
+    float* __restrict__ out, size_t ld, int vec_ok, int groups) {
   constexpr int kMaxKnots = 64;  // 8 KiB image: the arithmetic of this writer wants the occupancy
   constexpr int kPitch = kMaxKnots + 1;
   extern __shared__ __align__(16) float4 cal_cells[];  // [n_bands][n_el - 1], see stage_cal_cells
   __shared__ float2 tile[kTileDet * kPitch];
   __shared__ CalDet cdet[kTileDet];
-  __shared__ float red[8];
+  __shared__ float red[12];
   auto row_of = [&](int d) -> size_t { return rows ? (size_t)rows[d] : (size_t)d; };
 
   const int s_tile = blockIdx.x * kTileSamples;
-  const int d0 = blockIdx.y * kTileDet;
   const int sb = s_tile + threadIdx.x * kSamplesPerThread;
-  const int nd = min(kTileDet, D - d0);
 
+  // per-sample interval, weights and boresight: computed once, reused for `groups` tiles of
+  // 16 detector rows each (the float64 prologue is a third of a single tile's instructions)
   SampleWeights w;
   sample_weights(t, sb, T, n, ta0, inv_dta, w);
+  const KrjSamples ks = krj_prologue(cal_cells, red, bore_el, T, sb, cal_axis, cal_values, n_el, n_bands);
 
   const int s_last = min(s_tile + kTileSamples, T) - 1;
   const int jmin = interval_of((t[s_tile] - ta0) * inv_dta, n);
   const int jmax = interval_of((t[s_last] - ta0) * inv_dta, n) + 1;
   const int K = jmax - jmin + 1;
   const bool use_lds = K <= kMaxKnots;
-  if (use_lds) {
-    const int dl = threadIdx.x & (kTileDet - 1);
-    const int d = d0 + dl;
-    for (int r = threadIdx.x / kTileDet; r < K; r += kBlock / kTileDet) {
-      float2 v = make_float2(0.f, 0.f);
-      if (d < D) v = ym[(size_t)(jmin + r) * D + d];
-      tile[dl * kPitch + r] = v;
-    }
-  }
-  const KrjSamples ks = krj_prologue(cal_cells, cdet, red, bore_el, T, sb, s_tile, dxs, dys, band, scale, cal_axis,
-                                     cal_values, n_el, n_bands, d0, nd);  // ends with a barrier
-
   const float el_first = cal_cells[0].x, el_last = cal_axis[n_el - 1];
   const float el_inv = cal_cells[0].z;
   const bool full = (sb + kSamplesPerThread <= T) && vec_ok;
   int r[kSamplesPerThread];
 #pragma unroll
   for (int q = 0; q < kSamplesPerThread; ++q) r[q] = min(max(w.j[q] - jmin, 0), max(K - 2, 0));
-  // the loop body is instantiated once per knot source so that each instance
-  // addresses one memory space (a runtime select would force flat loads)
-  auto body = [&](auto from_lds) {
-  for (int dl = 0; dl < nd; ++dl) {
-    const CalDet c = cdet[dl];
-    const float4* C = cal_cells + c.band * (n_el - 1);
-    float o[kSamplesPerThread], sv[kSamplesPerThread];
-#pragma unroll
-    for (int q = 0; q < kSamplesPerThread; ++q) {
-      float2 k0, k1;
-      if constexpr (decltype(from_lds)::value) {
-        k0 = tile[dl * kPitch + r[q]];
-        k1 = tile[dl * kPitch + r[q] + 1];
-      } else {
-        k0 = ym[(size_t)w.j[q] * D + d0 + dl];
-        k1 = ym[(size_t)(w.j[q] + 1) * D + d0 + dl];
+
+  for (int g = 0; g < groups; ++g) {
+    const int d0 = (blockIdx.y * groups + g) * kTileDet;
+    if (d0 >= D) break;
+    const int nd = min(kTileDet, D - d0);
+    if (g > 0) __syncthreads();  // the previous group is done with tile[] and cdet[]
+    if (use_lds) {
+      const int dl = threadIdx.x & (kTileDet - 1);
+      const int d = d0 + dl;
+      for (int rr = threadIdx.x / kTileDet; rr < K; rr += kBlock / kTileDet) {
+        float2 v = make_float2(0.f, 0.f);
+        if (d < D) v = ym[(size_t)(jmin + rr) * D + d];
+        tile[dl * kPitch + rr] = v;
       }
-      sv[q] = c.scale * spline_eval(w, q, k0, k1);
     }
-    krj_row(c, C, n_el, el_first, el_last, el_inv, ks, sv, o);
-    float* dst = out + row_of(d0 + dl) * ld + sb;
-    if (full) {
-      const vfloat4 v = {o[0], o[1], o[2], o[3]};
-      __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(dst));
-    } else {
+    krj_stage_rows(cdet, red, dxs, dys, band, scale, n_bands, d0, nd);
+    __syncthreads();
+    // the loop body is instantiated once per knot source so that each instance
+    // addresses one memory space (a runtime select would force flat loads)
+    auto body = [&](auto from_lds) {
+    for (int dl = 0; dl < nd; ++dl) {
+      const CalDet c = cdet[dl];
+      const float4* C = cal_cells + c.band * (n_el - 1);
+      float o[kSamplesPerThread], sv[kSamplesPerThread];
 #pragma unroll
-      for (int q = 0; q < kSamplesPerThread; ++q)
-        if (sb + q < T) dst[q] = o[q];
+      for (int q = 0; q < kSamplesPerThread; ++q) {
+        float2 k0, k1;
+        if constexpr (decltype(from_lds)::value) {
+          k0 = tile[dl * kPitch + r[q]];
+          k1 = tile[dl * kPitch + r[q] + 1];
+        } else {
+          k0 = ym[(size_t)w.j[q] * D + d0 + dl];
+          k1 = ym[(size_t)(w.j[q] + 1) * D + d0 + dl];
+        }
+        sv[q] = c.scale * spline_eval(w, q, k0, k1);
+      }
+      krj_row(c, C, n_el, el_first, el_last, el_inv, ks, sv, o);
+      float* dst = out + row_of(d0 + dl) * ld + sb;
+      if (full) {
+        const vfloat4 v = {o[0], o[1], o[2], o[3]};
+        __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(dst));
+      } else {
+#pragma unroll
+        for (int q = 0; q < kSamplesPerThread; ++q)
+          if (sb + q < T) dst[q] = o[q];
+      }
     }
+    };
+    if (use_lds) body(std::true_type{}); else body(std::false_type{});
   }
-  };
-  if (use_lds) body(std::true_type{}); else body(std::false_type{});
 }
 
 // TOD.to("K_RJ") of a field that is already at the full rate (noise, map, cmb;
@@ -667,13 +698,14 @@ __global__ __launch_bounds__(kBlock) void tod_krj_kernel(
     const float* __restrict__ cal_values, int n_el, int n_bands, int vec_ok) {
   extern __shared__ __align__(16) float4 cal_cells[];
   __shared__ CalDet cdet[kTileDet];
-  __shared__ float red[8];
+  __shared__ float red[12];
   const int s_tile = blockIdx.x * kTileSamples;
   const int d0 = blockIdx.y * kTileDet;
   const int sb = s_tile + threadIdx.x * kSamplesPerThread;
   const int nd = min(kTileDet, D - d0);
-  const KrjSamples ks = krj_prologue(cal_cells, cdet, red, bore_el, T, sb, s_tile, dxs, dys, band, scale, cal_axis,
-                                     cal_values, n_el, n_bands, d0, nd);  // ends with a barrier
+  KrjSamples ks = krj_prologue(cal_cells, red, bore_el, T, sb, cal_axis, cal_values, n_el, n_bands);
+  krj_stage_rows(cdet, red, dxs, dys, band, scale, n_bands, d0, nd);
+  __syncthreads();
   if (sb >= T) return;
   const float el_first = cal_cells[0].x, el_last = cal_axis[n_el - 1];
   const float el_inv = cal_cells[0].z;
@@ -880,7 +912,13 @@ int mrx_spline_upsample_krj(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
   if (Ta < 4)
     return mrx_fail(ctx, MRX_ERR_UNSUPPORTED,
                     "cubic interpolation needs at least 4 coarse samples");
-  dim3 grid(mrx_ceil_div(T, kTileSamples), mrx_ceil_div(D, kTileDet));
+  // detector tiles per workgroup: the per-sample prologue is shared by all of them
+  int groups = ctx->options[MRX_OPT_UPSAMPLE_GROUPS];
+  if (groups <= 0) groups = 4;  // measured on atlast_10k: 1 -> 2.69 ms, 2 -> 2.55, 4 -> 2.48
+  while (groups > 1 && (long long)mrx_ceil_div(T, kTileSamples) *
+                               mrx_ceil_div(D, kTileDet * groups) < 4LL * 256 * 4)
+    groups /= 2;  // keep the chip full on small problems
+  dim3 grid(mrx_ceil_div(T, kTileSamples), mrx_ceil_div(D, kTileDet * groups));
   MRX_REQUIRE(ctx, grid.y <= 65535u, "D too large for one launch");
   const int vec_ok =
       (ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15u) == 0);
@@ -889,7 +927,7 @@ int mrx_spline_upsample_krj(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
                      ctx->stream, reinterpret_cast<const float2*>(d_ym), D, Ta,
                      ta0, 1.0 / dta, d_t, T, d_scale, d_rows, d_bore_el, d_dx,
                      d_dy, d_band, d_cal_axis_el, d_cal_values, n_el, n_bands,
-                     d_out, ld_out, vec_ok);
+                     d_out, ld_out, vec_ok, groups);
   MRX_CHECK_LAUNCH(ctx);
   return MRX_OK;
 }
