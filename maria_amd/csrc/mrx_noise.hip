@@ -210,8 +210,13 @@ __global__ __launch_bounds__(kBlock) void noise_pair_means(int n1, int n2, Spect
 // number of modes, or -1 for "any" (read per series, no register copy).
 constexpr int kPairsPerBlock = 4;
 
-template <int kIter, int kModes>
-__global__ __launch_bounds__(kBlock) void noise_spectrum_fft(
+// kThreads = 256.  The two LDS images of a long first transform (72 KiB at n2 = 4096) admit two
+// workgroups per CU; 1024-thread workgroups behind the same footprint (8 waves per SIMD) measured
+// 8 % SLOWER (15.6 vs 14.5 ms at 10 000 x 240 000): the kernel is bound by instruction count
+// (~147 VALU per cell: Philox ~50, Box-Muller ~30, modes ~20, transform ~55, final twiddle ~15;
+// VALU pipe ~60 % busy at two waves per SIMD), not by latency, and wider barriers cost more.
+template <int kIter, int kModes, int kThreads>
+__global__ __launch_bounds__(kThreads) void noise_spectrum_fft(
     float2* __restrict__ A, int n1, int n2, int log2n2, SpectrumArgs g, int pairs, uint32_t key0,
     uint32_t key1) {
   extern __shared__ float2 lds2[];
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(kBlock) void noise_spectrum_fft(
   const int n = n1 * n2;  // <= 2^23
   const float amp = g.w_ind * sqrtf(g.knee);
   const float inv_n = 1.0f / (float)n;
-  fill_twiddles(tw, n2);
+  fill_twiddles<kThreads>(tw, n2);
   const int half = n2 >> 1;
   constexpr int kRegModes = kModes > 0 ? kModes : 1;
   float2 f0[kIter][kRegModes], f1[kIter][kRegModes];
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(kBlock) void noise_spectrum_fft(
   if constexpr (kModes > 0) {
 #pragma unroll
     for (int it = 0; it < kIter; ++it) {
-      const int k2 = threadIdx.x + it * kBlock;
+      const int k2 = threadIdx.x + it * kThreads;
 #pragma unroll
       for (int m = 0; m < kModes; ++m) {
         f0[it][m] = k2 < half ? F[(size_t)m * n + k2] : make_float2(0.f, 0.f);
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(kBlock) void noise_spectrum_fft(
                             : make_float2(0.0f, 0.0f);
 #pragma unroll
     for (int it = 0; it < kIter; ++it) {
-      const int k2 = threadIdx.x + it * kBlock;
+      const int k2 = threadIdx.x + it * kThreads;
       if (k2 < half) {
         const U4 rnd = philox4x32_10(U4{(uint32_t)k1, (uint32_t)k2, series, kTagPink}, key0, key1);
         const float a0 = pink_amp(k1 + n1 * k2, n, amp, g.win.k_min);
@@ -279,9 +284,11 @@ __global__ __launch_bounds__(kBlock) void noise_spectrum_fft(
       }
     }
     __syncthreads();
-    const float2* res = fft_lds_inverse<4>(data, data + n2, tw, n2, log2n2);
+    // n2 = 2 kThreads kIter whenever kIter > 1: a compile-time length unrolls the butterfly loops
+    constexpr int kN = kIter > 1 ? 2 * kThreads * kIter : 0;
+    const float2* res = fft_lds_inverse<4, kN, kThreads>(data, data + n2, tw, n2, log2n2);
     float2* dst = A + ((size_t)pair * n1 + k1) * n2;
-    for (int j = threadIdx.x; j < n2; j += kBlock) {
+    for (int j = threadIdx.x; j < n2; j += kThreads) {
       // exp(2 pi i k1 j / N); k1*j < N <= 2^23 is exact in float32, and so is the fraction
       // of a revolution the hardware sine and cosine take (absolute error ~1e-6)
       const float rev = (float)(k1 * j) * inv_n;
@@ -293,24 +300,26 @@ __global__ __launch_bounds__(kBlock) void noise_spectrum_fft(
 
 typedef void (*SpectrumKernel)(float2*, int, int, int, SpectrumArgs, int, uint32_t, uint32_t);
 
-template <int kIter>
+template <int kIter, int kThreads>
 SpectrumKernel spectrum_kernel_modes(int n_modes) {
   switch (n_modes) {
-    case 0: return noise_spectrum_fft<kIter, 0>;
-    case 1: return noise_spectrum_fft<kIter, 1>;
-    case 5: return noise_spectrum_fft<kIter, 5>;
-    default: return noise_spectrum_fft<kIter, -1>;
+    case 0: return noise_spectrum_fft<kIter, 0, kThreads>;
+    case 1: return noise_spectrum_fft<kIter, 1, kThreads>;
+    case 5: return noise_spectrum_fft<kIter, 5, kThreads>;
+    default: return noise_spectrum_fft<kIter, -1, kThreads>;
   }
 }
 
-// the instantiation for a first transform of length n2 (64 .. 8192) and n_modes modes
-SpectrumKernel spectrum_kernel(int n2, int n_modes) {
+// the instantiation for a first transform of length n2 (64 .. 8192) and n_modes modes, and its
+// workgroup size
+SpectrumKernel spectrum_kernel(int n2, int n_modes, int* threads) {
+  *threads = kBlock;
   switch (n2 <= 512 ? 1 : n2 / 512) {
-    case 1: return spectrum_kernel_modes<1>(n_modes);
-    case 2: return spectrum_kernel_modes<2>(n_modes);
-    case 4: return spectrum_kernel_modes<4>(n_modes);
-    case 8: return spectrum_kernel_modes<8>(n_modes);
-    default: return spectrum_kernel_modes<16>(n_modes);
+    case 1: return spectrum_kernel_modes<1, kBlock>(n_modes);
+    case 2: return spectrum_kernel_modes<2, kBlock>(n_modes);
+    case 4: return spectrum_kernel_modes<4, kBlock>(n_modes);
+    case 8: return spectrum_kernel_modes<8, kBlock>(n_modes);
+    default: return spectrum_kernel_modes<16, kBlock>(n_modes);
   }
 }
 
@@ -600,7 +609,8 @@ int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T
   float2* A = F + (size_t)n_modes * n;                             // [pairs][n]
   const size_t lds1 = (size_t)(2 * n2 + n2 / 4) * sizeof(float2);
   const size_t lds2 = (size_t)(2 * kTileCells + n1 / 4) * sizeof(float2);
-  const SpectrumKernel pass1 = spectrum_kernel(n2, n_modes);
+  int threads1 = kBlock;
+  const SpectrumKernel pass1 = spectrum_kernel(n2, n_modes, &threads1);
   // every instantiation is sized for the longest first transform once (per context: the
   // attribute belongs to the device)
   MRX_LDS_CAP(ctx, pass1, (2 * 8192 + 8192 / 4) * sizeof(float2));
@@ -639,7 +649,7 @@ int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T
     sp.series0 = 16u + (uint32_t)((det_offset + d0) / 2);  // detector pair (2q, 2q+1) is series 16 + q
     h.mean = mean;
     hipLaunchKernelGGL(noise_pair_means, dim3(pairs), dim3(kBlock), 0, ctx->stream, n1, n2, sp, key0, key1);
-    hipLaunchKernelGGL(pass1, dim3(mrx_ceil_div(pairs, kPairsPerBlock), n1), dim3(kBlock), lds1,
+    hipLaunchKernelGGL(pass1, dim3(mrx_ceil_div(pairs, kPairsPerBlock), n1), dim3(threads1), lds1,
                        ctx->stream, A, n1, n2, l2, sp, pairs, key0, key1);
     if (n1 == 64 && !ctx->options[MRX_OPT_NOISE_GENERIC]) {
       const dim3 grid(mrx_ceil_div(j_used, kBlock), pairs);

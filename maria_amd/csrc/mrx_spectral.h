@@ -92,14 +92,18 @@ __device__ __forceinline__ float2 tw_at(const float2* tw, int idx, int q) {
 // One Stockham pass of radix R in {2, 4, 8} over 2^lj interleaved sequences of length n:
 // butterfly j (< n/R) of sequence b reads in[(j + r n/R) << lj | b], multiplies by
 // exp(2 pi i r k / (R ns)), k = j mod ns, and writes out[((j - k) R + k + m ns) << lj | b].
-template <int R>
-__device__ __forceinline__ void stockham_pass(const float2* in, float2* out, const float2* tw, int n,
+template <int R, int kN = 0, int kThreads = kBlock>
+__device__ __forceinline__ void stockham_pass(const float2* in, float2* out, const float2* tw, int n_rt,
                                               int ns, int lj) {
+  // kN > 0: the length is a compile-time constant (and lj = 0), so the butterfly loop has a
+  // fixed trip count and unrolls: all of a thread's LDS reads are in flight together, which
+  // is what a kernel at two waves per SIMD needs
+  const int n = kN > 0 ? kN : n_rt;
   const int per = n / R;          // butterflies per sequence
   const int q = n >> 2;
   const int bmask = (1 << lj) - 1;
   const int tstride = per / ns;   // n / (R ns): table index of exp(2 pi i / (R ns))
-  for (int jj = threadIdx.x; jj < (per << lj); jj += kBlock) {
+  auto butterfly = [&](int jj) {
     const int j = jj >> lj, b = jj & bmask;
     const int k = j & (ns - 1);
     float2 v[R];
@@ -142,6 +146,13 @@ __device__ __forceinline__ void stockham_pass(const float2* in, float2* out, con
     const int j0 = (j - k) * R + k;
 #pragma unroll
     for (int m = 0; m < R; ++m) out[((j0 + m * ns) << lj) + b] = v[m];
+  };
+  if constexpr (kN >= R * kThreads) {
+    constexpr int kTrips = kN / R / kThreads;
+#pragma unroll
+    for (int it = 0; it < kTrips; ++it) butterfly(threadIdx.x + it * kThreads);
+  } else {
+    for (int jj = threadIdx.x; jj < (per << lj); jj += kThreads) butterfly(jj);
   }
   __syncthreads();
 }
@@ -149,7 +160,7 @@ __device__ __forceinline__ void stockham_pass(const float2* in, float2* out, con
 // Passes of radix kRadix (8 or 4) while enough bits remain, then one smaller pass.  Which
 // radix is faster depends on the caller's mix of VALU and LDS work: measured, radix 8 for the
 // screens (n up to 8192, little else in the kernel) and radix 4 for the noise spectra.
-template <int kRadix = 8>
+template <int kRadix = 8, int kN = 0, int kThreads = kBlock>
 __device__ __forceinline__ float2* fft_lds_inverse_batched(float2* a, float2* b,
                                                            const float2* tw, int n,
                                                            int log2n, int lj) {
@@ -158,26 +169,26 @@ __device__ __forceinline__ float2* fft_lds_inverse_batched(float2* a, float2* b,
   float2* out = b;
   int ns = 1, s = 0;
   for (; s + kBits <= log2n; s += kBits, ns <<= kBits) {
-    stockham_pass<kRadix>(in, out, tw, n, ns, lj);
+    stockham_pass<kRadix, kN, kThreads>(in, out, tw, n, ns, lj);
     float2* t = in;
     in = out;
     out = t;
   }
   if (log2n - s == 2) {
-    stockham_pass<4>(in, out, tw, n, ns, lj);
+    stockham_pass<4, kN, kThreads>(in, out, tw, n, ns, lj);
     return out;
   }
   if (log2n - s == 1) {
-    stockham_pass<2>(in, out, tw, n, ns, lj);
+    stockham_pass<2, kN, kThreads>(in, out, tw, n, ns, lj);
     return out;
   }
   return in;
 }
 
-template <int kRadix = 8>
+template <int kRadix = 8, int kN = 0, int kThreads = kBlock>
 __device__ __forceinline__ float2* fft_lds_inverse(float2* a, float2* b, const float2* tw, int n,
                                                    int log2n) {
-  return fft_lds_inverse_batched<kRadix>(a, b, tw, n, log2n, 0);
+  return fft_lds_inverse_batched<kRadix, kN, kThreads>(a, b, tw, n, log2n, 0);
 }
 
 // ---- 64-point inverse FFT in registers --------------------------------------
@@ -231,8 +242,9 @@ __device__ __forceinline__ void fft64_inverse_reg(float (&re)[64], float (&im)[6
   fft64_stage<4>(re, im);
 }
 
+template <int kThreads = kBlock>
 __device__ __forceinline__ void fill_twiddles(float2* tw, int n) {
-  for (int k = threadIdx.x; k < n / 4; k += kBlock) {
+  for (int k = threadIdx.x; k < n / 4; k += kThreads) {
     float s, c;
     sincospif(2.0f * (float)k / (float)n, &s, &c);
     tw[k] = make_float2(c, s);
