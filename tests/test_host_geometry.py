@@ -197,3 +197,48 @@ def test_constructor_errors_mirror_the_reference():
         Atmosphere(model="4d")
     with pytest.raises(RuntimeError, match="must be initialized"):
         Atmosphere().simulate_pwv()
+
+
+# ---- the am spectrum loader (spectrum/atmosphere.py:17-57) ---------------------------------
+
+
+def _write_am_file(path, n_alt=3):
+    rng = np.random.default_rng(8)
+    alt = np.linspace(0.0, 5000.0, n_alt)
+    T = np.array([250.0, 270.0, 290.0])
+    pwv = np.linspace(0.0, 8.0, 9)
+    el = np.linspace(10.0, 90.0, 7)
+    nu = np.linspace(50e9, 300e9, 40)
+    shape = (n_alt, len(T), len(pwv), len(el), len(nu))
+    opacity = 0.02 + rng.random(shape) * 0.1
+    data = dict(side_altitude_m=alt, side_base_temperature_K=T, side_zenith_pwv_mm=pwv.astype(np.float32), side_elevation_deg=el,
+                side_nu_Hz=nu, opacity_nepers=opacity.astype(np.float32), rayleigh_jeans_temperature_K=(260.0 * (1 - np.exp(-opacity))).astype(np.float32),
+                excess_path_m=rng.random(shape).astype(np.float32))
+    np.savez(path, **data)
+    return data
+
+
+def test_am_spectrum_loader_interpolates_to_the_site_altitude(tmp_path):
+    from maria_amd.atmosphere import AtmosphericSpectrum
+
+    path = tmp_path / "chajnantor.npz"
+    data = _write_am_file(path)
+    sp = AtmosphericSpectrum(path, altitude=1250.0)
+    assert sp.region == "chajnantor" and sp.source == "am"
+    assert sp._emission.shape == (3, 9, 7, 40) and sp._opacity.dtype == np.float64
+    # linear in altitude between the nodes at 0 and 2500 m (interp1d, axis 0)
+    want = 0.5 * (data["opacity_nepers"][0].astype(float) + data["opacity_nepers"][1].astype(float))
+    np.testing.assert_allclose(sp._opacity, want, rtol=1e-7)  # scipy interpolates float32 tables in float32, as in the reference
+    assert sp.side_elevation[-1] == np.radians(90.1) and sp.side_elevation[0] == np.radians(10.0)
+    assert [len(a) for a in sp.points] == [3, 9, 7, 40]
+    with pytest.raises(ValueError):
+        AtmosphericSpectrum(path, altitude=6000.0)  # beyond the file's altitudes, like the reference's interp1d
+    # it drives the band tables exactly like the synthetic stand-in
+    band = Band(center=150e9, width=30e9, name="f150")
+    table = band.emission_table(sp)
+    assert table.shape == (3, 9, 7) and np.isfinite(table).all() and (table > 0).all()
+    atm = Atmosphere(spectrum=str(path), altitude=1250.0)
+    np.testing.assert_allclose(atm.spectrum._opacity, want, rtol=1e-7)
+    np.savez(tmp_path / "broken.npz", side_altitude_m=np.zeros(2))
+    with pytest.raises(KeyError):
+        AtmosphericSpectrum(tmp_path / "broken.npz", altitude=0.0)
