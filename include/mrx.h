@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MRX_VERSION 100 /* 0.1.0 */
+#define MRX_VERSION 110 /* 0.1.1: mrx_band_table.d_cubic, screen batches, communicator */
 
 typedef enum mrx_status {
   MRX_OK = 0,
@@ -142,6 +142,16 @@ typedef struct mrx_band_table {
   int32_t n_pwv, n_el;
   float w_t;               /* float32 (T0 - T[iT]) / (T[iT+1] - T[iT])        */
   int32_t t_oob;           /* 1 if T0 lies outside the table (result NaN)     */
+  /* interpolation_method="cubic" (band/band.py:288-300): the table interpolated linearly to
+   * T0 (scipy interp1d, float64) and then scipy's RegularGridInterpolator(method="cubic") on
+   * (pwv, el), i.e. the tensor-product not-a-knot cubic spline, float64.  The host expands
+   * that spline into one bicubic polynomial per grid cell:
+   *   d_cubic = [n_pwv float64 pwv nodes][n_el float64 el nodes]
+   *             [(n_pwv-1)*(n_el-1) cells, row-major (pwv, el)][16]: c[4*k + m] multiplies
+   *             (pwv - pwv_i)^m (el - el_j)^k.
+   * NULL selects the linear (jax, float32) lookup above.  A sample outside the grid sets
+   * MRX_FLAG_TABLE_OOB (scipy raises ValueError there). */
+  const double* d_cubic;
 } mrx_band_table;
 
 /* Builds the device-resident plan from the layer and table descriptors (host

@@ -75,6 +75,7 @@ class MrxBandTable(C.Structure):
         ("n_el", C.c_int32),
         ("w_t", C.c_float),
         ("t_oob", C.c_int32),
+        ("d_cubic", C.c_void_p),
     ]
 
 

@@ -65,6 +65,7 @@ struct mrx_table_dev {
   float w_t;
   int t_oob;
   float p_first, p_inv, e_first, e_inv;
+  const double* cubic;  // bicubic cells (mrx_band_table::d_cubic) or null
 };
 
 struct mrx_atm_plan {
@@ -359,11 +360,36 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         }
       }
     }
-    if (cp_.oob || cl.oob || tb.t_oob) {
+    if (!tb.cubic && (cp_.oob || cl.oob || tb.t_oob)) {
       val = __builtin_nanf("");
       if (t < Ta) iflags |= MRX_FLAG_TABLE_OOB;
     }
-    const float out = m00 * val;
+    float out = m00 * val;
+    if (tb.cubic) {
+      // interpolation_method="cubic" (band/band.py:288-300): scipy's tensor-product cubic
+      // spline on (pwv, el) in float64, expanded by the host into a bicubic per cell; the
+      // float64 product with the Mueller weight is rounded once (sim/atmosphere.py:64-65)
+      const double* __restrict__ X = tb.cubic;
+      const double* __restrict__ Y = X + tb.n_pwv;
+      const double* __restrict__ Cc = Y + tb.n_el;
+      const double xd = pwv[tt], yd = (double)xel;
+      int i = min(max(cp_.i, 0), tb.n_pwv - 2), j = min(max(cl.i, 0), tb.n_el - 2);
+      while (i < tb.n_pwv - 2 && X[i + 1] <= xd) ++i;  // the float32 cell is a guess for the float64 axis
+      while (i > 0 && X[i] > xd) --i;
+      while (j < tb.n_el - 2 && Y[j + 1] <= yd) ++j;
+      while (j > 0 && Y[j] > yd) --j;
+      const double u = xd - X[i], v = yd - Y[j];
+      const double* __restrict__ c = Cc + ((size_t)i * (tb.n_el - 1) + j) * 16;
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 3; k >= 0; --k) {
+        const double row = fma(fma(fma(c[4 * k + 3], u, c[4 * k + 2]), u, c[4 * k + 1]), u, c[4 * k]);
+        acc = fma(acc, v, row);
+      }
+      const bool inside = xd >= X[0] && xd <= X[tb.n_pwv - 1] && yd >= Y[0] && yd <= Y[tb.n_el - 1];
+      out = inside ? (float)((double)m00 * acc) : __builtin_nanf("");
+      if (!inside && t < Ta) iflags |= MRX_FLAG_TABLE_OOB;
+    }
     if (out != out && t < Ta) iflags |= MRX_FLAG_NAN;
     if (live && t < Ta) {
       const size_t o = (size_t)t * D + d;
@@ -495,6 +521,8 @@ int mrx_atm_plan_create(mrx_ctx* ctx, const mrx_layer* layers, int n_layers,
     h.off_el = floats;
     floats += t.n_el;
     h.p_first = h.p_inv = h.e_first = h.e_inv = 0.f;
+    h.cubic = t.d_cubic;
+    MRX_REQUIRE(ctx, !t.d_cubic || (t.n_pwv >= 4 && t.n_el >= 4), "the cubic lookup needs >= 4 nodes per axis");
   }
   std::vector<mrx_layer_dev> hlay((size_t)n_layers);
   for (int l = 0; l < n_layers; ++l) {

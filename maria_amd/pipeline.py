@@ -78,6 +78,41 @@ def table_slabs(table, T0):
     return np.ascontiguousarray(vals), w, oob
 
 
+def table_cubic_cells(table, T0):
+    """Host part of ``interpolation_method="cubic"`` (band/band.py:288-300): the band table
+    interpolated linearly to ``T0`` (scipy ``interp1d``, which raises ValueError outside the
+    temperature axis, as in the reference) and scipy's tensor-product not-a-knot cubic spline on
+    (pwv, el) expanded into one bicubic per grid cell (Taylor coefficients at the cell's lower
+    corner).  Returns the float64 buffer of ``mrx_band_table.d_cubic``:
+    [pwv nodes][el nodes][cells][16]."""
+    import scipy.interpolate
+
+    Tg, x, y = (np.asarray(table[k], float) for k in ("T", "pwv", "el"))
+    V = scipy.interpolate.interp1d(Tg, np.asarray(table["values"], float), kind="linear", axis=0)(T0)  # [n_pwv, n_el]
+    if len(x) < 4 or len(y) < 4:
+        raise ValueError("cubic interpolation needs at least 4 nodes per axis")
+    fact = (1.0, 1.0, 2.0, 6.0)
+    # The reference calls scipy's RegularGridInterpolator(method="cubic").  From scipy 1.13 on that
+    # is an NdBSpline whose coefficients come from an ITERATIVE solver (gcrotmk, atol 1e-6): it
+    # differs from the exact tensor-product spline by ~6e-6 of the table's scale.  To reproduce the
+    # reference and not the textbook, the cells are expanded from scipy's own spline object; older
+    # scipy (recursive 1-D splines, exact) and the fallback below give the exact tensor spline.
+    spline = getattr(scipy.interpolate.RegularGridInterpolator((x, y), V, method="cubic"), "_spline", None)
+    if spline is not None and hasattr(spline, "t"):
+        X0, Y0 = np.meshgrid(x[:-1], y[:-1], indexing="ij")
+        pts = np.stack([X0.ravel(), Y0.ravel()], axis=-1)
+        Cc = np.empty((len(x) - 1, len(y) - 1, 4, 4))
+        for k in range(4):
+            for m in range(4):
+                Cc[:, :, k, m] = spline(pts, nu=(m, k)).reshape(len(x) - 1, len(y) - 1) / (fact[m] * fact[k])
+    else:  # separable operator: Taylor coefficients in el of every pwv row's spline, then along pwv
+        sy = scipy.interpolate.make_interp_spline(y, V, k=3, axis=1)
+        A = np.stack([sy.derivative(k)(y[:-1]) / fact[k] if k else sy(y[:-1]) for k in range(4)], axis=-1)  # [n_pwv, n_el-1, 4]
+        sx = scipy.interpolate.make_interp_spline(x, A, k=3, axis=0)
+        Cc = np.stack([sx.derivative(m)(x[:-1]) / fact[m] if m else sx(x[:-1]) for m in range(4)], axis=-1)  # [.., 4(k), 4(m)]
+    return np.concatenate([x, y, np.ascontiguousarray(Cc).reshape(-1)])
+
+
 class DevicePath:
     """One observation (or one detector shard of it) on one GPU."""
 
@@ -90,6 +125,10 @@ class DevicePath:
         self.ctx = ctx or Context(index)
         self.ctx.set_stream(torch.cuda.current_stream(self.device))
         self.problem = problem
+        method = problem.get("interpolation_method", "linear")
+        if method not in ("linear", "cubic"):
+            raise ValueError(f"interpolation_method must be 'linear' or 'cubic', not {method!r}")
+        self.cubic = method == "cubic"
         sl = det_slice or slice(0, len(problem["offsets"]))
         self.det_slice = sl
         dev = self.device
@@ -139,16 +178,20 @@ class DevicePath:
         self._tables = (MrxBandTable * len(self.problem["tables"]))()
         for b, table in enumerate(self.problem["tables"]):
             vals, w, oob = table_slabs(table, self.problem["T0"])
-            bufs = (
+            bufs = [
                 _dev(vals, torch.float32, dev),
                 _dev(table["pwv"], torch.float32, dev),
                 _dev(table["el"], torch.float32, dev),
-            )
-            self._table_bufs.append(bufs)
+            ]
             tb = self._tables[b]
             tb.d_values, tb.d_axis_pwv, tb.d_axis_el = (x.data_ptr() for x in bufs)
             tb.n_pwv, tb.n_el = len(table["pwv"]), len(table["el"])
             tb.w_t, tb.t_oob = float(w), int(oob)
+            tb.d_cubic = None
+            if self.cubic:
+                bufs.append(_dev(table_cubic_cells(table, self.problem["T0"]), torch.float64, dev))
+                tb.d_cubic = bufs[-1].data_ptr()
+            self._table_bufs.append(tuple(bufs))
 
     def layer_offsets(self, layer):
         """f64 per-time offsets of mrx_layer (include/mrx.h):
@@ -375,6 +418,9 @@ class DevicePath:
         if word.value & _lib.FLAG_SCREEN_OOB:
             # atmosphere/atmosphere.py:368-369
             raise RuntimeError("A layer introduced nans into PWV simulation (line of sight left its screen).")
+        if self.cubic and word.value & _lib.FLAG_TABLE_OOB:
+            # scipy's RegularGridInterpolator(bounds_error=True), band/band.py:296-300
+            raise ValueError("One of the requested xi is out of bounds of the emission table (pwv, elevation).")
         return word.value
 
     def clear_flags(self):

@@ -207,22 +207,35 @@ def atmosphere_power(table, base_temperature, zenith_pwv, elevation):
     )
 
 
+def atmosphere_power_cubic(table, base_temperature, zenith_pwv, elevation):
+    """band/band.py:288-300 (``method != "linear"``): linear ``interp1d`` along the temperature
+    axis, then scipy's ``RegularGridInterpolator(method="cubic")`` on (pwv, el); float64."""
+    tiv = sp.interpolate.interp1d(np.asarray(table["T"], float), np.asarray(table["values"], float), kind="linear", axis=0)(base_temperature)
+    rgi = sp.interpolate.RegularGridInterpolator((np.asarray(table["pwv"], float), np.asarray(table["el"], float)), tiv, method="cubic")
+    return rgi((zenith_pwv, elevation))
+
+
 def mueller00(gamma):
     """array/array.py:204-218, element [0,0]: 1 unpolarised (gamma NaN), else 0.5."""
     gamma = np.asarray(gamma, float)
     return np.where(np.isnan(gamma), 0.5 * np.sqrt(2) ** 2, 0.5)
 
 
-def coarse_loading(pwv, theta, band_index, tables, base_temperature, m00):
-    """sim/atmosphere.py:39-65: per band emission x Mueller weight -> [D,Ta] float32."""
+def coarse_loading(pwv, theta, band_index, tables, base_temperature, m00, method="linear"):
+    """sim/atmosphere.py:39-65: per band emission x Mueller weight -> [D,Ta] float32.
+    ``method``: ``obs.atmosphere.interpolation_method`` (band/band.py:283-300)."""
     loading = np.zeros(pwv.shape, f32)
     for b, table in enumerate(tables):
         mask = np.asarray(band_index) == b
         if not mask.any():
             continue
         el = np.asarray(theta, f32)[mask].clip(max=np.pi / 2)
-        p = atmosphere_power(table, base_temperature, pwv[mask], el)
-        loading[mask] = np.asarray(m00, f32)[mask][:, None] * p
+        if method == "linear":
+            p = atmosphere_power(table, base_temperature, pwv[mask], el)
+            loading[mask] = np.asarray(m00, f32)[mask][:, None] * p
+        else:  # float64 from scipy, times the float64 Mueller element, stored into the float32 array
+            p = atmosphere_power_cubic(table, base_temperature, pwv[mask], el)
+            loading[mask] = np.asarray(m00, np.float64)[mask][:, None] * p
     return loading
 
 
@@ -317,7 +330,8 @@ def run_path(problem, return_intermediates=False):
     phi, theta = broadcast(problem["offsets"], problem["az_a"], problem["el_a"])
     pp = project_unit(phi, theta)
     pwv = simulate_pwv(pp, problem["layers"], problem["pwv0"], problem["timestep"])
-    loading_a = coarse_loading(pwv, theta, problem["band_index"], problem["tables"], problem["T0"], problem["m00"])
+    loading_a = coarse_loading(pwv, theta, problem["band_index"], problem["tables"], problem["T0"], problem["m00"],
+                               method=problem.get("interpolation_method", "linear"))
     tod = upsample_cubic(problem["ta"], loading_a, problem["t"])
     if problem.get("gain") is not None:
         tod = (tod * np.asarray(problem["gain"], f32)[:, None]).astype(f32)

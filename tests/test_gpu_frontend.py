@@ -224,3 +224,25 @@ def test_noise_is_drawn_from_the_loading_before_the_gain_error(gpu_ctx):
     assert np.array_equal(flat.data["noise"], gained.data["noise"])
     ratio = gained.data["atmosphere"][:, 500] / flat.data["atmosphere"][:, 500]
     assert ratio.std() > 0.1 and np.allclose(gained.data["atmosphere"], flat.data["atmosphere"] * ratio[:, None], rtol=2e-6)
+
+
+def test_simulation_with_cubic_interpolation(gpu_ctx):
+    """Atmosphere(interpolation_method="cubic") through the front end, against the oracle chain."""
+    from maria_amd.atmosphere import Atmosphere
+    from maria_amd.sim import Simulation
+    from oracle import hotpath
+
+    inst, plan, site = _setup(n=37, duration=20.0)
+    sim = Simulation(inst, plan, site, atmosphere="2d", noise=False, gain_seed=1,
+                     atmosphere_kwargs={"seed": 5, "n_layers": 3, "interpolation_method": "cubic"})
+    (tod,) = sim.run(units="pW")
+    obs = sim.obs_list[0]
+    assert obs.atmosphere.interpolation_method == "cubic"
+    prob = _oracle_problem(sim, obs)
+    prob["interpolation_method"] = "cubic"
+    ref = hotpath.run_path(prob)
+    data = tod.data["atmosphere"]
+    gain = data[:, 100] / ref[:, 100]
+    assert rel_err(data, ref * gain[:, None]) <= 2e-5
+    with pytest.raises(ValueError, match="interpolation_method"):
+        Atmosphere(interpolation_method="quintic")

@@ -294,3 +294,33 @@ def test_allgather_through_the_c_abi_single_rank(gpu_ctx):
     assert torch.equal(out, shard)
     assert g.bytes_received(T) == 0
     g.close()
+
+
+def test_cubic_emission_lookup_matches_scipy(gpu_ctx):
+    """interpolation_method="cubic" (band/band.py:288-300): linear in T, then scipy's
+    RegularGridInterpolator(method="cubic") on (pwv, el) in float64 -- in the kernel as one
+    bicubic per table cell expanded from scipy's own spline object."""
+    from maria_amd.pipeline import DevicePath
+    from oracle import hotpath
+
+    p = small_problem(n_det=83, n_bands=2, n_layers=3)
+    p["interpolation_method"] = "cubic"
+    path = DevicePath(p, device="cuda:0", ctx=gpu_ctx, keep_pwv=True)
+    tod = path.run().cpu().numpy()
+    assert path.check_flags() == 0
+    ref, mid = hotpath.run_path(p, return_intermediates=True)
+    got_a = path.coarse_loading().cpu().numpy()
+    assert rel_err(got_a, mid["loading_a"]) <= 2e-6
+    assert rel_err(tod, ref) <= 1e-5
+    # not the linear lookup: the two methods differ by far more than the tolerance
+    p_lin = dict(p, interpolation_method="linear")
+    lin = DevicePath(p_lin, device="cuda:0", ctx=gpu_ctx).run().cpu().numpy()
+    assert rel_err(lin, ref) > 1e-4
+    # scipy raises ValueError outside the grid (bounds_error=True), jax's linear lookup gives NaN
+    hot = dict(p, pwv0=11.5)  # beyond the table's 10 mm
+    bad = DevicePath(hot, device="cuda:0", ctx=gpu_ctx)
+    bad.run()
+    with pytest.raises(ValueError, match="out of bounds"):
+        bad.check_flags()
+    with pytest.raises(ValueError):
+        DevicePath(dict(p, T0=100.0), device="cuda:0", ctx=gpu_ctx)  # interp1d refuses a T0 off the axis
