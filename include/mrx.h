@@ -71,15 +71,17 @@ int mrx_synchronize(mrx_ctx* ctx);
  *    default evaluates the same ground projection directly from the unit
  *    line-of-sight vector: equal up to the float32 rounding noise of the chain,
  *    better conditioned near the zenith, and ~3x fewer instructions.
- *  MRX_OPT_AXIS_RECOMPUTE = 1: recompute the grid nodes of axes whose uniform
- *    hint verified as float32(g0 + i*dg) instead of fetching them from the axis
- *    arrays (identical results; measured 7 % slower on MI355X because the
- *    float64 node arithmetic costs more than two cached loads, so off by default).
+ *  MRX_OPT_AXIS_LITERAL = 1: mrx_atm_sample finds cell and weight on every screen axis with
+ *    jax's float32 rule (searchsorted on the float32 nodes, weight (x - lo)/(hi - lo)), also on
+ *    uniform axes.  The default computes the position in pixels in float64 on axes whose uniform
+ *    hint verified: equal to the literal rule up to the float32 rounding of the reference's own
+ *    coordinates (~1e-8 of the loading), at 3/4 of the instructions.  MRX_OPT_POINTING_CHAIN
+ *    implies the literal rule.
  *  MRX_OPT_SAMPLE_TIMES = 1|2|4: coarse time steps per thread in mrx_atm_sample
  *    (tuning; 0 = library default). */
 enum {
   MRX_OPT_POINTING_CHAIN = 0,
-  MRX_OPT_AXIS_RECOMPUTE = 1,
+  MRX_OPT_AXIS_LITERAL = 1,
   MRX_OPT_SAMPLE_TIMES = 2,
   MRX_OPT_SAMPLE_CHUNK = 3, /* time steps per workgroup (tuning; 0 = automatic) */
   MRX_OPT_UPSAMPLE_GROUPS = 4, /* 16-row detector tiles per workgroup of the TOD
@@ -124,8 +126,8 @@ typedef struct mrx_layer {
    * extrusion[i] = e0 + i*de (np.arange, atmosphere.py:241-245) and
    * cross_section[i] = c0 + i*dc (np.linspace, :208-219).  When
    * float32(e0 + i*de) reproduces d_axis_e bit for bit (checked on the device
-   * at plan creation) the kernel recomputes nodes instead of fetching them; the
-   * results are identical either way.  Set de / dc to 0 when unknown. */
+   * at plan creation) the kernel works in pixel coordinates, (x - e0)/de in float64,
+   * instead of searching the axis (see MRX_OPT_AXIS_LITERAL).  Set de / dc to 0 when unknown. */
   double e0, de, c0, dc;
   float pwv_rms;         /* float32(layer.pwv_rms), extrusion.py:100-105       */
   int32_t reserved;

@@ -12,10 +12,11 @@
 //   * layer descriptors are packed scalars (one s_load burst per layer, reused
 //     for kTimes time steps);
 //   * the per-time wind offsets of all layers are packed [t][layer];
-//   * grid nodes of a uniform axis are recomputed as float32(g0 + i*dg) instead
-//     of being fetched -- only after a device-side check at plan creation that
-//     this reproduces the caller's float32 axis array bit for bit; otherwise the
-//     array is searched (same results, slower);
+//   * on a uniform axis -- one whose float32 nodes a device-side check at plan
+//     creation finds equal to float32(g0 + i*dg) bit for bit -- cell and weight
+//     come from the line of sight's position in PIXELS, evaluated in float64
+//     (two fused multiply-adds per axis); otherwise the axis array is searched
+//     with jax's float32 rule (MRX_OPT_AXIS_LITERAL forces that everywhere);
 //   * the band tables and their axes are staged in LDS once per workgroup.
 // Per layer and sample that leaves only the 2x2 gather itself.
 //
@@ -50,12 +51,24 @@ struct mrx_layer_dev {
   double h, r00, r10, r01, r11;
   double hr00, hr10, hr01, hr11;  // h * r: the projection and the layer height in one product
   double e0, de, c0, dc;          // node(i) = float32(e0 + i*de) when uniform_*
+  double pe_x, pe_y, pc_x, pc_y;  // pixel coordinates: fe = px*pe_x + py*pe_y + offpx.x, fc likewise
   float e_first, e_inv, e_last;   // axis_e[0], 1/(axis_e[1]-axis_e[0]), axis_e[n-1]
   float c_first, c_inv, c_last;
   float pwv_rms;
   int n_e, n_c;
   int uniform_e, uniform_c;
 };
+
+// What the pixel-coordinate path needs of a layer, in one 64-byte line: the whole record is
+// one scalar load per layer and wave (the general descriptor above costs a dozen).
+struct alignas(64) mrx_layer_fast {
+  const float* values;
+  double pe_x, pe_y, pc_x, pc_y;
+  int n_e, n_c;
+  float pwv_rms;
+  int pixel;  // both axes verified uniform
+};
+static_assert(sizeof(mrx_layer_fast) == 64, "one cache line per layer");
 
 // Device-side band table descriptor: offsets (in floats) into the packed table
 // buffer, which is [values 2*np*ne][axis_pwv np][axis_el ne] per band.
@@ -70,11 +83,14 @@ struct mrx_table_dev {
 
 struct mrx_atm_plan {
   mrx_layer_dev* d_layers = nullptr;
+  mrx_layer_fast* d_fast = nullptr;
   double2* d_off = nullptr;  // [n_t][n_layers] (off_e, off_c)
+  double2* d_offpx = nullptr;  // [n_t][n_layers] ((off_e - e0)/de, (off_c - c0)/dc): the same in pixels
   mrx_table_dev* d_tables = nullptr;
   float* d_table_data = nullptr;
   int n_layers = 0, n_tables = 0, n_t = 0;
   int table_floats = 0;
+  bool all_pixel = false;  // every layer passed the uniform check: the lean kernel instance applies
 };
 
 namespace {
@@ -175,8 +191,9 @@ __device__ __forceinline__ float bilinear(gfloat* values, int nc,
 template <bool kLdsTables, bool kChain, int kT>
 // 8 waves per SIMD (<= 64 VGPRs): the kernel hides its gather latency with occupancy
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void atm_sample_kernel(
-    const mrx_layer_dev* __restrict__ layers, int n_layers,
-    const double2* __restrict__ off, const mrx_table_dev* __restrict__ tables,
+    const mrx_layer_dev* __restrict__ layers, const mrx_layer_fast* __restrict__ fast, int n_layers,
+    const double2* __restrict__ off, const double2* __restrict__ offpx,
+    const mrx_table_dev* __restrict__ tables,
     int n_tables, const float* __restrict__ table_data, int table_floats,
     const float* __restrict__ az, const float* __restrict__ el, int Ta,
     const float* __restrict__ dxs, const float* __restrict__ dys,
@@ -260,6 +277,35 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 
   // ---- layer stack (atmosphere/atmosphere.py:317-373) ---------------------
   for (int l = 0; l < n_layers; ++l) {
+    const mrx_layer_fast lf = fast[l];
+    if (lf.pixel && !force_arrays) {  // wave-uniform
+      // Uniform axes: the position on the grid in pixels, in float64.  The reference rounds
+      // the metre coordinate to float32 first (jax) and divides float32 differences; at 10 km
+      // from the origin that quantises the position to ~2e-4 pixel.  Here the weight keeps
+      // the float64 position -- closer to the exact bilinear value than the reference's own
+      // arithmetic, and within ~1e-8 of it in the loading -- for half the instructions: no
+      // node fetch, no cell search, no division.
+      gfloat* values = (gfloat*)lf.values;
+#pragma unroll
+      for (int tt = 0; tt < kT; ++tt) {
+        const int t = min(t0 + tt, Ta - 1);
+        const double2 o = offpx[(size_t)t * n_layers + l];
+        const double fe = fma(px[tt], lf.pe_x, fma(py[tt], lf.pe_y, o.x));
+        const double fc = fma(px[tt], lf.pc_x, fma(py[tt], lf.pc_y, o.y));
+        Cell ce, cc;
+        ce.i = min(max(__double2int_rz(fe), 0), lf.n_e - 2);
+        cc.i = min(max(__double2int_rz(fc), 0), lf.n_c - 2);
+        ce.w = (float)(fe - (double)ce.i);
+        cc.w = (float)(fc - (double)cc.i);
+        // inside the grid: 0 <= f <= n - 1 (the last node belongs to the last cell); NaN is outside
+        ce.oob = !(ce.w >= 0.0f && ce.w <= 1.0f);
+        cc.oob = !(cc.w >= 0.0f && cc.w <= 1.0f);
+        const float yv = bilinear(values, lf.n_c, ce, cc);
+        if (yv != yv) iflags |= MRX_FLAG_SCREEN_OOB;
+        pwv[tt] += (double)(lf.pwv_rms * yv);
+      }
+      continue;
+    }
     const mrx_layer_dev& ly = layers[l];
     const int nc = ly.n_c;
     float xe[kT], xc[kT], y[kT];
@@ -279,41 +325,19 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     gfloat* axis_e = (gfloat*)ly.axis_e;
     gfloat* axis_c = (gfloat*)ly.axis_c;
     bool miss[kT];
-    if (ly.uniform_e && ly.uniform_c && !force_arrays) {  // wave-uniform
-      // nodes recomputed as float32(g0 + i*dg): verified at plan creation
-      const double e0 = ly.e0, de = ly.de, c0 = ly.c0, dc = ly.dc;
+    {
+    // nodes fetched from the caller's axis arrays (L1-resident)
 #pragma unroll
-      for (int tt = 0; tt < kT; ++tt) {
-        miss[tt] = false;
-        const Cell ce = probe_cell<kChain>(
-            [=](int i, float& lo, float& hi) {
-              const double fi = (double)i;
-              lo = (float)(fi * de + e0);
-              hi = (float)((fi + 1.0) * de + e0);
-            },
-            ly.n_e, xe[tt], ly.e_first, ly.e_inv, ly.e_last, miss[tt]);
-        const Cell cc = probe_cell<kChain>(
-            [=](int i, float& lo, float& hi) {
-              const double fi = (double)i;
-              lo = (float)(fi * dc + c0);
-              hi = (float)((fi + 1.0) * dc + c0);
-            },
-            nc, xc[tt], ly.c_first, ly.c_inv, ly.c_last, miss[tt]);
-        y[tt] = bilinear(values, nc, ce, cc);
-      }
-    } else {
-      // nodes fetched from the caller's axis arrays (L1-resident)
-#pragma unroll
-      for (int tt = 0; tt < kT; ++tt) {
-        miss[tt] = false;
-        const Cell ce = probe_cell<kChain>(
-            [=](int i, float& lo, float& hi) { lo = axis_e[i]; hi = axis_e[i + 1]; },
-            ly.n_e, xe[tt], ly.e_first, ly.e_inv, ly.e_last, miss[tt]);
-        const Cell cc = probe_cell<kChain>(
-            [=](int i, float& lo, float& hi) { lo = axis_c[i]; hi = axis_c[i + 1]; },
-            nc, xc[tt], ly.c_first, ly.c_inv, ly.c_last, miss[tt]);
-        y[tt] = bilinear(values, nc, ce, cc);
-      }
+    for (int tt = 0; tt < kT; ++tt) {
+      miss[tt] = false;
+      const Cell ce = probe_cell<kChain>(
+          [=](int i, float& lo, float& hi) { lo = axis_e[i]; hi = axis_e[i + 1]; },
+          ly.n_e, xe[tt], ly.e_first, ly.e_inv, ly.e_last, miss[tt]);
+      const Cell cc = probe_cell<kChain>(
+          [=](int i, float& lo, float& hi) { lo = axis_c[i]; hi = axis_c[i + 1]; },
+          nc, xc[tt], ly.c_first, ly.c_inv, ly.c_last, miss[tt]);
+      y[tt] = bilinear(values, nc, ce, cc);
+    }
     }
 #pragma unroll
     for (int tt = 0; tt < kT; ++tt)
@@ -407,7 +431,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
 
 // Fills the axis-derived fields of each layer descriptor and checks whether
 // float32(g0 + i*dg) reproduces the axis arrays exactly.
-__global__ void plan_finish_layers(mrx_layer_dev* layers, int n_layers) {
+__global__ void plan_finish_layers(mrx_layer_dev* layers, mrx_layer_fast* fast, int n_layers) {
   const int l = blockIdx.x;
   mrx_layer_dev& ly = layers[l];
   __shared__ int ok_e, ok_c;
@@ -440,14 +464,25 @@ __global__ void plan_finish_layers(mrx_layer_dev* layers, int n_layers) {
     ly.c_inv = ok_c ? (float)(1.0 / ly.dc)
                     : (float)((double)(ly.n_c - 1) /
                               ((double)ly.c_last - (double)ly.c_first));
+    mrx_layer_fast& f = fast[l];
+    f.values = ly.values;
+    f.pe_x = ly.pe_x; f.pe_y = ly.pe_y; f.pc_x = ly.pc_x; f.pc_y = ly.pc_y;
+    f.n_e = ly.n_e; f.n_c = ly.n_c;
+    f.pwv_rms = ly.pwv_rms;
+    f.pixel = ok_e && ok_c && ly.de > 0.0 && ly.dc > 0.0;
   }
 }
 
-__global__ void plan_pack_offsets(double2* off, const double* off_e,
-                                  const double* off_c, int l, int n_layers,
+__global__ void plan_pack_offsets(double2* off, double2* offpx, const mrx_layer_dev* layers,
+                                  const double* off_e, const double* off_c, int l, int n_layers,
                                   int n_t) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < n_t) off[(size_t)t * n_layers + l] = make_double2(off_e[t], off_c[t]);
+  if (t >= n_t) return;
+  const mrx_layer_dev& ly = layers[l];
+  off[(size_t)t * n_layers + l] = make_double2(off_e[t], off_c[t]);
+  const bool uni = ly.uniform_e && ly.uniform_c && ly.de > 0.0 && ly.dc > 0.0;  // set by plan_finish_layers, earlier on this stream
+  offpx[(size_t)t * n_layers + l] =
+      uni ? make_double2((off_e[t] - ly.e0) / ly.de, (off_c[t] - ly.c0) / ly.dc) : make_double2(0.0, 0.0);
 }
 
 __global__ void plan_pack_table(float* data, mrx_table_dev* tables, int b,
@@ -473,6 +508,8 @@ void plan_free(mrx_atm_plan* p) {
   if (!p) return;
   if (p->d_layers) (void)hipFree(p->d_layers);
   if (p->d_off) (void)hipFree(p->d_off);
+  if (p->d_offpx) (void)hipFree(p->d_offpx);
+  if (p->d_fast) (void)hipFree(p->d_fast);
   if (p->d_tables) (void)hipFree(p->d_tables);
   if (p->d_table_data) (void)hipFree(p->d_table_data);
   delete p;
@@ -535,6 +572,10 @@ int mrx_atm_plan_create(mrx_ctx* ctx, const mrx_layer* layers, int n_layers,
     h.r00 = y.r00; h.r10 = y.r10; h.r01 = y.r01; h.r11 = y.r11;
     h.hr00 = y.h * y.r00; h.hr10 = y.h * y.r10; h.hr01 = y.h * y.r01; h.hr11 = y.h * y.r11;
     h.e0 = y.e0; h.de = y.de; h.c0 = y.c0; h.dc = y.dc;
+    h.pe_x = y.de != 0.0 ? y.h * y.r00 / y.de : 0.0;
+    h.pe_y = y.de != 0.0 ? y.h * y.r10 / y.de : 0.0;
+    h.pc_x = y.dc != 0.0 ? y.h * y.r01 / y.dc : 0.0;
+    h.pc_y = y.dc != 0.0 ? y.h * y.r11 / y.dc : 0.0;
     h.pwv_rms = y.pwv_rms;
     h.n_e = y.n_e;
     h.n_c = y.n_c;
@@ -553,6 +594,8 @@ int mrx_atm_plan_create(mrx_ctx* ctx, const mrx_layer* layers, int n_layers,
   if (n_layers > 0) {
     e = hipMalloc(&p->d_layers, sizeof(mrx_layer_dev) * n_layers);
     if (ok()) e = hipMalloc(&p->d_off, sizeof(double2) * (size_t)n_layers * n_t);
+    if (ok()) e = hipMalloc(&p->d_offpx, sizeof(double2) * (size_t)n_layers * n_t);
+    if (ok()) e = hipMalloc(&p->d_fast, sizeof(mrx_layer_fast) * n_layers);
     if (ok())
       e = hipMemcpyAsync(p->d_layers, hlay.data(),
                          sizeof(mrx_layer_dev) * n_layers,
@@ -566,10 +609,10 @@ int mrx_atm_plan_create(mrx_ctx* ctx, const mrx_layer* layers, int n_layers,
                        ctx->stream);
   if (ok() && n_layers > 0) {
     hipLaunchKernelGGL(plan_finish_layers, dim3(n_layers), dim3(256), 0,
-                       ctx->stream, p->d_layers, n_layers);
+                       ctx->stream, p->d_layers, p->d_fast, n_layers);
     for (int l = 0; l < n_layers; ++l)
       hipLaunchKernelGGL(plan_pack_offsets, dim3(mrx_ceil_div(n_t, 256)),
-                         dim3(256), 0, ctx->stream, p->d_off,
+                         dim3(256), 0, ctx->stream, p->d_off, p->d_offpx, p->d_layers,
                          layers[l].d_off_e, layers[l].d_off_c, l, n_layers,
                          n_t);
   }
@@ -578,8 +621,13 @@ int mrx_atm_plan_create(mrx_ctx* ctx, const mrx_layer* layers, int n_layers,
       hipLaunchKernelGGL(plan_pack_table, dim3(1), dim3(256), 0, ctx->stream,
                          p->d_table_data, p->d_tables, b, tables[b].d_values,
                          tables[b].d_axis_pwv, tables[b].d_axis_el);
+  std::vector<mrx_layer_fast> hfast((size_t)n_layers);
+  if (ok() && n_layers > 0)
+    e = hipMemcpyAsync(hfast.data(), p->d_fast, sizeof(mrx_layer_fast) * n_layers, hipMemcpyDeviceToHost, ctx->stream);
   if (ok()) e = hipGetLastError();
   if (ok()) e = hipStreamSynchronize(ctx->stream);  // host vectors go away
+  p->all_pixel = n_layers > 0;
+  for (auto& f : hfast) p->all_pixel = p->all_pixel && f.pixel != 0;
   if (!ok()) {
     plan_free(p);
     return mrx_fail(ctx, MRX_ERR_HIP, "plan upload failed: %s",
@@ -653,13 +701,16 @@ int mrx_atm_sample(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d_az,
   const bool lds = plan->table_floats <= kMaxLdsTableFloats;
   const size_t lds_bytes = lds ? sizeof(float) * (size_t)plan->table_floats : 0;
   const bool chain = ctx->options[MRX_OPT_POINTING_CHAIN] != 0;
+  // (an instance compiled without the general path, for plans whose layers are all uniform,
+  // measured SLOWER -- 1.27 vs 1.00 ms -- whatever the occupancy bound: kept out)
+  const bool literal = ctx->options[MRX_OPT_AXIS_LITERAL] != 0 || chain;
 #define MRX_LAUNCH_SAMPLE(L, C, T)                                             \
   hipLaunchKernelGGL((atm_sample_kernel<L, C, T>), grid, dim3(kBlock),         \
-                     lds_bytes, ctx->stream, plan->d_layers, plan->n_layers,   \
-                     plan->d_off, plan->d_tables, plan->n_tables,              \
+                     lds_bytes, ctx->stream, plan->d_layers, plan->d_fast, plan->n_layers, \
+                     plan->d_off, plan->d_offpx, plan->d_tables, plan->n_tables, \
                      plan->d_table_data, plan->table_floats, d_az, d_el, Ta,   \
                      d_dx, d_dy, d_band, d_mueller00, D, pwv0, d_pwv,          \
-                     d_loading, d_flags, ctx->options[MRX_OPT_AXIS_RECOMPUTE] == 0, chunk, nbx, (int)items)
+                     d_loading, d_flags, literal, chunk, nbx, (int)items)
 #define MRX_LAUNCH_SAMPLE_T(L, C)                                              \
   do {                                                                         \
     if (kt == 1) MRX_LAUNCH_SAMPLE(L, C, 1);                                   \

@@ -107,7 +107,7 @@ def main():
             path.ctx.set_option(0, chain)
             path.ctx.set_option(1, arrays)
             med, mn = timeit(path.sample, reps)
-            print(f"sample chain={chain} axis_recompute={arrays}: median {med:.3f} ms min {mn:.3f} ms")
+            print(f"sample chain={chain} axis_literal={arrays}: median {med:.3f} ms min {mn:.3f} ms")
     path.ctx.set_option(0, 0)
     path.ctx.set_option(1, 0)
     for kt in (1, 2, 4):

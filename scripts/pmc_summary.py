@@ -45,6 +45,29 @@ def main():
                    "source": f"{prefix}_pmc_hbm_traffic.csv"}, f, indent=1)
     for r in rows:
         print(f"{r[0]:32s} launches {r[1]:4d}  read {r[4]/1e6:10.2f} MB  written {r[5]/1e6:10.2f} MB")
+    # the SQ / TCP / LDS counter passes: per-launch averages of every kernel of the step
+    lines = []
+    for sub in ("pmc_sq", "pmc_tcp", "pmc_lds"):
+        path = f"{src}/{sub}/run_counter_collection.csv"
+        try:
+            tot, cnt = collections.defaultdict(collections.Counter), collections.Counter()
+            with open(path) as f:
+                for row in csv.DictReader(f):
+                    name = row["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "")
+                    name = re.split(r"[(]", name)[0].strip()
+                    tot[name][row["Counter_Name"]] += float(row["Counter_Value"])
+                    cnt[(name, row["Counter_Name"])] += 1
+        except OSError:
+            continue
+        lines.append(f"# pass {sub}: rocprofv3 --kernel-trace --pmc <counters below> -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline")
+        for k in sorted(tot):
+            if k.startswith("__amd") or k.startswith("at::") or k.startswith("plan_"):
+                continue
+            lines.append(f"{k:44s} launches {max(cnt[(k, c)] for c in tot[k]):3d}  " + " ".join(f"{c}={v / cnt[(k, c)]:.4g}" for c, v in sorted(tot[k].items())))
+    if lines:
+        with open(f"{prefix}_kernel_pmc.txt", "w") as f:
+            f.write("# per-launch averages; SQ_* cycle counters are in quad-cycles summed over waves (MI355X_MICROARCH.md)\n")
+            f.write("\n".join(lines) + "\n")
 
 
 if __name__ == "__main__":
