@@ -250,7 +250,7 @@ def main():
         },
         "second_kernel": {
             "kernel": "atm_sample_kernel",
-            "bound": "valu + vector-memory issue (not hbm): see DESIGN 3.2 and profiles/r02_sample_pmc.txt",
+            "bound": "valu + vector-memory issue (not hbm): see DESIGN 3.2 and profiles/r02_kernel_pmc.txt",
             "ms_per_launch": sm_ms,
             "bytes_per_launch": sm_bytes,
             "achieved_GBps": sm_bytes / (sm_ms * 1e-3) / 1e9,

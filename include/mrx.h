@@ -338,6 +338,23 @@ int mrx_screen_work_floats(int ny, int nx, int n_screens, size_t* floats);
 int mrx_screen_generate_batch(mrx_ctx* ctx, uint64_t seed, int ny, int nx,
                               const mrx_screen_desc* screens, int n_screens,
                               float* d_work, size_t work_floats);
+/* model="3d" (atmosphere/atmosphere.py:28,141-279, extrusion.py:69-77): ONE process holds many
+ * layers whose turbulence is correlated vertically -- a Matern(nu = 1/3, r0) field in three
+ * dimensions, PSD(k) ~ (k0^2 + |k|^2)^-(nu + 3/2), sampled on the layers' heights.  Three transform
+ * passes on a periodic nh x ny x nx domain (powers of two; nh in [8, 2048]): along h per (ky, kx)
+ * cell, keeping only the requested height planes (linear interpolation between the two FFT planes
+ * around plane_pos[p], in units of dh from plane 0, times plane_scale[p] -- the caller's variance
+ * correction 1/sqrt((1-w)^2 + w^2 + 2 w (1-w) rho(dh)), or NULL); then the two passes of
+ * mrx_screen_generate_batch per plane, with the beam smoothing folded in.  `planes[p]` gives each
+ * plane's output block and beam (d_out, out_ny, out_nx, ld_out, sigma_y, sigma_x; the other fields are
+ * ignored).  Cell (kz, ky, kx) uses Philox counter (kx, ky, stream << 16 | kz mod nh/2, 0x33440000). */
+int mrx_screen3d_work_floats(int nh, int ny, int nx, int n_planes, size_t* floats);
+int mrx_screen_generate_3d(mrx_ctx* ctx, uint64_t seed, uint32_t stream, int nh, int ny, int nx,
+                           double dh, double dy, double dx, double r0, double nu,
+                           const double* plane_pos, const double* plane_scale,
+                           const mrx_screen_desc* planes, int n_planes, float* d_work,
+                           size_t work_floats);
+
 /* One unsmoothed screen over the whole domain.  d_work: mrx_screen_work_floats(ny, nx, 1)
  * floats (a buffer of 2*ny*nx float2, the size earlier versions asked for, is ample). */
 int mrx_screen_generate(mrx_ctx* ctx, uint64_t seed, uint32_t stream, int ny,

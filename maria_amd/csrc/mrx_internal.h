@@ -44,6 +44,8 @@ struct mrx_ctx {
     bool valid = false;
     int ny = 0, nx = 0;
     double dy = 0, dx = 0, r0 = 0, nu = 0;
+    int nh = 0;     // 0: a 2-D spectrum
+    double dh = 0;
   } psd[kPsdSlots];
   int psd_next = 0;
   double* d_reduce = nullptr;  // kPsdSlots doubles

@@ -24,6 +24,7 @@
 // The random number of spectrum cell (kx, ky) depends only on (seed, stream,
 // kx, ky), so every GPU regenerates bit-identical screens with no broadcast.
 #include <cmath>
+#include <vector>
 
 #include "mrx_internal.h"
 
@@ -55,6 +56,8 @@ struct ScreenLayerArgs {
   const double* psd_sum;  // device scalar: sum of the PSD over the grid
   const float* taps_y;    // [kMaxFusedRadius + 1] normalised Gaussian taps, zero beyond the radius
   const float* taps_x;
+  int from_work;          // 1: the half spectrum of this plane already sits in `work` (3-D generator,
+                          // written by screen3d_fft_h); pass 1 transforms it in place instead of drawing
   double dy, dx, k0sq;
   unsigned long long ld_out;
   float expo;
@@ -131,6 +134,29 @@ __global__ __launch_bounds__(kBlock) void screen_half_spectrum_fft_y(
   // one Philox call feeds two cells: words (x, y) -> ky index iy, (z, w) -> iy + ny/2
   const int half = ny >> 1;
   constexpr float kRoot = 0.70710678118654752f;
+  if (L.from_work) {
+    // 3-D generator: the column of this height plane's half spectrum was produced by the
+    // transform along h.  Its cells are independent complex Gaussians; on the two self-mirrored
+    // columns the Hermitian symmetry in ky is imposed here: S' = (S[ky] + conj S[-ky]) / sqrt 2
+    // keeps the (real) covariance along h and makes S'[-ky] = conj S'[ky]; the self-conjugate
+    // cells become sqrt 2 Re S.
+    const float2* src = L.work + (size_t)ix * (ny + kPitchPad);
+    for (int iy = threadIdx.x; iy < half; iy += kBlock) {
+      const float2 a = src[iy], b = src[iy + half];
+      if (!edge) {
+        data[iy] = a;
+        data[iy + half] = b;
+      } else if (iy == 0) {
+        data[0] = make_float2(1.41421356f * a.x, 0.0f);
+        data[half] = make_float2(1.41421356f * b.x, 0.0f);
+      } else {
+        const float2 m = src[ny - iy];
+        const float2 h = make_float2(kRoot * (a.x + m.x), kRoot * (a.y - m.y));
+        data[iy] = h;
+        data[ny - iy] = make_float2(h.x, -h.y);
+      }
+    }
+  } else
   for (int iy = threadIdx.x; iy < half; iy += kBlock) {
     const U4 rnd = philox4x32_10(U4{(uint32_t)ix, (uint32_t)iy, L.stream, 0u}, key0, key1);
     const double ky0 = wavenumber(iy, ny, L.dy), ky1 = wavenumber(iy + half, ny, L.dy);
@@ -314,6 +340,87 @@ __global__ __launch_bounds__(kBlock) void screen_c2r_x(const ScreenBatchArgs arg
   }
 }
 
+// ---- 3-D generator (model="3d": one process of many layers, vertically correlated) ----
+// PSD(k) ~ (k0^2 + |k|^2)^-(nu + 3/2) in three dimensions.  Pass 0: one workgroup per (tile of J
+// consecutive ky, kx): draws the nh cells along kz of each (ky, kx) straight into LDS
+// (interleaved batch of J sequences), inverse FFT along h, and writes the half spectra of the
+// requested height planes -- linear interpolation between the two FFT planes around each plane's
+// height, rescaled to keep the variance -- as plane[p][kx][ky], the layout pass 1 reads.
+constexpr uint32_t kTag3d = 0x33440000u;  // counter word 3 of the 3-D draws
+
+struct Screen3dPlane {
+  float2* work;   // [nx/2 + 1][ny + kPitchPad] half spectrum of this plane
+  int h0;         // FFT plane below the layer's height
+  float w, scale; // weight of plane h0 + 1; variance correction of the interpolation
+};
+
+struct Screen3dArgs {
+  const Screen3dPlane* planes;  // device array [n_planes]
+  int n_planes;
+  double dh, dy, dx, k0sq;
+  float expo;
+  uint32_t stream;
+};
+
+__global__ __launch_bounds__(kBlock) void screen3d_fft_h(const Screen3dArgs g, int nh, int ny, int nx,
+                                                         int log2nh, int lj, uint32_t key0, uint32_t key1) {
+  extern __shared__ __align__(16) float2 lds2[];
+  const int J = 1 << lj;
+  const int cells = nh << lj;
+  float2* data = lds2;
+  float2* tw = lds2 + 2 * cells;
+  const int ix = blockIdx.y;       // 0 .. nx/2
+  const int iy0 = blockIdx.x << lj;
+  const double kx = wavenumber(ix, nx, g.dx);
+  fill_twiddles(tw, nh);
+  const int half = nh >> 1;
+  constexpr float kRoot = 0.70710678118654752f;
+  // one Philox call feeds the cells kz = iz and iz + nh/2 of one (ky, kx)
+  for (int e = threadIdx.x; e < (half << lj); e += kBlock) {
+    const int iz = e >> lj, b = e & (J - 1);
+    const int iy = iy0 + b;
+    const U4 rnd = philox4x32_10(U4{(uint32_t)ix, (uint32_t)iy, (g.stream << 16) | (uint32_t)iz, kTag3d}, key0, key1);
+    const double ky = wavenumber(iy, ny, g.dy);
+    const double kz0 = wavenumber(iz, nh, g.dh), kz1 = wavenumber(iz + half, nh, g.dh);
+    const double kk = g.k0sq + kx * kx + ky * ky;
+    const float amp0 = kRoot * spectrum_amp(kk + kz0 * kz0, g.expo);
+    const float amp1 = kRoot * spectrum_amp(kk + kz1 * kz1, g.expo);
+    const float2 g0 = box_muller(rnd.x, rnd.y), g1 = box_muller(rnd.z, rnd.w);
+    data[(iz << lj) | b] = make_float2(amp0 * g0.x, amp0 * g0.y);
+    data[((iz + half) << lj) | b] = make_float2(amp1 * g1.x, amp1 * g1.y);
+  }
+  __syncthreads();
+  const float2* res = fft_lds_inverse_batched(data, data + cells, tw, nh, log2nh, lj);
+  for (int e = threadIdx.x; e < (g.n_planes << lj); e += kBlock) {
+    const int p = e >> lj, b = e & (J - 1);
+    const Screen3dPlane pl = g.planes[p];
+    const float2 a = res[(pl.h0 << lj) | b], c = res[(min(pl.h0 + 1, nh - 1) << lj) | b];
+    const float wa = (1.0f - pl.w) * pl.scale, wc = pl.w * pl.scale;
+    pl.work[(size_t)ix * (ny + kPitchPad) + iy0 + b] = make_float2(wa * a.x + wc * c.x, wa * a.y + wc * c.y);
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void psd_sum3d_kernel(double* __restrict__ sum, int nh, int ny, int nx, double dh,
+                                                           double dy, double dx, double k0sq, float expo) {
+  __shared__ double part[kBlock / 64];
+  double acc = 0.0;
+  const size_t n = (size_t)nh * ny * nx;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const int ix = (int)(i % nx), iy = (int)((i / nx) % ny), iz = (int)(i / ((size_t)nx * ny));
+    const double kx = wavenumber(ix, nx, dx), ky = wavenumber(iy, ny, dy), kz = wavenumber(iz, nh, dh);
+    const float amp = spectrum_amp(k0sq + kx * kx + ky * ky + kz * kz, expo);
+    acc += (double)amp * (double)amp;
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int w = 0; w < kBlock / 64; ++w) s += part[w];
+    atomicAdd(sum, s);
+  }
+}
+
 // sum over the grid of amp^2 (what Var[real part] equals), float64
 __global__ __launch_bounds__(kBlock) void psd_sum_kernel(
     double* __restrict__ sum, int ny, int nx, double dy, double dx,
@@ -387,7 +494,7 @@ int ilog2_exact(int n) {
 // The normalisation depends on the grid and spectrum only, not on the draw: it
 // is reduced once per (ny, nx, dy, dx, r0, nu) and kept in a device slot.
 int psd_sum_slot(mrx_ctx* ctx, int ny, int nx, double dy, double dx, double r0,
-                 double nu, const double** d_sum) {
+                 double nu, const double** d_sum, int nh = 0, double dh = 0.0) {
   if (!ctx->d_reduce) {
     MRX_HIP(ctx, hipMalloc(&ctx->d_reduce, mrx_ctx::kPsdSlots * sizeof(double)));
     ctx->reduce_cap = mrx_ctx::kPsdSlots;
@@ -395,7 +502,7 @@ int psd_sum_slot(mrx_ctx* ctx, int ny, int nx, double dy, double dx, double r0,
   for (int i = 0; i < mrx_ctx::kPsdSlots; ++i) {
     const auto& k = ctx->psd[i];
     if (k.valid && k.ny == ny && k.nx == nx && k.dy == dy && k.dx == dx &&
-        k.r0 == r0 && k.nu == nu) {
+        k.r0 == r0 && k.nu == nu && k.nh == nh && k.dh == dh) {
       *d_sum = ctx->d_reduce + i;
       return MRX_OK;
     }
@@ -404,16 +511,21 @@ int psd_sum_slot(mrx_ctx* ctx, int ny, int nx, double dy, double dx, double r0,
   ctx->psd_next = (ctx->psd_next + 1) % mrx_ctx::kPsdSlots;
   double* dst = ctx->d_reduce + slot;
   const double k0sq = 2.0 * nu / (r0 * r0);
-  const float expo = (float)(-(nu + 1.0) / 2.0);
+  // sqrt of the PSD: (nu + 1)/2 in two dimensions, (nu + 3/2)/2 in three
+  const float expo = (float)(nh > 0 ? -(nu + 1.5) / 2.0 : -(nu + 1.0) / 2.0);
   MRX_HIP(ctx, hipMemsetAsync(dst, 0, sizeof(double), ctx->stream));
-  const size_t n = (size_t)ny * nx;
+  const size_t n = (size_t)ny * nx * (nh > 0 ? nh : 1);
   const int blocks = (int)((n + kBlock - 1) / kBlock < 2048
                                ? (n + kBlock - 1) / kBlock
                                : 2048);
-  hipLaunchKernelGGL(psd_sum_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream,
-                     dst, ny, nx, dy, dx, k0sq, expo);
+  if (nh > 0)
+    hipLaunchKernelGGL(psd_sum3d_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, dst, nh, ny, nx, dh, dy, dx,
+                       k0sq, expo);
+  else
+    hipLaunchKernelGGL(psd_sum_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream,
+                       dst, ny, nx, dy, dx, k0sq, expo);
   MRX_CHECK_LAUNCH(ctx);
-  ctx->psd[slot] = {true, ny, nx, dy, dx, r0, nu};
+  ctx->psd[slot] = {true, ny, nx, dy, dx, r0, nu, nh, dh};
   *d_sum = dst;
   return MRX_OK;
 }
@@ -443,22 +555,14 @@ int mrx_screen_work_floats(int ny, int nx, int n_screens, size_t* floats) {
   return MRX_OK;
 }
 
-int mrx_screen_generate_batch(mrx_ctx* ctx, uint64_t seed, int ny, int nx,
-                              const mrx_screen_desc* screens, int n_screens, float* d_work,
-                              size_t work_floats) {
-  MRX_ENTER(ctx);
-  if (!ctx) return MRX_ERR_INVALID;
-  MRX_REQUIRE(ctx, n_screens >= 0, "negative count");
-  if (n_screens == 0) return MRX_OK;
-  MRX_REQUIRE(ctx, screens && d_work, "null pointer");
+// Passes 1 and 2 for n_screens screens that share one FFT domain, kMaxBatch per launch.
+// spectra != nullptr: plane i's half spectrum is already in its slot of d_work (3-D generator)
+// and d_sum3d is the normalisation; otherwise every screen draws its own 2-D spectrum.
+static int run_screen_passes(mrx_ctx* ctx, uint64_t seed, int ny, int nx, const mrx_screen_desc* screens,
+                             int n_screens, float* d_work, bool from_work, const double* d_sum3d) {
   const int ly = ilog2_exact(ny), lx = ilog2_exact(nx);
-  if (ly < 0 || lx < 0 || ny < 64 || nx < 64 || ny > 8192 || nx > 8192)
-    return mrx_fail(ctx, MRX_ERR_UNSUPPORTED,
-                    "screen sides must be powers of two in [64, 8192] (got %d x %d)", ny, nx);
   size_t need = 0;
   mrx_screen_work_floats(ny, nx, n_screens, &need);
-  MRX_REQUIRE(ctx, work_floats >= need, "work buffer smaller than mrx_screen_work_floats()");
-  MRX_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(d_work) & 15u) == 0, "d_work must be 16-byte aligned");
   const size_t per_screen = need / (size_t)n_screens;
   const uint32_t key0 = (uint32_t)seed, key1 = (uint32_t)(seed >> 32);
   const int n2 = nx / 2;
@@ -483,7 +587,7 @@ int mrx_screen_generate_batch(mrx_ctx* ctx, uint64_t seed, int ny, int nx,
     for (int i = 0; i < nb; ++i) {
       const mrx_screen_desc& d = screens[first + i];
       MRX_REQUIRE(ctx, d.d_out != nullptr, "null output pointer");
-      MRX_REQUIRE(ctx, d.dy > 0 && d.dx > 0 && d.r0 > 0 && d.nu > 0,
+      MRX_REQUIRE(ctx, from_work || (d.dy > 0 && d.dx > 0 && d.r0 > 0 && d.nu > 0),
                   "steps, r0 and nu must be positive");
       const int out_ny = d.out_ny > 0 ? d.out_ny : ny, out_nx = d.out_nx > 0 ? d.out_nx : nx;
       MRX_REQUIRE(ctx, out_ny <= ny && out_nx <= nx, "written block larger than the FFT domain");
@@ -491,17 +595,21 @@ int mrx_screen_generate_batch(mrx_ctx* ctx, uint64_t seed, int ny, int nx,
       MRX_REQUIRE(ctx, ld >= (size_t)out_nx, "ld_out smaller than the row");
       MRX_REQUIRE(ctx, d.sigma_y >= 0.0 && d.sigma_x >= 0.0, "sigma must be >= 0");
       ScreenLayerArgs& L = args.l[i];
-      const double* d_sum = nullptr;
-      int rc = psd_sum_slot(ctx, ny, nx, d.dy, d.dx, d.r0, d.nu, &d_sum);
-      if (rc != MRX_OK) return rc;
+      const double* d_sum = d_sum3d;
+      int rc = MRX_OK;
+      if (!from_work) {
+        rc = psd_sum_slot(ctx, ny, nx, d.dy, d.dx, d.r0, d.nu, &d_sum);
+        if (rc != MRX_OK) return rc;
+      }
       L.work = reinterpret_cast<float2*>(d_work) + (size_t)(first + i) * (per_screen / 2);
       L.out = d.d_out;
       L.psd_sum = d_sum;
       L.dy = d.dy;
       L.dx = d.dx;
-      L.k0sq = 2.0 * d.nu / (d.r0 * d.r0);
+      L.k0sq = from_work ? 0.0 : 2.0 * d.nu / (d.r0 * d.r0);
       L.ld_out = ld;
       L.expo = (float)(-(d.nu + 1.0) / 2.0);
+      L.from_work = from_work ? 1 : 0;
       // scipy: radius = int(truncate * sigma + 0.5), truncate = 4; a sigma <= 1e-15 skips the axis
       const int ry = d.sigma_y > 1e-15 ? (int)(4.0 * d.sigma_y + 0.5) : 0;
       const int rx = d.sigma_x > 1e-15 ? (int)(4.0 * d.sigma_x + 0.5) : 0;
@@ -534,12 +642,101 @@ int mrx_screen_generate_batch(mrx_ctx* ctx, uint64_t seed, int ny, int nx,
       const ScreenLayerArgs& L = args.l[i];
       MRX_REQUIRE(ctx, L.ld_out == (unsigned long long)L.out_nx,
                   "a beam wider than 32 pixels needs a contiguous output (ld_out == out_nx)");
+      MRX_REQUIRE(ctx, !from_work, "a beam wider than 32 pixels is not supported by the 3-D generator");
       // the half spectra are consumed: the work buffer is free scratch now
       int rc = mrx_gauss_smooth2d(ctx, L.out, L.out, d_work, L.out_ny, L.out_nx, d.sigma_y, d.sigma_x, 4.0);
       if (rc != MRX_OK) return rc;
     }
   }
   return MRX_OK;
+}
+
+int mrx_screen_generate_batch(mrx_ctx* ctx, uint64_t seed, int ny, int nx,
+                              const mrx_screen_desc* screens, int n_screens, float* d_work,
+                              size_t work_floats) {
+  MRX_ENTER(ctx);
+  if (!ctx) return MRX_ERR_INVALID;
+  MRX_REQUIRE(ctx, n_screens >= 0, "negative count");
+  if (n_screens == 0) return MRX_OK;
+  MRX_REQUIRE(ctx, screens && d_work, "null pointer");
+  const int ly = ilog2_exact(ny), lx = ilog2_exact(nx);
+  if (ly < 0 || lx < 0 || ny < 64 || nx < 64 || ny > 8192 || nx > 8192)
+    return mrx_fail(ctx, MRX_ERR_UNSUPPORTED,
+                    "screen sides must be powers of two in [64, 8192] (got %d x %d)", ny, nx);
+  size_t need = 0;
+  mrx_screen_work_floats(ny, nx, n_screens, &need);
+  MRX_REQUIRE(ctx, work_floats >= need, "work buffer smaller than mrx_screen_work_floats()");
+  MRX_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(d_work) & 15u) == 0, "d_work must be 16-byte aligned");
+  return run_screen_passes(ctx, seed, ny, nx, screens, n_screens, d_work, false, nullptr);
+}
+
+int mrx_screen3d_work_floats(int nh, int ny, int nx, int n_planes, size_t* floats) {
+  if (!floats || nh <= 0 || ny <= 0 || nx <= 0 || n_planes < 0) return MRX_ERR_INVALID;
+  size_t planes = 0;
+  mrx_screen_work_floats(ny, nx, n_planes, &planes);
+  *floats = planes + 8 * (size_t)n_planes + 16;  // + the device copy of the plane table
+  return MRX_OK;
+}
+
+int mrx_screen_generate_3d(mrx_ctx* ctx, uint64_t seed, uint32_t stream, int nh, int ny, int nx,
+                           double dh, double dy, double dx, double r0, double nu,
+                           const double* plane_pos, const double* plane_scale,
+                           const mrx_screen_desc* planes, int n_planes, float* d_work,
+                           size_t work_floats) {
+  MRX_ENTER(ctx);
+  if (!ctx) return MRX_ERR_INVALID;
+  MRX_REQUIRE(ctx, n_planes >= 0, "negative count");
+  if (n_planes == 0) return MRX_OK;
+  MRX_REQUIRE(ctx, planes && plane_pos && d_work, "null pointer");
+  MRX_REQUIRE(ctx, dh > 0 && dy > 0 && dx > 0 && r0 > 0 && nu > 0, "steps, r0 and nu must be positive");
+  MRX_REQUIRE(ctx, stream < 65536u, "the 3-D generator takes streams below 65536");
+  const int lh = ilog2_exact(nh), ly = ilog2_exact(ny), lx = ilog2_exact(nx);
+  if (lh < 0 || ly < 0 || lx < 0 || nh < 8 || nh > 2048 || ny < 64 || nx < 64 || ny > 8192 || nx > 8192)
+    return mrx_fail(ctx, MRX_ERR_UNSUPPORTED,
+                    "3-D domain: nh a power of two in [8, 2048], ny and nx in [64, 8192] (got %d x %d x %d)", nh, ny, nx);
+  size_t need = 0, plane_floats = 0;
+  mrx_screen3d_work_floats(nh, ny, nx, n_planes, &need);
+  mrx_screen_work_floats(ny, nx, n_planes, &plane_floats);
+  MRX_REQUIRE(ctx, work_floats >= need, "work buffer smaller than mrx_screen3d_work_floats()");
+  MRX_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(d_work) & 15u) == 0, "d_work must be 16-byte aligned");
+  const size_t per_plane = plane_floats / (size_t)n_planes;  // floats
+  std::vector<Screen3dPlane> table((size_t)n_planes);
+  for (int p = 0; p < n_planes; ++p) {
+    const double pos = plane_pos[p];
+    MRX_REQUIRE(ctx, pos >= 0.0 && pos <= (double)(nh - 1), "plane position outside the FFT planes");
+    int h0 = (int)pos;
+    if (h0 > nh - 2) h0 = nh - 2;
+    table[(size_t)p].work = reinterpret_cast<float2*>(d_work) + (size_t)p * (per_plane / 2);
+    table[(size_t)p].h0 = h0;
+    table[(size_t)p].w = (float)(pos - (double)h0);
+    table[(size_t)p].scale = plane_scale ? (float)plane_scale[p] : 1.0f;
+  }
+  static_assert(sizeof(Screen3dPlane) <= 8 * sizeof(float), "plane table slot");
+  Screen3dPlane* d_table = reinterpret_cast<Screen3dPlane*>(d_work + ((plane_floats + 3) & ~(size_t)3));
+  MRX_HIP(ctx, hipMemcpyAsync(d_table, table.data(), sizeof(Screen3dPlane) * (size_t)n_planes, hipMemcpyHostToDevice,
+                              ctx->stream));
+  MRX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the host table goes out of scope
+  const double* d_sum = nullptr;
+  int rc = psd_sum_slot(ctx, ny, nx, dy, dx, r0, nu, &d_sum, nh, dh);
+  if (rc != MRX_OK) return rc;
+
+  Screen3dArgs g{};
+  g.planes = d_table;
+  g.n_planes = n_planes;
+  g.dh = dh;
+  g.dy = dy;
+  g.dx = dx;
+  g.k0sq = 2.0 * nu / (r0 * r0);
+  g.expo = (float)(-(nu + 1.5) / 2.0);
+  g.stream = stream;
+  int lj = 0;
+  while (((nh << (lj + 1)) <= 2048) && (1 << (lj + 1)) <= ny) ++lj;  // J sequences of nh cells: <= 2048 per workgroup
+  const size_t lds0 = (size_t)(2 * (nh << lj) + nh / 4) * sizeof(float2);
+  MRX_LDS_CAP(ctx, screen3d_fft_h, lds0);
+  hipLaunchKernelGGL(screen3d_fft_h, dim3(ny >> lj, nx / 2 + 1), dim3(kBlock), lds0, ctx->stream, g, nh, ny, nx, lh, lj,
+                     (uint32_t)seed, (uint32_t)(seed >> 32));
+  MRX_CHECK_LAUNCH(ctx);
+  return run_screen_passes(ctx, seed, ny, nx, planes, n_planes, d_work, true, d_sum);
 }
 
 int mrx_screen_generate(mrx_ctx* ctx, uint64_t seed, uint32_t stream, int ny,

@@ -59,6 +59,52 @@ def hermitian_philox_screen(philox4x32, seed, stream, ny, nx, dy, dx, r0, nu):
     return np.fft.irfft2(H, s=(ny, nx)) * (ny * nx) / np.sqrt((amp**2).sum())
 
 
+def psd_amplitude_3d(nh, ny, nx, dh, dy, dx, r0, nu):
+    kz = 2 * np.pi * np.fft.fftfreq(nh, dh)[:, None, None]
+    ky = 2 * np.pi * np.fft.fftfreq(ny, dy)[None, :, None]
+    kx = 2 * np.pi * np.fft.fftfreq(nx, dx)[None, None, :]
+    return (2.0 * nu / r0**2 + kx**2 + ky**2 + kz**2) ** (-(nu + 1.5) / 2.0)
+
+
+def hermitian_philox_screens_3d(philox4x32, seed, stream, nh, ny, nx, dh, dy, dx, r0, nu, plane_pos, plane_scale=None):
+    """The height planes mrx_screen_generate_3d defines (include/mrx.h), rebuilt on the host:
+    independent cells on kx <= nx/2, inverse FFT along h, linear interpolation to the planes,
+    Hermitian symmetrisation of the two self-mirrored columns, numpy's irfft2 per plane."""
+    amp = psd_amplitude_3d(nh, ny, nx, dh, dy, dx, r0, nu)
+    H = np.zeros((nh, ny, nx // 2 + 1), complex)
+
+    def normal_pair(a, b):
+        u1 = ((a >> 8) + 0.5) / 16777216.0
+        u2 = (b >> 8) / 16777216.0
+        rad = np.sqrt(-2 * np.log(u1))
+        return complex(rad * np.cos(2 * np.pi * u2), rad * np.sin(2 * np.pi * u2))
+
+    for ix in range(nx // 2 + 1):
+        for iy in range(ny):
+            for iz in range(nh // 2):
+                w = philox4x32(seed, (ix, iy, (stream << 16) | iz, 0x33440000))
+                H[iz, iy, ix] = amp[iz, iy, ix] * normal_pair(w[0], w[1]) / np.sqrt(2)
+                H[iz + nh // 2, iy, ix] = amp[iz + nh // 2, iy, ix] * normal_pair(w[2], w[3]) / np.sqrt(2)
+    S = np.fft.ifft(H, axis=0) * nh  # [h, ky, kx]
+    norm = np.sqrt((amp**2).sum())
+    half = ny // 2
+    out = []
+    for p, pos in enumerate(plane_pos):
+        h0 = min(int(pos), nh - 2)
+        w = pos - h0
+        P = ((1 - w) * S[h0] + w * S[h0 + 1]) * (1.0 if plane_scale is None else plane_scale[p])
+        for ix in (0, nx // 2):
+            col = P[:, ix].copy()
+            new = col.copy()
+            for iy in range(1, half):
+                new[iy] = (col[iy] + np.conj(col[ny - iy])) / np.sqrt(2)
+                new[ny - iy] = np.conj(new[iy])
+            new[0], new[half] = np.sqrt(2) * col[0].real, np.sqrt(2) * col[half].real
+            P[:, ix] = new
+        out.append(np.fft.irfft2(P, s=(ny, nx)) * (ny * nx) / norm)
+    return out
+
+
 def radial_covariance(screen, dy, dx, lags_px):
     """Empirical covariance of a periodic screen at integer-pixel lags along both
     axes (FFT autocorrelation); returns (r_metres, cov) for each axis."""

@@ -257,3 +257,84 @@ def test_lds_fft_matches_numpy(gpu_ctx, n, lj):
     got = d_out.cpu().numpy()
     ref = np.fft.ifft(x.astype(np.complex128), axis=1) * n
     assert np.abs(got - ref).max() <= 1e-6 * np.log2(n) * np.abs(ref).max()
+
+
+def _generate_3d(ctx, seed, stream, nh, ny, nx, dh, dy, dx, r0, nu, plane_pos, plane_scale=None, sigma=0.0, out_shape=None):
+    import ctypes as C
+
+    import torch
+
+    from maria_amd import _lib
+    from maria_amd._lib import ptr
+
+    n = len(plane_pos)
+    oy, ox = out_shape or (ny, nx)
+    outs = [torch.full((oy, ox), float("nan"), dtype=torch.float32, device="cuda:0") for _ in range(n)]
+    descs = (_lib.MrxScreenDesc * n)()
+    for d, o in zip(descs, outs):
+        d.d_out, d.out_ny, d.out_nx, d.ld_out = o.data_ptr(), oy, ox, 0
+        d.sigma_y = d.sigma_x = sigma
+    need = C.c_size_t()
+    _lib.load().mrx_screen3d_work_floats(nh, ny, nx, n, C.byref(need))
+    work = torch.empty(need.value, dtype=torch.float32, device="cuda:0")
+    pos = (C.c_double * n)(*plane_pos)
+    scl = (C.c_double * n)(*plane_scale) if plane_scale is not None else None
+    ctx.call("mrx_screen_generate_3d", seed, stream, nh, ny, nx, dh, dy, dx, r0, nu, pos, scl, descs, n, ptr(work), work.numel())
+    return [o.cpu().numpy() for o in outs]
+
+
+def test_screen_3d_matches_numpy(gpu_ctx):
+    """The three transform passes of the 3-D generator against numpy on the same Philox cells:
+    on-grid and interpolated planes, with a variance scale."""
+    from maria_amd._lib import philox4x32
+    from oracle import screens
+
+    nh, ny, nx = 8, 64, 64
+    args = (nh, ny, nx, 30.0, 20.0, 25.0, 400.0, 1.0 / 3.0)
+    pos, scale = [0.0, 2.5, 6.0, 6.75], [1.0, 1.1, 1.0, 0.9]
+    got = _generate_3d(gpu_ctx, 5, 3, *args, pos, scale)
+    ref = screens.hermitian_philox_screens_3d(philox4x32, 5, 3, *args, pos, scale)
+    for g, r in zip(got, ref):
+        assert np.abs(g - r).max() <= 3e-5 * np.abs(r).max()
+
+
+def test_screen_3d_statistics_match_matern(gpu_ctx):
+    """model="3d": layers of one process are slices of a 3-D Matern(nu = 1/3, r0) field
+    (atmosphere/atmosphere.py:249): unit variance, the Matern structure function inside a
+    plane, and the same function of the vertical separation between planes."""
+    from oracle import functions, screens
+
+    nh, ny, nx = 256, 256, 256
+    d, r0, nu = 20.0, 600.0, 1.0 / 3.0
+    pos = [40.0, 41.0, 42.0, 44.0, 48.0, 56.0, 72.0]
+    lags = np.array([1, 2, 4, 8, 16, 32])
+    var, sf_v, sf_x = [], np.zeros(len(pos) - 1), np.zeros(len(lags))
+    nrep = 6
+    for rep in range(nrep):
+        planes = _generate_3d(gpu_ctx, 77, rep, nh, ny, nx, d, d, d, r0, nu, pos)
+        base = planes[0].astype(np.float64)
+        var.append(np.mean([np.mean(p.astype(np.float64) ** 2) for p in planes]))
+        # structure functions directly (differences: the large-scale modes of a realisation cancel)
+        sf_v += np.array([np.mean((base - p) ** 2) for p in planes[1:]]) / nrep
+        sf_x += np.array([np.mean((base - np.roll(base, -k, axis=1)) ** 2) for k in lags]) / nrep
+    assert abs(np.mean(var) - 1) < 0.08, var
+    dz = (np.array(pos[1:]) - pos[0]) * d
+    # (1) the generator's own definition: covariance = inverse transform of the squared amplitudes
+    amp2 = screens.psd_amplitude_3d(nh, ny, nx, d, d, d, r0, nu) ** 2
+    model = np.fft.ifftn(amp2).real
+    model /= model[0, 0, 0]
+    want_v = 2 * (1 - model[(np.array(pos[1:]) - pos[0]).astype(int), 0, 0])
+    want_x = 2 * (1 - model[0, 0, lags])
+    assert np.abs(sf_v / want_v - 1).max() < 0.1, (sf_v, want_v)
+    assert np.abs(sf_x / want_x - 1).max() < 0.1, (sf_x, want_x)
+    # (2) the target, Matern(nu = 1/3): the spectrum stops at the grid's Nyquist frequency, which
+    # matters for so rough a field (structure function ~ r^(2/3)) only within a few pixels -- the
+    # scales the beam smoothing removes anyway (3d layers: sigma >= 0.85 pixel, extrusion.py:20-22)
+    ref = lambda r: functions.approximate_normalized_matern(np.asarray(r, float), nu=nu, r0=r0)  # noqa: E731
+    far_v, far_x = dz >= 8 * d, lags >= 8
+    assert np.abs(sf_v[far_v] / (2 * (1 - ref(dz[far_v]))) - 1).max() < 0.15, (sf_v, 2 * (1 - ref(dz)))
+    assert np.abs(sf_x[far_x] / (2 * (1 - ref(lags[far_x] * d))) - 1).max() < 0.15, (sf_x, 2 * (1 - ref(lags * d)))
+    # deterministic, and another stream is another field
+    a = _generate_3d(gpu_ctx, 77, 0, nh, ny, nx, d, d, d, r0, nu, pos[:2])
+    b = _generate_3d(gpu_ctx, 77, 0, nh, ny, nx, d, d, d, r0, nu, pos[:2])
+    assert all(np.array_equal(x, y) for x, y in zip(a, b))
