@@ -526,7 +526,7 @@ int mrx_atm_plan_create(mrx_ctx* ctx, const mrx_layer* layers, int n_layers,
   if (!ctx || !out) return MRX_ERR_INVALID;
   *out = nullptr;
   MRX_REQUIRE(ctx, layers != nullptr || n_layers == 0, "layers is null");
-  MRX_REQUIRE(ctx, n_layers >= 0 && n_layers <= 64, "0 <= n_layers <= 64");
+  MRX_REQUIRE(ctx, n_layers >= 0 && n_layers <= 1024, "0 <= n_layers <= 1024");  // model="3d": hundreds of layers
   MRX_REQUIRE(ctx, tables != nullptr && n_tables >= 1 && n_tables <= 1024,
               "need 1..1024 band tables");
   MRX_REQUIRE(ctx, n_t >= 1, "n_t must be positive");

@@ -263,34 +263,62 @@ class DevicePath:
         fft_shapes = [tuple(l.get("fft_shape") or sh) for l, sh in zip(layers, shapes)]
         if getattr(self, "_gen_screens", None) is None:
             self._gen_screens = [torch.empty(sh, dtype=torch.float32, device=dev) for sh in shapes]
-            self._gen_groups = {}
-            for l, f in enumerate(fft_shapes):
-                self._gen_groups.setdefault(f, []).append(l)
+            # layers that are slices of one 3-D volume (model="3d") are generated together;
+            # the others in groups that share a 2-D FFT domain
+            self._gen_groups, self._gen_volumes = {}, {}
+            for l, (layer, f) in enumerate(zip(layers, fft_shapes)):
+                vol = layer.get("volume")
+                if vol is not None:
+                    self._gen_volumes.setdefault((vol["id"], vol["nh"], f), []).append(l)
+                else:
+                    self._gen_groups.setdefault(f, []).append(l)
             need = 0
+            n = C.c_size_t()
             for (fe, fc), members in self._gen_groups.items():
-                n = C.c_size_t()
                 _lib.load().mrx_screen_work_floats(fe, fc, len(members), C.byref(n))
+                need = max(need, n.value)
+            for (_, nh, (fe, fc)), members in self._gen_volumes.items():
+                _lib.load().mrx_screen3d_work_floats(nh, fe, fc, len(members), C.byref(n))
                 need = max(need, n.value)
             self._gen_work = torch.empty(need, dtype=torch.float32, device=dev)
             self.set_screens(self._gen_screens)
+
+        def describe(members):
+            descs = (_lib.MrxScreenDesc * len(members))()
+            for d, l in zip(descs, members):
+                layer, out = layers[l], self._gen_screens[l]
+                de = float(layer["extrusion"][1] - layer["extrusion"][0])
+                dc = float(layer["cross_section"][1] - layer["cross_section"][0])
+                sigma = float(layer.get("beam_sigma", 0) or 0) if smooth else 0.0
+                d.d_out, d.stream = out.data_ptr(), l
+                d.out_ny, d.out_nx, d.ld_out = out.shape[0], out.shape[1], out.stride(0)
+                d.dy, d.dx, d.r0, d.nu = de, dc, float(layer["r0"]), float(layer["nu"])
+                d.sigma_y, d.sigma_x = sigma / de, sigma / dc
+            return descs
+
         with _range("Generating turbulence"):
             for (fe, fc), members in self._gen_groups.items():
                 if only is not None:
                     members = [l for l in members if l in only]
                     if not members:
                         continue
-                descs = (_lib.MrxScreenDesc * len(members))()
-                for d, l in zip(descs, members):
-                    layer, out = layers[l], self._gen_screens[l]
-                    de = float(layer["extrusion"][1] - layer["extrusion"][0])
-                    dc = float(layer["cross_section"][1] - layer["cross_section"][0])
-                    sigma = float(layer.get("beam_sigma", 0) or 0) if smooth else 0.0
-                    d.d_out, d.stream = out.data_ptr(), l
-                    d.out_ny, d.out_nx, d.ld_out = out.shape[0], out.shape[1], out.stride(0)
-                    d.dy, d.dx, d.r0, d.nu = de, dc, float(layer["r0"]), float(layer["nu"])
-                    d.sigma_y, d.sigma_x = sigma / de, sigma / dc
                 self.ctx.call(
-                    "mrx_screen_generate_batch", self.problem["seed"], fe, fc, descs, len(members),
+                    "mrx_screen_generate_batch", self.problem["seed"], fe, fc, describe(members), len(members),
+                    ptr(self._gen_work), self._gen_work.numel(),
+                )
+            for (vid, nh, (fe, fc)), members in self._gen_volumes.items():
+                # one volume is one draw: `only` does not split it (a rank that owns any of its layers makes all)
+                if only is not None and not any(l in only for l in members):
+                    continue
+                first = layers[members[0]]
+                vol = first["volume"]
+                de = float(first["extrusion"][1] - first["extrusion"][0])
+                dc = float(first["cross_section"][1] - first["cross_section"][0])
+                pos = (C.c_double * len(members))(*[layers[l]["volume"]["pos"] for l in members])
+                scl = (C.c_double * len(members))(*[layers[l]["volume"]["scale"] for l in members])
+                self.ctx.call(
+                    "mrx_screen_generate_3d", self.problem["seed"], int(vid) & 0xFFFF, nh, fe, fc, float(vol["dh"]), de, dc,
+                    float(first["r0"]), float(first["nu"]), pos, scl, describe(members), len(members),
                     ptr(self._gen_work), self._gen_work.numel(),
                 )
         return self._gen_screens

@@ -73,6 +73,11 @@ def fast_psd_inverse(M):
 H_BOUNDARIES_2D = np.array([0.0, 500.0, 1000.0, 1500.0, 2000.0, 3000.0, 5000.0, 8000.0, 12000.0])
 
 
+MIN_RES = {"2d": 2, "3d": 15}  # extrusion.py:20-22
+MIN_RES_PER_BEAM = {"2d": 0.1, "3d": 0.5}
+MIN_RES_PER_FOV = {"2d": 0.02, "3d": 0.1}
+
+
 def generate_layers(
     field_of_view,
     band_fwhm_args,
@@ -81,9 +86,11 @@ def generate_layers(
     site_altitude,
     pwv,
     pwv_rms_frac=3e-2,
-    min_res=2.0,
-    min_res_per_beam=0.1,
-    min_res_per_fov=0.02,
+    min_res=None,
+    min_res_per_beam=None,
+    min_res_per_fov=None,
+    mode="2d",
+    max_height=2e3,
 ):
     """extrusion.py:27-110 in "2d" mode with ``angular=False``.
 
@@ -93,6 +100,9 @@ def generate_layers(
     divergence`` (what ``Weather.__call__`` interpolates, weather/__init__.py:222).
     Returns a dict of per-layer arrays.
     """
+    min_res = min_res or MIN_RES[mode]
+    min_res_per_beam = min_res_per_beam or MIN_RES_PER_BEAM[mode]
+    min_res_per_fov = min_res_per_fov or MIN_RES_PER_FOV[mode]
     h_samples = np.arange(0.0, 20000.0, 1e0)
     z_samples = h_samples / np.sin(min_el)
     fwhm = np.min(
@@ -104,10 +114,21 @@ def generate_layers(
     res_samples = np.minimum(1e3, np.maximum.reduce([r1, r2, r3]))
     res_func = sp.interpolate.interp1d(h_samples, res_samples)
 
-    h_boundaries = H_BOUNDARIES_2D
+    if mode == "2d":
+        h_boundaries = H_BOUNDARIES_2D
+        process_index = np.arange(len(h_boundaries) - 1)
+    else:  # extrusion.py:69-77
+        h_boundaries = [0]
+        while True:
+            new_h = h_boundaries[-1] + res_func(h_boundaries[-1])
+            if new_h > max_height:
+                break
+            h_boundaries.append(h_boundaries[-1] + res_func(h_boundaries[-1]))
+        h_boundaries = np.array(h_boundaries, float)
+        process_index = np.zeros(len(h_boundaries) - 1, int)
     h = (h_boundaries[1:] + h_boundaries[:-1]) / 2
     layers = {
-        "process_index": np.arange(len(h)),
+        "process_index": process_index,
         "h": h,
         "dh": np.diff(h_boundaries),
         "res": res_func(h),
@@ -154,3 +175,30 @@ def process_geometry(layer, all_res_min, outer_pp, timestep, n_t):
         nu=5 / 6,
         extrusion_res=float(np.gradient(extrusion).mean()),
     )
+
+
+def process_geometry_multi(layers, members, all_res_min, outer_pp, timestep, n_t, model="3d"):
+    """One process of several layers (atmosphere.py:117-257, ``model="3d"``): the water-weighted
+    wind (:148-151), the hull of the first and the last layer (:153-186), one transform, one
+    extrusion grid, a cross-section grid PER LAYER at that layer's resolution (:208-219), the
+    outer scale from the mean height (:247) and nu = 1/3 (:249).  ``layers``: dict of per-layer
+    arrays from ``generate_layers``; ``members``: indices of this process's layers."""
+    members = np.asarray(members)
+    w = (layers["absolute_humidity"] * layers["temperature"] * layers["divergence"])[members]
+    vx = (w[:, None] * (layers["wind_east"][members][:, None] * np.ones(n_t))).sum(axis=0) / w.sum()
+    vy = (w[:, None] * (layers["wind_north"][members][:, None] * np.ones(n_t))).sum(axis=0) / w.sum()
+    vz = np.zeros(n_t)
+    ends = members[[0, -1]] if len(members) > 1 else members[[0]]
+    pts = np.concatenate([(layers["h"][l] * outer_pp + np.cumsum(timestep * np.c_[vx, vy, vz][None], axis=-2))[None] for l in ends], axis=0).reshape(-1, 3)
+    pts[..., 2] += 1e-6 * np.random.standard_normal(pts[..., 2].shape)
+    transform = compute_aligning_transform(pts, signature=(True, True, False))
+    tp = pts @ transform
+    cross = {}
+    for l in members:
+        res = layers["res"][l]
+        n_cross = int(np.maximum(2, (np.ptp(tp[:, 1]) + 2 * res) / res))
+        cross[int(l)] = np.linspace(tp[:, 1].min() - res, tp[:, 1].max() + res, n_cross)
+    extrusion = np.arange(tp[:, 0].min() - 2 * all_res_min, tp[:, 0].max() + 2 * all_res_min, all_res_min)
+    outer_scale = np.maximum(1e3, 300 + layers["h"][members].mean() / 10)
+    return dict(vx=vx, vy=vy, transform=transform, cross_sections=cross, extrusion=extrusion, r0=float(outer_scale),
+                nu=1 / 3 if model == "3d" else 5 / 6, cross_extent=float(np.ptp(tp[:, 1])))

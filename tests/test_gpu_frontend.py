@@ -246,3 +246,50 @@ def test_simulation_with_cubic_interpolation(gpu_ctx):
     assert rel_err(data, ref * gain[:, None]) <= 2e-5
     with pytest.raises(ValueError, match="interpolation_method"):
         Atmosphere(interpolation_method="quintic")
+
+
+def test_simulation_3d_model(gpu_ctx):
+    """Simulation(atmosphere="3d") (atmosphere/atmosphere.py:28,141-279, extrusion.py:69-77): one
+    process of many thin layers sampled like any other layer stack (oracle chain on the downloaded
+    screens), whose screens are vertically correlated slices of one volume."""
+    from maria_amd.instrument import Band, Detectors, Instrument, Site
+    from maria_amd.sim import Plan, Simulation
+    from oracle import functions, hotpath
+
+    bands = [Band(center=150e9, width=30e9, name="f150")]
+    inst = Instrument(Detectors.hexagon(37, 0.3, bands, primary_size=25.0))
+    plan = Plan.daisy(start_time=1.7e9, duration=30.0, sample_rate=20.0, scan_center=(130.0, 52.0), radius=0.3, speed=0.3)
+    sim = Simulation(inst, plan, Site(altitude=1800.0), atmosphere="3d", noise=False,
+                     atmosphere_kwargs={"weather": {"pwv": 1.2}, "max_height": 400.0, "seed": 21})
+    (tod,) = sim.run(units="pW")
+    obs = sim.obs_list[0]
+    atm = obs.atmosphere
+    L = len(atm.layers["h"])
+    assert L > 10 and len(atm.processes) == 1 and atm.processes[0]["nu"] == pytest.approx(1 / 3)
+    data = tod.data["atmosphere"]
+    assert data.shape == (inst.dets.n, len(plan.time)) and np.isfinite(data).all()
+    path = atm._device_path()
+    screens = [b[0].cpu().numpy() for b in path._layer_bufs]
+    assert len(screens) == L
+    prob = dict(
+        t=obs.coords.t, ta=atm.boresight.t, az_a=atm.boresight.az, el_a=atm.boresight.el,
+        offsets=inst.dets.offsets, band_index=inst.dets.band_index, m00=inst.dets.mueller00(),
+        layers=[dict(l, values=s) for l, s in zip(atm._layer_list(), screens)],
+        tables=atm._tables(inst.dets), T0=float(atm.weather.temperature[0]), pwv0=float(atm.weather.pwv),
+        timestep=float(atm.timestep), gain=None,
+    )
+    ref = hotpath.run_path(prob)
+    assert rel_err(data, ref) <= 1e-5
+    # neighbouring layers are strongly correlated, distant ones less: the Matern(1/3) of their separation
+    atm._realisation -= 1
+    atm.simulate_pwv(instrument=None)  # the same volume, unsmoothed
+    raw = [b[0].cpu().numpy().astype(np.float64) for b in path._layer_bufs]
+    h = atm.layers["h"]
+    sf = lambda a, b: np.mean((a - b) ** 2)  # noqa: E731
+    near, far = sf(raw[0], raw[1]), sf(raw[0], raw[L - 1])
+    want_near = 2 * (1 - functions.approximate_normalized_matern(np.array([h[1] - h[0]]), nu=1 / 3, r0=atm.processes[0]["r0"])[0])
+    want_far = 2 * (1 - functions.approximate_normalized_matern(np.array([h[L - 1] - h[0]]), nu=1 / 3, r0=atm.processes[0]["r0"])[0])
+    assert near < 0.5 * far
+    assert 0.3 * want_near < near < 1.5 * want_near and 0.5 * want_far < far < 1.6 * want_far, (near, want_near, far, want_far)
+    with pytest.raises(ValueError, match="Invalid model"):
+        Simulation(inst, plan, Site(altitude=1800.0), atmosphere="5d", noise=False)

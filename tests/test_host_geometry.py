@@ -242,3 +242,55 @@ def test_am_spectrum_loader_interpolates_to_the_site_altitude(tmp_path):
     np.savez(tmp_path / "broken.npz", side_altitude_m=np.zeros(2))
     with pytest.raises(KeyError):
         AtmosphericSpectrum(tmp_path / "broken.npz", altitude=0.0)
+
+
+# ---- model="3d" (extrusion.py:69-77, atmosphere.py:141-279) ----------------------------------
+
+
+def _sim3d(max_height=400.0):
+    bands = [Band(center=150e9, width=30e9, name="f150")]
+    inst = Instrument(Detectors.hexagon(37, 0.3, bands, primary_size=25.0))
+    plan = Plan.daisy(start_time=1.7e9, duration=30.0, sample_rate=20.0, scan_center=(130.0, 52.0), radius=0.3, speed=0.3)
+    site = Site(altitude=1800.0)
+    kw = dict(weather={"pwv": 1.2}, max_height=max_height)
+    return Simulation(inst, plan, site, atmosphere="3d", atmosphere_kwargs=kw, noise=False), inst, plan, site
+
+
+def test_3d_layer_table_and_process_equal_the_oracle():
+    sim, inst, plan, site = _sim3d()
+    obs = sim.obs_list[0]
+    atm = obs.atmosphere
+    ref = geometry.generate_layers(
+        inst.dets.field_of_view, [(25.0, b.center) for b in inst.dets.bands], float(obs.boresight.el.min()),
+        _weather_dict(atm.weather), site.altitude, pwv=atm.weather.pwv, mode="3d", max_height=400.0,
+    )
+    assert len(ref["h"]) > 10 and (ref["process_index"] == 0).all()
+    for key in ("h", "dh", "res", "z", "pwv_rms", "wind_east", "wind_north", "temperature"):
+        np.testing.assert_allclose(atm.layers[key], ref[key], rtol=1e-12, err_msg=key)
+    assert np.array_equal(atm.layers["process_index"], ref["process_index"])
+    assert (ref["res"] >= 15.0).all()  # MIN_RES["3d"]
+    # one process holding every layer, nu = 1/3, the water-weighted wind, the outer scale of the mean height
+    assert list(atm.processes) == [0]
+    proc = atm.processes[0]
+    ta, az_a, el_a = hotpath.downsample(plan.time, plan.phi, plan.theta, atm.timestep)
+    outer_pp = hotpath.project_unit(*hotpath.broadcast(inst.dets.outer().offsets, az_a, el_a))
+    np.random.seed(3)
+    want = geometry.process_geometry_multi(ref, np.arange(len(ref["h"])), ref["res"].min(), outer_pp, atm.timestep, len(ta))
+    assert proc["nu"] == pytest.approx(1 / 3) and proc["r0"] == want["r0"]
+    np.testing.assert_allclose(proc["vx"], want["vx"], rtol=1e-12)
+    np.testing.assert_allclose(proc["vy"], want["vy"], rtol=1e-12)
+    assert len(proc["layers"]) == len(ref["h"])
+    ex, er = proc["extrusion"], want["extrusion"]
+    assert ex[1] - ex[0] == pytest.approx(ref["res"].min(), rel=1e-12) and abs(len(ex) - len(er)) <= 2
+    cs = proc["cross_section"]
+    width = cs[-1] - cs[0] - 2 * proc["layers"][0]["res"]
+    assert width <= want["cross_extent"] * (1 + 1e-4) + 1e-3 and width >= 0.98 * want["cross_extent"] - 0.05
+    # the product keeps ONE cross grid at the finest layer's resolution (the reference: one per layer)
+    assert cs[1] - cs[0] <= min(np.diff(c)[0] for c in want["cross_sections"].values()) * (1 + 1e-9)
+    # the layers are planes of one volume: positions in units of the thinnest slab, variance scales >= 1
+    vol = proc["volume"]
+    pos = np.array([l["volume"]["pos"] for l in proc["layers"]])
+    np.testing.assert_allclose(pos, (ref["h"] - ref["h"][0]) / np.diff(ref["h"]).min(), rtol=1e-12)
+    assert vol["nh"] >= pos.max() + 1 and (vol["nh"] & (vol["nh"] - 1)) == 0
+    assert all(1.0 <= l["volume"]["scale"] < 1.2 for l in proc["layers"])
+    assert [l["layer_index"] for l in atm._layer_list()] == list(range(len(ref["h"])))
