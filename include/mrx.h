@@ -89,6 +89,8 @@ enum {
   MRX_OPT_NOISE_GENERIC = 5, /* 1: the LDS second pass even where the register one applies (tests) */
   MRX_OPT_SAMPLE_WGS_PER_CU = 6, /* mrx_atm_sample runs as a resident grid of this many workgroups
                                     per CU that walk the work items (tuning; 0 = default, 8) */
+  MRX_OPT_SAMPLE_TILES = 7, /* 1: mrx_atm_sample stages each work item's screen windows in LDS
+                               (measured slower than the global gathers; off by default) */
   MRX_OPT_COUNT = 8
 };
 int mrx_set_option(mrx_ctx* ctx, int option, int value);

@@ -178,6 +178,72 @@ __device__ __forceinline__ float bilinear(gfloat* values, int nc,
   return (ce.oob || cc.oob) ? __builtin_nanf("") : y;
 }
 
+// Band emission of one (detector, step) (band/band.py:264-300) and the Mueller weight
+// (sim/atmosphere.py:64-65): the float32 trilinear lookup in the reference's summation order,
+// or the float64 bicubic of interpolation_method="cubic".  `tdata` holds the band tables (LDS or
+// global).  in_t: the step exists (flags are only raised for real steps).
+__device__ __forceinline__ float band_loading(const mrx_table_dev& tb, const float* __restrict__ tdata, double pwv,
+                                              float theta, float m00, bool in_t, uint32_t& iflags) {
+  const float* __restrict__ ax_p = tdata + tb.off_pwv;
+  const float* __restrict__ ax_e = tdata + tb.off_el;
+  const float* __restrict__ tv = tdata + tb.off_values;
+  const int slab = tb.n_pwv * tb.n_el;
+  const float p_last = ax_p[tb.n_pwv - 1], e_last = ax_e[tb.n_el - 1];
+  const float xp = (float)pwv;
+  const float xel = fminf(theta, kHalfPiF);  // .clip(max=pi/2), sim/atmosphere.py:60
+  const Cell cp_ = find_cell([=](int i) { return ax_p[i]; }, tb.n_pwv, xp,
+                             tb.p_first, tb.p_inv, p_last);
+  const Cell cl = find_cell([=](int i) { return ax_e[i]; }, tb.n_el, xel,
+                            tb.e_first, tb.e_inv, e_last);
+  const float* q = tv + cp_.i * tb.n_el + cl.i;
+  float val = 0.0f;
+#pragma unroll
+  for (int ia = 0; ia < 2; ++ia) {
+    const float w1 = 1.0f * (ia ? tb.w_t : 1.0f - tb.w_t);
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+      const float w2 = w1 * (ib ? cp_.w : 1.0f - cp_.w);
+#pragma unroll
+      for (int ic = 0; ic < 2; ++ic) {
+        const float w3 = w2 * (ic ? cl.w : 1.0f - cl.w);
+        val = val + q[ia * slab + ib * tb.n_el + ic] * w3;
+      }
+    }
+  }
+  if (!tb.cubic && (cp_.oob || cl.oob || tb.t_oob)) {
+    val = __builtin_nanf("");
+    if (in_t) iflags |= MRX_FLAG_TABLE_OOB;
+  }
+  float out = m00 * val;
+  if (tb.cubic) {
+    // interpolation_method="cubic" (band/band.py:288-300): scipy's tensor-product cubic
+    // spline on (pwv, el) in float64, expanded by the host into a bicubic per cell; the
+    // float64 product with the Mueller weight is rounded once (sim/atmosphere.py:64-65)
+    const double* __restrict__ X = tb.cubic;
+    const double* __restrict__ Y = X + tb.n_pwv;
+    const double* __restrict__ Cc = Y + tb.n_el;
+    const double xd = pwv, yd = (double)xel;
+    int i = min(max(cp_.i, 0), tb.n_pwv - 2), j = min(max(cl.i, 0), tb.n_el - 2);
+    while (i < tb.n_pwv - 2 && X[i + 1] <= xd) ++i;  // the float32 cell is a guess for the float64 axis
+    while (i > 0 && X[i] > xd) --i;
+    while (j < tb.n_el - 2 && Y[j + 1] <= yd) ++j;
+    while (j > 0 && Y[j] > yd) --j;
+    const double u = xd - X[i], v = yd - Y[j];
+    const double* __restrict__ c = Cc + ((size_t)i * (tb.n_el - 1) + j) * 16;
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 3; k >= 0; --k) {
+      const double row = fma(fma(fma(c[4 * k + 3], u, c[4 * k + 2]), u, c[4 * k + 1]), u, c[4 * k]);
+      acc = fma(acc, v, row);
+    }
+    const bool inside = xd >= X[0] && xd <= X[tb.n_pwv - 1] && yd >= Y[0] && yd <= Y[tb.n_el - 1];
+    out = inside ? (float)((double)m00 * acc) : __builtin_nanf("");
+    if (!inside && in_t) iflags |= MRX_FLAG_TABLE_OOB;
+  }
+  if (out != out && in_t) iflags |= MRX_FLAG_NAN;
+  return out;
+}
+
 // kChain = true follows the reference's float32 chain literally (atan2 -> phi,
 // asin -> theta, then tan/cos/sin of those: coords/transforms.py:20-28 and
 // coordinates.py:339-347).  kChain = false (default) uses the identity behind
@@ -242,11 +308,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
   const float m00 = mueller00[dd];
   if (live && (b < 0 || b >= n_tables)) iflags |= MRX_FLAG_NAN;
   const mrx_table_dev tb = tables[min(max(b, 0), n_tables - 1)];
-  const float* __restrict__ ax_p = tdata + tb.off_pwv;
-  const float* __restrict__ ax_e = tdata + tb.off_el;
-  const float* __restrict__ tv = tdata + tb.off_values;
-  const int slab = tb.n_pwv * tb.n_el;
-  const float p_last = ax_p[tb.n_pwv - 1], e_last = ax_e[tb.n_el - 1];
 
   for (int it = 0; it < chunk && t_first + it < Ta; it += kT) {
   const int t0 = t_first + it;
@@ -359,62 +420,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
     }
   }
 
-  // ---- band emission (band/band.py:264-286), float32 ----------------------
+  // ---- band emission (band/band.py:264-300) and Mueller weight -----------
 #pragma unroll
   for (int tt = 0; tt < kT; ++tt) {
     const int t = t0 + tt;
-    const float xp = (float)pwv[tt];
-    const float xel = fminf(theta[tt], kHalfPiF);  // .clip(max=pi/2), sim/atmosphere.py:60
-    const Cell cp_ = find_cell([=](int i) { return ax_p[i]; }, tb.n_pwv, xp,
-                               tb.p_first, tb.p_inv, p_last);
-    const Cell cl = find_cell([=](int i) { return ax_e[i]; }, tb.n_el, xel,
-                              tb.e_first, tb.e_inv, e_last);
-    const float* q = tv + cp_.i * tb.n_el + cl.i;
-    float val = 0.0f;
-#pragma unroll
-    for (int ia = 0; ia < 2; ++ia) {
-      const float w1 = 1.0f * (ia ? tb.w_t : 1.0f - tb.w_t);
-#pragma unroll
-      for (int ib = 0; ib < 2; ++ib) {
-        const float w2 = w1 * (ib ? cp_.w : 1.0f - cp_.w);
-#pragma unroll
-        for (int ic = 0; ic < 2; ++ic) {
-          const float w3 = w2 * (ic ? cl.w : 1.0f - cl.w);
-          val = val + q[ia * slab + ib * tb.n_el + ic] * w3;
-        }
-      }
-    }
-    if (!tb.cubic && (cp_.oob || cl.oob || tb.t_oob)) {
-      val = __builtin_nanf("");
-      if (t < Ta) iflags |= MRX_FLAG_TABLE_OOB;
-    }
-    float out = m00 * val;
-    if (tb.cubic) {
-      // interpolation_method="cubic" (band/band.py:288-300): scipy's tensor-product cubic
-      // spline on (pwv, el) in float64, expanded by the host into a bicubic per cell; the
-      // float64 product with the Mueller weight is rounded once (sim/atmosphere.py:64-65)
-      const double* __restrict__ X = tb.cubic;
-      const double* __restrict__ Y = X + tb.n_pwv;
-      const double* __restrict__ Cc = Y + tb.n_el;
-      const double xd = pwv[tt], yd = (double)xel;
-      int i = min(max(cp_.i, 0), tb.n_pwv - 2), j = min(max(cl.i, 0), tb.n_el - 2);
-      while (i < tb.n_pwv - 2 && X[i + 1] <= xd) ++i;  // the float32 cell is a guess for the float64 axis
-      while (i > 0 && X[i] > xd) --i;
-      while (j < tb.n_el - 2 && Y[j + 1] <= yd) ++j;
-      while (j > 0 && Y[j] > yd) --j;
-      const double u = xd - X[i], v = yd - Y[j];
-      const double* __restrict__ c = Cc + ((size_t)i * (tb.n_el - 1) + j) * 16;
-      double acc = 0.0;
-#pragma unroll
-      for (int k = 3; k >= 0; --k) {
-        const double row = fma(fma(fma(c[4 * k + 3], u, c[4 * k + 2]), u, c[4 * k + 1]), u, c[4 * k]);
-        acc = fma(acc, v, row);
-      }
-      const bool inside = xd >= X[0] && xd <= X[tb.n_pwv - 1] && yd >= Y[0] && yd <= Y[tb.n_el - 1];
-      out = inside ? (float)((double)m00 * acc) : __builtin_nanf("");
-      if (!inside && t < Ta) iflags |= MRX_FLAG_TABLE_OOB;
-    }
-    if (out != out && t < Ta) iflags |= MRX_FLAG_NAN;
+    const float out = band_loading(tb, tdata, pwv[tt], theta[tt], m00, t < Ta, iflags);
     if (live && t < Ta) {
       const size_t o = (size_t)t * D + d;
       loading[o] = out;
@@ -424,6 +434,212 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
   }  // chunk loop
   if (live) myflags |= iflags;
   }  // item loop
+  if (myflags) atomicOr(flags, myflags);
+}
+
+
+// ---- the same sampling with the screens tiled in LDS ---------------------------------------
+// For plans whose layers are all uniform (pixel coordinates).  A work item is 256 detectors that
+// form a compact patch of the focal plane (the caller's Z-order) x `chunk` consecutive steps, so
+// on every layer its lines of sight stay inside a small window of the screen: the patch's
+// footprint plus what scan and wind move it in `chunk` steps (atlast_10k, 16 steps: 6 KB summed
+// over 8 layers in the median, 21 KB at the 99th percentile).  The item
+//   1. bounds (px, py) over its detectors and steps (one pass over the pointing, a workgroup
+//      min/max), maps that box through each layer's affine map: a window per layer;
+//   2. stages the windows that fit the LDS budget with coalesced row reads;
+//   3. samples: the 2x2 corners come from LDS.  A lane whose cell is not inside the window
+//      (a layer that did not fit, or rounding at the window's edge) reads global memory.
+// The divergent 8-byte global gathers are 0.2-0.37 ms of the kernel (a gather occupies the CU's
+// address unit ~17 cycles; a build without them runs in 0.65 ms).  MEASURED, this kernel does not
+// collect that: 1.05-1.15 ms against 0.86 ms for the global-gather kernel on atlast_10k, and
+// 3.17 against 2.79 ms when pipelined beside the writer -- the bound pass, four extra barriers per
+// item, the per-layer window record and the in-window test cost more than the gathers did.  It is
+// kept behind MRX_OPT_SAMPLE_TILES (off) with its parity test; DESIGN 3.2.
+constexpr int kWinBudgetFloats = 5120;  // 20 KiB of screen windows per workgroup
+constexpr int kMaxTiledLayers = 16;
+
+struct TileWin {
+  int e_lo, c_lo;   // first row / column of the window on the screen
+  int we, wc;       // rows, columns (0 rows: the layer is not in LDS)
+  int off;          // float offset of the window in the LDS pool
+};
+
+template <bool kLdsTables>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) void atm_sample_tiled_kernel(
+    const mrx_layer_fast* __restrict__ fast, int n_layers, const double2* __restrict__ offpx,
+    const mrx_table_dev* __restrict__ tables, int n_tables, const float* __restrict__ table_data,
+    int table_floats, const float* __restrict__ az, const float* __restrict__ el, int Ta,
+    const float* __restrict__ dxs, const float* __restrict__ dys, const int32_t* __restrict__ band,
+    const float* __restrict__ mueller00, int D, double pwv0, double* __restrict__ pwv_out,
+    float* __restrict__ loading, uint32_t* __restrict__ flags, int chunk, int nbx, int n_items) {
+  extern __shared__ float lds_dyn[];  // [screen windows: kWinBudgetFloats][band tables]
+  __shared__ float4 bore[kMaxChunk];
+  __shared__ float red[4][4];        // per wave: px min, px max, py min, py max
+  __shared__ TileWin win[kMaxTiledLayers];
+  float* pool = lds_dyn;
+  float* lds_tables = lds_dyn + kWinBudgetFloats;
+  if (kLdsTables)
+    for (int i = threadIdx.x; i < table_floats; i += kBlock) lds_tables[i] = table_data[i];
+  const float* __restrict__ tdata = kLdsTables ? lds_tables : table_data;
+  uint32_t myflags = 0u;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const int t_first = (item / nbx) * chunk;
+    const int steps = min(chunk, Ta - t_first);
+    uint32_t iflags = 0u;
+    __syncthreads();  // the previous item is done with bore[], win[] and the pool
+    if ((int)threadIdx.x < chunk) {
+      const int t = min(t_first + (int)threadIdx.x, Ta - 1);
+      const float a = el[t] - kHalfPiF;  // transforms.py:22
+      const float z = az[t];
+      bore[threadIdx.x] = make_float4(cosf(a), sinf(a), cosf(z), sinf(z));
+    }
+    __syncthreads();
+
+    const int d = (item % nbx) * kBlock + threadIdx.x;
+    const bool live = d < D;
+    const int dd = live ? d : D - 1;
+    // per-detector constants (coords/transforms.py:14-23), float32
+    const float dx = dxs[dd], dy = dys[dd];
+    const float r = sqrtf(dx * dx + dy * dy);
+    const float p = atan2f(-dx, -dy);
+    const float sr = sinf(r), cr = cosf(r);
+    const float A = sr * cosf(p), Y = sr * sinf(p);
+    const int b = band[dd];
+    const float m00 = mueller00[dd];
+    if (live && (b < 0 || b >= n_tables)) iflags |= MRX_FLAG_NAN;
+    const mrx_table_dev tb = tables[min(max(b, 0), n_tables - 1)];
+
+    // ---- 1. bounds of the unit-height projection over the item ------------------------------
+    float pxl = 3.0e38f, pxh = -3.0e38f, pyl = 3.0e38f, pyh = -3.0e38f;
+    for (int it = 0; it < steps; ++it) {
+      const float4 bt = bore[it];
+      const float re = A * bt.x - cr * bt.y, im = A * bt.y + cr * bt.x;
+      const float inv_im = 1.0f / im;
+      const float fx = (re * bt.z - Y * bt.w) * inv_im, fy = (Y * bt.z + re * bt.w) * inv_im;
+      pxl = fminf(pxl, fx); pxh = fmaxf(pxh, fx);
+      pyl = fminf(pyl, fy); pyh = fmaxf(pyh, fy);
+    }
+#pragma unroll
+    for (int m = 32; m > 0; m >>= 1) {
+      pxl = fminf(pxl, __shfl_xor(pxl, m, 64)); pxh = fmaxf(pxh, __shfl_xor(pxh, m, 64));
+      pyl = fminf(pyl, __shfl_xor(pyl, m, 64)); pyh = fmaxf(pyh, __shfl_xor(pyh, m, 64));
+    }
+    if (lane == 0) {
+      red[wave][0] = pxl; red[wave][1] = pxh; red[wave][2] = pyl; red[wave][3] = pyh;
+    }
+    __syncthreads();
+    // ---- windows: one thread per layer; the pool is filled smallest window first ------------
+    if ((int)threadIdx.x < n_layers) {
+      const int l = threadIdx.x;
+      const double x0 = fminf(fminf(red[0][0], red[1][0]), fminf(red[2][0], red[3][0]));
+      const double x1 = fmaxf(fmaxf(red[0][1], red[1][1]), fmaxf(red[2][1], red[3][1]));
+      const double y0 = fminf(fminf(red[0][2], red[1][2]), fminf(red[2][2], red[3][2]));
+      const double y1 = fmaxf(fmaxf(red[0][3], red[1][3]), fmaxf(red[2][3], red[3][3]));
+      const mrx_layer_fast lf = fast[l];
+      // offsets over the item's steps (monotone in t for a steady wind; take both ends and the middle)
+      double oe0 = 1e300, oe1 = -1e300, oc0 = 1e300, oc1 = -1e300;
+      for (int it = 0; it < steps; ++it) {
+        const double2 o = offpx[(size_t)(t_first + it) * n_layers + l];
+        oe0 = fmin(oe0, o.x); oe1 = fmax(oe1, o.x); oc0 = fmin(oc0, o.y); oc1 = fmax(oc1, o.y);
+      }
+      // an affine map takes its extremes over a box at the box's corners
+      const double ea = lf.pe_x * (lf.pe_x >= 0 ? x0 : x1) + lf.pe_y * (lf.pe_y >= 0 ? y0 : y1) + oe0;
+      const double eb = lf.pe_x * (lf.pe_x >= 0 ? x1 : x0) + lf.pe_y * (lf.pe_y >= 0 ? y1 : y0) + oe1;
+      const double ca = lf.pc_x * (lf.pc_x >= 0 ? x0 : x1) + lf.pc_y * (lf.pc_y >= 0 ? y0 : y1) + oc0;
+      const double cb = lf.pc_x * (lf.pc_x >= 0 ? x1 : x0) + lf.pc_y * (lf.pc_y >= 0 ? y1 : y0) + oc1;
+      TileWin w;
+      // one pixel of margin each side against the float32 rounding of the bounds; cells i, i + 1
+      w.e_lo = min(max((int)fmax(fmin(ea, 2.0e9), -1.0) - 1, 0), lf.n_e - 2);
+      w.c_lo = min(max((int)fmax(fmin(ca, 2.0e9), -1.0) - 1, 0), lf.n_c - 2);
+      const int e_hi = min(max((int)fmax(fmin(eb, 2.0e9), -1.0) + 2, 1), lf.n_e - 1);
+      const int c_hi = min(max((int)fmax(fmin(cb, 2.0e9), -1.0) + 2, 1), lf.n_c - 1);
+      w.we = e_hi - w.e_lo + 1;
+      w.wc = c_hi - w.c_lo + 1;
+      w.off = 0;
+      if (!(ea == ea && eb == eb && ca == ca && cb == cb) || w.we < 2 || w.wc < 2 ||
+          (long long)w.we * w.wc > kWinBudgetFloats)
+        w.we = 0;
+      win[l] = w;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {  // pack: layers in order while they fit (lower layers are smaller and come first)
+      int used = 0;
+      for (int l = 0; l < n_layers; ++l) {
+        const int need = win[l].we * win[l].wc;
+        if (need > 0 && used + need <= kWinBudgetFloats) {
+          win[l].off = used;
+          used += need;
+        } else {
+          win[l].we = 0;
+        }
+      }
+    }
+    __syncthreads();
+    // ---- 2. stage the windows: a wave per row, lanes along the row ---------------------------
+    for (int l = 0; l < n_layers; ++l) {
+      const TileWin w = win[l];
+      if (w.we == 0) continue;  // uniform
+      const mrx_layer_fast lf = fast[l];
+      gfloat* src = (gfloat*)lf.values + (size_t)w.e_lo * lf.n_c + w.c_lo;
+      for (int rr = wave; rr < w.we; rr += kBlock / 64)
+        for (int cc = lane; cc < w.wc; cc += 64) pool[w.off + rr * w.wc + cc] = src[(size_t)rr * lf.n_c + cc];
+    }
+    __syncthreads();
+
+    // ---- 3. the steps ---------------------------------------------------------------------------
+    for (int it = 0; it < steps; ++it) {
+      const int t = t_first + it;
+      const float4 bt = bore[it];
+      const float re = A * bt.x - cr * bt.y, im = A * bt.y + cr * bt.x;
+      const float theta = asinf(im);
+      const float inv_im = 1.0f / im;
+      const double px = (double)((re * bt.z - Y * bt.w) * inv_im);
+      const double py = (double)((Y * bt.z + re * bt.w) * inv_im);
+      double pwv = pwv0;
+      for (int l = 0; l < n_layers; ++l) {
+        const mrx_layer_fast lf = fast[l];
+        const TileWin w = win[l];
+        const double2 o = offpx[(size_t)t * n_layers + l];
+        const double fe = fma(px, lf.pe_x, fma(py, lf.pe_y, o.x));
+        const double fc = fma(px, lf.pc_x, fma(py, lf.pc_y, o.y));
+        Cell ce, cc;
+        ce.i = min(max(__double2int_rz(fe), 0), lf.n_e - 2);
+        cc.i = min(max(__double2int_rz(fc), 0), lf.n_c - 2);
+        ce.w = (float)(fe - (double)ce.i);
+        cc.w = (float)(fc - (double)cc.i);
+        ce.oob = !(ce.w >= 0.0f && ce.w <= 1.0f);
+        cc.oob = !(cc.w >= 0.0f && cc.w <= 1.0f);
+        const int re_ = ce.i - w.e_lo, rc_ = cc.i - w.c_lo;
+        // (a layer that is not in LDS has we = 0: no cell is inside)
+        const bool inw = (unsigned)re_ < (unsigned)max(w.we - 1, 0) && (unsigned)rc_ < (unsigned)max(w.wc - 1, 0);
+        float yv;
+        if (__builtin_amdgcn_ballot_w64(!inw) == 0) {  // the whole wave inside the window
+          const float* q = pool + w.off + re_ * w.wc + rc_;
+          const float v00 = q[0], v01 = q[1], v10 = q[w.wc], v11 = q[w.wc + 1];
+          const float we0 = 1.0f - ce.w, we1 = ce.w, wc0 = 1.0f - cc.w, wc1 = cc.w;
+          float y = 0.0f;
+          y = y + v00 * (we0 * wc0);
+          y = y + v01 * (we0 * wc1);
+          y = y + v10 * (we1 * wc0);
+          y = y + v11 * (we1 * wc1);
+          yv = (ce.oob || cc.oob) ? __builtin_nanf("") : y;
+        } else {
+          yv = bilinear((gfloat*)lf.values, lf.n_c, ce, cc);
+        }
+        pwv += (double)(lf.pwv_rms * yv);
+      }
+      if (pwv != pwv) iflags |= MRX_FLAG_SCREEN_OOB;  // only a line of sight off a screen makes it NaN
+      const float out = band_loading(tb, tdata, pwv, theta, m00, true, iflags);
+      if (live) {
+        const size_t oo = (size_t)t * D + d;
+        loading[oo] = out;
+        if (pwv_out) pwv_out[oo] = pwv;
+      }
+    }
+    if (live) myflags |= iflags;
+  }
   if (myflags) atomicOr(flags, myflags);
 }
 
@@ -701,9 +917,26 @@ int mrx_atm_sample(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d_az,
   const bool lds = plan->table_floats <= kMaxLdsTableFloats;
   const size_t lds_bytes = lds ? sizeof(float) * (size_t)plan->table_floats : 0;
   const bool chain = ctx->options[MRX_OPT_POINTING_CHAIN] != 0;
-  // (an instance compiled without the general path, for plans whose layers are all uniform,
-  // measured SLOWER -- 1.27 vs 1.00 ms -- whatever the occupancy bound: kept out)
+  // (an instance of the general kernel compiled without the literal path, for plans whose layers
+  // are all uniform, measured SLOWER -- 1.27 vs 1.00 ms -- whatever the occupancy bound: kept out)
   const bool literal = ctx->options[MRX_OPT_AXIS_LITERAL] != 0 || chain;
+  if (plan->all_pixel && !literal && plan->n_layers <= kMaxTiledLayers && ctx->options[MRX_OPT_SAMPLE_TILES]) {
+    const size_t lds_t = sizeof(float) * ((size_t)kWinBudgetFloats + (lds ? (size_t)plan->table_floats : 0));
+    if (lds) {
+      MRX_LDS_CAP(ctx, atm_sample_tiled_kernel<true>, lds_t);
+      hipLaunchKernelGGL(atm_sample_tiled_kernel<true>, grid, dim3(kBlock), lds_t, ctx->stream, plan->d_fast,
+                         plan->n_layers, plan->d_offpx, plan->d_tables, plan->n_tables, plan->d_table_data,
+                         plan->table_floats, d_az, d_el, Ta, d_dx, d_dy, d_band, d_mueller00, D, pwv0, d_pwv,
+                         d_loading, d_flags, chunk, nbx, (int)items);
+    } else {
+      hipLaunchKernelGGL(atm_sample_tiled_kernel<false>, grid, dim3(kBlock), lds_t, ctx->stream, plan->d_fast,
+                         plan->n_layers, plan->d_offpx, plan->d_tables, plan->n_tables, plan->d_table_data,
+                         plan->table_floats, d_az, d_el, Ta, d_dx, d_dy, d_band, d_mueller00, D, pwv0, d_pwv,
+                         d_loading, d_flags, chunk, nbx, (int)items);
+    }
+    MRX_CHECK_LAUNCH(ctx);
+    return MRX_OK;
+  }
 #define MRX_LAUNCH_SAMPLE(L, C, T)                                             \
   hipLaunchKernelGGL((atm_sample_kernel<L, C, T>), grid, dim3(kBlock),         \
                      lds_bytes, ctx->stream, plan->d_layers, plan->d_fast, plan->n_layers, \
