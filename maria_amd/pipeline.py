@@ -398,29 +398,44 @@ class DevicePath:
         self._pipe = st
         return st
 
-    def _run_pipelined(self, out, blocks, resident_wgs_per_cu=4, writer_events=None):
+    def _run_pipelined(self, out, blocks, resident_wgs_per_cu=4, writer_events=None, serial_events=None):
         """sample + prepare of block b on the side stream, the writer of block b on the caller's
         stream behind an event; block 0's sampler takes the whole chip (nothing to run beside).
         ``writer_events``: a list that receives one (start, end) pair of timing events per writer
-        launch, recorded on the stream the writer runs on (bench.py's live kernel timing)."""
+        launch, recorded on the stream the writer runs on (bench.py's live kernel timing).
+        ``serial_events``: run the same block launches back to back on the caller's stream instead
+        (no overlap) and append (t0, t1, t2, t3) timing events per block around sample / prepare /
+        upsample: the per-stage breakdown of exactly the launches the pipelined step makes."""
         if self.plan is None:
             raise RuntimeError("no screens bound: call set_screens() or generate_screens() first")
         st = self._pipeline_state(blocks)
         main, side, ctx2 = torch.cuda.current_stream(self.device), st["side"], st["ctx2"]
-        st["start"].record(main)  # screens (and the previous run's writers) come first
-        side.wait_event(st["start"])
+        serial = serial_events is not None
+        if serial:
+            side, ctx2 = main, self.ctx
+        else:
+            st["start"].record(main)  # screens (and the previous run's writers) come first
+            side.wait_event(st["start"])
         sl = lambda t, lo, hi: None if t is None else ptr(t[lo:hi])  # noqa: E731
         for i, (lo, hi) in enumerate(st["bounds"]):
             n = hi - lo
-            ctx2.set_option(_lib.OPT_SAMPLE_WGS_PER_CU, 0 if i == 0 else resident_wgs_per_cu)
+            ctx2.set_option(_lib.OPT_SAMPLE_WGS_PER_CU, 0 if (i == 0 or serial) else resident_wgs_per_cu)
+            if serial:
+                tev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                tev[0].record(main)
             ctx2.call(
                 "mrx_atm_sample", self.plan, ptr(self.d_az), ptr(self.d_el), self.Ta,
                 sl(self.d_dx, lo, hi), sl(self.d_dy, lo, hi), sl(self.d_band, lo, hi), sl(self.d_m00, lo, hi), n,
                 self.pwv0, None, ptr(st["loading"][i]), ptr(self.d_flags),
             )
+            if serial:
+                tev[1].record(main)
             ctx2.call("mrx_spline_prepare", ptr(st["loading"][i]), n, self.Ta, ptr(st["ym"][i]))
-            st["ready"][i].record(side)
-            main.wait_event(st["ready"][i])
+            if serial:
+                tev[2].record(main)
+            else:
+                st["ready"][i].record(side)
+                main.wait_event(st["ready"][i])
             if self.d_rows is not None:
                 dst, rows = out, sl(self.d_rows, lo, hi)
             else:
@@ -435,6 +450,9 @@ class DevicePath:
             if writer_events is not None:
                 ev[1].record(main)
                 writer_events.append(ev)
+            if serial:
+                tev[3].record(main)
+                serial_events.append(tev)
         self._pipelined = True
         return out
 
