@@ -308,7 +308,8 @@ def main():
         with open(traffic_file) as f:
             tr = json.load(f)
         if tr.get("config") == args.config and tr.get("kernel") == result["roofline"]["kernel"] and world == 1:
-            result["roofline"]["traffic"] = tr["hbm_bytes_per_launch"] * (up_bytes / alone_bytes) if tr.get("launch_rows", D) == D else tr["hbm_bytes_per_launch"]
+            # per launch of the profiled run; scaled by rows when this run cuts the shard differently
+            result["roofline"]["traffic"] = tr["hbm_bytes_per_launch"] * tr.get("launches_per_step", 1) / n_launch
             result["roofline"]["traffic_source"] = tr["source"]
         break
 
