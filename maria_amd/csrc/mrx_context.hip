@@ -15,10 +15,9 @@ int mrx_init(int device, mrx_ctx** out) {
   mrx_ctx* ctx = new (std::nothrow) mrx_ctx();
   if (!ctx) return MRX_ERR_ALLOC;
   ctx->device = device;
-  if (hipSetDevice(device) != hipSuccess) {
-    delete ctx;
-    return MRX_ERR_NO_DEVICE;
-  }
+  // the calling thread's current device is the caller's business (torch's, in a multi-GPU
+  // process): switch for the duration of the call only
+  mrx_device_guard guard(ctx);
   hipDeviceProp_t prop;
   if (hipGetDeviceProperties(&prop, device) != hipSuccess) {
     delete ctx;
@@ -40,7 +39,8 @@ int mrx_init(int device, mrx_ctx** out) {
 
 int mrx_destroy(mrx_ctx* ctx) {
   if (!ctx) return MRX_ERR_INVALID;
-  (void)hipSetDevice(ctx->device);
+  {
+  mrx_device_guard guard(ctx);
   for (auto& slot : ctx->taps)
     if (slot.d_taps) (void)hipFree(slot.d_taps);
   for (auto& slot : ctx->ftaps)
@@ -48,6 +48,7 @@ int mrx_destroy(mrx_ctx* ctx) {
   if (ctx->d_reduce) (void)hipFree(ctx->d_reduce);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+  }
   delete ctx;
   return MRX_OK;
 }

@@ -362,8 +362,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
         ce.oob = !(ce.w >= 0.0f && ce.w <= 1.0f);
         cc.oob = !(cc.w >= 0.0f && cc.w <= 1.0f);
         const float yv = bilinear(values, lf.n_c, ce, cc);
-        if (yv != yv) iflags |= MRX_FLAG_SCREEN_OOB;
-        pwv[tt] += (double)(lf.pwv_rms * yv);
+        pwv[tt] += (double)(lf.pwv_rms * yv);  // a NaN (line of sight off the screen) stays in the sum
       }
       continue;
     }
@@ -413,12 +412,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) 
       }
 #pragma unroll
     for (int tt = 0; tt < kT; ++tt) {
-      if (y[tt] != y[tt]) iflags |= MRX_FLAG_SCREEN_OOB;
       // layer.pwv_rms * y is a float32 product (jax array), accumulated into
       // the float64 numpy array (atmosphere.py:373).
       pwv[tt] += (double)(ly.pwv_rms * y[tt]);
     }
   }
+  // only a line of sight off a screen (jax's NaN fill) makes the sum NaN: one test per step
+  // instead of one per layer (pwv0 and the screens are finite)
+#pragma unroll
+  for (int tt = 0; tt < kT; ++tt)
+    if (pwv[tt] != pwv[tt] && t0 + tt < Ta) iflags |= MRX_FLAG_SCREEN_OOB;
 
   // ---- band emission (band/band.py:264-300) and Mueller weight -----------
 #pragma unroll
