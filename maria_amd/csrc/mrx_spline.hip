@@ -269,8 +269,11 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_kernel(
   constexpr int kPitch = kMaxKnots + 1;
   // destination row of detector d (wave-uniform): the caller may keep its
   // detectors in a locality order and still get the TOD in its own row order
-  auto row_of = [&](int d) -> size_t { return rows ? (size_t)rows[d] : (size_t)d; };
   __shared__ float2 tile[kTileDet * kPitch];
+  // the group's destination rows are staged with the knots: a scalar load of rows[d] inside the
+  // row loop would stall every iteration on its latency
+  __shared__ int row_lds[kTileDet];
+  auto row_of = [&](int dl, int d) -> size_t { return rows ? (size_t)row_lds[dl] : (size_t)d; };
   const int s_tile = blockIdx.x * kTileSamples;
   const int sb = s_tile + threadIdx.x * kSamplesPerThread;
 
@@ -296,6 +299,7 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_kernel(
     const int nd = min(kTileDet, D - d0);
     if (K <= kMaxKnots) {
       if (g > 0) __syncthreads();  // the previous group is done with the image
+      if (rows && (int)threadIdx.x < nd) row_lds[threadIdx.x] = rows[d0 + threadIdx.x];
       {  // 16 lanes cover the 16 detector rows of one knot: 128 contiguous bytes
         const int dl = threadIdx.x & (kTileDet - 1);
         const int d = d0 + dl;
@@ -321,17 +325,17 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_kernel(
           }
           const vfloat4 v = {o[0], o[1], o[2], o[3]};
 #ifdef MRX_PLAIN_STORE
-          *reinterpret_cast<vfloat4*>(out + row_of(d0 + dl) * ld + sb) = v;
+          *reinterpret_cast<vfloat4*>(out + row_of(dl, d0 + dl) * ld + sb) = v;
 #else
           __builtin_nontemporal_store(
-              v, reinterpret_cast<vfloat4*>(out + row_of(d0 + dl) * ld + sb));
+              v, reinterpret_cast<vfloat4*>(out + row_of(dl, d0 + dl) * ld + sb));
 #endif
         }
       } else {
         for (int dl = 0; dl < nd; ++dl) {
           const float2* row = tile + dl * kPitch;
           const float gsc = kHasScale ? scale[d0 + dl] : 1.0f;
-          float* dst = out + row_of(d0 + dl) * ld + sb;
+          float* dst = out + row_of(dl, d0 + dl) * ld + sb;
 #pragma unroll
           for (int q = 0; q < kSamplesPerThread; ++q)
             if (sb + q < T) dst[q] = gsc * spline_eval(w, q, row[r[q]], row[r[q] + 1]);
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_kernel(
       for (int dl = 0; dl < nd; ++dl) {
         const int d = d0 + dl;
         const float gsc = kHasScale ? scale[d] : 1.0f;
-        float* dst = out + row_of(d) * ld + sb;
+        float* dst = out + (rows ? (size_t)rows[d] : (size_t)d) * ld + sb;
 #pragma unroll
         for (int q = 0; q < kSamplesPerThread; ++q)
           if (sb + q < T)
@@ -611,7 +615,8 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
   __shared__ float2 tile[kTileDet * kPitch];
   __shared__ CalDet cdet[kTileDet];
   __shared__ float red[12];
-  auto row_of = [&](int d) -> size_t { return rows ? (size_t)rows[d] : (size_t)d; };
+  __shared__ int row_lds[kTileDet];  // destination rows of the group (see spline_upsample_kernel)
+  auto row_of = [&](int dl, int d) -> size_t { return rows ? (size_t)row_lds[dl] : (size_t)d; };
 
   const int s_tile = blockIdx.x * kTileSamples;
   const int sb = s_tile + threadIdx.x * kSamplesPerThread;
@@ -649,6 +654,7 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
       }
     }
     krj_stage_rows(cdet, red, dxs, dys, band, scale, n_bands, d0, nd);
+    if (rows && (int)threadIdx.x < nd) row_lds[threadIdx.x] = rows[d0 + threadIdx.x];
     __syncthreads();
     // the loop body is instantiated once per knot source so that each instance
     // addresses one memory space (a runtime select would force flat loads)
@@ -670,7 +676,7 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
         sv[q] = c.scale * spline_eval(w, q, k0, k1);
       }
       krj_row(c, C, n_el, el_first, el_last, el_inv, ks, sv, o);
-      float* dst = out + row_of(d0 + dl) * ld + sb;
+      float* dst = out + row_of(dl, d0 + dl) * ld + sb;
       if (full) {
         const vfloat4 v = {o[0], o[1], o[2], o[3]};
         __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(dst));
@@ -703,8 +709,10 @@ __global__ __launch_bounds__(kBlock) void tod_krj_kernel(
   const int d0 = blockIdx.y * kTileDet;
   const int sb = s_tile + threadIdx.x * kSamplesPerThread;
   const int nd = min(kTileDet, D - d0);
+  __shared__ int row_lds[kTileDet];
   KrjSamples ks = krj_prologue(cal_cells, red, bore_el, T, sb, cal_axis, cal_values, n_el, n_bands);
   krj_stage_rows(cdet, red, dxs, dys, band, scale, n_bands, d0, nd);
+  if ((int)threadIdx.x < nd) row_lds[threadIdx.x] = rows ? rows[d0 + threadIdx.x] : d0 + (int)threadIdx.x;
   __syncthreads();
   if (sb >= T) return;
   const float el_first = cal_cells[0].x, el_last = cal_axis[n_el - 1];
@@ -713,7 +721,7 @@ __global__ __launch_bounds__(kBlock) void tod_krj_kernel(
   for (int dl = 0; dl < nd; ++dl) {
     const CalDet c = cdet[dl];
     const float4* C = cal_cells + c.band * (n_el - 1);
-    float* row = data + (rows ? (size_t)rows[d0 + dl] : (size_t)(d0 + dl)) * ld + sb;
+    float* row = data + (size_t)row_lds[dl] * ld + sb;
     float v[kSamplesPerThread];
     if (full) {
       const vfloat4 x = __builtin_nontemporal_load(reinterpret_cast<const vfloat4*>(row));
