@@ -63,7 +63,7 @@ def parse_args():
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-allgather", action="store_true", help="skip the separately timed all-gather at N > 1")
     ap.add_argument("--gather-reps", type=int, default=3)
-    ap.add_argument("--blocks", type=int, default=None, help="detector blocks of the pipelined TOD synthesis (default: 4 from 4096 rows up; 1 = serial)")
+    ap.add_argument("--blocks", type=int, default=None, help="detector blocks of the pipelined TOD synthesis (default: DevicePath.default_blocks(); 1 = serial)")
     return ap.parse_args()
 
 
@@ -164,7 +164,7 @@ def main():
             exchange_layer_screens(path._gen_screens)
 
     writer_events = []
-    n_blocks = args.blocks if args.blocks is not None else (4 if D >= 4096 else 1)
+    n_blocks = args.blocks if args.blocks is not None else path.default_blocks()
 
     def step(ev=None):
         """One pass: screens, then the TOD synthesis -- detector blocks pipelined on two streams

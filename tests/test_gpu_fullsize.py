@@ -72,12 +72,12 @@ def test_runs_are_deterministic_and_shards_bit_identical(full):
 
 def test_pipelined_run_is_bit_identical_to_the_serial_one(full):
     """DevicePath.run() cuts the shard into detector blocks and runs the sampler of block b+1
-    beside the writer of block b on two streams (the default from 4096 rows up): same kernels,
+    beside the writer of block b on two streams (the default from 4096 rows up; the first block is half as long as the others so that the writer starts early): same kernels,
     same rows, same bits -- for several block counts, and twice in a row (buffer reuse)."""
     import torch
 
     p, path, tod = full
-    for blocks in (4, 3, 7, 4):
+    for blocks in (4, 3, 7, 8, 4):
         out = torch.full_like(tod, float("nan"))
         path.run(out, blocks=blocks)
         torch.cuda.synchronize()
