@@ -34,10 +34,16 @@
 // screens use, k = k1 + N1 k2, t = j + N2 m:
 //   pass 1  per (series, k1): build the cells, transform over k2 (length N2),
 //           multiply by exp(2 pi i k1 j / N)                   -> A[k1][j]  (HBM)
-//   pass 2  transform over k1 (length N1) and finish the sample: white draw,
-//           scale, store.  N1 = 64 (periods up to 2^19): one thread per j, the
-//           transform in registers.  Otherwise a workgroup takes J = 4096/N1
-//           adjacent j through LDS.
+//   pass 2  transform over k1 (length N1) and finish the sample: scale, store.
+//           N1 = 64 (periods up to 2^19): one thread per j, the transform in
+//           registers.  Otherwise a workgroup takes J = 4096/N1 adjacent j
+//           through LDS.
+// A detector's own white part, sqrt(fs) w[d,t], is drawn in the same spectrum: white
+// noise of period N has variance fs/N in every cell and any T of its N samples are
+// independent, and the sum of two independent Gaussian series is the Gaussian series of
+// the summed spectra -- one draw of amplitude sqrt(fs/N + (1-c) knee/|k|) per cell
+// instead of a spectral draw per cell plus a time-domain draw per sample (-20 % of the
+// arithmetic).  Only the cells below k_cut keep two draws (see window_mean_factor).
 // HBM traffic per detector: 8 N bytes of scratch (A written and read once, shared
 // by two detectors) + 4 T of TOD; the arithmetic (Philox, Box-Muller, ~5 log2 N
 // flops per cell) is what bounds the kernels.
@@ -57,6 +63,7 @@ using namespace mrx_dev;
 constexpr uint32_t kTagPink = 0x50494e4bu;   // counter word 3: 'PINK'
 constexpr uint32_t kTagWhite = 0x57484954u;  // 'WHIT'
 constexpr uint32_t kTagMode = 0x4d4f4445u;   // 'MODE'
+constexpr uint32_t kTagOwnWhite = 0x57485432u;  // 'WHT2': white part of a pair's cells below k_cut
 constexpr int kTileCells = 4096;             // complex values per workgroup of the LDS pass 2
 constexpr int kMaxModes = 8;
 
@@ -67,6 +74,13 @@ typedef float vfloat2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float pink_amp(int k, int n, float sqrt_knee, int k_min) {
   const int kk = k < n - k ? k : n - k;
   return kk < k_min ? 0.0f : sqrt_knee * __builtin_amdgcn_rsqf((float)kk);
+}
+
+// own part of a pair's cell k above k_cut: white of variance white_var and pink of variance
+// pink_var / |k| in one draw
+__device__ __forceinline__ float merged_amp(int k, int n, float white_var, float pink_var, int k_min) {
+  const int kk = k < n - k ? k : n - k;
+  return __builtin_sqrtf(white_var + (kk < k_min ? 0.0f : pink_var / (float)kk));
 }
 
 // four white normals for samples 4 q .. 4 q + 3 of row `id`
@@ -158,6 +172,7 @@ struct SpectrumArgs {
   int row0, rows;      // series s holds rows row0 + 2 s and row0 + 2 s + 1 (< row0 + rows)
   float w_ind, w_corr;
   float knee;
+  float white_var;     // fs / N: a detector's own white part, per cell
   uint32_t series0;    // Philox id of series 0
   WindowArgs win;
 };
@@ -216,7 +231,7 @@ constexpr int kPairsPerBlock = 4;
 // (~147 VALU per cell: Philox ~50, Box-Muller ~30, modes ~20, transform ~55, final twiddle ~15;
 // VALU pipe ~60 % busy at two waves per SIMD), not by latency, and wider barriers cost more.
 template <int kIter, int kModes, int kThreads>
-__global__ __launch_bounds__(kThreads) void noise_spectrum_fft(
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(kIter <= 8 && kModes >= 0 ? 2 : 1, 2))) void noise_spectrum_fft(
     float2* __restrict__ A, int n1, int n2, int log2n2, SpectrumArgs g, int pairs, uint32_t key0,
     uint32_t key1) {
   extern __shared__ float2 lds2[];
@@ -243,6 +258,32 @@ __global__ __launch_bounds__(kThreads) void noise_spectrum_fft(
     }
   }
   const int n_modes = kModes >= 0 ? kModes : g.n_modes;
+  // the same for every series of the block: the merged amplitudes of the thread's cells, which of
+  // them lie below k_cut, the first of the thread's final twiddles exp(2 pi i k1 j / N)
+  // (j = tid + i kThreads: the others by multiplication with the uniform step)
+  float am0[kIter], am1[kIter];
+  uint32_t low = 0;
+  const float pink_var = amp * amp;
+#pragma unroll
+  for (int it = 0; it < kIter; ++it) {
+    const int k2 = threadIdx.x + it * kThreads;
+    const int ka = k1 + n1 * k2, kb = k1 + n1 * (k2 + half);
+    am0[it] = merged_amp(ka, n, g.white_var, pink_var, g.win.k_min);
+    am1[it] = merged_amp(kb, n, g.white_var, pink_var, g.win.k_min);
+    if (k2 < half) {
+      if ((ka < n - ka ? ka : n - ka) < g.win.k_cut) low |= 1u << (2 * it);
+      if ((kb < n - kb ? kb : n - kb) < g.win.k_cut) low |= 2u << (2 * it);
+    }
+  }
+  const float sw = __builtin_sqrtf(g.white_var);
+  float2 tw_first, tw_step;
+  {
+    // k1 * j < N <= 2^23 is exact in float32, and so is the fraction of a revolution the
+    // hardware sine and cosine take (absolute error ~1e-6)
+    const float r0 = (float)(k1 * (int)threadIdx.x) * inv_n, r1 = (float)(k1 * kThreads) * inv_n;
+    tw_first = make_float2(__builtin_amdgcn_cosf(r0), __builtin_amdgcn_sinf(r0));
+    tw_step = make_float2(__builtin_amdgcn_cosf(r1), __builtin_amdgcn_sinf(r1));
+  }
   for (int p = 0; p < kPairsPerBlock; ++p) {
     const int pair = blockIdx.x * kPairsPerBlock + p;
     if (pair >= pairs) break;  // uniform
@@ -261,10 +302,22 @@ __global__ __launch_bounds__(kThreads) void noise_spectrum_fft(
       const int k2 = threadIdx.x + it * kThreads;
       if (k2 < half) {
         const U4 rnd = philox4x32_10(U4{(uint32_t)k1, (uint32_t)k2, series, kTagPink}, key0, key1);
-        const float a0 = pink_amp(k1 + n1 * k2, n, amp, g.win.k_min);
-        const float a1 = pink_amp(k1 + n1 * (k2 + half), n, amp, g.win.k_min);
         const float2 g0 = box_muller(rnd.x, rnd.y), g1 = box_muller(rnd.z, rnd.w);
-        float2 x0 = make_float2(a0 * g0.x, a0 * g0.y), x1 = make_float2(a1 * g1.x, a1 * g1.y);
+        float2 x0 = make_float2(am0[it] * g0.x, am0[it] * g0.y), x1 = make_float2(am1[it] * g1.x, am1[it] * g1.y);
+        if ((low >> (2 * it)) & 3u) {
+          // below k_cut the pink part keeps its own draw (noise_pair_means redraws exactly it)
+          // and the white part gets another
+          const U4 rw = philox4x32_10(U4{(uint32_t)k1, (uint32_t)k2, series, kTagOwnWhite}, key0, key1);
+          const float2 h0 = box_muller(rw.x, rw.y), h1 = box_muller(rw.z, rw.w);
+          if ((low >> (2 * it)) & 1u) {
+            const float a0 = pink_amp(k1 + n1 * k2, n, amp, g.win.k_min);
+            x0 = make_float2(a0 * g0.x + sw * h0.x, a0 * g0.y + sw * h0.y);
+          }
+          if ((low >> (2 * it)) & 2u) {
+            const float a1 = pink_amp(k1 + n1 * (k2 + half), n, amp, g.win.k_min);
+            x1 = make_float2(a1 * g1.x + sw * h1.x, a1 * g1.y + sw * h1.y);
+          }
+        }
         if constexpr (kModes > 0) {
 #pragma unroll
           for (int m = 0; m < kModes; ++m) {
@@ -288,11 +341,12 @@ __global__ __launch_bounds__(kThreads) void noise_spectrum_fft(
     constexpr int kN = kIter > 1 ? 2 * kThreads * kIter : 0;
     const float2* res = fft_lds_inverse<4, kN, kThreads>(data, data + n2, tw, n2, log2n2);
     float2* dst = A + ((size_t)pair * n1 + k1) * n2;
-    for (int j = threadIdx.x; j < n2; j += kThreads) {
-      // exp(2 pi i k1 j / N); k1*j < N <= 2^23 is exact in float32, and so is the fraction
-      // of a revolution the hardware sine and cosine take (absolute error ~1e-6)
-      const float rev = (float)(k1 * j) * inv_n;
-      dst[j] = cmul(res[j], make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev)));
+    float2 w = tw_first;
+#pragma unroll
+    for (int i = 0; i < 2 * kIter; ++i) {
+      const int j = threadIdx.x + i * kThreads;
+      if (j < n2) dst[j] = cmul(res[j], w);
+      w = cmul(w, tw_step);
     }
     __syncthreads();  // the next series reuses both LDS images
   }
@@ -339,10 +393,11 @@ struct CombineArgs {
 };
 
 // one group of 4 consecutive samples of one row, given its pink + correlated part
+template <bool kDrawWhite>
 __device__ __forceinline__ void finish4(const CombineArgs& g, int row, size_t t0, vfloat4 pink,
                                         uint32_t key0, uint32_t key1) {
-  const vfloat4 w = white4(t0 >> 2, g.id0 + (uint32_t)row, key0, key1);
-  vfloat4 v = g.sqrt_fs * w + pink;
+  vfloat4 v = pink;  // from the spectrum: the white part is in it
+  if constexpr (kDrawWhite) v += g.sqrt_fs * white4(t0 >> 2, g.id0 + (uint32_t)row, key0, key1);
   const float sc = g.scale ? g.scale[row] : 1.0f;
   float* dst = g.out + (size_t)row * g.ld + t0;
   const bool full = g.vec_ok && t0 + 4 <= (size_t)g.T;
@@ -395,19 +450,17 @@ __global__ __launch_bounds__(kBlock) void noise_fft_combine(
     const size_t t0 = (size_t)n2 * m + j0 + b;
     if (t0 >= (size_t)g.T) continue;
     const float2 r0 = res[e], r1 = res[e + 1], r2 = res[e + 2], r3 = res[e + 3];
-    finish4(g, row_a, t0, vfloat4{r0.x, r1.x, r2.x, r3.x} - mean_a, key0, key1);
+    finish4<false>(g, row_a, t0, vfloat4{r0.x, r1.x, r2.x, r3.x} - mean_a, key0, key1);
     if (row_a + 1 < g.row0 + g.rows)
-      finish4(g, row_a + 1, t0, vfloat4{r0.y, r1.y, r2.y, r3.y} - mean_b, key0, key1);
+      finish4<false>(g, row_a + 1, t0, vfloat4{r0.y, r1.y, r2.y, r3.y} - mean_b, key0, key1);
   }
 }
 
 // pass 2 when n1 == 64 (every period up to 2^19 samples): one thread per j, the
 // 64-point transform over k1 in registers -- no LDS, no barrier.  Lane l of a wave
 // holds samples t = j0 + l + n2 m, so each (m, row) is one 256-byte store per wave.
-// The white draws are keyed by (j, m / 4): a Philox call gives the normals of 4
-// values of m at one j.
 template <bool kExtras>
-__global__ __launch_bounds__(kBlock) void noise_fft64_combine(
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) void noise_fft64_combine(
     const float2* __restrict__ A, int n2, CombineArgs g, uint32_t key0, uint32_t key1) {
   const int j = blockIdx.x * kBlock + threadIdx.x;
   if (j >= n2 || j >= g.T) return;
@@ -426,42 +479,31 @@ __global__ __launch_bounds__(kBlock) void noise_fft64_combine(
   const float sa = g.scale ? g.scale[row_a] : 1.0f, sb = g.scale ? g.scale[row_b] : 1.0f;
   float* out_a = g.out + (size_t)row_a * g.ld + j;
   float* out_b = g.out + (size_t)row_b * g.ld + j;
-  const uint32_t id_a = g.id0 + (uint32_t)row_a, id_b = g.id0 + (uint32_t)row_b;
   const float mean_a = g.mean ? (float)g.mean[blockIdx.y].x : 0.0f, mean_b = g.mean ? (float)g.mean[blockIdx.y].y : 0.0f;
 #pragma unroll
-  for (int mq = 0; mq < 16; ++mq) {
-    const U4 ra = philox4x32_10(U4{(uint32_t)j, id_a, 0x100u + mq, kTagWhite}, key0, key1);
-    const U4 rb = philox4x32_10(U4{(uint32_t)j, id_b, 0x100u + mq, kTagWhite}, key0, key1);
-    const float2 wa0 = box_muller(ra.x, ra.y), wa1 = box_muller(ra.z, ra.w);
-    const float2 wb0 = box_muller(rb.x, rb.y), wb1 = box_muller(rb.z, rb.w);
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int m = 4 * mq + q;
-      const size_t t = (size_t)j + (size_t)n2 * m;
-      if (t >= (size_t)g.T) continue;
-      const float wa = q == 0 ? wa0.x : q == 1 ? wa0.y : q == 2 ? wa1.x : wa1.y;
-      const float wb = q == 0 ? wb0.x : q == 1 ? wb0.y : q == 2 ? wb1.x : wb1.y;
-      float va = g.sqrt_fs * wa + (re[fft64_pos(m)] - mean_a);
-      float vb = g.sqrt_fs * wb + (im[fft64_pos(m)] - mean_b);
-      const size_t o = (size_t)n2 * m;
-      if (kExtras) {
-        float aa = sa, ab = sb;
-        if (g.loading) {
-          aa += g.per_loading * g.loading[(size_t)row_a * g.ld_loading + t];
-          ab += g.per_loading * g.loading[(size_t)row_b * g.ld_loading + t];
-        }
-        va *= aa;
-        vb *= ab;
-        if (g.accumulate) {
-          va += out_a[o];
-          vb += out_b[o];
-        }
-        out_a[o] = va;
-        if (has_b) out_b[o] = vb;
-      } else {
-        __builtin_nontemporal_store(sa * va, out_a + o);
-        if (has_b) __builtin_nontemporal_store(sb * vb, out_b + o);
+  for (int m = 0; m < 64; ++m) {
+    const size_t t = (size_t)j + (size_t)n2 * m;
+    if (t >= (size_t)g.T) continue;
+    float va = re[fft64_pos(m)] - mean_a;
+    float vb = im[fft64_pos(m)] - mean_b;
+    const size_t o = (size_t)n2 * m;
+    if (kExtras) {
+      float aa = sa, ab = sb;
+      if (g.loading) {
+        aa += g.per_loading * g.loading[(size_t)row_a * g.ld_loading + t];
+        ab += g.per_loading * g.loading[(size_t)row_b * g.ld_loading + t];
       }
+      va *= aa;
+      vb *= ab;
+      if (g.accumulate) {
+        va += out_a[o];
+        vb += out_b[o];
+      }
+      out_a[o] = va;
+      if (has_b) out_b[o] = vb;
+    } else {
+      __builtin_nontemporal_store(sa * va, out_a + o);
+      if (has_b) __builtin_nontemporal_store(sb * vb, out_b + o);
     }
   }
 }
@@ -470,7 +512,7 @@ __global__ __launch_bounds__(kBlock) void noise_fft64_combine(
 __global__ __launch_bounds__(kBlock) void noise_white_kernel(CombineArgs g, uint32_t key0, uint32_t key1) {
   const size_t t0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * 4;
   if (t0 >= (size_t)g.T) return;
-  finish4(g, g.row0 + blockIdx.y, t0, vfloat4{0.f, 0.f, 0.f, 0.f}, key0, key1);
+  finish4<true>(g, g.row0 + blockIdx.y, t0, vfloat4{0.f, 0.f, 0.f, 0.f}, key0, key1);
 }
 
 // test hook: the in-LDS transforms on caller data (rows of n complex values;
@@ -619,6 +661,7 @@ int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T
   SpectrumArgs sp{};
   sp.knee = (float)knee;
   sp.w_ind = 1.0f;
+  sp.white_var = (float)(sample_rate / (double)n);
   sp.win.T = T;
   sp.win.k_min = (int)((n + (size_t)T - 1) / (size_t)T);  // ceil(N / T): nothing slower than the TOD
   sp.win.k_cut = (int)(64LL * sp.win.k_min < (long long)(n / 2) ? 64 * sp.win.k_min : n / 2);

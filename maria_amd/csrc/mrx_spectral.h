@@ -38,7 +38,8 @@ __host__ __device__ inline U4 philox4x32_10(U4 c, uint32_t k0, uint32_t k1) {
 __device__ __forceinline__ float2 box_muller(uint32_t a, uint32_t b) {
   const float u1 = ((float)(a >> 8) + 0.5f) * (1.0f / 16777216.0f);  // (0,1)
   const float u2 = (float)(b >> 8) * (1.0f / 16777216.0f);           // [0,1)
-  const float rad = sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // -2 ln u1
+  // v_sqrt_f32 as it is (1 ulp): sqrtf() adds a dozen instructions of denormal scaling and rounding repair
+  const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // -2 ln u1
   return make_float2(rad * __builtin_amdgcn_cosf(u2), rad * __builtin_amdgcn_sinf(u2));
 }
 
