@@ -86,7 +86,7 @@ enum {
   MRX_OPT_SAMPLE_CHUNK = 3, /* time steps per workgroup (tuning; 0 = automatic) */
   MRX_OPT_UPSAMPLE_GROUPS = 4, /* 16-row detector tiles per workgroup of the TOD
                                   writer (tuning; 0 = automatic) */
-  MRX_OPT_NOISE_GENERIC = 5, /* 1: the LDS second pass even where the register one applies (tests) */
+  MRX_OPT_NOISE_GENERIC = 5, /* bit 0: the LDS second pass even where the register one applies; bit 1: the Stockham first pass even where the radix-16 register one applies (tests, A/B runs) */
   MRX_OPT_SAMPLE_WGS_PER_CU = 6, /* mrx_atm_sample runs as a resident grid of this many workgroups
                                     per CU that walk the work items (tuning; 0 = default, 8) */
   MRX_OPT_SAMPLE_TILES = 7, /* 1: mrx_atm_sample stages each work item's screen windows in LDS

@@ -377,6 +377,114 @@ SpectrumKernel spectrum_kernel(int n2, int n_modes, int* threads) {
   }
 }
 
+// pass 1 for n2 = 4096 (periods of 2^18 samples: 131 072 < T <= 262 144): a thread builds its 16
+// cells k2 = t + 256 b in registers -- they are the inputs of the first radix-16 transform of
+// fft4096_workgroup -- so the spectrum never goes through LDS before the transform.  The cells of
+// all kPairsPerBlock series are built first, cell by cell, so that a cell's mode spectra are read
+// once and dropped (16 cells x kModes spectra do not fit the register file beside the data); then
+// the series are transformed one after the other.  Same draws, same cells as noise_spectrum_fft
+// (the two agree to rounding).
+template <int kModes>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) void noise_spectrum_r16(
+    float2* __restrict__ A, int n1, SpectrumArgs g, int pairs, uint32_t key0, uint32_t key1) {
+  extern __shared__ float2 lds2[];
+  float2* ex1 = lds2;
+  float2* ex2 = lds2 + kFft4096Image;
+  constexpr int n2 = 4096, half = 2048;
+  const int t = threadIdx.x;
+  const int k1 = blockIdx.y;
+  const int n = n1 * n2;
+  const float amp = g.w_ind * sqrtf(g.knee);
+  const float pink_var = amp * amp;
+  const float sw = __builtin_sqrtf(g.white_var);
+  const int pair0 = blockIdx.x * kPairsPerBlock;
+  constexpr int kRegModes = kModes > 0 ? kModes : 1;
+  float2 v[kPairsPerBlock][16];
+#pragma unroll
+  for (int b = 0; b < 8; ++b) {
+    const int k2 = t + 256 * b;
+    const int ka = k1 + n1 * k2, kb = k1 + n1 * (k2 + half);
+    const float am0 = merged_amp(ka, n, g.white_var, pink_var, g.win.k_min);
+    const float am1 = merged_amp(kb, n, g.white_var, pink_var, g.win.k_min);
+    const bool low0 = (ka < n - ka ? ka : n - ka) < g.win.k_cut, low1 = (kb < n - kb ? kb : n - kb) < g.win.k_cut;
+    float2 f0[kRegModes], f1[kRegModes];
+    if constexpr (kModes > 0) {
+#pragma unroll
+      for (int m = 0; m < kModes; ++m) {
+        f0[m] = g.F[(size_t)m * n + (size_t)k1 * n2 + k2];
+        f1[m] = g.F[(size_t)m * n + (size_t)k1 * n2 + k2 + half];
+      }
+    }
+#pragma unroll
+    for (int p = 0; p < kPairsPerBlock; ++p) {
+      const int pair = pair0 + p;
+      if (pair >= pairs) break;  // uniform
+      const uint32_t series = g.series0 + pair;
+      const U4 rnd = philox4x32_10(U4{(uint32_t)k1, (uint32_t)k2, series, kTagPink}, key0, key1);
+      const float2 g0 = box_muller(rnd.x, rnd.y), g1 = box_muller(rnd.z, rnd.w);
+      float2 x0 = make_float2(am0 * g0.x, am0 * g0.y), x1 = make_float2(am1 * g1.x, am1 * g1.y);
+      if (low0 || low1) {
+        // below k_cut the pink part keeps its own draw (noise_pair_means redraws exactly it)
+        const U4 rw = philox4x32_10(U4{(uint32_t)k1, (uint32_t)k2, series, kTagOwnWhite}, key0, key1);
+        const float2 h0 = box_muller(rw.x, rw.y), h1 = box_muller(rw.z, rw.w);
+        if (low0) {
+          const float a0 = pink_amp(ka, n, amp, g.win.k_min);
+          x0 = make_float2(a0 * g0.x + sw * h0.x, a0 * g0.y + sw * h0.y);
+        }
+        if (low1) {
+          const float a1 = pink_amp(kb, n, amp, g.win.k_min);
+          x1 = make_float2(a1 * g1.x + sw * h1.x, a1 * g1.y + sw * h1.y);
+        }
+      }
+      if constexpr (kModes > 0) {
+        // the pair's mode coefficients sqrt(c) (B[a,m] + i B[b,m]): uniform, scalar registers
+        const int row_a = g.row0 + 2 * pair;
+        const bool has_b = row_a + 1 < g.row0 + g.rows;
+#pragma unroll
+        for (int m = 0; m < kModes; ++m) {
+          const float2 coef = make_float2(g.w_corr * g.basis[(size_t)row_a * kModes + m],
+                                          has_b ? g.w_corr * g.basis[(size_t)(row_a + 1) * kModes + m] : 0.0f);
+          x0 = cadd(x0, cmul(coef, f0[m]));
+          x1 = cadd(x1, cmul(coef, f1[m]));
+        }
+      }
+      v[p][b] = x0;
+      v[p][b + 8] = x1;
+    }
+  }
+  const float inv_n = 1.0f / (float)n;
+  const float r0 = (float)(k1 * t) * inv_n, r1 = (float)(k1 * 256) * inv_n;  // k1 j < N <= 2^23: exact
+  const float2 tw_first = make_float2(__builtin_amdgcn_cosf(r0), __builtin_amdgcn_sinf(r0));
+  const float2 tw_step = make_float2(__builtin_amdgcn_cosf(r1), __builtin_amdgcn_sinf(r1));
+#pragma unroll
+  for (int p = 0; p < kPairsPerBlock; ++p) {
+    const int pair = pair0 + p;
+    if (pair >= pairs) break;  // uniform
+    fft4096_workgroup(v[p], ex1, ex2);
+    float2* dst = A + ((size_t)pair * n1 + k1) * n2 + t;
+    float2 w = tw_first;
+#pragma unroll
+    for (int f = 0; f < 16; ++f) {
+      dst[256 * f] = cmul(v[p][dft16_pos(f)], w);
+      w = cmul(w, tw_step);
+    }
+  }
+}
+
+typedef void (*SpectrumR16Kernel)(float2*, int, SpectrumArgs, int, uint32_t, uint32_t);
+
+SpectrumR16Kernel spectrum_r16_kernel(int n_modes) {
+  switch (n_modes) {
+    case 0: return noise_spectrum_r16<0>;
+    case 1: return noise_spectrum_r16<1>;
+    case 2: return noise_spectrum_r16<2>;
+    case 3: return noise_spectrum_r16<3>;
+    case 4: return noise_spectrum_r16<4>;
+    case 5: return noise_spectrum_r16<5>;
+    default: return nullptr;  // more modes than registers: the Stockham kernel
+  }
+}
+
 struct CombineArgs {
   const float* scale;    // [rows] or null
   const float* loading;  // [rows][ld_loading] or null
@@ -532,6 +640,16 @@ __global__ __launch_bounds__(kBlock) void fft_rows_kernel(const float2* __restri
   for (int e = threadIdx.x; e < cells; e += kBlock) out[(size_t)blockIdx.x * cells + e] = res[e];
 }
 
+__global__ __launch_bounds__(kBlock) void fft4096_rows_kernel(const float2* __restrict__ in, float2* __restrict__ out) {
+  extern __shared__ float2 lds2[];
+  float2 v[16];
+#pragma unroll
+  for (int b = 0; b < 16; ++b) v[b] = in[(size_t)blockIdx.x * 4096 + threadIdx.x + 256 * b];
+  fft4096_workgroup(v, lds2, lds2 + kFft4096Image);
+#pragma unroll
+  for (int f = 0; f < 16; ++f) out[(size_t)blockIdx.x * 4096 + threadIdx.x + 256 * f] = v[dft16_pos(f)];
+}
+
 __global__ __launch_bounds__(64) void fft64_reg_rows_kernel(const float2* __restrict__ in, float2* __restrict__ out, int rows) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
@@ -657,6 +775,11 @@ int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T
   // attribute belongs to the device)
   MRX_LDS_CAP(ctx, pass1, (2 * 8192 + 8192 / 4) * sizeof(float2));
   MRX_LDS_CAP(ctx, noise_fft_combine, lds2);
+  // periods of 2^18 samples: the register transform (option bit 1 keeps the Stockham kernel, for A/B runs)
+  const size_t lds_r16 = 2 * (size_t)kFft4096Image * sizeof(float2);
+  const SpectrumR16Kernel pass1_r16 =
+      n2 == 4096 && !(ctx->options[MRX_OPT_NOISE_GENERIC] & 2) ? spectrum_r16_kernel(n_modes) : nullptr;
+  if (pass1_r16) MRX_LDS_CAP(ctx, pass1_r16, lds_r16);
 
   SpectrumArgs sp{};
   sp.knee = (float)knee;
@@ -692,9 +815,13 @@ int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T
     sp.series0 = 16u + (uint32_t)((det_offset + d0) / 2);  // detector pair (2q, 2q+1) is series 16 + q
     h.mean = mean;
     hipLaunchKernelGGL(noise_pair_means, dim3(pairs), dim3(kBlock), 0, ctx->stream, n1, n2, sp, key0, key1);
-    hipLaunchKernelGGL(pass1, dim3(mrx_ceil_div(pairs, kPairsPerBlock), n1), dim3(threads1), lds1,
-                       ctx->stream, A, n1, n2, l2, sp, pairs, key0, key1);
-    if (n1 == 64 && !ctx->options[MRX_OPT_NOISE_GENERIC]) {
+    if (pass1_r16)
+      hipLaunchKernelGGL(pass1_r16, dim3(mrx_ceil_div(pairs, kPairsPerBlock), n1), dim3(kBlock), lds_r16,
+                         ctx->stream, A, n1, sp, pairs, key0, key1);
+    else
+      hipLaunchKernelGGL(pass1, dim3(mrx_ceil_div(pairs, kPairsPerBlock), n1), dim3(threads1), lds1,
+                         ctx->stream, A, n1, n2, l2, sp, pairs, key0, key1);
+    if (n1 == 64 && !(ctx->options[MRX_OPT_NOISE_GENERIC] & 1)) {
       const dim3 grid(mrx_ceil_div(j_used, kBlock), pairs);
       if (h.loading || h.accumulate)
         hipLaunchKernelGGL(noise_fft64_combine<true>, grid, dim3(kBlock), 0, ctx->stream, A, n2, h, key0, key1);
@@ -714,6 +841,15 @@ int mrx_fft_rows(mrx_ctx* ctx, const float* d_in, int rows, int n, int interleav
   MRX_ENTER(ctx);
   if (!ctx) return MRX_ERR_INVALID;
   const int l = ilog2(n);
+  if (ctx && interleave_log2 == -2) {  // the workgroup register transform: n must be 4096
+    MRX_REQUIRE(ctx, d_in && d_out && rows >= 1 && n == 4096, "bad argument");
+    const size_t lds = 2 * (size_t)kFft4096Image * sizeof(float2);
+    MRX_LDS_CAP(ctx, fft4096_rows_kernel, lds);
+    hipLaunchKernelGGL(fft4096_rows_kernel, dim3(rows), dim3(kBlock), lds, ctx->stream,
+                       reinterpret_cast<const float2*>(d_in), reinterpret_cast<float2*>(d_out));
+    MRX_CHECK_LAUNCH(ctx);
+    return MRX_OK;
+  }
   if (ctx && interleave_log2 == -1) {  // the register transform: n must be 64
     MRX_REQUIRE(ctx, d_in && d_out && rows >= 1 && n == 64, "bad argument");
     hipLaunchKernelGGL(fft64_reg_rows_kernel, dim3(mrx_ceil_div(rows, 64)), dim3(64), 0, ctx->stream,

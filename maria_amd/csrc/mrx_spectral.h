@@ -243,6 +243,121 @@ __device__ __forceinline__ void fft64_inverse_reg(float (&re)[64], float (&im)[6
   fft64_stage<4>(re, im);
 }
 
+// ---- 4096-point inverse FFT of a 256-thread workgroup, 16 values per thread in registers ----
+// Three radix-16 register transforms and two exchanges through LDS (4 LDS accesses per value and
+// two barriers, against 12 accesses and six barriers of the radix-4 Stockham passes above).
+constexpr float kCos16[16] = {1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f, 0.0f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f,
+                              -1.0f, -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f, 0.0f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f};
+constexpr float kSin16[16] = {0.0f, 0.38268343236508977f, 0.70710678118654752f, 0.92387953251128674f, 1.0f, 0.92387953251128674f, 0.70710678118654752f, 0.38268343236508977f,
+                              0.0f, -0.38268343236508977f, -0.70710678118654752f, -0.92387953251128674f, -1.0f, -0.92387953251128674f, -0.70710678118654752f, -0.38268343236508977f};
+
+// a exp(2 pi i P / 16), P a compile-time constant: the multiples of a quarter turn are moves,
+// the odd multiples of an eighth two additions and two multiplications
+template <int P>
+__device__ __forceinline__ float2 mul_w16(float2 a) {
+  constexpr int p = P & 15;
+  constexpr float h = 0.70710678118654752f;
+  if constexpr (p == 0) return a;
+  else if constexpr (p == 4) return make_float2(-a.y, a.x);
+  else if constexpr (p == 8) return make_float2(-a.x, -a.y);
+  else if constexpr (p == 12) return make_float2(a.y, -a.x);
+  else if constexpr (p == 2) return make_float2(h * (a.x - a.y), h * (a.x + a.y));
+  else if constexpr (p == 6) return make_float2(-h * (a.x + a.y), h * (a.x - a.y));
+  else if constexpr (p == 10) return make_float2(h * (a.y - a.x), -h * (a.x + a.y));
+  else if constexpr (p == 14) return make_float2(h * (a.x + a.y), h * (a.y - a.x));
+  else return make_float2(a.x * kCos16[p] - a.y * kSin16[p], a.x * kSin16[p] + a.y * kCos16[p]);
+}
+
+// y[m] = sum_r x[r] i^(r m), in place
+__device__ __forceinline__ void radix4_inverse(float2& x0, float2& x1, float2& x2, float2& x3) {
+  const float2 t0 = cadd(x0, x2), t1 = csub(x0, x2);
+  const float2 t2 = cadd(x1, x3), t3 = cmul_i(csub(x1, x3));
+  x0 = cadd(t0, t2);
+  x1 = cadd(t1, t3);
+  x2 = csub(t0, t2);
+  x3 = csub(t1, t3);
+}
+
+// 16-point inverse DFT in place: output d ends up at position dft16_pos(d) (its two base-4
+// digits swapped).  b = 4 b1 + b0, d = 4 d1 + d0: w^(b d) = i^(b1 d0) i^(b0 d1) w^(b0 d0).
+__host__ __device__ constexpr int dft16_pos(int d) { return ((d & 3) << 2) | (d >> 2); }
+
+__device__ __forceinline__ void dft16(float2 (&v)[16]) {
+  // over b1 for every b0: v[b0 + 4 d0] <- sum_b1 v[b0 + 4 b1] i^(b1 d0)
+  radix4_inverse(v[0], v[4], v[8], v[12]);
+  radix4_inverse(v[1], v[5], v[9], v[13]);
+  radix4_inverse(v[2], v[6], v[10], v[14]);
+  radix4_inverse(v[3], v[7], v[11], v[15]);
+  // w^(b0 d0)
+  v[5] = mul_w16<1>(v[5]);
+  v[6] = mul_w16<2>(v[6]);
+  v[7] = mul_w16<3>(v[7]);
+  v[9] = mul_w16<2>(v[9]);
+  v[10] = mul_w16<4>(v[10]);
+  v[11] = mul_w16<6>(v[11]);
+  v[13] = mul_w16<3>(v[13]);
+  v[14] = mul_w16<6>(v[14]);
+  v[15] = mul_w16<9>(v[15]);
+  // over b0 for every d0: v[d1 + 4 d0] <- sum_b0 v[b0 + 4 d0] i^(b0 d1)
+  radix4_inverse(v[0], v[1], v[2], v[3]);
+  radix4_inverse(v[4], v[5], v[6], v[7]);
+  radix4_inverse(v[8], v[9], v[10], v[11]);
+  radix4_inverse(v[12], v[13], v[14], v[15]);
+}
+
+__device__ __forceinline__ float2 csq(float2 a) { return make_float2(a.x * a.x - a.y * a.y, 2.0f * a.x * a.y); }
+
+// w[d] = w1^d, d < 16, by squarings and products four deep (error ~4 ulp)
+__device__ __forceinline__ void powers16(float2 w1, float2 (&w)[16]) {
+  w[0] = make_float2(1.0f, 0.0f);
+  w[1] = w1;
+  w[2] = csq(w1);
+  w[3] = cmul(w[2], w1);
+  w[4] = csq(w[2]);
+  w[5] = cmul(w[4], w1);
+  w[6] = csq(w[3]);
+  w[7] = cmul(w[4], w[3]);
+  w[8] = csq(w[4]);
+  w[9] = cmul(w[8], w1);
+  w[10] = csq(w[5]);
+  w[11] = cmul(w[8], w[3]);
+  w[12] = csq(w[6]);
+  w[13] = cmul(w[8], w[5]);
+  w[14] = csq(w[7]);
+  w[15] = cmul(w[8], w[7]);
+}
+
+constexpr int kFft4096Pitch = 17;                                 // float2 per 16 values: both exchanges conflict-free
+constexpr int kFft4096Image = 4096 / 16 * kFft4096Pitch;          // float2 per exchange image (34 816 bytes)
+
+// in: v[b] = x[t + 256 b]; out: v[dft16_pos(f)] = y[t + 256 f], y[j] = sum_k x[k] exp(2 pi i j k / 4096).
+// k = t + 256 b, j = d + 16 c:  exp(2 pi i k j / 4096) = exp(2 pi i t d / 4096) exp(2 pi i t c / 256) exp(2 pi i b d / 16);
+// t = u + 16 v, c = e + 16 f:  exp(2 pi i t c / 256)  = exp(2 pi i u e / 256)  exp(2 pi i u f / 16)  exp(2 pi i v e / 16).
+// ex1 and ex2: kFft4096Image float2 each.  A caller that loops needs no barrier of its own: the
+// next call writes ex1 after this call's second barrier, which every read of ex1 precedes, and
+// ex2 after its own first barrier, which every thread reaches after its reads of ex2 here.
+__device__ __forceinline__ void fft4096_workgroup(float2 (&v)[16], float2* ex1, float2* ex2) {
+  const int t = threadIdx.x, lo = t & 15, hi = t >> 4;
+  float2 w[16];
+  dft16(v);  // over b
+  powers16(make_float2(__builtin_amdgcn_cosf((float)t * (1.0f / 4096.0f)), __builtin_amdgcn_sinf((float)t * (1.0f / 4096.0f))), w);
+#pragma unroll
+  for (int d = 0; d < 16; ++d) ex1[t * kFft4096Pitch + d] = d ? cmul(v[dft16_pos(d)], w[d]) : v[0];
+  __syncthreads();
+  // u = lo, d = hi: over v
+#pragma unroll
+  for (int q = 0; q < 16; ++q) v[q] = ex1[(lo + 16 * q) * kFft4096Pitch + hi];
+  dft16(v);
+  powers16(make_float2(__builtin_amdgcn_cosf((float)lo * (1.0f / 256.0f)), __builtin_amdgcn_sinf((float)lo * (1.0f / 256.0f))), w);
+#pragma unroll
+  for (int e = 0; e < 16; ++e) ex2[(hi + 16 * e) * kFft4096Pitch + lo] = e ? cmul(v[dft16_pos(e)], w[e]) : v[0];
+  __syncthreads();
+  // d = lo, e = hi (d + 16 e = t): over u
+#pragma unroll
+  for (int q = 0; q < 16; ++q) v[q] = ex2[t * kFft4096Pitch + q];
+  dft16(v);
+}
+
 template <int kThreads = kBlock>
 __device__ __forceinline__ void fill_twiddles(float2* tw, int n) {
   for (int k = threadIdx.x; k < n / 4; k += kThreads) {

@@ -79,6 +79,23 @@ def test_spectrum_matches_reference_model(gpu_ctx, T, fs, knee, generic):
         assert abs(got / want - 1) < 0.12, (lo, hi, got, want)
 
 
+@pytest.mark.parametrize("modes", [0, 2, 5])
+def test_register_first_pass_matches_the_stockham_one(gpu_ctx, modes):
+    """Periods of 2^18 samples build the spectrum in registers and transform it with three radix-16
+    register passes; option bit 1 keeps the LDS Stockham kernel.  Same draws, same cells: the two
+    series agree to float32 rounding (1/f noise: compared against the largest sample)."""
+    D, T, fs, knee = 11, 150000, 400.0, 3.0
+    rng = np.random.default_rng(0)
+    basis = None if modes == 0 else rng.normal(size=(D, modes)) / np.sqrt(modes)
+    a = _generate(gpu_ctx, D, T, fs, knee, corr=0.4, basis=basis, seed=21).cpu().numpy()
+    gpu_ctx.set_option(5, 2)
+    try:
+        b = _generate(gpu_ctx, D, T, fs, knee, corr=0.4, basis=basis, seed=21).cpu().numpy()
+    finally:
+        gpu_ctx.set_option(5, 0)
+    assert np.abs(a).max() > 10 and np.abs(a - b).max() <= 2e-5 * np.abs(b).max()
+
+
 def test_matches_oracle_generator_statistics(gpu_ctx):
     """Against the numpy restatement of the reference on the same parameters: equal band
     powers (three octaves below, at and above the knee) within sampling error."""
