@@ -86,12 +86,16 @@ enum {
   MRX_OPT_SAMPLE_CHUNK = 3, /* time steps per workgroup (tuning; 0 = automatic) */
   MRX_OPT_UPSAMPLE_GROUPS = 4, /* 16-row detector tiles per workgroup of the TOD
                                   writer (tuning; 0 = automatic) */
-  MRX_OPT_NOISE_GENERIC = 5, /* bit 0: the LDS second pass even where the register one applies; bit 1: the Stockham first pass even where the radix-16 register one applies (tests, A/B runs) */
+  MRX_OPT_NOISE_GENERIC = 5, /* bit 0: the LDS second pass even where the register one applies;
+                                bit 1: the Stockham first pass even where the radix-16 register
+                                one applies (tests, A/B runs) */
   MRX_OPT_SAMPLE_WGS_PER_CU = 6, /* mrx_atm_sample runs as a resident grid of this many workgroups
                                     per CU that walk the work items (tuning; 0 = default, 8) */
   MRX_OPT_SAMPLE_TILES = 7, /* 1: mrx_atm_sample stages each work item's screen windows in LDS
                                (measured slower than the global gathers; off by default) */
-  MRX_OPT_COUNT = 8
+  MRX_OPT_NOISE_LANES = 8, /* streams mrx_noise_generate spreads its batches over (1..4; 0 = automatic:
+                              up to 4, each with at least 128 detectors of the work buffer) */
+  MRX_OPT_COUNT = 9
 };
 int mrx_set_option(mrx_ctx* ctx, int option, int value);
 const char* mrx_last_error(const mrx_ctx* ctx);
@@ -488,7 +492,8 @@ int mrx_sosfilt(mrx_ctx* ctx, const double* sos, int n_sections, const double* d
 /* Test hook for the in-LDS inverse FFT both generators are built on: `rows` independent rows
  * of n << interleave_log2 complex float32 values, each holding 2^interleave_log2 interleaved
  * sequences of length n (a power of two >= 4; at most 8192 values per row); unnormalised
- * (numpy.fft.ifft(x) * n).  interleave_log2 = -1: the 64-point register transform, n = 64. */
+ * (numpy.fft.ifft(x) * n).  interleave_log2 = -1: the 64-point register transform, n = 64;
+ * -2: the 4096-point workgroup transform (three radix-16 register passes), n = 4096. */
 int mrx_fft_rows(mrx_ctx* ctx, const float* d_in, int rows, int n, int interleave_log2,
                  float* d_out);
 
@@ -500,10 +505,11 @@ int mrx_fft_rows(mrx_ctx* ctx, const float* d_in, int rows, int n, int interleav
  * w white N(0,1); p_d independent pink series with two-sided spectrum (knee/2)/|f| (equal
  * to the white level at f = knee); M_m = sqrt(fs) w'_m + P_m the modes (white + pink, the
  * generator applied to itself, generation.py:41-43); c = corr_prop.  The reference
- * filters white noise with a length-T FFT per detector; here the pink and correlated parts
- * are synthesised in the frequency domain on a power-of-two period N >= T (a four-step FFT
- * whose real and imaginary parts serve two detectors; the modes enter as tabulated
- * Hermitian spectra) and cut to T samples: same spectrum, different realisation and
+ * filters white noise with a length-T FFT per detector; here all three parts of a detector
+ * are synthesised in the frequency domain on a power-of-two period N >= T (one draw per cell
+ * of variance fs/N + (1-c) knee/|k|; a four-step FFT whose real and imaginary parts serve two
+ * detectors; the modes enter as tabulated Hermitian spectra) and cut to T samples (any T of
+ * the N samples of white noise of period N are independent): same spectrum, different realisation and
  * period -- statistical parity, like the screens.  As in the reference, whose period is the
  * TOD itself, the pink and correlated parts carry no power below fs/T and have zero mean over
  * the T samples (the cells below ceil(N/T) are dropped, the window mean is subtracted).  With knee = 0 the
@@ -519,8 +525,11 @@ int mrx_fft_rows(mrx_ctx* ctx, const float* d_in, int rows, int n, int interleav
  *  d_out        [D][ld_out] float32, written (accumulate = 0) or added to (accumulate = 1:
  *               noise straight into an existing TOD)
  *  d_work       16-byte aligned scratch of work_floats floats; mrx_noise_work_floats(T,
- *               n_modes, batch) gives the size that processes `batch` detectors per pass
- *               (4 N + 8 bytes per detector + 8 N per mode).
+ *               n_modes, batch) gives the size that holds `batch` detectors in flight
+ *               (4 N + 8 bytes per detector + 8 N per mode).  From 256 detectors up the batches
+ *               are spread over up to four streams (the context's stream forks and joins: the call
+ *               is ordered on it like any other), each with an equal share of the buffer:
+ *               1024 detectors in flight is a good size (MRX_OPT_NOISE_LANES).
  * mrx_noise_period: N = n1 * n2 for T samples (T <= 2^23). */
 int mrx_noise_period(int T, int* n1, int* n2);
 int mrx_noise_work_floats(int T, int n_modes, int batch, size_t* floats);

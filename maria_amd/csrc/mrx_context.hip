@@ -46,6 +46,10 @@ int mrx_destroy(mrx_ctx* ctx) {
   for (auto& slot : ctx->ftaps)
     if (slot.d_taps) (void)hipFree(slot.d_taps);
   if (ctx->d_reduce) (void)hipFree(ctx->d_reduce);
+  for (hipStream_t st : ctx->side_streams)
+    if (st) (void)hipStreamDestroy(st);
+  for (hipEvent_t ev : ctx->side_ev)
+    if (ev) (void)hipEventDestroy(ev);
   if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
   if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
   }

@@ -57,11 +57,15 @@ struct mrx_ctx {
     const void* fn = nullptr;
     size_t bytes = 0;
   } lds_caps[kLdsSlots];
-  // second stream + events of the block-pipelined TOD synthesis (mrx_atm_tod), made on demand
-  hipStream_t side_stream = nullptr;
-  static constexpr int kPipeEvents = 34;
-  hipEvent_t pipe_ev[kPipeEvents] = {nullptr};
+  // side streams + fork/join events of entry points that spread independent batches over
+  // several streams (mrx_noise_generate), made on demand by mrx_side_streams
+  static constexpr int kSideStreams = 3;
+  hipStream_t side_streams[kSideStreams] = {nullptr};
+  hipEvent_t side_ev[kSideStreams + 1] = {nullptr};  // [0]: fork, [1 + i]: join of side stream i
 };
+
+// the first n side streams (n <= kSideStreams) and their events exist after this returns MRX_OK
+inline int mrx_side_streams(mrx_ctx* ctx, int n);
 
 inline int mrx_fail(mrx_ctx* ctx, int code, const char* fmt, ...) {
   if (ctx) {
@@ -94,6 +98,16 @@ inline int mrx_fail(mrx_ctx* ctx, int code, const char* fmt, ...) {
       return mrx_fail((ctx), MRX_ERR_HIP, "kernel launch failed: %s (%s:%d)", \
                       hipGetErrorString(e__), __FILE__, __LINE__);           \
   } while (0)
+
+inline int mrx_side_streams(mrx_ctx* ctx, int n) {
+  if (n > mrx_ctx::kSideStreams) return mrx_fail(ctx, MRX_ERR_INVALID, "at most %d side streams", mrx_ctx::kSideStreams);
+  if (!ctx->side_ev[0]) MRX_HIP(ctx, hipEventCreateWithFlags(&ctx->side_ev[0], hipEventDisableTiming));
+  for (int i = 0; i < n; ++i) {
+    if (!ctx->side_streams[i]) MRX_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_streams[i], hipStreamNonBlocking));
+    if (!ctx->side_ev[1 + i]) MRX_HIP(ctx, hipEventCreateWithFlags(&ctx->side_ev[1 + i], hipEventDisableTiming));
+  }
+  return MRX_OK;
+}
 
 // Entry points that launch or allocate run on the context's own device, whatever the
 // calling thread's current device is; the caller's device is restored on return.

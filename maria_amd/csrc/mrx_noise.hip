@@ -321,15 +321,15 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(kIter 
         if constexpr (kModes > 0) {
 #pragma unroll
           for (int m = 0; m < kModes; ++m) {
-            x0 = cadd(x0, cmul(coef[m], f0[it][m]));
-            x1 = cadd(x1, cmul(coef[m], f1[it][m]));
+            x0 = cfma(coef[m], f0[it][m], x0);
+            x1 = cfma(coef[m], f1[it][m], x1);
           }
         } else if constexpr (kModes < 0) {
 #pragma unroll
           for (int m = 0; m < kMaxModes; ++m)
             if (m < n_modes) {
-              x0 = cadd(x0, cmul(coef[m], F[(size_t)m * n + k2]));
-              x1 = cadd(x1, cmul(coef[m], F[(size_t)m * n + k2 + half]));
+              x0 = cfma(coef[m], F[(size_t)m * n + k2], x0);
+              x1 = cfma(coef[m], F[(size_t)m * n + k2 + half], x1);
             }
         }
         data[k2] = x0;
@@ -444,8 +444,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         for (int m = 0; m < kModes; ++m) {
           const float2 coef = make_float2(g.w_corr * g.basis[(size_t)row_a * kModes + m],
                                           has_b ? g.w_corr * g.basis[(size_t)(row_a + 1) * kModes + m] : 0.0f);
-          x0 = cadd(x0, cmul(coef, f0[m]));
-          x1 = cadd(x1, cmul(coef, f1[m]));
+          x0 = cfma(coef, f0[m], x0);
+          x1 = cfma(coef, f1[m], x1);
         }
       }
       v[p][b] = x0;
@@ -804,8 +804,26 @@ int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T
   }
   // tiles of the LDS pass 2 that hold a sample t < T: j0 < min(T, n2)
   const int j_used = (long long)T < n2 ? T : n2;
-  for (int d0 = 0; d0 < D; d0 += 2 * pairs_max) {
-    const int count = D - d0 < 2 * pairs_max ? D - d0 : 2 * pairs_max;
+  // Lanes: the batches go round-robin onto up to four streams (the context's and its side
+  // streams), each with its own share of the work buffer.  Pass 1 is arithmetic-bound and pass 2
+  // HBM-bound, and both end in a tail of half-empty CUs: batches in flight on other lanes fill
+  // both (measured at 10 000 x 240 000: 10.0 ms on one lane, 8.3 ms on four).
+  const int pairs_total = (D + 1) / 2;
+  int lanes = ctx->options[MRX_OPT_NOISE_LANES] > 0 ? ctx->options[MRX_OPT_NOISE_LANES] : 4;
+  if (lanes > 1 + mrx_ctx::kSideStreams) lanes = 1 + mrx_ctx::kSideStreams;
+  while (lanes > 1 && (pairs_max / lanes < 64 || (long long)(lanes - 1) * (pairs_max / lanes) >= pairs_total)) --lanes;
+  const int pairs_lane = pairs_max / lanes;
+  if (lanes > 1) {
+    const int rc = mrx_side_streams(ctx, lanes - 1);
+    if (rc != MRX_OK) return rc;
+    MRX_HIP(ctx, hipEventRecord(ctx->side_ev[0], ctx->stream));  // after the tables and whatever precedes the call
+    for (int l = 1; l < lanes; ++l) MRX_HIP(ctx, hipStreamWaitEvent(ctx->side_streams[l - 1], ctx->side_ev[0], 0));
+  }
+  int batch = 0;
+  for (int d0 = 0; d0 < D; d0 += 2 * pairs_lane, ++batch) {
+    const int lane = batch % lanes;
+    hipStream_t stream = lane ? ctx->side_streams[lane - 1] : ctx->stream;
+    const int count = D - d0 < 2 * pairs_lane ? D - d0 : 2 * pairs_lane;
     const int pairs = (count + 1) / 2;
     CombineArgs h = g;
     h.row0 = d0;
@@ -813,25 +831,31 @@ int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T
     sp.row0 = d0;
     sp.rows = count;
     sp.series0 = 16u + (uint32_t)((det_offset + d0) / 2);  // detector pair (2q, 2q+1) is series 16 + q
-    h.mean = mean;
-    hipLaunchKernelGGL(noise_pair_means, dim3(pairs), dim3(kBlock), 0, ctx->stream, n1, n2, sp, key0, key1);
+    sp.win.mean = mean + (size_t)lane * pairs_lane;
+    h.mean = sp.win.mean;
+    float2* Al = A + (size_t)lane * pairs_lane * n;
+    hipLaunchKernelGGL(noise_pair_means, dim3(pairs), dim3(kBlock), 0, stream, n1, n2, sp, key0, key1);
     if (pass1_r16)
       hipLaunchKernelGGL(pass1_r16, dim3(mrx_ceil_div(pairs, kPairsPerBlock), n1), dim3(kBlock), lds_r16,
-                         ctx->stream, A, n1, sp, pairs, key0, key1);
+                         stream, Al, n1, sp, pairs, key0, key1);
     else
       hipLaunchKernelGGL(pass1, dim3(mrx_ceil_div(pairs, kPairsPerBlock), n1), dim3(threads1), lds1,
-                         ctx->stream, A, n1, n2, l2, sp, pairs, key0, key1);
+                         stream, Al, n1, n2, l2, sp, pairs, key0, key1);
     if (n1 == 64 && !(ctx->options[MRX_OPT_NOISE_GENERIC] & 1)) {
       const dim3 grid(mrx_ceil_div(j_used, kBlock), pairs);
       if (h.loading || h.accumulate)
-        hipLaunchKernelGGL(noise_fft64_combine<true>, grid, dim3(kBlock), 0, ctx->stream, A, n2, h, key0, key1);
+        hipLaunchKernelGGL(noise_fft64_combine<true>, grid, dim3(kBlock), 0, stream, Al, n2, h, key0, key1);
       else
-        hipLaunchKernelGGL(noise_fft64_combine<false>, grid, dim3(kBlock), 0, ctx->stream, A, n2, h, key0, key1);
+        hipLaunchKernelGGL(noise_fft64_combine<false>, grid, dim3(kBlock), 0, stream, Al, n2, h, key0, key1);
     } else {
       hipLaunchKernelGGL(noise_fft_combine, dim3(mrx_ceil_div(j_used, 1 << lj), pairs), dim3(kBlock), lds2,
-                         ctx->stream, A, n1, n2, l1, lj, h, key0, key1);
+                         stream, Al, n1, n2, l1, lj, h, key0, key1);
     }
     MRX_CHECK_LAUNCH(ctx);
+  }
+  for (int l = 1; l < lanes; ++l) {  // join: the context's stream continues after every lane
+    MRX_HIP(ctx, hipEventRecord(ctx->side_ev[l], ctx->side_streams[l - 1]));
+    MRX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->side_ev[l], 0));
   }
   return MRX_OK;
 }

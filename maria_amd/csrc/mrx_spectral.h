@@ -53,6 +53,11 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) {
   return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x);
 }
 
+// a b + c in four fused multiply-adds (cadd(c, cmul(a, b)) takes six instructions: nothing may be reassociated)
+__device__ __forceinline__ float2 cfma(float2 a, float2 b, float2 c) {
+  return make_float2(__builtin_fmaf(-a.y, b.y, __builtin_fmaf(a.x, b.x, c.x)), __builtin_fmaf(a.y, b.x, __builtin_fmaf(a.x, b.y, c.y)));
+}
+
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 cmul_i(float2 a) { return make_float2(-a.y, a.x); }  // i a

@@ -47,7 +47,7 @@ def diameter(offsets):
     return float(scipy.spatial.distance.pdist(pts).max())
 
 
-def simulate_noise(ctx, dets, T, sample_rate, seed, noise_kwargs=None, device="cuda:0", batch=512, out=None, loading=None,
+def simulate_noise(ctx, dets, T, sample_rate, seed, noise_kwargs=None, device="cuda:0", batch=1024, out=None, loading=None,
                    det_slice=None):
     """sim/noise.py:18-63: one band at a time, [ndet, T] float32 in pW on the device.
     ``dets`` is a ``maria_amd.instrument.Detectors``; bands carry ``NEP`` (W sqrt(s)), ``knee``

@@ -26,11 +26,12 @@ def main():
     ctx = Context(0)
     ctx.set_stream(torch.cuda.current_stream(dev))
     ctx.set_option(5, int(os.environ.get("MRX_NOISE_GENERIC", "0")))
+    ctx.set_option(8, int(os.environ.get("MRX_NOISE_LANES", "0")))
     off = synthetic.hex_pack(D, np.radians(1.0))
     B = torch.as_tensor(np.ascontiguousarray(mnoise.spatial_basis(off, 5, 16, mnoise.diameter(off)), np.float32)).to(dev)
     scale = torch.full((D,), 1e-5, dtype=torch.float32, device=dev)
     out = torch.empty((D, T), dtype=torch.float32, device=dev)
-    for batch in [int(b) for b in os.environ.get("MRX_NOISE_BATCH", "256").split(",")]:
+    for batch in [int(b) for b in os.environ.get("MRX_NOISE_BATCH", "1024").split(",")]:
         need = C.c_size_t()
         ctx.lib.mrx_noise_work_floats(T, 5, batch, C.byref(need))
         work = torch.empty(need.value, dtype=torch.float32, device=dev)
