@@ -399,7 +399,33 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   const float sw = __builtin_sqrtf(g.white_var);
   const int pair0 = blockIdx.x * kPairsPerBlock;
   constexpr int kRegModes = kModes > 0 ? kModes : 1;
+  // the pairs' mode coefficients sqrt(c) (B[a,m] + i B[b,m]) go through LDS: as scalar loads inside
+  // the cell loop each is a stall of its full latency (four in a row per cell and pair: a quarter
+  // of the kernel's time), and hoisted into registers they cost more than the file has left
+  __shared__ float2 coef[kPairsPerBlock][kMaxModes];
+  if constexpr (kModes > 0) {
+    if (t < kPairsPerBlock * kModes) {
+      const int p = t / kModes, m = t - p * kModes;
+      const int pair = pair0 + p < pairs ? pair0 + p : pairs - 1;
+      const int row_a = g.row0 + 2 * pair;
+      const bool has_b = row_a + 1 < g.row0 + g.rows;
+      coef[p][m] = make_float2(g.w_corr * g.basis[(size_t)row_a * kModes + m],
+                               has_b ? g.w_corr * g.basis[(size_t)(row_a + 1) * kModes + m] : 0.0f);
+    }
+    __syncthreads();
+  }
   float2 v[kPairsPerBlock][16];
+  // the mode spectra of cells b + 1 are fetched while the cells b are built: at two waves per
+  // SIMD a load waited for on the spot is a stall of its full latency, eight times per block
+  float2 f0[kRegModes], f1[kRegModes], nf0[kRegModes], nf1[kRegModes];
+  const float2* Fk = g.F + (size_t)k1 * n2 + t;
+  if constexpr (kModes > 0) {
+#pragma unroll
+    for (int m = 0; m < kModes; ++m) {
+      nf0[m] = Fk[(size_t)m * n];
+      nf1[m] = Fk[(size_t)m * n + half];
+    }
+  }
 #pragma unroll
   for (int b = 0; b < 8; ++b) {
     const int k2 = t + 256 * b;
@@ -407,12 +433,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const float am0 = merged_amp(ka, n, g.white_var, pink_var, g.win.k_min);
     const float am1 = merged_amp(kb, n, g.white_var, pink_var, g.win.k_min);
     const bool low0 = (ka < n - ka ? ka : n - ka) < g.win.k_cut, low1 = (kb < n - kb ? kb : n - kb) < g.win.k_cut;
-    float2 f0[kRegModes], f1[kRegModes];
     if constexpr (kModes > 0) {
 #pragma unroll
       for (int m = 0; m < kModes; ++m) {
-        f0[m] = g.F[(size_t)m * n + (size_t)k1 * n2 + k2];
-        f1[m] = g.F[(size_t)m * n + (size_t)k1 * n2 + k2 + half];
+        f0[m] = nf0[m];
+        f1[m] = nf1[m];
+        if (b + 1 < 8) {
+          nf0[m] = Fk[(size_t)m * n + 256 * (b + 1)];
+          nf1[m] = Fk[(size_t)m * n + 256 * (b + 1) + half];
+        }
       }
     }
 #pragma unroll
@@ -437,15 +466,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         }
       }
       if constexpr (kModes > 0) {
-        // the pair's mode coefficients sqrt(c) (B[a,m] + i B[b,m]): uniform, scalar registers
-        const int row_a = g.row0 + 2 * pair;
-        const bool has_b = row_a + 1 < g.row0 + g.rows;
 #pragma unroll
         for (int m = 0; m < kModes; ++m) {
-          const float2 coef = make_float2(g.w_corr * g.basis[(size_t)row_a * kModes + m],
-                                          has_b ? g.w_corr * g.basis[(size_t)(row_a + 1) * kModes + m] : 0.0f);
-          x0 = cfma(coef, f0[m], x0);
-          x1 = cfma(coef, f1[m], x1);
+          x0 = cfma(coef[p][m], f0[m], x0);
+          x1 = cfma(coef[p][m], f1[m], x1);
         }
       }
       v[p][b] = x0;
