@@ -184,6 +184,8 @@ SIGNATURES = {
     "mrx_screen_psd_sum": (_i, [_vp, _i, _i, _d, _d, _d, _d, C.POINTER(_d)]),
     "mrx_map_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _sz]),
     "mrx_bin_map": (_i, [_vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "mrx_bin_map_work_bytes": (_i, [_vp, _i, _i, _vp, _vp]),
+    "mrx_bin_map_bucketed": (_i, [_vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz]),
     "mrx_tod_detrend_window": (_i, [_vp, _vp, _sz, _i, _i, _i, _vp, _vp]),
     "mrx_sosfilt_chunk": (_i, []),
     "mrx_sosfilt_work_doubles": (_i, [_i, _i, _i, C.POINTER(_sz)]),

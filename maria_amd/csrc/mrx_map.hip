@@ -437,6 +437,219 @@ __global__ __launch_bounds__(kBlock) void bin_map_kernel(MapArgs g, BinArgs b) {
   }
 }
 
+// ---- bucketed binning (nearest pixel): no global atomics on scattered addresses ----------
+// Scattered float atomics execute at the memory side at a tenth of the contiguous rate
+// (MI355X_MICROARCH.md, Global float atomics), and the focal plane is sparser than the map, so
+// privatising tiles in LDS merges next to nothing.  Instead the samples are routed
+// to the map: pass A computes every sample's pixel once, sorts its tile's samples by map region
+// (64 x 32 pixels of one plane) with an LDS counting sort and writes them, region by region,
+// into the tile's slot of the work buffer plus one word per (region, tile) that says where;
+// pass B gives every region to a few workgroups that read the region's segments, accumulate in
+// LDS (float64 ds_add) and add the finished block to the map: atomics again, but on whole rows
+// of 64 pixels.  The result equals mrx_bin_map's to float64 rounding (the order of the sums
+// differs).
+constexpr int kBinBx = 64, kBinBy = 32;
+constexpr int kBinRegionPx = kBinBx * kBinBy;              // 2048 pixels: 11 bits
+constexpr int kBinMaxRegions = 2048;
+constexpr int kBinTileEntries = kTileDet * kTileSamples;   // 16 384 samples per tile
+constexpr uint32_t kBinNone = 0xffffffffu;
+
+struct BinEntry {
+  uint32_t local;  // pixel inside the region: (eta & 31) << 6 | (xi & 63)
+  uint32_t det;
+  float w, d;      // sample weight and signal
+};
+static_assert(sizeof(BinEntry) == 16, "BinEntry is one 16-byte store");
+
+struct BucketArgs {
+  int nbx, nby, R;     // regions per row / per column of a plane, in all (channels x nby x nbx)
+  int s0, s1;          // samples [s0, s1) of this time chunk
+  int tiles_x;         // sample tiles of the chunk; tile = blockIdx.y * tiles_x + blockIdx.x
+  int n_tiles;
+  uint32_t* tab;       // [R][n_tiles]: (first entry of the region in the tile's slot) << 16 | count
+  BinEntry* entries;   // [n_tiles][kBinTileEntries]
+};
+
+template <bool kChain>
+__global__ __launch_bounds__(kBlock) void bin_bucket_kernel(MapArgs g, BinArgs b, BucketArgs k) {
+  __shared__ DetConst dets[kTileDet];
+  __shared__ uint32_t part[kBlock];
+  extern __shared__ uint32_t bucket_lds[];
+  uint32_t* words = bucket_lds;                    // [kBinTileEntries] region << 11 | local, by (detector, thread, q)
+  uint32_t* hist = bucket_lds + kBinTileEntries;   // [R]
+  uint32_t* cursor = hist + k.R;                   // [R]
+  const int d0 = blockIdx.y * kTileDet;
+  const int sb = k.s0 + blockIdx.x * kTileSamples + threadIdx.x * kSamplesPerThread;
+  const int nd = min(kTileDet, g.D - d0);
+  const int tile = blockIdx.y * k.tiles_x + blockIdx.x;
+  if ((int)threadIdx.x < nd) dets[threadIdx.x] = make_det_const(g, d0 + threadIdx.x);
+  for (int i = threadIdx.x; i < k.R; i += kBlock) hist[i] = 0u;
+  const Axis ax_eta = g.eta, ax_xi = g.xi;
+  SampleConst sc[kSamplesPerThread];
+#pragma unroll
+  for (int q = 0; q < kSamplesPerThread; ++q) {
+    sample_const(g, sb + q, kChain, sc[q]);
+    sc[q].s = min(max(sb + q, 0), g.T - 1);
+  }
+  __syncthreads();
+  // sweep 1: the pixel of every sample, the tile's histogram over regions
+  for (int dl = 0; dl < nd; ++dl) {
+    const DetConst dc = dets[dl];
+    const int d = d0 + dl;
+    const int chan = b.channel ? min(max(b.channel[d], 0), g.C - 1) : 0;
+#pragma unroll
+    for (int q = 0; q < kSamplesPerThread; ++q) {
+      uint32_t word = kBinNone;
+      if (sb + q < k.s1) {
+        float ox, oy, el_d;
+        sample_offsets<kChain, false>(g, dc, sc[q], ox, oy, el_d);
+        int e0, e1, x0, x1;
+        double pe, px;
+        axis_weights(ax_eta, (double)oy, false, e0, e1, pe);
+        axis_weights(ax_xi, (double)ox, false, x0, x1, px);
+        const uint32_t r = (uint32_t)((chan * k.nby + (e0 >> 5)) * k.nbx + (x0 >> 6));
+        word = (r << 11) | (uint32_t)(((e0 & 31) << 6) | (x0 & 63));
+        atomicAdd(&hist[r], 1u);
+      }
+      words[(dl * kBlock + threadIdx.x) * kSamplesPerThread + q] = word;
+    }
+  }
+  __syncthreads();
+  // exclusive scan of the histogram: where each region's samples start in the tile's slot
+  const int per = (k.R + kBlock - 1) / kBlock;
+  const int r_lo = threadIdx.x * per, r_hi = min(r_lo + per, k.R);
+  uint32_t mine = 0;
+  for (int r = r_lo; r < r_hi; ++r) mine += hist[r];
+  part[threadIdx.x] = mine;
+  __syncthreads();
+  for (int off = 1; off < kBlock; off <<= 1) {
+    const uint32_t add = (int)threadIdx.x >= off ? part[threadIdx.x - off] : 0u;
+    __syncthreads();
+    part[threadIdx.x] += add;
+    __syncthreads();
+  }
+  uint32_t run = part[threadIdx.x] - mine;
+  for (int r = r_lo; r < r_hi; ++r) {
+    const uint32_t c = hist[r];
+    cursor[r] = run;
+    if (c) k.tab[(size_t)r * k.n_tiles + tile] = (run << 16) | c;
+    run += c;
+  }
+  __syncthreads();
+  // sweep 2: every sample to its place
+  BinEntry* slot = k.entries + (size_t)tile * kBinTileEntries;
+  for (int dl = 0; dl < nd; ++dl) {
+    const int d = d0 + dl;
+#pragma unroll
+    for (int q = 0; q < kSamplesPerThread; ++q) {
+      const uint32_t word = words[(dl * kBlock + threadIdx.x) * kSamplesPerThread + q];
+      if (word == kBinNone) continue;
+      const uint32_t pos = atomicAdd(&cursor[word >> 11], 1u);
+      BinEntry en;
+      en.local = word & (uint32_t)(kBinRegionPx - 1);
+      en.det = (uint32_t)d;
+      en.w = b.weight ? b.weight[(size_t)d * b.ld_w + sb + q] : 1.0f;
+      en.d = b.tod[(size_t)d * b.ld_tod + sb + q];
+      slot[pos] = en;
+    }
+  }
+}
+
+// pass B: block (region, split): the region's segments of the split's tiles into LDS, then the
+// block of 64 x 32 pixels into the map
+__global__ __launch_bounds__(kBlock) void bin_accumulate_kernel(MapArgs g, BinArgs b, BucketArgs k, int splits) {
+  extern __shared__ double bin_acc[];  // [S][2][kBinRegionPx]: sum, weight
+  __shared__ uint32_t seg[kBlock];
+  __shared__ int seg_tile[kBlock];
+  __shared__ int seg_end[kBlock];
+  __shared__ int n_seg;
+  // workgroup b runs on XCD b mod 8: with the region straight from blockIdx.x and a power-of-two
+  // number of regions per map row, an XCD would own whole columns of the map -- and the columns
+  // under the scan's centre hold several times the samples of those at its rim (measured: 20 ms
+  // against 9 ms for this kernel).  Rotating by the split spreads every column over the XCDs.
+  const int r = (int)((blockIdx.x + blockIdx.y) % (unsigned)k.R);
+  for (int i = threadIdx.x; i < g.S * 2 * kBinRegionPx; i += kBlock) bin_acc[i] = 0.0;
+  const int per = (k.n_tiles + splits - 1) / splits;
+  const int t0 = blockIdx.y * per, t1 = min(k.n_tiles, t0 + per);
+  const uint32_t* row = k.tab + (size_t)r * k.n_tiles;
+  bool any = false;
+  for (int base = t0; base < t1; base += kBlock) {
+    if (threadIdx.x == 0) n_seg = 0;
+    __syncthreads();
+    const int tile = base + threadIdx.x;
+    const uint32_t v = tile < t1 ? row[tile] : 0u;
+    if (v & 0xffffu) {
+      const int at = atomicAdd(&n_seg, 1);
+      seg[at] = v;
+      seg_tile[at] = tile;
+    }
+    __syncthreads();
+    const int n = n_seg;
+    if (n == 0) continue;  // uniform
+    any = true;
+    // the batch's segments as one list of entries: an inclusive scan of the counts, then every
+    // thread strides through the list (its segment index only ever moves forward) -- all lanes
+    // busy and the loads of successive entries independent, instead of one wave per segment
+    // waiting out the memory latency of each
+    seg_end[threadIdx.x] = (int)threadIdx.x < n ? (int)(seg[threadIdx.x] & 0xffffu) : 0;
+    __syncthreads();
+    for (int off = 1; off < kBlock; off <<= 1) {
+      const int add = (int)threadIdx.x >= off ? seg_end[threadIdx.x - off] : 0;
+      __syncthreads();
+      seg_end[threadIdx.x] += add;
+      __syncthreads();
+    }
+    const int total = seg_end[n - 1];
+    // kPer entries per thread and trip, kBlock apart: every load instruction reads 1 KiB of
+    // consecutive entries (lanes on consecutive entries; 16-byte loads at a 64-byte lane stride
+    // ran 40 % slower), and the loads of a trip are issued together -- the kernel is bound by
+    // memory latency, not by bytes
+    constexpr int kPer = 4;
+    int cur = 0;
+    for (int j0 = threadIdx.x; j0 < total; j0 += kBlock * kPer) {
+      BinEntry en[kPer];
+#pragma unroll
+      for (int i = 0; i < kPer; ++i) {
+        const int j = j0 + i * kBlock;
+        en[i].local = kBinNone;
+        if (j < total) {
+          while (j >= seg_end[cur]) ++cur;
+          const int first = cur ? seg_end[cur - 1] : 0;
+          en[i] = k.entries[(size_t)seg_tile[cur] * kBinTileEntries + (seg[cur] >> 16) + (j - first)];
+        }
+      }
+      for (int s = 0; s < g.S; ++s) {
+        double m[kPer];
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) m[i] = en[i].local != kBinNone ? g.stokes_w[(size_t)en[i].det * g.S + s] : 0.0;
+#pragma unroll
+        for (int i = 0; i < kPer; ++i) {
+          if (m[i] == 0.0) continue;  // zero weight: nothing to add (np.abs(P) entries that are 0); padding
+          const double W = (double)en[i].w;
+          atomicAdd(&bin_acc[(s * 2) * kBinRegionPx + en[i].local], m[i] * (W * (double)en[i].d));
+          atomicAdd(&bin_acc[(s * 2 + 1) * kBinRegionPx + en[i].local], fabs(m[i]) * W);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (!any) return;  // uniform: n_seg is read by every thread between barriers
+  const int per_plane = k.nby * k.nbx;
+  const int chan = r / per_plane, rem = r - chan * per_plane;
+  const int by = rem / k.nbx, bx = rem - by * k.nbx;
+  const size_t plane = (size_t)g.n_eta * g.n_xi;
+  for (int s = 0; s < g.S; ++s) {
+    const size_t base = ((size_t)s * g.C + chan) * plane;
+    for (int i = threadIdx.x; i < kBinRegionPx; i += kBlock) {
+      const double wv = bin_acc[(s * 2 + 1) * kBinRegionPx + i];
+      const int e = (by << 5) + (i >> 6), x = (bx << 6) + (i & 63);
+      if (wv == 0.0 || e >= g.n_eta || x >= g.n_xi) continue;
+      atomicAdd(b.sum + base + (size_t)e * g.n_xi + x, bin_acc[(s * 2) * kBinRegionPx + i]);
+      atomicAdd(b.wgt + base + (size_t)e * g.n_xi + x, wv);
+    }
+  }
+}
+
 template <bool kChain, bool kCal, int kS>
 __global__ __launch_bounds__(kBlock) void map_sample_kernel(MapArgs g) {
   __shared__ DetConst dets[kTileDet];
@@ -609,15 +822,11 @@ int mrx_map_sample(mrx_ctx* ctx, const mrx_sky_map* map, const mrx_map_cal* cal,
   return MRX_OK;
 }
 
-int mrx_bin_map(mrx_ctx* ctx, const mrx_sky_map* map, const float* d_tod, size_t ld_tod,
-                const float* d_weight, size_t ld_weight, const float* d_az, const float* d_el, int T,
-                const double* d_transform, const float* d_dx, const float* d_dy,
-                const double* d_stokes_w, const int32_t* d_channel, int D, double* d_sum,
-                double* d_wgt) {
-  MRX_ENTER(ctx);
-  if (!ctx) return MRX_ERR_INVALID;
-  MRX_REQUIRE(ctx, D >= 0 && T >= 0, "negative size");
-  if (D == 0 || T == 0) return MRX_OK;
+static int bin_map_args(mrx_ctx* ctx, const mrx_sky_map* map, const float* d_tod, size_t ld_tod,
+                        const float* d_weight, size_t ld_weight, const float* d_az, const float* d_el, int T,
+                        const double* d_transform, const float* d_dx, const float* d_dy,
+                        const double* d_stokes_w, const int32_t* d_channel, int D, double* d_sum,
+                        double* d_wgt, MapArgs& g, BinArgs& b) {
   MRX_REQUIRE(ctx, map && d_tod && d_az && d_el && d_dx && d_dy && d_stokes_w && d_sum && d_wgt, "null pointer");
   MRX_REQUIRE(ctx, map->n_channels >= 1 && map->n_stokes >= 1 && map->n_stokes <= kMaxStokes &&
                        map->n_eta >= 2 && map->n_xi >= 2,
@@ -625,7 +834,7 @@ int mrx_bin_map(mrx_ctx* ctx, const mrx_sky_map* map, const float* d_tod, size_t
   MRX_REQUIRE(ctx, map->deta != 0.0 && map->dxi != 0.0, "map axes need a non-zero step");
   MRX_REQUIRE(ctx, (long long)map->n_eta * map->n_xi < (1LL << 31), "a map plane must hold fewer than 2^31 pixels");
   MRX_REQUIRE(ctx, ld_tod >= (size_t)T && (!d_weight || ld_weight >= (size_t)T), "leading dimension smaller than T");
-  MapArgs g{};
+  g = MapArgs{};
   g.eta = Axis{map->n_eta, map->eta0, 1.0 / map->deta};
   g.xi = Axis{map->n_xi, map->xi0, 1.0 / map->dxi};
   g.C = map->n_channels;
@@ -649,7 +858,24 @@ int mrx_bin_map(mrx_ctx* ctx, const mrx_sky_map* map, const float* d_tod, size_t
   g.stokes_w = d_stokes_w;
   g.D = D;
   g.T = T;
-  BinArgs b{d_tod, ld_tod, d_weight, ld_weight, d_channel, d_sum, d_wgt};
+  b = BinArgs{d_tod, ld_tod, d_weight, ld_weight, d_channel, d_sum, d_wgt};
+  return MRX_OK;
+}
+
+int mrx_bin_map(mrx_ctx* ctx, const mrx_sky_map* map, const float* d_tod, size_t ld_tod,
+                const float* d_weight, size_t ld_weight, const float* d_az, const float* d_el, int T,
+                const double* d_transform, const float* d_dx, const float* d_dy,
+                const double* d_stokes_w, const int32_t* d_channel, int D, double* d_sum,
+                double* d_wgt) {
+  MRX_ENTER(ctx);
+  if (!ctx) return MRX_ERR_INVALID;
+  MRX_REQUIRE(ctx, D >= 0 && T >= 0, "negative size");
+  if (D == 0 || T == 0) return MRX_OK;
+  MapArgs g;
+  BinArgs b;
+  const int rc = bin_map_args(ctx, map, d_tod, ld_tod, d_weight, ld_weight, d_az, d_el, T, d_transform, d_dx, d_dy,
+                              d_stokes_w, d_channel, D, d_sum, d_wgt, g, b);
+  if (rc != MRX_OK) return rc;
   dim3 grid(mrx_ceil_div(T, kTileSamples), mrx_ceil_div(D, kTileDet));
   MRX_REQUIRE(ctx, grid.y <= 65535u, "D too large for one launch");
   if (ctx->options[MRX_OPT_POINTING_CHAIN])
@@ -657,6 +883,82 @@ int mrx_bin_map(mrx_ctx* ctx, const mrx_sky_map* map, const float* d_tod, size_t
   else
     hipLaunchKernelGGL(bin_map_kernel<false>, grid, dim3(kBlock), 0, ctx->stream, g, b);
   MRX_CHECK_LAUNCH(ctx);
+  return MRX_OK;
+}
+
+// regions of a map for the bucketed form, or 0 when it does not apply
+static int bin_regions(const mrx_sky_map* map, int* nbx, int* nby) {
+  if (!map || map->bilinear || map->n_eta < 2 || map->n_xi < 2 || map->n_channels < 1) return 0;
+  *nbx = mrx_ceil_div(map->n_xi, kBinBx);
+  *nby = mrx_ceil_div(map->n_eta, kBinBy);
+  const long long R = (long long)map->n_channels * *nbx * *nby;
+  return R <= kBinMaxRegions ? (int)R : 0;
+}
+
+int mrx_bin_map_work_bytes(const mrx_sky_map* map, int D, int T, size_t* min_bytes, size_t* full_bytes) {
+  int nbx, nby;
+  const int R = bin_regions(map, &nbx, &nby);
+  if (!R || D < 1 || T < 1 || !min_bytes || !full_bytes) return R ? MRX_ERR_INVALID : MRX_ERR_UNSUPPORTED;
+  // one column of tiles (all detectors x 1024 samples): its slots and its words of the table
+  const size_t col = (size_t)mrx_ceil_div(D, kTileDet) * ((size_t)kBinTileEntries * sizeof(BinEntry) + (size_t)R * sizeof(uint32_t));
+  *min_bytes = col;
+  *full_bytes = col * (size_t)mrx_ceil_div(T, kTileSamples);
+  return MRX_OK;
+}
+
+int mrx_bin_map_bucketed(mrx_ctx* ctx, const mrx_sky_map* map, const float* d_tod, size_t ld_tod,
+                         const float* d_weight, size_t ld_weight, const float* d_az, const float* d_el, int T,
+                         const double* d_transform, const float* d_dx, const float* d_dy,
+                         const double* d_stokes_w, const int32_t* d_channel, int D, double* d_sum,
+                         double* d_wgt, void* d_work, size_t work_bytes) {
+  MRX_ENTER(ctx);
+  if (!ctx) return MRX_ERR_INVALID;
+  MRX_REQUIRE(ctx, D >= 0 && T >= 0, "negative size");
+  if (D == 0 || T == 0) return MRX_OK;
+  BucketArgs k{};
+  k.R = bin_regions(map, &k.nbx, &k.nby);
+  if (!k.R)
+    return mrx_fail(ctx, MRX_ERR_UNSUPPORTED, "mrx_bin_map_bucketed: nearest-pixel maps of at most %d regions of %d x %d pixels (use mrx_bin_map)",
+                    kBinMaxRegions, kBinBx, kBinBy);
+  MapArgs g;
+  BinArgs b;
+  const int rc = bin_map_args(ctx, map, d_tod, ld_tod, d_weight, ld_weight, d_az, d_el, T, d_transform, d_dx, d_dy,
+                              d_stokes_w, d_channel, D, d_sum, d_wgt, g, b);
+  if (rc != MRX_OK) return rc;
+  const int tiles_y = mrx_ceil_div(D, kTileDet);
+  MRX_REQUIRE(ctx, tiles_y <= 65535, "D too large for one launch");
+  const size_t col = (size_t)tiles_y * ((size_t)kBinTileEntries * sizeof(BinEntry) + (size_t)k.R * sizeof(uint32_t));
+  MRX_REQUIRE(ctx, d_work && (reinterpret_cast<uintptr_t>(d_work) & 15u) == 0 && work_bytes >= col,
+              "work buffer: 16-byte aligned, at least mrx_bin_map_work_bytes' minimum");
+  const int cols_total = mrx_ceil_div(T, kTileSamples);
+  int cols = (int)(work_bytes / col < (size_t)cols_total ? work_bytes / col : (size_t)cols_total);
+  // the table's words (base << 16 | count) index a region's row by tile: [R][n_tiles] uint32 behind the slots
+  const size_t lds_a = ((size_t)kBinTileEntries + 2 * (size_t)k.R) * sizeof(uint32_t);
+  const size_t lds_b = (size_t)g.S * 2 * kBinRegionPx * sizeof(double);
+  const bool chain = ctx->options[MRX_OPT_POINTING_CHAIN] != 0;
+  if (chain) MRX_LDS_CAP(ctx, bin_bucket_kernel<true>, lds_a);
+  else MRX_LDS_CAP(ctx, bin_bucket_kernel<false>, lds_a);
+  MRX_LDS_CAP(ctx, bin_accumulate_kernel, lds_b);
+  // enough workgroups per region to fill the chip: the regions under the scan hold most samples
+  // (the time does not depend on the number from 8192 items up: measured)
+  int splits = 32768 / k.R;
+  splits = splits < 1 ? 1 : splits;
+  for (int c0 = 0; c0 < cols_total; c0 += cols) {
+    const int nc = cols_total - c0 < cols ? cols_total - c0 : cols;
+    k.tiles_x = nc;
+    k.n_tiles = nc * tiles_y;
+    k.s0 = c0 * kTileSamples;
+    k.s1 = (long long)(c0 + nc) * kTileSamples < (long long)T ? (c0 + nc) * kTileSamples : T;
+    k.entries = reinterpret_cast<BinEntry*>(d_work);
+    k.tab = reinterpret_cast<uint32_t*>(k.entries + (size_t)k.n_tiles * kBinTileEntries);
+    MRX_HIP(ctx, hipMemsetAsync(k.tab, 0, (size_t)k.R * k.n_tiles * sizeof(uint32_t), ctx->stream));
+    const dim3 grid_a(nc, tiles_y);
+    if (chain) hipLaunchKernelGGL(bin_bucket_kernel<true>, grid_a, dim3(kBlock), lds_a, ctx->stream, g, b, k);
+    else hipLaunchKernelGGL(bin_bucket_kernel<false>, grid_a, dim3(kBlock), lds_a, ctx->stream, g, b, k);
+    const int sp = splits < k.n_tiles ? splits : k.n_tiles;
+    hipLaunchKernelGGL(bin_accumulate_kernel, dim3(k.R, sp), dim3(kBlock), lds_b, ctx->stream, g, b, k, sp);
+    MRX_CHECK_LAUNCH(ctx);
+  }
   return MRX_OK;
 }
 

@@ -1,6 +1,6 @@
 """``BinMapper`` (maria/mappers/bin_mapper.py): the TODs binned back onto a tangent-plane grid,
 ``map = ((W * D) @ P) / (W @ |P|)`` with the Stokes-weighted pointing matrix of
-map/projection.py:134-179 -- on the device as float64 atomic adds (``mrx_bin_map``), never
+map/projection.py:134-179 -- on the device (``mrx_bin_map_bucketed`` / ``mrx_bin_map``), never
 materialising P.  ``tod_preprocessing`` runs ``maria_amd.tod_processing.process_tod`` first, as
 mappers/base.py:138 does; the map post-processing pipeline stays with maria's front end."""
 
@@ -16,6 +16,35 @@ from ._lib import Context, MrxSkyMap, ptr
 from .map import ProjectionMap, mueller_row
 
 logger = logging.getLogger("maria")
+
+
+# work buffer of the bucketed binning: all samples in one go needs 16 bytes per sample; beyond this
+# the call walks the time axis in chunks
+BIN_WORK_LIMIT_BYTES = 24 << 30
+
+
+def bin_map(ctx, sky, signal, weight, az, el, transform, dx, dy, stokes_w, channel, msum, mwgt, bucketed=None):
+    """``map_sum += (W * D) @ P``, ``map_wgt += W @ |P|`` for one TOD on the device
+    (mappers/bin_mapper.py:84-120).  Nearest-pixel maps of up to 2048 regions take
+    ``mrx_bin_map_bucketed`` (samples routed to map regions, summed in LDS: no scattered global
+    atomics); bilinear and larger maps ``mrx_bin_map`` (float64 atomics).  ``bucketed``: force
+    (True) or forbid (False) the first form."""
+    D, T = signal.shape
+    args = (C.byref(sky), ptr(signal), signal.stride(0), ptr(weight), 0 if weight is None else weight.stride(0),
+            ptr(az), ptr(el), T, ptr(transform), ptr(dx), ptr(dy), ptr(stokes_w), ptr(channel), D, ptr(msum), ptr(mwgt))
+    lo, full = C.c_size_t(), C.c_size_t()
+    fits = ctx.lib.mrx_bin_map_work_bytes(C.byref(sky), D, T, C.byref(lo), C.byref(full)) == 0
+    if bucketed is True and not fits:
+        raise ValueError("the bucketed binning takes nearest-pixel maps of at most 2048 regions of 64 x 32 pixels")
+    if fits and bucketed is not False:
+        free = torch.cuda.mem_get_info(signal.device)[0]
+        size = max(lo.value, min(full.value, BIN_WORK_LIMIT_BYTES, max(free // 2, lo.value)))
+        work = torch.empty(size, dtype=torch.uint8, device=signal.device)
+        ctx.call("mrx_bin_map_bucketed", *args, ptr(work), work.numel())
+        torch.cuda.current_stream(signal.device).synchronize()  # the buffer goes back to the allocator
+        del work
+    else:
+        ctx.call("mrx_bin_map", *args)
 
 
 class BinMapper:
@@ -90,9 +119,7 @@ class BinMapper:
             d_chan = torch.as_tensor(chan).to(dev)
             az, el = f32(coords._baz), f32(coords._bel)
             dx, dy = f32(coords.offsets[:, 0]), f32(coords.offsets[:, 1])
-            ctx.call("mrx_bin_map", C.byref(sky), ptr(signal), signal.stride(0), ptr(weight), 0 if weight is None else weight.stride(0),
-                     ptr(az), ptr(el), signal.shape[1],
-                     ptr(transform), ptr(dx), ptr(dy), ptr(stokes_w), ptr(d_chan), dets.n, ptr(msum), ptr(mwgt))
+            bin_map(ctx, sky, signal, weight, az, el, transform, dx, dy, stokes_w, d_chan, msum, mwgt)
             torch.cuda.current_stream(dev).synchronize()
         data = (msum / mwgt).cpu().numpy()  # 0/0 = nan where nothing was observed, as numpy gives the reference
         self.products = {"data": data, "weight": mwgt.cpu().numpy(), "sum": msum.cpu().numpy()}

@@ -80,7 +80,7 @@ def bench_bin():
     tod = torch.randn((D, T), dtype=torch.float32, device=dev)
     d_az, d_el, d_dx, d_dy = f32(az), f32(el), f32(off[:, 0]), f32(off[:, 1])
     d_sw = torch.ones((D, 1), dtype=torch.float64, device=dev)
-    for n in (256, 1024):
+    for n in (256, 1024, 2048):
         for bil in (0, 1):
             msum = torch.zeros((1, 1, n, n), dtype=torch.float64, device=dev)
             mwgt = torch.zeros_like(msum)
@@ -91,7 +91,23 @@ def bench_bin():
             med, mn = timeit(fn, 3)
             print(f"bin_map {n}x{n} bilinear={bil}: D={D} T={T}: median {med:.2f} ms -> {D*T/med/1e6:.1f} G samples/s "
                   f"({4.0*D*T/med/1e6:.0f} GB/s of TOD read); hit pixels {int((mwgt > 0).sum())}")
-
+            if bil == 0:
+                lo, full = C.c_size_t(), C.c_size_t()
+                ctx.lib.mrx_bin_map_work_bytes(C.byref(sky), D, T, C.byref(lo), C.byref(full))
+                one_atomic = mwgt / 4  # timeit ran the atomic form 4 times into the same maps
+                for frac in (1.0, 0.25):
+                    work = torch.empty(int(full.value * frac), dtype=torch.uint8, device=dev)
+                    mwgt.zero_()
+                    msum.zero_()
+                    fn2 = lambda: ctx.call("mrx_bin_map_bucketed", C.byref(sky), ptr(tod), tod.stride(0), None, 0, ptr(d_az), ptr(d_el), T, None,  # noqa: E731
+                                           ptr(d_dx), ptr(d_dy), ptr(d_sw), None, D, ptr(msum), ptr(mwgt), ptr(work), work.numel())
+                    fn2()
+                    torch.cuda.synchronize()
+                    same = float((mwgt - one_atomic).abs().max())
+                    med, mn = timeit(fn2, 3)
+                    print(f"bin_map_bucketed {n}x{n}: work {work.numel() / 2**30:.1f} GiB: median {med:.2f} ms -> {D*T/med/1e6:.1f} G samples/s; "
+                          f"max |hits - atomic form's| {same:.3g}")
+                    del work
 
 if __name__ == "__main__" and os.environ.get("MRX_BENCH_BIN"):
     bench_bin()

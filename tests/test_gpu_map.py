@@ -240,6 +240,66 @@ def test_simulation_with_map(gpu_ctx, frame):
     np.testing.assert_allclose(tod2.data["map"], got * factor, rtol=3e-6, atol=1e-7 * np.abs(got * factor).max())
 
 
+@pytest.mark.parametrize("shape,chunked", [((12, 16), False), ((70, 150), False), ((70, 150), True), ((33, 64), True)])
+def test_bucketed_bin_map_matches_the_atomic_form_and_the_oracle(gpu_ctx, shape, chunked):
+    """mrx_bin_map_bucketed: samples routed to map regions of 64 x 32 pixels and summed in LDS.
+    Against mrx_bin_map on the same inputs (float64 rounding: the order of the sums differs) --
+    weights, two Stokes planes, two channels, samples beyond the grid, a detector count that is
+    no multiple of 16, a length that is no multiple of 1024, maps of one and of several regions,
+    and the time axis walked in chunks of one column of tiles (the minimum work buffer)."""
+    import ctypes as C
+
+    import torch
+
+    from maria_amd._lib import MrxSkyMap, ptr
+    from oracle import hotpath, mapsample
+
+    rng = np.random.default_rng(16)
+    t, az, el, off = _scan(D=37, T=3301, fov_deg=0.5)
+    transform = _sky_rotation(t)
+    centre = _centre(az, el, transform)
+    az_d, el_d = hotpath.broadcast(off, az, el)
+    ox = mapsample.phi_theta_to_offsets(*mapsample.frame_angles(az_d, el_d, transform), *centre)
+    n_eta, n_xi = shape
+    half_eta, half_xi = 0.8 * float(np.abs(ox[..., 1]).max()), 0.8 * float(np.abs(ox[..., 0]).max())
+    eta = np.linspace(half_eta, -half_eta, n_eta)
+    xi = np.linspace(-half_xi, half_xi, n_xi)
+    tod = rng.normal(1.0, 0.5, (len(off), len(t))).astype(np.float32)
+    wts = rng.uniform(0.5, 2.0, tod.shape).astype(np.float32)
+    gamma = np.where(np.arange(len(off)) % 2 == 0, np.nan, rng.uniform(0, np.pi, len(off)))
+    sw = mapsample.mueller_row(gamma)[:, :2]
+    chan = (np.arange(len(off)) % 2).astype(np.int32)
+    dev = "cuda:0"
+    f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)  # noqa: E731
+    d_tod, d_w, d_az, d_el, d_dx, d_dy = f32(tod), f32(wts), f32(az), f32(el), f32(off[:, 0]), f32(off[:, 1])
+    d_sw = torch.as_tensor(np.ascontiguousarray(sw, np.float64)).to(dev)
+    d_tr = torch.as_tensor(transform.reshape(-1, 9)).to(dev)
+    d_chan = torch.as_tensor(chan).to(dev)
+    sky = MrxSkyMap(None, 2, 2, n_eta, n_xi, float(eta[0]), float(eta[1] - eta[0]), float(xi[0]), float(xi[1] - xi[0]),
+                    centre[0], centre[1], 0, 0)
+    args = (C.byref(sky), ptr(d_tod), d_tod.stride(0), ptr(d_w), d_w.stride(0), ptr(d_az), ptr(d_el), len(t),
+            ptr(d_tr), ptr(d_dx), ptr(d_dy), ptr(d_sw), ptr(d_chan), len(off))
+    ref = [torch.zeros((2, 2, n_eta, n_xi), dtype=torch.float64, device=dev) for _ in range(2)]
+    gpu_ctx.call("mrx_bin_map", *args, ptr(ref[0]), ptr(ref[1]))
+    lo, full = C.c_size_t(), C.c_size_t()
+    assert gpu_ctx.lib.mrx_bin_map_work_bytes(C.byref(sky), len(off), len(t), C.byref(lo), C.byref(full)) == 0
+    assert full.value == 4 * lo.value  # ceil(3301 / 1024) columns of tiles
+    work = torch.empty(lo.value if chunked else full.value, dtype=torch.uint8, device=dev)
+    got = [torch.full((2, 2, n_eta, n_xi), 1.0, dtype=torch.float64, device=dev) for _ in range(2)]  # adds to what is there
+    gpu_ctx.call("mrx_bin_map_bucketed", *args, ptr(got[0]), ptr(got[1]), ptr(work), work.numel())
+    for g, r in zip(got, ref):
+        g, r = g.cpu().numpy() - 1.0, r.cpu().numpy()
+        assert np.abs(r).max() > 0 and np.abs(g - r).max() <= 1e-12 * np.abs(r).max()
+    ref_sum, ref_wgt = mapsample.bin_map(az_d, el_d, tod, wts, eta, xi, centre, sw, 2, channel=chan, n_channels=2,
+                                         transform_stack=transform, bilinear=False)
+    assert abs(float(got[1].sum() - got[1].numel()) / ref_wgt.sum() - 1) < 1e-9  # every sample lands somewhere
+    # what the bucketed form does not take
+    bil = MrxSkyMap(None, 2, 2, n_eta, n_xi, float(eta[0]), float(eta[1] - eta[0]), float(xi[0]), float(xi[1] - xi[0]), centre[0], centre[1], 1, 0)
+    assert gpu_ctx.lib.mrx_bin_map_work_bytes(C.byref(bil), len(off), len(t), C.byref(lo), C.byref(full)) != 0
+    big = MrxSkyMap(None, 2, 2, 4096, 4096, 1.0, -1e-3, -1.0, 1e-3, centre[0], centre[1], 0, 0)
+    assert gpu_ctx.lib.mrx_bin_map_work_bytes(C.byref(big), len(off), len(t), C.byref(lo), C.byref(full)) != 0
+
+
 @pytest.mark.parametrize("bilinear", [False, True])
 def test_bin_map_matches_oracle(gpu_ctx, bilinear, pointing_mode):
     """mrx_bin_map (BinMapper.run, mappers/bin_mapper.py:84-120): the transpose of the pointing
