@@ -9,7 +9,7 @@ cp $SRC/bench.json $ROOT/profiles/${TAG}_bench.json
 # writer launches per step = the detector blocks the profiled bench line reports
 BLOCKS=$(python3 -c "import json,sys; print(json.load(open(sys.argv[1]))['stage_ms']['detector_blocks'])" $SRC/bench.json)
 python3 $ROOT/scripts/pmc_summary.py $SRC $ROOT/profiles/$TAG $BLOCKS
-for k in krj noise map; do [ -f $SRC/$k/run_kernel_stats.csv ] && cp $SRC/$k/run_kernel_stats.csv $ROOT/profiles/${TAG}_${k}_kernel_stats.csv; done
+for k in krj noise map bin; do [ -f $SRC/$k/run_kernel_stats.csv ] && cp $SRC/$k/run_kernel_stats.csv $ROOT/profiles/${TAG}_${k}_kernel_stats.csv; done
 grep -h "pW\|groups" $SRC/krj_bench.log > $ROOT/profiles/${TAG}_krj_bench.txt
 grep -h "^noise" $SRC/noise_bench.log > $ROOT/profiles/${TAG}_noise_bench.txt
 python3 - $SRC/noise_pmc/run_counter_collection.csv > $ROOT/profiles/${TAG}_noise_pmc.txt <<'PY'
@@ -25,5 +25,6 @@ for k in sorted(tot):
     if k.startswith("noise"):
         print(f"{k:40s} launches {max(cnt[(k, c)] for c in tot[k]):4d} " + " ".join(f"{c}={v / cnt[(k, c)]:.4g}" for c, v in sorted(tot[k].items())))
 PY
+grep -h "^bin_map" $SRC/bin_bench.log > $ROOT/profiles/${TAG}_bin_bench.txt
 grep -h "^map_sample" $SRC/map_bench.log > $ROOT/profiles/${TAG}_map_bench.txt
 ls -la $ROOT/profiles | grep $TAG

@@ -20,6 +20,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/krj -o run -- pytho
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/noise -o run -- python3 $ROOT/scripts/noise_bench.py 10000 240000 3 > $OUT/noise_bench.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/noise_pmc -o run -- python3 $ROOT/scripts/noise_bench.py 10000 240000 1 > $OUT/noise_pmc.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/map -o run -- python3 $ROOT/scripts/map_bench.py 10000 240000 2 > $OUT/map_bench.log 2>&1
+MRX_BENCH_BIN=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bin -o run -- python3 $ROOT/scripts/map_bench.py 10000 240000 > $OUT/bin_bench.log 2>&1
 cd $ROOT
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.log
 tail -c 400 $OUT/bench.json
