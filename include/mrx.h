@@ -256,6 +256,22 @@ int mrx_spline_upsample_krj(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
                             const float* d_cal_values, int n_el, int n_bands,
                             float* d_out, size_t ld_out);
 
+/* TOD.to("K_RJ") applied to the COARSE loading before the spline: d_out[j * D + d] =
+ * d_loading[j * D + d] / den_band(d)(el_det(d, j)), time-major like mrx_atm_sample's output,
+ * with the detector elevation of coarse step j from the coarse boresight elevation (the same
+ * float32 formula as mrx_spline_upsample_krj).  mrx_spline_prepare + mrx_spline_upsample of
+ * d_out then give the K_RJ TOD at the pW writer's cost (HBM-bound instead of arithmetic-bound).
+ * It is S[y / g] in place of the reference's S[y] / g (S the spline, g = den(el_det(t))): the
+ * two differ by the spline's interpolation error on g alone -- g is smooth in time but for the
+ * kinks where a detector's elevation crosses a node of the table's axis, where the error is at
+ * most 0.25 x (jump of the relative slope of den at the node) x (elevation step per coarse
+ * sample).  The caller bounds that on the host and takes mrx_spline_upsample_krj when it is
+ * not far below the tolerance (maria_amd/pipeline.py: DevicePath.coarse_krj_bound). */
+int mrx_coarse_to_krj(mrx_ctx* ctx, const float* d_loading, int D, int Ta, const float* d_bore_el_coarse,
+                      const float* d_dx, const float* d_dy, const int32_t* d_band,
+                      const float* d_cal_axis_el, const float* d_cal_values, int n_el, int n_bands,
+                      float* d_out);
+
 /* TOD.to("K_RJ") of a field that is already at the full rate -- the noise (and later map /
  * cmb) fields, tod/tod.py:106-142 -- in place: d_data[row(d) * ld + s] *= d_scale[d] /
  * den_band(d)(el(d, s)), with the arguments of mrx_spline_upsample_krj. */

@@ -691,6 +691,43 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
   }
 }
 
+// TOD.to("K_RJ") on the COARSE grid, before the spline: out[j][d] = loading[j][d] /
+// den_band(d)(el_det(d, j)) with the detector elevation of the full formula at coarse step j.
+// The reference divides the full-rate spline S[y](t) by g(t) = den(el_det(t)) sample by sample;
+// S[y / g] differs from S[y] / g by the spline's interpolation error on g alone (g is smooth in
+// time but for the kinks where the elevation crosses a node of the table's axis): the host
+// bounds it before choosing this form (DevicePath.coarse_krj_bound) and the TOD is then written
+// by the plain pW writer.  Time-major like the sampler's output: lanes are detectors.
+constexpr int kCoarseKrjSteps = 32;
+
+__global__ __launch_bounds__(kBlock) void coarse_krj_kernel(
+    const float* __restrict__ loading, int D, int Ta, const float* __restrict__ bore_el,
+    const float* __restrict__ dxs, const float* __restrict__ dys, const int32_t* __restrict__ band,
+    const float* __restrict__ cal_axis, const float* __restrict__ cal_values, int n_el, int n_bands,
+    float* __restrict__ out) {
+  extern __shared__ __align__(16) float4 cal_cells[];  // [n_bands][n_el - 1], see stage_cal_cells
+  __shared__ float2 trig[kCoarseKrjSteps];  // (cos, sin) of (boresight elevation - pi/2) of the block's steps
+  stage_cal_cells(cal_cells, cal_axis, cal_values, n_el, n_bands);
+  const int j0 = blockIdx.y * kCoarseKrjSteps, j1 = min(j0 + kCoarseKrjSteps, Ta);
+  if ((int)threadIdx.x < j1 - j0) {
+    const float a = bore_el[j0 + threadIdx.x] - 1.57079637050628662109375f;
+    trig[threadIdx.x] = make_float2(cosf(a), sinf(a));
+  }
+  __syncthreads();
+  const int d = blockIdx.x * kBlock + threadIdx.x;
+  if (d >= D) return;
+  const CalDet c = make_cal_det(dxs[d], dys[d], min(max(band[d], 0), n_bands - 1), 1.0f);
+  const float4* C = cal_cells + c.band * (n_el - 1);
+  const float el_first = cal_cells[0].x, el_last = cal_axis[n_el - 1], el_inv = cal_cells[0].z;
+  for (int j = j0; j < j1; ++j) {
+    // coords/transforms.py:20-28 in float32: im = sin(el_det), el_det = asin(im)
+    const float2 cs = trig[j - j0];
+    const float im = __fadd_rn(__fmul_rn(c.a_re, cs.y), __fmul_rn(c.a_im, cs.x));
+    const float den = den_lookup(asinf(im), C, n_el, el_first, el_last, el_inv);
+    out[(size_t)j * D + d] = loading[(size_t)j * D + d] * __builtin_amdgcn_rcpf(den);
+  }
+}
+
 // TOD.to("K_RJ") of a field that is already at the full rate (noise, map, cmb;
 // tod/tod.py:106-142), in place: data[row(d)][s] *= scale_d / den_band(d)(el(d, s)).
 // Same tile as the fused writer: 16 detectors x 1024 samples per workgroup, 16-byte
@@ -936,6 +973,27 @@ int mrx_spline_upsample_krj(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
                      ta0, 1.0 / dta, d_t, T, d_scale, d_rows, d_bore_el, d_dx,
                      d_dy, d_band, d_cal_axis_el, d_cal_values, n_el, n_bands,
                      d_out, ld_out, vec_ok, groups);
+  MRX_CHECK_LAUNCH(ctx);
+  return MRX_OK;
+}
+
+int mrx_coarse_to_krj(mrx_ctx* ctx, const float* d_loading, int D, int Ta, const float* d_bore_el_coarse,
+                      const float* d_dx, const float* d_dy, const int32_t* d_band,
+                      const float* d_cal_axis_el, const float* d_cal_values, int n_el, int n_bands,
+                      float* d_out) {
+  MRX_ENTER(ctx);
+  if (!ctx) return MRX_ERR_INVALID;
+  MRX_REQUIRE(ctx, D >= 0 && Ta >= 0, "negative size");
+  if (D == 0 || Ta == 0) return MRX_OK;
+  MRX_REQUIRE(ctx, d_loading && d_out && d_bore_el_coarse && d_dx && d_dy && d_band && d_cal_axis_el && d_cal_values,
+              "null pointer");
+  MRX_REQUIRE(ctx, n_el >= 2 && n_bands >= 1 && (size_t)n_el * (1 + n_bands) <= 8192,
+              "calibration tables need 2 <= n_el and n_el*(1+n_bands) <= 8192");
+  const dim3 grid(mrx_ceil_div(D, kBlock), mrx_ceil_div(Ta, kCoarseKrjSteps));
+  MRX_REQUIRE(ctx, grid.y <= 65535u, "Ta too large for one launch");
+  const size_t lds = sizeof(float4) * (size_t)(n_el - 1) * n_bands;
+  hipLaunchKernelGGL(coarse_krj_kernel, grid, dim3(kBlock), lds, ctx->stream, d_loading, D, Ta, d_bore_el_coarse,
+                     d_dx, d_dy, d_band, d_cal_axis_el, d_cal_values, n_el, n_bands, d_out);
   MRX_CHECK_LAUNCH(ctx);
   return MRX_OK;
 }

@@ -334,8 +334,10 @@ class DevicePath:
             self.pwv0, ptr(self.d_pwv), ptr(self.d_loading), ptr(self.d_flags),
         )
 
-    def prepare(self):
-        self.ctx.call("mrx_spline_prepare", ptr(self.d_loading), self.D, self.Ta, ptr(self.d_ym))
+    def prepare(self, krj=False):
+        """Second derivatives of the coarse loading (``krj``: of the coarse loading in K_RJ that
+        coarse_to_krj() made)."""
+        self.ctx.call("mrx_spline_prepare", ptr(self.d_loading_krj if krj else self.d_loading), self.D, self.Ta, ptr(self.d_ym))
 
     def upsample(self, out):
         self.ctx.call(
@@ -357,7 +359,7 @@ class DevicePath:
         """[D, Ta] float64 zenith-scaled pwv in the caller's detector order."""
         return self.d_pwv.T.index_select(0, self._d_inverse)
 
-    def run(self, out=None, blocks=None, writer_events=None):
+    def run(self, out=None, blocks=None, writer_events=None, krj=False):
         """The whole path for this shard; returns the [D, T] float32 TOD tensor.  The
         stages carry the reference's progress-bar names as profiler ranges (roctx via
         torch.cuda.nvtx).
@@ -367,17 +369,27 @@ class DevicePath:
         side stream) runs beside the HBM-bound writer of block b: 2.79 against 3.10 ms on
         atlast_10k with 4 blocks.  Default: ``default_blocks()`` (never with
         ``keep_pwv``: its consumers want whole coarse arrays); ``blocks=1`` runs the stages back
-        to back on the caller's stream."""
+        to back on the caller's stream.  ``krj``: the TOD in K_RJ (set_calibration first): the
+        conversion is applied to the coarse loading before the spline when coarse_krj_bound() allows
+        (the pW writer then writes K_RJ), per sample by mrx_spline_upsample_krj otherwise."""
         if out is None:
             out = torch.empty((self.D, self.T), dtype=torch.float32, device=self.device)
         if blocks is None:
             blocks = self.default_blocks()
+        if krj and not self.coarse_krj_bound() <= self.COARSE_KRJ_LIMIT:
+            # the per-sample conversion fused into the writer (set_calibration first)
+            self.sample()
+            self.prepare()
+            self.upsample_krj(out)
+            return out
         if blocks > 1 and self.d_pwv is None:
-            return self._run_pipelined(out, blocks, writer_events=writer_events)
+            return self._run_pipelined(out, blocks, writer_events=writer_events, krj=krj)
         with _range("Sampling turbulence + Computing atmospheric emission"):
             self.sample()
         with _range("Upsampling atmospheric loading"):
-            self.prepare()
+            if krj:
+                self.coarse_to_krj()
+            self.prepare(krj=krj)
             self.upsample(out)
         return out
 
@@ -410,7 +422,7 @@ class DevicePath:
         self._pipe = st
         return st
 
-    def _run_pipelined(self, out, blocks, resident_wgs_per_cu=4, writer_events=None, serial_events=None):
+    def _run_pipelined(self, out, blocks, resident_wgs_per_cu=4, writer_events=None, serial_events=None, krj=False):
         """sample + prepare of block b on the side stream, the writer of block b on the caller's
         stream behind an event; block 0's sampler takes the whole chip (nothing to run beside).
         ``writer_events``: a list that receives one (start, end) pair of timing events per writer
@@ -442,6 +454,8 @@ class DevicePath:
             )
             if serial:
                 tev[1].record(main)
+            if krj:  # TOD.to("K_RJ") on the coarse grid: the writer below then writes K_RJ at the pW writer's cost
+                self.coarse_to_krj(st["loading"][i], n, slice(lo, hi), ctx2)
             ctx2.call("mrx_spline_prepare", ptr(st["loading"][i]), n, self.Ta, ptr(st["ym"][i]))
             if serial:
                 tev[2].record(main)
@@ -508,6 +522,64 @@ class DevicePath:
         self._cal = dict(
             axis=_dev(el_axis, torch.float32, dev), values=_dev(dens, torch.float32, dev), n_el=len(el_axis), n_bands=nb,
             bore_el=_dev(bore_el, torch.float32, dev), dx=_dev(off[:, 0], torch.float32, dev), dy=_dev(off[:, 1], torch.float32, dev),
+            axis_np=el_axis.astype(np.float32).astype(np.float64), values_np=dens.astype(np.float64),
+            radius=float(np.hypot(off[:, 0], off[:, 1]).max()) if len(off) else 0.0,
+        )
+
+    # the coarse-grid form of the K_RJ conversion is taken when this estimate of its deviation from the
+    # per-sample form stays below a third of the parity tolerance (1e-5)
+    COARSE_KRJ_LIMIT = 3.0e-6
+
+    def coarse_krj_bound(self):
+        """Estimate of max |S[y/g] - S[y]/g| / |S[y]/g| (S: the spline in time, g: the K_RJ
+        denominator at the detector's elevation), i.e. of what dividing the COARSE loading by g
+        (mrx_coarse_to_krj, then the pW writer) changes against dividing every full-rate sample
+        (mrx_spline_upsample_krj, the reference's order, tod/tod.py:106-142).  Both are the same
+        linear functional of y but for the spline's interpolation error on g(t) = den(el(t)):
+        (a) where a detector's elevation crosses a node of the table's axis between two knots g has
+        a kink, and an interpolant misses a kink by at most 0.25 x (slope jump) x (knot spacing) --
+        0.3 here for the spline's ringing; measured on the daisy scan: 0.15;
+        (b) inside a cell g is linear in el, so the error is the spline's error on el(t),
+        (5/384) h^4 d4el/dt4 -- estimated from fourth differences of the coarse boresight.
+        inf when the form does not apply: a NaN in the collapsed table, a detector that may leave
+        the table's elevation axis, or one that comes within 7 deg of the zenith (its elevation
+        is not smooth in time there)."""
+        c = self._cal
+        ax, den = c["axis_np"], c["values_np"]
+        el = np.asarray(self.problem["el_a"], float)
+        if not np.isfinite(den).all() or len(el) < 5:
+            return float("inf")
+        lo, hi = el.min() - 1.05 * c["radius"], el.max() + 1.05 * c["radius"]
+        if lo < ax[0] or hi > ax[-1] or hi > np.radians(83.0):
+            return float("inf")
+        # only the part of the axis the detectors visit counts: the cells that overlap [lo, hi] and the
+        # nodes between them
+        i0 = max(int(np.searchsorted(ax, lo, side="right")) - 1, 0)
+        i1 = min(int(np.searchsorted(ax, hi, side="left")), len(ax) - 1)  # cells i0 .. i1 - 1
+        slope = np.diff(den, axis=1) / np.diff(ax)[None, :]
+        inner = slice(i0, i1 - 1)  # jumps between cells k and k + 1, k = i0 .. i1 - 2, sit at node k + 1
+        rel_jump = (np.abs(np.diff(slope, axis=1))[:, inner] / np.abs(den[:, 1:-1][:, inner])).max() if i1 - i0 > 1 else 0.0
+        cells = slice(i0, i1)
+        rel_slope = (np.abs(slope[:, cells]) / np.minimum(np.abs(den[:, 1:]), np.abs(den[:, :-1]))[:, cells]).max()
+        step = np.abs(np.diff(el)).max()
+        d4 = np.abs(np.diff(el, n=4)).max()
+        # + 4e-7: the two forms round differently in float32 (and the per-sample writer interpolates
+        # the reciprocal over 4 samples)
+        return float(1.1 * (0.3 * rel_jump * step + (5.0 / 384.0) * rel_slope * d4) + 4e-7)
+
+    def coarse_to_krj(self, loading=None, n=None, rows=slice(None), ctx=None):
+        """mrx_coarse_to_krj on the coarse loading (``loading``: a block's [Ta, n] buffer, in
+        place; default: the whole shard's into a buffer of its own, which prepare(krj=True) reads)."""
+        c = self._cal
+        if loading is None:
+            if getattr(self, "d_loading_krj", None) is None:
+                self.d_loading_krj = torch.empty_like(self.d_loading)
+            src, dst, n = self.d_loading, self.d_loading_krj, self.D
+        else:
+            src = dst = loading
+        (ctx or self.ctx).call(
+            "mrx_coarse_to_krj", ptr(src), n, self.Ta, ptr(self.d_el), ptr(c["dx"][rows]), ptr(c["dy"][rows]), ptr(self.d_band[rows]),
+            ptr(c["axis"]), ptr(c["values"]), c["n_el"], c["n_bands"], ptr(dst),
         )
 
     def upsample_krj(self, out):

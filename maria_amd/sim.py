@@ -331,17 +331,26 @@ class Simulation:
     def _compute_atmospheric_loading(self, obs, gain=None, units="pW", metadata=None):
         """Spline solve + cubic upsample of the coarse loading the sampling kernel already
         wrote (emission and Mueller weight are fused into it), scaled by ``gain``; with
-        ``units="K_RJ"`` the division of ``TOD.to`` (tod/tod.py:90-142) is fused in."""
+        ``units="K_RJ"`` the division of ``TOD.to`` (tod/tod.py:90-142) is fused in: on the coarse grid
+        before the spline where ``DevicePath.coarse_krj_bound`` allows, per sample in the writer otherwise."""
         import torch
 
         path = obs.atmosphere._device_path()
         path.set_gain(gain)
         out = torch.empty((path.D, path.T), dtype=torch.float32, device=path.device)
-        path.prepare()
         if units == "K_RJ":
             self._set_calibration(obs, metadata)
-            path.upsample_krj(out)
+            if path.coarse_krj_bound() <= path.COARSE_KRJ_LIMIT:
+                # the conversion on the coarse grid, then the pW writer (HBM-bound): the two orders of
+                # "divide" and "interpolate" differ by less than a quarter of the parity tolerance here
+                path.coarse_to_krj()
+                path.prepare(krj=True)
+                path.upsample(out)
+            else:
+                path.prepare()
+                path.upsample_krj(out)
         else:
+            path.prepare()
             path.upsample(out)
         return out
 

@@ -24,3 +24,14 @@ for rep in range(1):
     print(os.environ.get("MRX_LIB_PATH", "default"), "pW  %.3f ms" % timeit(lambda: path.upsample(tod), 12)[0],
           "| K_RJ fused %.3f ms" % timeit(lambda: path.upsample_krj(tod), 12)[0],
           "| in place %.3f ms" % timeit(lambda: path.to_krj(tod), 12)[0], flush=True)
+# the whole TOD synthesis in the default units (screens excluded): per-sample conversion in the writer
+# against the conversion on the coarse grid + pW writer, serial and block-pipelined
+def per_sample():
+    path.sample(); path.prepare(); path.upsample_krj(tod)
+print("coarse K_RJ bound %.3g (limit %.3g)" % (path.coarse_krj_bound(), path.COARSE_KRJ_LIMIT))
+print("TOD synthesis in K_RJ: per-sample writer %.3f ms | coarse form, serial %.3f ms | coarse form, pipelined %.3f ms | pW pipelined %.3f ms" % (
+    timeit(per_sample, 10)[0], timeit(lambda: path.run(tod, blocks=1, krj=True), 10)[0], timeit(lambda: path.run(tod, krj=True), 10)[0],
+    timeit(lambda: path.run(tod), 10)[0]), flush=True)
+a = path.run(torch.empty_like(tod), krj=True)
+per_sample()
+print("max relative deviation of the coarse form from the per-sample writer: %.3g" % float(((a - tod).abs() / tod.abs()).max()))
