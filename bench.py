@@ -147,12 +147,33 @@ def main():
     want_gather = world > 1 and not args.no_allgather and scaling == "strong" and args.backend == "nccl"
     gather_note = None
     if want_gather:
-        try:
-            gatherer = TodGather(path.ctx, n_total, world, rank)
+        # The communicator comes up in a helper thread with a deadline: a rendezvous that never
+        # completes must cost the all-gather figure, not the benchmark line.  The ranks then agree
+        # (a torch.distributed reduction) on whether every one of them has it.
+        import threading
+
+        box = {}
+
+        def make():
+            try:
+                torch.cuda.set_device(local_rank)  # the current device is per thread
+                box["gatherer"] = TodGather(path.ctx, n_total, world, rank)
+            except Exception as exc:  # pragma: no cover - depends on the node
+                box["note"] = f"{type(exc).__name__}: {exc}"[:300]
+
+        th = threading.Thread(target=make, daemon=True)
+        th.start()
+        th.join(150.0)
+        if th.is_alive():
+            box["note"] = "the RCCL communicator did not come up within 150 s"
+        ok = torch.tensor([1 if "gatherer" in box else 0], dtype=torch.int32, device=red_device)
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 1:
+            gatherer = box["gatherer"]
             full = gatherer.full_buffer(T, device)
             tod = gatherer.my_rows(full)
-        except Exception as exc:  # pragma: no cover - depends on the node
-            gather_note = f"{type(exc).__name__}: {exc}"[:300]
+        else:
+            gather_note = box.get("note", "another rank could not create the communicator")
             gatherer, full = None, None
     if full is None:
         tod = torch.empty((D, T), dtype=torch.float32, device=device)
