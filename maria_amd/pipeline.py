@@ -393,6 +393,8 @@ class DevicePath:
             self.upsample(out)
         return out
 
+    prepare_on_writer_stream = True
+
     def default_blocks(self):
         """Detector blocks of the pipelined run: 8 from 8192 rows up, 4 from 4096 (measured on
         atlast_10k, several boxes: 8 blocks -7...-10 %, 4 blocks -4...-9 % against the serial path)."""
@@ -456,10 +458,17 @@ class DevicePath:
                 tev[1].record(main)
             if krj:  # TOD.to("K_RJ") on the coarse grid: the writer below then writes K_RJ at the pW writer's cost
                 self.coarse_to_krj(st["loading"][i], n, slice(lo, hi), ctx2)
-            ctx2.call("mrx_spline_prepare", ptr(st["loading"][i]), n, self.Ta, ptr(st["ym"][i]))
+            prep_ctx = ctx2
+            if not serial and self.prepare_on_writer_stream:
+                # the sampler stream is the critical path while a writer streams beside it (it runs at
+                # half its stand-alone rate there): the spline solve goes in front of the writer instead
+                st["ready"][i].record(side)
+                main.wait_event(st["ready"][i])
+                prep_ctx = self.ctx
+            prep_ctx.call("mrx_spline_prepare", ptr(st["loading"][i]), n, self.Ta, ptr(st["ym"][i]))
             if serial:
                 tev[2].record(main)
-            else:
+            elif not self.prepare_on_writer_stream:
                 st["ready"][i].record(side)
                 main.wait_event(st["ready"][i])
             if self.d_rows is not None:
