@@ -478,19 +478,19 @@ int mrx_bin_map(mrx_ctx* ctx, const mrx_sky_map* map, const float* d_tod, size_t
                 const double* d_stokes_w, const int32_t* d_channel, int D, double* d_sum,
                 double* d_wgt);
 
-/* The same for nearest-pixel maps (bilinear = 0, the mapper's default) without global atomics
- * on scattered pixels -- they execute at the memory side at a tenth of the contiguous rate, and
- * the focal plane is sparser than the map, so nothing merges on the way.  The samples are
- * routed to the map instead: every sample's pixel is computed once, a tile's samples (16
- * detectors x 1024 samples) are sorted by map region (64 x 32 pixels of one plane) into the
+/* The same without global atomics on scattered pixels -- they execute at the memory side at a
+ * tenth of the contiguous rate, and the focal plane is sparser than the map, so nothing merges on
+ * the way.  The samples are routed to the map instead: every sample's pixel(s) are computed
+ * once, a tile's contributions (nearest pixel: 16 detectors x 1024 samples, one each; bilinear:
+ * 8 x 256, up to four each) are sorted by map region (64 x 32 pixels of one plane) into the
  * tile's slot of the work buffer, and each region's segments are then summed in LDS (float64)
- * and added to the map as whole rows.  Same arguments and same result to float64 rounding
- * (the order of the sums differs).  MRX_ERR_UNSUPPORTED for bilinear maps and for maps of more
- * than 2048 regions (n_channels * ceil(n_eta / 32) * ceil(n_xi / 64)): call mrx_bin_map.
+ * and added to the map as whole rows.  Same arguments and same result to float64 rounding (the
+ * order of the sums differs).  MRX_ERR_UNSUPPORTED for maps of more than 2048 regions
+ * (n_channels * ceil(n_eta / 32) * ceil(n_xi / 64)): call mrx_bin_map.
  *  d_work   16-byte aligned; mrx_bin_map_work_bytes gives the least size (one column of tiles:
- *           ceil(D / 16) * (256 KiB + 4 * regions)) and the size that takes all T samples in
- *           one go (that times ceil(T / 1024): 16 bytes per sample); with less the call
- *           walks the time axis in chunks. */
+ *           all detectors x one tile of samples) and the size that takes all T samples in one
+ *           go (16 bytes per contribution: 16 per sample nearest, 64 bilinear, + 4 bytes per
+ *           (region, tile)); with less the call walks the time axis in chunks. */
 int mrx_bin_map_work_bytes(const mrx_sky_map* map, int D, int T, size_t* min_bytes, size_t* full_bytes);
 int mrx_bin_map_bucketed(mrx_ctx* ctx, const mrx_sky_map* map, const float* d_tod, size_t ld_tod,
                          const float* d_weight, size_t ld_weight, const float* d_az, const float* d_el, int T,

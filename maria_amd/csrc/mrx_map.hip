@@ -437,27 +437,38 @@ __global__ __launch_bounds__(kBlock) void bin_map_kernel(MapArgs g, BinArgs b) {
   }
 }
 
-// ---- bucketed binning (nearest pixel): no global atomics on scattered addresses ----------
+// ---- bucketed binning: no global atomics on scattered addresses ---------------------------
 // Scattered float atomics execute at the memory side at a tenth of the contiguous rate
 // (MI355X_MICROARCH.md, Global float atomics), and the focal plane is sparser than the map, so
 // privatising tiles in LDS merges next to nothing.  Instead the samples are routed
-// to the map: pass A computes every sample's pixel once, sorts its tile's samples by map region
-// (64 x 32 pixels of one plane) with an LDS counting sort and writes them, region by region,
-// into the tile's slot of the work buffer plus one word per (region, tile) that says where;
-// pass B gives every region to a few workgroups that read the region's segments, accumulate in
-// LDS (float64 ds_add) and add the finished block to the map: atomics again, but on whole rows
-// of 64 pixels.  The result equals mrx_bin_map's to float64 rounding (the order of the sums
-// differs).
+// to the map: pass A computes every sample's pixel(s) once, sorts its tile's contributions by
+// map region (64 x 32 pixels of one plane) with an LDS counting sort and writes them, region by
+// region, into the tile's slot of the work buffer plus one word per (region, tile) that says
+// where; pass B gives every region to a few workgroups that read the region's segments,
+// accumulate in LDS (float64 ds_add) and add the finished block to the map: atomics again, but
+// on whole rows of 64 pixels.  The result equals mrx_bin_map's to float64 rounding (the order of
+// the sums differs).  Nearest pixel: a tile is 16 detectors x 1024 samples, one contribution per
+// sample.  Bilinear: 8 detectors x 256 samples, up to four contributions per sample (corners of
+// zero weight are dropped); the float32 offsets of the tile's samples stay in LDS between the
+// two sweeps so that the weights are formed once more without the pointing.
 constexpr int kBinBx = 64, kBinBy = 32;
-constexpr int kBinRegionPx = kBinBx * kBinBy;              // 2048 pixels: 11 bits
+constexpr int kBinRegionPx = kBinBx * kBinBy;  // 2048 pixels: 11 bits
 constexpr int kBinMaxRegions = 2048;
-constexpr int kBinTileEntries = kTileDet * kTileSamples;   // 16 384 samples per tile
 constexpr uint32_t kBinNone = 0xffffffffu;
 
+template <bool kBil>
+struct BinTile {
+  static constexpr int kDet = kBil ? 8 : 16;     // detectors per tile
+  static constexpr int kSpt = kBil ? 1 : 4;      // samples per thread
+  static constexpr int kCorners = kBil ? 4 : 1;
+  static constexpr int kSamples = kBlock * kSpt;
+  static constexpr int kEntries = kDet * kSamples * kCorners;  // 16 384 / 8 192 contributions per tile at most
+};
+
 struct BinEntry {
-  uint32_t local;  // pixel inside the region: (eta & 31) << 6 | (xi & 63)
-  uint32_t det;
-  float w, d;      // sample weight and signal
+  uint32_t local;  // pixel inside the region, (eta & 31) << 6 | (xi & 63), | detector within the tile << 11
+  float d;         // signal
+  double ww;       // sample weight x corner weight
 };
 static_assert(sizeof(BinEntry) == 16, "BinEntry is one 16-byte store");
 
@@ -466,56 +477,89 @@ struct BucketArgs {
   int s0, s1;          // samples [s0, s1) of this time chunk
   int tiles_x;         // sample tiles of the chunk; tile = blockIdx.y * tiles_x + blockIdx.x
   int n_tiles;
+  int tile_det, tile_entries;  // BinTile<>::kDet, kEntries of the form in use
   uint32_t* tab;       // [R][n_tiles]: (first entry of the region in the tile's slot) << 16 | count
-  BinEntry* entries;   // [n_tiles][kBinTileEntries]
+  BinEntry* entries;   // [n_tiles][tile_entries]
 };
 
-template <bool kChain>
+// the contributions of one sample: pixel (region << 11 | local) and weight per corner
+template <bool kBil>
+__device__ __forceinline__ void bin_corners(const MapArgs& g, const BucketArgs& k, const Axis& ax_eta, const Axis& ax_xi,
+                                            float ox, float oy, int chan, uint32_t (&word)[BinTile<kBil>::kCorners],
+                                            double (&wc)[BinTile<kBil>::kCorners]) {
+  int e0, e1, x0, x1;
+  double pe, px;
+  axis_weights(ax_eta, (double)oy, kBil, e0, e1, pe);
+  axis_weights(ax_xi, (double)ox, kBil, x0, x1, px);
+  auto pixel = [&](int e, int x) {
+    const uint32_t r = (uint32_t)((chan * k.nby + (e >> 5)) * k.nbx + (x >> 6));
+    return (r << 11) | (uint32_t)(((e & 31) << 6) | (x & 63));
+  };
+  if constexpr (kBil) {
+    // the order and the weights of bin_map_kernel: (e0,x0), (e1,x0), (e0,x1), (e1,x1)
+    word[0] = pixel(e0, x0); wc[0] = (1.0 - pe) * (1.0 - px);
+    word[1] = pixel(e1, x0); wc[1] = pe * (1.0 - px);
+    word[2] = pixel(e0, x1); wc[2] = (1.0 - pe) * px;
+    word[3] = pixel(e1, x1); wc[3] = pe * px;
+  } else {
+    word[0] = pixel(e0, x0);
+    wc[0] = 1.0;
+  }
+}
+
+template <bool kChain, bool kBil>
 __global__ __launch_bounds__(kBlock) void bin_bucket_kernel(MapArgs g, BinArgs b, BucketArgs k) {
-  __shared__ DetConst dets[kTileDet];
+  using Tile = BinTile<kBil>;
+  constexpr int kDet = Tile::kDet, kSpt = Tile::kSpt, kCorners = Tile::kCorners;
+  __shared__ DetConst dets[kDet];
   __shared__ uint32_t part[kBlock];
   extern __shared__ uint32_t bucket_lds[];
-  uint32_t* words = bucket_lds;                    // [kBinTileEntries] region << 11 | local, by (detector, thread, q)
-  uint32_t* hist = bucket_lds + kBinTileEntries;   // [R]
-  uint32_t* cursor = hist + k.R;                   // [R]
-  const int d0 = blockIdx.y * kTileDet;
-  const int sb = k.s0 + blockIdx.x * kTileSamples + threadIdx.x * kSamplesPerThread;
-  const int nd = min(kTileDet, g.D - d0);
+  uint32_t* words = bucket_lds;              // [kEntries] region << 11 | local, by (detector, thread, q, corner)
+  uint32_t* hist = bucket_lds + Tile::kEntries;  // [R]
+  uint32_t* cursor = hist + k.R;             // [R]
+  float2* oxy = reinterpret_cast<float2*>(cursor + k.R);  // bilinear: [kDet][kSamples] offsets of the samples
+  const int d0 = blockIdx.y * kDet;
+  const int sb = k.s0 + blockIdx.x * Tile::kSamples + threadIdx.x * kSpt;
+  const int nd = min(kDet, g.D - d0);
   const int tile = blockIdx.y * k.tiles_x + blockIdx.x;
   if ((int)threadIdx.x < nd) dets[threadIdx.x] = make_det_const(g, d0 + threadIdx.x);
   for (int i = threadIdx.x; i < k.R; i += kBlock) hist[i] = 0u;
   const Axis ax_eta = g.eta, ax_xi = g.xi;
-  SampleConst sc[kSamplesPerThread];
+  SampleConst sc[kSpt];
 #pragma unroll
-  for (int q = 0; q < kSamplesPerThread; ++q) {
+  for (int q = 0; q < kSpt; ++q) {
     sample_const(g, sb + q, kChain, sc[q]);
     sc[q].s = min(max(sb + q, 0), g.T - 1);
   }
   __syncthreads();
-  // sweep 1: the pixel of every sample, the tile's histogram over regions
+  // sweep 1: the pixels of every sample, the tile's histogram over regions
   for (int dl = 0; dl < nd; ++dl) {
     const DetConst dc = dets[dl];
     const int d = d0 + dl;
     const int chan = b.channel ? min(max(b.channel[d], 0), g.C - 1) : 0;
 #pragma unroll
-    for (int q = 0; q < kSamplesPerThread; ++q) {
-      uint32_t word = kBinNone;
+    for (int q = 0; q < kSpt; ++q) {
+      uint32_t word[kCorners];
+      double wc[kCorners];
+#pragma unroll
+      for (int c = 0; c < kCorners; ++c) word[c] = kBinNone;
       if (sb + q < k.s1) {
         float ox, oy, el_d;
         sample_offsets<kChain, false>(g, dc, sc[q], ox, oy, el_d);
-        int e0, e1, x0, x1;
-        double pe, px;
-        axis_weights(ax_eta, (double)oy, false, e0, e1, pe);
-        axis_weights(ax_xi, (double)ox, false, x0, x1, px);
-        const uint32_t r = (uint32_t)((chan * k.nby + (e0 >> 5)) * k.nbx + (x0 >> 6));
-        word = (r << 11) | (uint32_t)(((e0 & 31) << 6) | (x0 & 63));
-        atomicAdd(&hist[r], 1u);
+        if (kBil) oxy[(dl * kBlock + threadIdx.x) * kSpt + q] = make_float2(ox, oy);
+        bin_corners<kBil>(g, k, ax_eta, ax_xi, ox, oy, chan, word, wc);
+#pragma unroll
+        for (int c = 0; c < kCorners; ++c) {
+          if (wc[c] == 0.0) word[c] = kBinNone;  // a corner of zero weight adds nothing (np.abs(P) entries that are 0)
+          else atomicAdd(&hist[word[c] >> 11], 1u);
+        }
       }
-      words[(dl * kBlock + threadIdx.x) * kSamplesPerThread + q] = word;
+#pragma unroll
+      for (int c = 0; c < kCorners; ++c) words[((dl * kBlock + threadIdx.x) * kSpt + q) * kCorners + c] = word[c];
     }
   }
   __syncthreads();
-  // exclusive scan of the histogram: where each region's samples start in the tile's slot
+  // exclusive scan of the histogram: where each region's contributions start in the tile's slot
   const int per = (k.R + kBlock - 1) / kBlock;
   const int r_lo = threadIdx.x * per, r_hi = min(r_lo + per, k.R);
   uint32_t mine = 0;
@@ -536,21 +580,35 @@ __global__ __launch_bounds__(kBlock) void bin_bucket_kernel(MapArgs g, BinArgs b
     run += c;
   }
   __syncthreads();
-  // sweep 2: every sample to its place
-  BinEntry* slot = k.entries + (size_t)tile * kBinTileEntries;
+  // sweep 2: every contribution to its place
+  BinEntry* slot = k.entries + (size_t)tile * Tile::kEntries;
   for (int dl = 0; dl < nd; ++dl) {
     const int d = d0 + dl;
+    const int chan = b.channel ? min(max(b.channel[d], 0), g.C - 1) : 0;
 #pragma unroll
-    for (int q = 0; q < kSamplesPerThread; ++q) {
-      const uint32_t word = words[(dl * kBlock + threadIdx.x) * kSamplesPerThread + q];
-      if (word == kBinNone) continue;
-      const uint32_t pos = atomicAdd(&cursor[word >> 11], 1u);
-      BinEntry en;
-      en.local = word & (uint32_t)(kBinRegionPx - 1);
-      en.det = (uint32_t)d;
-      en.w = b.weight ? b.weight[(size_t)d * b.ld_w + sb + q] : 1.0f;
-      en.d = b.tod[(size_t)d * b.ld_tod + sb + q];
-      slot[pos] = en;
+    for (int q = 0; q < kSpt; ++q) {
+      if (sb + q >= k.s1) continue;
+      uint32_t word[kCorners];
+      double wc[kCorners];
+      if (kBil) {
+        const float2 o = oxy[(dl * kBlock + threadIdx.x) * kSpt + q];
+        bin_corners<kBil>(g, k, ax_eta, ax_xi, o.x, o.y, chan, word, wc);
+      } else {
+        wc[0] = 1.0;
+      }
+      const double W = b.weight ? (double)b.weight[(size_t)d * b.ld_w + sb + q] : 1.0;
+      const float D = b.tod[(size_t)d * b.ld_tod + sb + q];
+#pragma unroll
+      for (int c = 0; c < kCorners; ++c) {
+        const uint32_t wd = words[((dl * kBlock + threadIdx.x) * kSpt + q) * kCorners + c];
+        if (wd == kBinNone) continue;
+        const uint32_t pos = atomicAdd(&cursor[wd >> 11], 1u);
+        BinEntry en;
+        en.local = (wd & (uint32_t)(kBinRegionPx - 1)) | ((uint32_t)dl << 11);
+        en.d = D;
+        en.ww = W * wc[c];
+        slot[pos] = en;
+      }
     }
   }
 }
@@ -559,9 +617,10 @@ __global__ __launch_bounds__(kBlock) void bin_bucket_kernel(MapArgs g, BinArgs b
 // block of 64 x 32 pixels into the map
 __global__ __launch_bounds__(kBlock) void bin_accumulate_kernel(MapArgs g, BinArgs b, BucketArgs k, int splits) {
   extern __shared__ double bin_acc[];  // [S][2][kBinRegionPx]: sum, weight
-  __shared__ uint32_t seg[kBlock];
-  __shared__ int seg_tile[kBlock];
-  __shared__ int seg_end[kBlock];
+  __shared__ uint32_t seg_cnt[kBlock];   // a batch's non-empty segments: count,
+  __shared__ uint32_t seg_base[kBlock];  // index of the first entry in the work buffer minus its place in the batch's list,
+  __shared__ int seg_d0[kBlock];         // first detector of the tile,
+  __shared__ int seg_end[kBlock];        // inclusive scan of the counts
   __shared__ int n_seg;
   // workgroup b runs on XCD b mod 8: with the region straight from blockIdx.x and a power-of-two
   // number of regions per map row, an XCD would own whole columns of the map -- and the columns
@@ -580,8 +639,9 @@ __global__ __launch_bounds__(kBlock) void bin_accumulate_kernel(MapArgs g, BinAr
     const uint32_t v = tile < t1 ? row[tile] : 0u;
     if (v & 0xffffu) {
       const int at = atomicAdd(&n_seg, 1);
-      seg[at] = v;
-      seg_tile[at] = tile;
+      seg_cnt[at] = v & 0xffffu;
+      seg_base[at] = (uint32_t)tile * (uint32_t)k.tile_entries + (v >> 16);  // < 2^32: the host bounds the chunk
+      seg_d0[at] = (tile / k.tiles_x) * k.tile_det;
     }
     __syncthreads();
     const int n = n_seg;
@@ -591,7 +651,7 @@ __global__ __launch_bounds__(kBlock) void bin_accumulate_kernel(MapArgs g, BinAr
     // thread strides through the list (its segment index only ever moves forward) -- all lanes
     // busy and the loads of successive entries independent, instead of one wave per segment
     // waiting out the memory latency of each
-    seg_end[threadIdx.x] = (int)threadIdx.x < n ? (int)(seg[threadIdx.x] & 0xffffu) : 0;
+    seg_end[threadIdx.x] = (int)threadIdx.x < n ? (int)seg_cnt[threadIdx.x] : 0;
     __syncthreads();
     for (int off = 1; off < kBlock; off <<= 1) {
       const int add = (int)threadIdx.x >= off ? seg_end[threadIdx.x - off] : 0;
@@ -599,6 +659,8 @@ __global__ __launch_bounds__(kBlock) void bin_accumulate_kernel(MapArgs g, BinAr
       seg_end[threadIdx.x] += add;
       __syncthreads();
     }
+    if ((int)threadIdx.x < n) seg_base[threadIdx.x] -= (uint32_t)(seg_end[threadIdx.x] - (int)seg_cnt[threadIdx.x]);
+    __syncthreads();
     const int total = seg_end[n - 1];
     // kPer entries per thread and trip, kBlock apart: every load instruction reads 1 KiB of
     // consecutive entries (lanes on consecutive entries; 16-byte loads at a 64-byte lane stride
@@ -608,26 +670,28 @@ __global__ __launch_bounds__(kBlock) void bin_accumulate_kernel(MapArgs g, BinAr
     int cur = 0;
     for (int j0 = threadIdx.x; j0 < total; j0 += kBlock * kPer) {
       BinEntry en[kPer];
+      int det[kPer];
 #pragma unroll
       for (int i = 0; i < kPer; ++i) {
         const int j = j0 + i * kBlock;
         en[i].local = kBinNone;
+        det[i] = 0;
         if (j < total) {
           while (j >= seg_end[cur]) ++cur;
-          const int first = cur ? seg_end[cur - 1] : 0;
-          en[i] = k.entries[(size_t)seg_tile[cur] * kBinTileEntries + (seg[cur] >> 16) + (j - first)];
+          en[i] = k.entries[seg_base[cur] + (uint32_t)j];
+          det[i] = seg_d0[cur] + (int)(en[i].local >> 11);
         }
       }
       for (int s = 0; s < g.S; ++s) {
         double m[kPer];
 #pragma unroll
-        for (int i = 0; i < kPer; ++i) m[i] = en[i].local != kBinNone ? g.stokes_w[(size_t)en[i].det * g.S + s] : 0.0;
+        for (int i = 0; i < kPer; ++i) m[i] = en[i].local != kBinNone ? g.stokes_w[(size_t)det[i] * g.S + s] : 0.0;
 #pragma unroll
         for (int i = 0; i < kPer; ++i) {
           if (m[i] == 0.0) continue;  // zero weight: nothing to add (np.abs(P) entries that are 0); padding
-          const double W = (double)en[i].w;
-          atomicAdd(&bin_acc[(s * 2) * kBinRegionPx + en[i].local], m[i] * (W * (double)en[i].d));
-          atomicAdd(&bin_acc[(s * 2 + 1) * kBinRegionPx + en[i].local], fabs(m[i]) * W);
+          const uint32_t px = en[i].local & (uint32_t)(kBinRegionPx - 1);
+          atomicAdd(&bin_acc[(s * 2) * kBinRegionPx + px], m[i] * (en[i].ww * (double)en[i].d));
+          atomicAdd(&bin_acc[(s * 2 + 1) * kBinRegionPx + px], fabs(m[i]) * en[i].ww);
         }
       }
     }
@@ -888,21 +952,44 @@ int mrx_bin_map(mrx_ctx* ctx, const mrx_sky_map* map, const float* d_tod, size_t
 
 // regions of a map for the bucketed form, or 0 when it does not apply
 static int bin_regions(const mrx_sky_map* map, int* nbx, int* nby) {
-  if (!map || map->bilinear || map->n_eta < 2 || map->n_xi < 2 || map->n_channels < 1) return 0;
+  if (!map || map->n_eta < 2 || map->n_xi < 2 || map->n_channels < 1) return 0;
   *nbx = mrx_ceil_div(map->n_xi, kBinBx);
   *nby = mrx_ceil_div(map->n_eta, kBinBy);
   const long long R = (long long)map->n_channels * *nbx * *nby;
   return R <= kBinMaxRegions ? (int)R : 0;
 }
 
+// tile geometry of the form a map takes
+struct BinGeometry {
+  int tile_det, tile_samples, tile_entries;
+  size_t lds_a;
+};
+
+static BinGeometry bin_geometry(bool bilinear, int R) {
+  BinGeometry q;
+  if (bilinear) {
+    q.tile_det = BinTile<true>::kDet;
+    q.tile_samples = BinTile<true>::kSamples;
+    q.tile_entries = BinTile<true>::kEntries;
+  } else {
+    q.tile_det = BinTile<false>::kDet;
+    q.tile_samples = BinTile<false>::kSamples;
+    q.tile_entries = BinTile<false>::kEntries;
+  }
+  q.lds_a = ((size_t)q.tile_entries + 2 * (size_t)R) * sizeof(uint32_t) +
+            (bilinear ? (size_t)q.tile_det * q.tile_samples * sizeof(float2) : 0);
+  return q;
+}
+
 int mrx_bin_map_work_bytes(const mrx_sky_map* map, int D, int T, size_t* min_bytes, size_t* full_bytes) {
   int nbx, nby;
   const int R = bin_regions(map, &nbx, &nby);
   if (!R || D < 1 || T < 1 || !min_bytes || !full_bytes) return R ? MRX_ERR_INVALID : MRX_ERR_UNSUPPORTED;
-  // one column of tiles (all detectors x 1024 samples): its slots and its words of the table
-  const size_t col = (size_t)mrx_ceil_div(D, kTileDet) * ((size_t)kBinTileEntries * sizeof(BinEntry) + (size_t)R * sizeof(uint32_t));
+  const BinGeometry q = bin_geometry(map->bilinear != 0, R);
+  // one column of tiles (all detectors x one tile of samples): its slots and its words of the table
+  const size_t col = (size_t)mrx_ceil_div(D, q.tile_det) * ((size_t)q.tile_entries * sizeof(BinEntry) + (size_t)R * sizeof(uint32_t));
   *min_bytes = col;
-  *full_bytes = col * (size_t)mrx_ceil_div(T, kTileSamples);
+  *full_bytes = col * (size_t)mrx_ceil_div(T, q.tile_samples);
   return MRX_OK;
 }
 
@@ -918,26 +1005,32 @@ int mrx_bin_map_bucketed(mrx_ctx* ctx, const mrx_sky_map* map, const float* d_to
   BucketArgs k{};
   k.R = bin_regions(map, &k.nbx, &k.nby);
   if (!k.R)
-    return mrx_fail(ctx, MRX_ERR_UNSUPPORTED, "mrx_bin_map_bucketed: nearest-pixel maps of at most %d regions of %d x %d pixels (use mrx_bin_map)",
+    return mrx_fail(ctx, MRX_ERR_UNSUPPORTED, "mrx_bin_map_bucketed: maps of at most %d regions of %d x %d pixels (use mrx_bin_map)",
                     kBinMaxRegions, kBinBx, kBinBy);
   MapArgs g;
   BinArgs b;
   const int rc = bin_map_args(ctx, map, d_tod, ld_tod, d_weight, ld_weight, d_az, d_el, T, d_transform, d_dx, d_dy,
                               d_stokes_w, d_channel, D, d_sum, d_wgt, g, b);
   if (rc != MRX_OK) return rc;
-  const int tiles_y = mrx_ceil_div(D, kTileDet);
+  const bool bil = map->bilinear != 0;
+  const BinGeometry q = bin_geometry(bil, k.R);
+  k.tile_det = q.tile_det;
+  k.tile_entries = q.tile_entries;
+  const int tiles_y = mrx_ceil_div(D, q.tile_det);
   MRX_REQUIRE(ctx, tiles_y <= 65535, "D too large for one launch");
-  const size_t col = (size_t)tiles_y * ((size_t)kBinTileEntries * sizeof(BinEntry) + (size_t)k.R * sizeof(uint32_t));
+  const size_t col = (size_t)tiles_y * ((size_t)q.tile_entries * sizeof(BinEntry) + (size_t)k.R * sizeof(uint32_t));
   MRX_REQUIRE(ctx, d_work && (reinterpret_cast<uintptr_t>(d_work) & 15u) == 0 && work_bytes >= col,
               "work buffer: 16-byte aligned, at least mrx_bin_map_work_bytes' minimum");
-  const int cols_total = mrx_ceil_div(T, kTileSamples);
+  const int cols_total = mrx_ceil_div(T, q.tile_samples);
   int cols = (int)(work_bytes / col < (size_t)cols_total ? work_bytes / col : (size_t)cols_total);
-  // the table's words (base << 16 | count) index a region's row by tile: [R][n_tiles] uint32 behind the slots
-  const size_t lds_a = ((size_t)kBinTileEntries + 2 * (size_t)k.R) * sizeof(uint32_t);
+  // pass B indexes the entries of a chunk with 32 bits
+  while ((long long)cols * tiles_y * q.tile_entries > (1LL << 32) - 1) cols = (cols + 1) / 2;
   const size_t lds_b = (size_t)g.S * 2 * kBinRegionPx * sizeof(double);
   const bool chain = ctx->options[MRX_OPT_POINTING_CHAIN] != 0;
-  if (chain) MRX_LDS_CAP(ctx, bin_bucket_kernel<true>, lds_a);
-  else MRX_LDS_CAP(ctx, bin_bucket_kernel<false>, lds_a);
+  typedef void (*BucketKernel)(MapArgs, BinArgs, BucketArgs);
+  const BucketKernel pass_a = bil ? (chain ? bin_bucket_kernel<true, true> : bin_bucket_kernel<false, true>)
+                                  : (chain ? bin_bucket_kernel<true, false> : bin_bucket_kernel<false, false>);
+  MRX_LDS_CAP(ctx, pass_a, q.lds_a);
   MRX_LDS_CAP(ctx, bin_accumulate_kernel, lds_b);
   // enough workgroups per region to fill the chip: the regions under the scan hold most samples
   // (the time does not depend on the number from 8192 items up: measured)
@@ -947,14 +1040,12 @@ int mrx_bin_map_bucketed(mrx_ctx* ctx, const mrx_sky_map* map, const float* d_to
     const int nc = cols_total - c0 < cols ? cols_total - c0 : cols;
     k.tiles_x = nc;
     k.n_tiles = nc * tiles_y;
-    k.s0 = c0 * kTileSamples;
-    k.s1 = (long long)(c0 + nc) * kTileSamples < (long long)T ? (c0 + nc) * kTileSamples : T;
+    k.s0 = c0 * q.tile_samples;
+    k.s1 = (long long)(c0 + nc) * q.tile_samples < (long long)T ? (c0 + nc) * q.tile_samples : T;
     k.entries = reinterpret_cast<BinEntry*>(d_work);
-    k.tab = reinterpret_cast<uint32_t*>(k.entries + (size_t)k.n_tiles * kBinTileEntries);
+    k.tab = reinterpret_cast<uint32_t*>(k.entries + (size_t)k.n_tiles * q.tile_entries);
     MRX_HIP(ctx, hipMemsetAsync(k.tab, 0, (size_t)k.R * k.n_tiles * sizeof(uint32_t), ctx->stream));
-    const dim3 grid_a(nc, tiles_y);
-    if (chain) hipLaunchKernelGGL(bin_bucket_kernel<true>, grid_a, dim3(kBlock), lds_a, ctx->stream, g, b, k);
-    else hipLaunchKernelGGL(bin_bucket_kernel<false>, grid_a, dim3(kBlock), lds_a, ctx->stream, g, b, k);
+    hipLaunchKernelGGL(pass_a, dim3(nc, tiles_y), dim3(kBlock), q.lds_a, ctx->stream, g, b, k);
     const int sp = splits < k.n_tiles ? splits : k.n_tiles;
     hipLaunchKernelGGL(bin_accumulate_kernel, dim3(k.R, sp), dim3(kBlock), lds_b, ctx->stream, g, b, k, sp);
     MRX_CHECK_LAUNCH(ctx);

@@ -18,24 +18,24 @@ from .map import ProjectionMap, mueller_row
 logger = logging.getLogger("maria")
 
 
-# work buffer of the bucketed binning: all samples in one go needs 16 bytes per sample; beyond this
+# work buffer of the bucketed binning: all samples in one go needs 16 bytes per sample (64 bilinear); beyond this
 # the call walks the time axis in chunks
 BIN_WORK_LIMIT_BYTES = 24 << 30
 
 
 def bin_map(ctx, sky, signal, weight, az, el, transform, dx, dy, stokes_w, channel, msum, mwgt, bucketed=None):
     """``map_sum += (W * D) @ P``, ``map_wgt += W @ |P|`` for one TOD on the device
-    (mappers/bin_mapper.py:84-120).  Nearest-pixel maps of up to 2048 regions take
+    (mappers/bin_mapper.py:84-120).  Maps of up to 2048 regions of 64 x 32 pixels take
     ``mrx_bin_map_bucketed`` (samples routed to map regions, summed in LDS: no scattered global
-    atomics); bilinear and larger maps ``mrx_bin_map`` (float64 atomics).  ``bucketed``: force
-    (True) or forbid (False) the first form."""
+    atomics); larger ones ``mrx_bin_map`` (float64 atomics).  ``bucketed``: force (True) or
+    forbid (False) the first form."""
     D, T = signal.shape
     args = (C.byref(sky), ptr(signal), signal.stride(0), ptr(weight), 0 if weight is None else weight.stride(0),
             ptr(az), ptr(el), T, ptr(transform), ptr(dx), ptr(dy), ptr(stokes_w), ptr(channel), D, ptr(msum), ptr(mwgt))
     lo, full = C.c_size_t(), C.c_size_t()
     fits = ctx.lib.mrx_bin_map_work_bytes(C.byref(sky), D, T, C.byref(lo), C.byref(full)) == 0
     if bucketed is True and not fits:
-        raise ValueError("the bucketed binning takes nearest-pixel maps of at most 2048 regions of 64 x 32 pixels")
+        raise ValueError("the bucketed binning takes maps of at most 2048 regions of 64 x 32 pixels")
     if fits and bucketed is not False:
         free = torch.cuda.mem_get_info(signal.device)[0]
         size = max(lo.value, min(full.value, BIN_WORK_LIMIT_BYTES, max(free // 2, lo.value)))

@@ -39,12 +39,12 @@ def main():
     msum = torch.zeros((1, 1, n, n), dtype=torch.float64, device=dev)
     mwgt = torch.zeros_like(msum)
     step = 0.05 / n
-    sky = MrxSkyMap(None, 1, 1, n, n, 0.025, -step, -0.025, step, float(np.mean(az)), float(np.mean(el)), 0, 0)
+    sky = MrxSkyMap(None, 1, 1, n, n, 0.025, -step, -0.025, step, float(np.mean(az)), float(np.mean(el)), int(os.environ.get("MRX_BIN_BILINEAR", "0")), 0)
     args = (C.byref(sky), ptr(tod), tod.stride(0), None, 0, ptr(d_az), ptr(d_el), T, None, ptr(d_dx), ptr(d_dy), ptr(d_sw), None, D, ptr(msum), ptr(mwgt))
     if bucketed:
         lo, full = C.c_size_t(), C.c_size_t()
         ctx.lib.mrx_bin_map_work_bytes(C.byref(sky), D, T, C.byref(lo), C.byref(full))
-        work = torch.empty(full.value, dtype=torch.uint8, device=dev)
+        work = torch.empty(min(full.value, 40 << 30), dtype=torch.uint8, device=dev)
         fn = lambda: ctx.call("mrx_bin_map_bucketed", *args, ptr(work), work.numel())  # noqa: E731
     else:
         fn = lambda: ctx.call("mrx_bin_map", *args)  # noqa: E731

@@ -240,13 +240,15 @@ def test_simulation_with_map(gpu_ctx, frame):
     np.testing.assert_allclose(tod2.data["map"], got * factor, rtol=3e-6, atol=1e-7 * np.abs(got * factor).max())
 
 
-@pytest.mark.parametrize("shape,chunked", [((12, 16), False), ((70, 150), False), ((70, 150), True), ((33, 64), True)])
-def test_bucketed_bin_map_matches_the_atomic_form_and_the_oracle(gpu_ctx, shape, chunked):
+@pytest.mark.parametrize("shape,chunked,bilinear", [((12, 16), False, 0), ((70, 150), False, 0), ((70, 150), True, 0), ((33, 64), True, 0),
+                                                    ((12, 16), False, 1), ((70, 150), True, 1), ((33, 64), False, 1)])
+def test_bucketed_bin_map_matches_the_atomic_form_and_the_oracle(gpu_ctx, shape, chunked, bilinear):
     """mrx_bin_map_bucketed: samples routed to map regions of 64 x 32 pixels and summed in LDS.
     Against mrx_bin_map on the same inputs (float64 rounding: the order of the sums differs) --
     weights, two Stokes planes, two channels, samples beyond the grid, a detector count that is
     no multiple of 16, a length that is no multiple of 1024, maps of one and of several regions,
-    and the time axis walked in chunks of one column of tiles (the minimum work buffer)."""
+    and the time axis walked in chunks of one column of tiles (the minimum work buffer); nearest
+    pixel (tiles of 16 detectors x 1024 samples) and bilinear (8 x 256, four corners a sample)."""
     import ctypes as C
 
     import torch
@@ -276,14 +278,14 @@ def test_bucketed_bin_map_matches_the_atomic_form_and_the_oracle(gpu_ctx, shape,
     d_tr = torch.as_tensor(transform.reshape(-1, 9)).to(dev)
     d_chan = torch.as_tensor(chan).to(dev)
     sky = MrxSkyMap(None, 2, 2, n_eta, n_xi, float(eta[0]), float(eta[1] - eta[0]), float(xi[0]), float(xi[1] - xi[0]),
-                    centre[0], centre[1], 0, 0)
+                    centre[0], centre[1], bilinear, 0)
     args = (C.byref(sky), ptr(d_tod), d_tod.stride(0), ptr(d_w), d_w.stride(0), ptr(d_az), ptr(d_el), len(t),
             ptr(d_tr), ptr(d_dx), ptr(d_dy), ptr(d_sw), ptr(d_chan), len(off))
     ref = [torch.zeros((2, 2, n_eta, n_xi), dtype=torch.float64, device=dev) for _ in range(2)]
     gpu_ctx.call("mrx_bin_map", *args, ptr(ref[0]), ptr(ref[1]))
     lo, full = C.c_size_t(), C.c_size_t()
     assert gpu_ctx.lib.mrx_bin_map_work_bytes(C.byref(sky), len(off), len(t), C.byref(lo), C.byref(full)) == 0
-    assert full.value == 4 * lo.value  # ceil(3301 / 1024) columns of tiles
+    assert full.value == (13 if bilinear else 4) * lo.value  # ceil(3301 / 256) or ceil(3301 / 1024) columns of tiles
     work = torch.empty(lo.value if chunked else full.value, dtype=torch.uint8, device=dev)
     got = [torch.full((2, 2, n_eta, n_xi), 1.0, dtype=torch.float64, device=dev) for _ in range(2)]  # adds to what is there
     gpu_ctx.call("mrx_bin_map_bucketed", *args, ptr(got[0]), ptr(got[1]), ptr(work), work.numel())
@@ -291,11 +293,9 @@ def test_bucketed_bin_map_matches_the_atomic_form_and_the_oracle(gpu_ctx, shape,
         g, r = g.cpu().numpy() - 1.0, r.cpu().numpy()
         assert np.abs(r).max() > 0 and np.abs(g - r).max() <= 1e-12 * np.abs(r).max()
     ref_sum, ref_wgt = mapsample.bin_map(az_d, el_d, tod, wts, eta, xi, centre, sw, 2, channel=chan, n_channels=2,
-                                         transform_stack=transform, bilinear=False)
+                                         transform_stack=transform, bilinear=bool(bilinear))
     assert abs(float(got[1].sum() - got[1].numel()) / ref_wgt.sum() - 1) < 1e-9  # every sample lands somewhere
-    # what the bucketed form does not take
-    bil = MrxSkyMap(None, 2, 2, n_eta, n_xi, float(eta[0]), float(eta[1] - eta[0]), float(xi[0]), float(xi[1] - xi[0]), centre[0], centre[1], 1, 0)
-    assert gpu_ctx.lib.mrx_bin_map_work_bytes(C.byref(bil), len(off), len(t), C.byref(lo), C.byref(full)) != 0
+    # what the bucketed form does not take: more than 2048 regions
     big = MrxSkyMap(None, 2, 2, 4096, 4096, 1.0, -1e-3, -1.0, 1e-3, centre[0], centre[1], 0, 0)
     assert gpu_ctx.lib.mrx_bin_map_work_bytes(C.byref(big), len(off), len(t), C.byref(lo), C.byref(full)) != 0
 
