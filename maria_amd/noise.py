@@ -77,12 +77,19 @@ def simulate_noise(ctx, dets, T, sample_rate, seed, noise_kwargs=None, device="c
         per_loading = float(getattr(band, "NEP_per_loading", 0.0))
         if per_loading and loading is None:
             raise ValueError(f"band {band.name} has NEP_per_loading != 0: pass the summed loading (sim/noise.py:35-37)")
-        offs = dets.offsets[idx]
-        fov = diameter(offs)
-        if fov > 0 and len(idx) > 16:  # sim/noise.py:42-50
-            basis = spatial_basis(offs, k=5, n_side=16, scale=fov * kw.get("correlated_noise_spatial_scale", 0))
-        else:
-            basis = np.ones((len(idx), 1))
+        # the basis depends on the band's focal-plane geometry alone (a 256 x 256 SVD and a cubic
+        # interpolation on the host: 40 ms a band): kept on the Detectors object between observations
+        cache = dets.__dict__.setdefault("_noise_basis_cache", {})
+        key = (b, len(idx), float(kw.get("correlated_noise_spatial_scale", 0)), hash(dets.offsets[idx].tobytes()))
+        basis = cache.get(key)
+        if basis is None:
+            offs = dets.offsets[idx]
+            fov = diameter(offs)
+            if fov > 0 and len(idx) > 16:  # sim/noise.py:42-50
+                basis = spatial_basis(offs, k=5, n_side=16, scale=fov * kw.get("correlated_noise_spatial_scale", 0))
+            else:
+                basis = np.ones((len(idx), 1))
+            cache[key] = basis
         basis = basis[offset : offset + last - first]
         count = last - first
         d_basis = torch.as_tensor(np.ascontiguousarray(basis, np.float32)).to(dev)
