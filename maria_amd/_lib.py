@@ -21,6 +21,7 @@ FLAG_TABLE_OOB = 2
 FLAG_NAN = 4
 OPT_POINTING_CHAIN = 0
 OPT_AXIS_LITERAL = 1
+OPT_SAMPLE_TIMES = 2
 OPT_SAMPLE_WGS_PER_CU = 6
 OPT_SAMPLE_TILES = 7
 OPT_NOISE_GENERIC = 5

@@ -255,8 +255,13 @@ __device__ __forceinline__ float band_loading(const mrx_table_dev& tb, const flo
 // two differ by the float32 rounding noise of the chain itself (<= ~1e-6
 // relative in px, py near the zenith), far inside the 1e-5 parity tolerance.
 template <bool kLdsTables, bool kChain, int kT>
-// 8 waves per SIMD (<= 64 VGPRs): the kernel hides its gather latency with occupancy
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8))) void atm_sample_kernel(
+// kT = 1: 8 waves per SIMD (<= 64 VGPRs): alone on the chip the kernel hides its gather latency
+// with occupancy.  kT = 2, 4: two or four time steps of a detector interleaved in one thread at 5
+// waves per SIMD (<= 96 VGPRs) -- for the small resident grid that runs beside the TOD writer
+// (3 workgroups per CU: 3 x 96 registers for the sampler, 3 x 72 for the writer), where
+// instruction-level parallelism has to stand in for the waves the writer's share takes away
+// (pipelined step 2.73 -> 2.62 ms; at 64 registers these instances spill 41 / 77 values)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kT == 1 ? 8 : 5, kT == 1 ? 8 : 5))) void atm_sample_kernel(
     const mrx_layer_dev* __restrict__ layers, const mrx_layer_fast* __restrict__ fast, int n_layers,
     const double2* __restrict__ off, const double2* __restrict__ offpx,
     const mrx_table_dev* __restrict__ tables,

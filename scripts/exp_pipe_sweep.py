@@ -14,8 +14,10 @@ def wall(fn, n=10):
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
 print("serial (1 block): %.3f ms" % wall(lambda: path.run(tod, blocks=1)), flush=True)
-for B in (2, 3, 4, 5, 6, 8):
+kt = int(os.environ.get("MRX_SAMPLE_TIMES", "2"))  # time steps interleaved per thread in the co-running sampler
+blocks = [int(b) for b in os.environ.get("MRX_BLOCKS", "2,3,4,5,6,8").split(",")]
+for B in blocks:
     row = []
-    for k in (3, 4, 5, 6):
-        row.append("%d/CU %.3f" % (k, wall(lambda: path._run_pipelined(tod, B, resident_wgs_per_cu=k))))
+    for k in (2, 3, 4, 5, 6):
+        row.append("%d/CU %.3f" % (k, wall(lambda: path._run_pipelined(tod, B, resident_wgs_per_cu=k, resident_times=kt))))
     print(f"blocks={B}: " + "  ".join(row), flush=True)
