@@ -12,3 +12,5 @@ path = DevicePath(p, device="cuda:0")
 path.generate_screens()
 med, mn = timeit(path.generate_screens, int(sys.argv[2]) if len(sys.argv) > 2 else 20)
 print(f"{cfg}: screens median {med:.3f} ms min {mn:.3f} ms")
+med, mn = timeit(lambda: path.generate_screens(smooth=False), 20)
+print(f"{cfg}: screens without the beam smoothing median {med:.3f} ms min {mn:.3f} ms")
