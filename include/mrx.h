@@ -529,7 +529,8 @@ int mrx_sosfilt(mrx_ctx* ctx, const double* sos, int n_sections, const double* d
  * of n << interleave_log2 complex float32 values, each holding 2^interleave_log2 interleaved
  * sequences of length n (a power of two >= 4; at most 8192 values per row); unnormalised
  * (numpy.fft.ifft(x) * n).  interleave_log2 = -1: the 64-point register transform, n = 64;
- * -2: the 4096-point workgroup transform (three radix-16 register passes), n = 4096. */
+ * -2: the 4096-point workgroup transform (three radix-16 register passes), n = 4096;
+ * -3: its 16 x RB x 16 form for n = 1024, 2048, 4096 (16 / RB rows per workgroup). */
 int mrx_fft_rows(mrx_ctx* ctx, const float* d_in, int rows, int n, int interleave_log2,
                  float* d_out);
 

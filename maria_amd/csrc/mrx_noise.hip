@@ -674,6 +674,25 @@ __global__ __launch_bounds__(kBlock) void fft4096_rows_kernel(const float2* __re
   for (int f = 0; f < 16; ++f) out[(size_t)blockIdx.x * 4096 + threadIdx.x + 256 * f] = v[dft16_pos(f)];
 }
 
+// test hook of fft_regs<RB>: rows of 256 RB values, 16 / RB rows per workgroup
+template <int RB>
+__global__ __launch_bounds__(kBlock) void fft_regs_rows_kernel(const float2* __restrict__ in, float2* __restrict__ out, int rows) {
+  extern __shared__ float2 lds2[];
+  constexpr int T = 16 * RB, n = 256 * RB;
+  const int which = threadIdx.x / T, t = threadIdx.x % T;
+  const int row = blockIdx.x * (kBlock / T) + which;
+  const bool live = row < rows;
+  float2* ex1 = lds2 + which * 2 * kFft4096Pitch * T;
+  float2 v[16];
+#pragma unroll
+  for (int b = 0; b < 16; ++b) v[b] = live ? in[(size_t)row * n + t + T * b] : make_float2(0.f, 0.f);
+  fft_regs<RB>(v, ex1, ex1 + kFft4096Pitch * T, t);
+  if (live) {
+#pragma unroll
+    for (int f = 0; f < 16; ++f) out[(size_t)row * n + t + T * f] = v[dft16_pos(f)];
+  }
+}
+
 __global__ __launch_bounds__(64) void fft64_reg_rows_kernel(const float2* __restrict__ in, float2* __restrict__ out, int rows) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= rows) return;
@@ -889,6 +908,24 @@ int mrx_fft_rows(mrx_ctx* ctx, const float* d_in, int rows, int n, int interleav
   MRX_ENTER(ctx);
   if (!ctx) return MRX_ERR_INVALID;
   const int l = ilog2(n);
+  if (ctx && interleave_log2 == -3) {  // fft_regs<RB>: n = 1024, 2048 or 4096
+    MRX_REQUIRE(ctx, d_in && d_out && rows >= 1 && (n == 1024 || n == 2048 || n == 4096), "bad argument");
+    const size_t lds = 2 * (size_t)kFft4096Pitch * 256 * sizeof(float2);  // 16 / RB transforms of 17 * 16 RB values, twice
+    const float2* in = reinterpret_cast<const float2*>(d_in);
+    float2* out = reinterpret_cast<float2*>(d_out);
+    if (n == 1024) {
+      MRX_LDS_CAP(ctx, fft_regs_rows_kernel<4>, lds);
+      hipLaunchKernelGGL(fft_regs_rows_kernel<4>, dim3(mrx_ceil_div(rows, 4)), dim3(kBlock), lds, ctx->stream, in, out, rows);
+    } else if (n == 2048) {
+      MRX_LDS_CAP(ctx, fft_regs_rows_kernel<8>, lds);
+      hipLaunchKernelGGL(fft_regs_rows_kernel<8>, dim3(mrx_ceil_div(rows, 2)), dim3(kBlock), lds, ctx->stream, in, out, rows);
+    } else {
+      MRX_LDS_CAP(ctx, fft_regs_rows_kernel<16>, lds);
+      hipLaunchKernelGGL(fft_regs_rows_kernel<16>, dim3(rows), dim3(kBlock), lds, ctx->stream, in, out, rows);
+    }
+    MRX_CHECK_LAUNCH(ctx);
+    return MRX_OK;
+  }
   if (ctx && interleave_log2 == -2) {  // the workgroup register transform: n must be 4096
     MRX_REQUIRE(ctx, d_in && d_out && rows >= 1 && n == 4096, "bad argument");
     const size_t lds = 2 * (size_t)kFft4096Image * sizeof(float2);

@@ -363,6 +363,52 @@ __device__ __forceinline__ void fft4096_workgroup(float2 (&v)[16], float2* ex1, 
   dft16(v);
 }
 
+// ---- the same scheme for n = 256 RB points, RB = 4, 8, 16, by T = 16 RB threads -------------
+// (RB = 16 is fft4096_workgroup).  k = t + T b, j = d + 16 c:
+//   exp(2 pi i k j / n) = exp(2 pi i t d / n) exp(2 pi i t c / T) exp(2 pi i b d / 16);
+// t = u + 16 v (v < RB), c = e + RB f (e < RB, f < 16):
+//   exp(2 pi i t c / T) = exp(2 pi i u e / T) exp(2 pi i u f / 16) exp(2 pi i v e / RB).
+// Pass A: 16-point transform over b and the twiddle; pass B: 16/RB transforms of RB points over v
+// per thread (thread (u, dg) takes d = dg + RB g) and the twiddle; pass C: 16-point transform over
+// u.  in: v[b] = x[t + T b]; out: v[dft16_pos(f)] = y[t + T f].  ex1, ex2: 17 T float2 each, the
+// transform's own; every thread of the workgroup calls it (two workgroup barriers inside), so a
+// workgroup of 256 threads runs 16 / RB transforms side by side.
+template <int RB>
+__device__ __forceinline__ void fft_regs(float2 (&v)[16], float2* ex1, float2* ex2, int t) {
+  static_assert(RB == 4 || RB == 8 || RB == 16, "256 RB points, RB = 4, 8 or 16");
+  constexpr int T = 16 * RB, G = 16 / RB;
+  constexpr float inv_n = 1.0f / (float)(256 * RB), inv_t = 1.0f / (float)T;
+  const int lo = t & 15, hi = t >> 4;
+  float2 w[16];
+  dft16(v);
+  powers16(make_float2(__builtin_amdgcn_cosf((float)t * inv_n), __builtin_amdgcn_sinf((float)t * inv_n)), w);
+#pragma unroll
+  for (int d = 0; d < 16; ++d) ex1[t * kFft4096Pitch + d] = d ? cmul(v[dft16_pos(d)], w[d]) : v[0];
+  __syncthreads();
+  powers16(make_float2(__builtin_amdgcn_cosf((float)lo * inv_t), __builtin_amdgcn_sinf((float)lo * inv_t)), w);
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const int d = hi + RB * g;
+    float2 a[RB];
+#pragma unroll
+    for (int q = 0; q < RB; ++q) a[q] = ex1[(lo + 16 * q) * kFft4096Pitch + d];
+    if constexpr (RB == 16) {
+      dft16(a);
+#pragma unroll
+      for (int e = 0; e < RB; ++e) ex2[(d + 16 * e) * kFft4096Pitch + lo] = e ? cmul(a[dft16_pos(e)], w[e]) : a[0];
+    } else {
+      if constexpr (RB == 8) dft8(a);
+      else radix4_inverse(a[0], a[1], a[2], a[3]);
+#pragma unroll
+      for (int e = 0; e < RB; ++e) ex2[(d + 16 * e) * kFft4096Pitch + lo] = e ? cmul(a[e], w[e]) : a[0];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) v[q] = ex2[t * kFft4096Pitch + q];
+  dft16(v);
+}
+
 template <int kThreads = kBlock>
 __device__ __forceinline__ void fill_twiddles(float2* tw, int n) {
   for (int k = threadIdx.x; k < n / 4; k += kThreads) {

@@ -240,7 +240,7 @@ def test_generate_screens_end_to_end(gpu_ctx):
     assert rel_err(tod, ref) <= 1e-5
 
 
-@pytest.mark.parametrize("n,lj", [(4, 0), (8, 0), (64, 0), (128, 0), (2048, 0), (4096, 0), (8192, 0), (64, 6), (128, 5), (1024, 2), (4, 3), (32, 4), (64, -1), (4096, -2)])
+@pytest.mark.parametrize("n,lj", [(4, 0), (8, 0), (64, 0), (128, 0), (2048, 0), (4096, 0), (8192, 0), (64, 6), (128, 5), (1024, 2), (4, 3), (32, 4), (64, -1), (4096, -2), (1024, -3), (2048, -3), (4096, -3)])
 def test_lds_fft_matches_numpy(gpu_ctx, n, lj):
     """The in-LDS Stockham transform (and its interleaved-sequences form) against
     numpy.fft.ifft: the building block of both spectral generators."""
@@ -249,7 +249,8 @@ def test_lds_fft_matches_numpy(gpu_ctx, n, lj):
     from maria_amd._lib import ptr
 
     rng = np.random.default_rng(n + lj)
-    # lj = -1: the 64-point register transform; lj = -2: the 4096-point radix-16 workgroup transform
+    # lj = -1: the 64-point register transform; lj = -2: the 4096-point radix-16 workgroup transform;
+    # lj = -3: fft_regs<RB> (16 x RB x 16, RB = 4, 8, 16: several rows per workgroup, an odd row count)
     rows, J = (3, 1 << lj) if lj >= 0 else (200 if lj == -1 else 5, 1)
     x = (rng.normal(size=(rows, n, J)) + 1j * rng.normal(size=(rows, n, J))).astype(np.complex64)
     d_in = torch.as_tensor(np.ascontiguousarray(x)).to("cuda:0")
