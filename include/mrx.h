@@ -95,7 +95,9 @@ enum {
                                (measured slower than the global gathers; off by default) */
   MRX_OPT_NOISE_LANES = 8, /* streams mrx_noise_generate spreads its batches over (1..4; 0 = automatic:
                               up to 4, each with at least 128 detectors of the work buffer) */
-  MRX_OPT_COUNT = 9
+  MRX_OPT_SCREEN_STOCKHAM = 9, /* 1: the screen generator's transforms as LDS Stockham passes even
+                                  where the register transforms apply (tests, A/B runs) */
+  MRX_OPT_COUNT = 10
 };
 int mrx_set_option(mrx_ctx* ctx, int option, int value);
 const char* mrx_last_error(const mrx_ctx* ctx);

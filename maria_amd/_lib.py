@@ -26,6 +26,7 @@ OPT_SAMPLE_WGS_PER_CU = 6
 OPT_SAMPLE_TILES = 7
 OPT_NOISE_GENERIC = 5
 OPT_NOISE_LANES = 8
+OPT_SCREEN_STOCKHAM = 9
 
 _STATUS = {
     0: "MRX_OK",

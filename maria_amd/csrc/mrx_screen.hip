@@ -23,6 +23,7 @@
 // full-spectrum form with its transpose and the two separate stencil passes.
 // The random number of spectrum cell (kx, ky) depends only on (seed, stream,
 // kx, ky), so every GPU regenerates bit-identical screens with no broadcast.
+#include <algorithm>
 #include <cmath>
 #include <vector>
 
@@ -120,14 +121,63 @@ __device__ __forceinline__ float2 smooth_complex_at(const float2* col, int y, in
   return acc;
 }
 
-// pass 1: spectrum column kx of one layer, all ky; inverse FFT along y; Gaussian along y
-__global__ __launch_bounds__(kBlock) void screen_half_spectrum_fft_y(
-    const ScreenBatchArgs args, int ny, int nx, int log2ny, uint32_t key0, uint32_t key1) {
-  extern __shared__ __align__(16) float2 lds2[];
-  const ScreenLayerArgs& L = args.l[blockIdx.y];
+// Epilogue of pass 1 for one column: the transformed column `res` (LDS, natural order) through the
+// Gaussian along y (scipy.ndimage.gaussian_filter along axis 0 of the written block, reflect at its
+// edges) into G[kx][.]; `nt` threads (t = 0 .. nt - 1) work on the column.
+__device__ __forceinline__ void smooth_column_store(const ScreenLayerArgs& L, const float2* res, float2* dst, int t, int nt) {
+  if (L.ry > 0) {
+    const int r = L.ry, n = L.out_ny;
+    const float* __restrict__ taps = L.taps_y;
+    if (r <= kFastRadius) {
+      constexpr int R = kFastRadius;
+      float tp[R + 1];
+      uniform_taps(taps, tp);
+      for (int y0 = 2 * t; y0 < n; y0 += 2 * nt) {
+        float2 win[2 + 2 * R];
+        if (y0 >= R && y0 + 2 + R <= n) {
+          const float4* wp = reinterpret_cast<const float4*>(res + (y0 - R));
+#pragma unroll
+          for (int j = 0; j < 1 + R; ++j) {
+            const float4 q = wp[j];
+            win[2 * j] = make_float2(q.x, q.y);
+            win[2 * j + 1] = make_float2(q.z, q.w);
+          }
+        } else {  // the window crosses an end of the column: gather it through the reflection
+#pragma unroll
+          for (int j = 0; j < 2 + 2 * R; ++j) win[j] = res[reflect_index(y0 - R + j, n)];
+        }
+        float2 acc[2];
+#pragma unroll
+        for (int v = 0; v < 2; ++v) acc[v] = make_float2(tp[0] * win[R + v].x, tp[0] * win[R + v].y);
+#pragma unroll
+        for (int k = 1; k <= R; ++k) {
+          const float w = tp[k];
+#pragma unroll
+          for (int v = 0; v < 2; ++v) {
+            acc[v].x = fmaf(w, win[R + v - k].x + win[R + v + k].x, acc[v].x);
+            acc[v].y = fmaf(w, win[R + v - k].y + win[R + v + k].y, acc[v].y);
+          }
+        }
+        if (y0 + 2 <= n) {
+          *reinterpret_cast<float4*>(dst + y0) = make_float4(acc[0].x, acc[0].y, acc[1].x, acc[1].y);
+        } else {
+          dst[y0] = acc[0];
+        }
+      }
+    } else {
+      for (int y = t; y < n; y += nt) dst[y] = smooth_complex_at(res, y, n, r, taps);
+    }
+  } else {
+    for (int y = t; y < L.out_ny; y += nt) dst[y] = res[y];
+  }
+}
+
+// pass 1 for one column by the whole workgroup: spectrum column kx = ix of one layer, all ky, into
+// LDS; Stockham inverse FFT along y; Gaussian along y.  lds2: 2 ny + ny / 4 float2.
+__device__ __forceinline__ void half_spectrum_column_stockham(const ScreenLayerArgs& L, float2* lds2, int ix, int ny, int nx,
+                                                              int log2ny, uint32_t key0, uint32_t key1) {
   float2* data = lds2;
   float2* tw = lds2 + 2 * ny;
-  const int ix = blockIdx.x;  // 0 .. nx/2
   const double kx = wavenumber(ix, nx, L.dx);
   const bool edge = ix == 0 || 2 * ix == nx;
   fill_twiddles(tw, ny);
@@ -179,53 +229,69 @@ __global__ __launch_bounds__(kBlock) void screen_half_spectrum_fft_y(
   }
   __syncthreads();
   const float2* res = fft_lds_inverse(data, data + ny, tw, ny, log2ny);
-  float2* dst = L.work + (size_t)ix * (ny + kPitchPad);
-  if (L.ry > 0) {
-    // scipy.ndimage.gaussian_filter along axis 0 of the written block (reflect at its edges)
-    const int r = L.ry, n = L.out_ny;
-    const float* __restrict__ taps = L.taps_y;
-    if (r <= kFastRadius) {
-      constexpr int R = kFastRadius;
-      float tp[R + 1];
-      uniform_taps(taps, tp);
-      for (int y0 = 2 * threadIdx.x; y0 < n; y0 += 2 * kBlock) {
-        float2 win[2 + 2 * R];
-        if (y0 >= R && y0 + 2 + R <= n) {
-          const float4* wp = reinterpret_cast<const float4*>(res + (y0 - R));
-#pragma unroll
-          for (int j = 0; j < 1 + R; ++j) {
-            const float4 q = wp[j];
-            win[2 * j] = make_float2(q.x, q.y);
-            win[2 * j + 1] = make_float2(q.z, q.w);
-          }
-        } else {  // the window crosses an end of the column: gather it through the reflection
-#pragma unroll
-          for (int j = 0; j < 2 + 2 * R; ++j) win[j] = res[reflect_index(y0 - R + j, n)];
-        }
-        float2 acc[2];
-#pragma unroll
-        for (int v = 0; v < 2; ++v) acc[v] = make_float2(tp[0] * win[R + v].x, tp[0] * win[R + v].y);
-#pragma unroll
-        for (int k = 1; k <= R; ++k) {
-          const float w = tp[k];
-#pragma unroll
-          for (int v = 0; v < 2; ++v) {
-            acc[v].x = fmaf(w, win[R + v - k].x + win[R + v + k].x, acc[v].x);
-            acc[v].y = fmaf(w, win[R + v - k].y + win[R + v + k].y, acc[v].y);
-          }
-        }
-        if (y0 + 2 <= n) {
-          *reinterpret_cast<float4*>(dst + y0) = make_float4(acc[0].x, acc[0].y, acc[1].x, acc[1].y);
-        } else {
-          dst[y0] = acc[0];
-        }
-      }
-    } else {
-      for (int y = threadIdx.x; y < n; y += kBlock) dst[y] = smooth_complex_at(res, y, n, r, taps);
-    }
-  } else {
-    for (int y = threadIdx.x; y < L.out_ny; y += kBlock) dst[y] = res[y];
+  smooth_column_store(L, res, L.work + (size_t)ix * (ny + kPitchPad), threadIdx.x, kBlock);
+}
+
+// pass 1, every column (0 .. nx/2) through the Stockham transform: one workgroup per (kx, layer)
+__global__ __launch_bounds__(kBlock) void screen_half_spectrum_fft_y(
+    const ScreenBatchArgs args, int ny, int nx, int log2ny, uint32_t key0, uint32_t key1) {
+  extern __shared__ __align__(16) float2 lds2[];
+  half_spectrum_column_stockham(args.l[blockIdx.y], lds2, blockIdx.x, ny, nx, log2ny, key0, key1);
+}
+
+// pass 1 with the transform in registers (fft_regs: ny = 256 RB, 16 RB threads a column, 16 / RB
+// columns a workgroup) for the interior columns 0 < kx < nx/2: a thread draws its 16 cells
+// ky = t + T b straight into the registers the first radix-16 pass reads -- the same Philox
+// cells, the same values as the Stockham kernel to rounding.  The two self-mirrored columns
+// (Hermitian in ky: a cell's mirror belongs to another thread) take the Stockham form in the
+// launch's last two workgroups (the LDS of the register form covers its 2 ny + ny/4 values).
+template <int RB>
+__global__ __launch_bounds__(kBlock) void screen_half_spectrum_regs(const ScreenBatchArgs args, int nx, uint32_t key0,
+                                                                    uint32_t key1) {
+  extern __shared__ __align__(16) float2 lds2[];
+  constexpr int T = 16 * RB, ny = 256 * RB, half = ny / 2, kCols = kBlock / T;
+  const ScreenLayerArgs& L = args.l[blockIdx.y];
+  if (blockIdx.x + 2 >= gridDim.x) {  // the last two workgroups: kx = 0 and kx = nx/2 (uniform)
+    half_spectrum_column_stockham(L, lds2, blockIdx.x + 1 == gridDim.x ? nx / 2 : 0, ny, nx, 8 + (RB == 4 ? 2 : RB == 8 ? 3 : 4),
+                                  key0, key1);
+    return;
   }
+  const int which = threadIdx.x / T, t = threadIdx.x % T;
+  const int ix = 1 + blockIdx.x * kCols + which;
+  const bool live = ix < nx / 2;  // uniform over the column's waves
+  float2* ex1 = lds2 + (size_t)which * 2 * kFft4096Pitch * T;
+  float2* ex2 = ex1 + kFft4096Pitch * T;
+  float2 v[16];
+#pragma unroll
+  for (int b = 0; b < 16; ++b) v[b] = make_float2(0.f, 0.f);
+  if (live) {
+    if (L.from_work) {
+      const float2* src = L.work + (size_t)ix * (ny + kPitchPad);
+#pragma unroll
+      for (int b = 0; b < 16; ++b) v[b] = src[t + T * b];
+    } else {
+      constexpr float kRoot = 0.70710678118654752f;
+      const double kx = wavenumber(ix, nx, L.dx);
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {  // one Philox call feeds two cells: ky index iy and iy + ny/2 (T * 8 = ny/2)
+        const int iy = t + T * b;
+        const U4 rnd = philox4x32_10(U4{(uint32_t)ix, (uint32_t)iy, L.stream, 0u}, key0, key1);
+        const double ky0 = wavenumber(iy, ny, L.dy), ky1 = wavenumber(iy + half, ny, L.dy);
+        const float amp0 = spectrum_amp(L.k0sq + kx * kx + ky0 * ky0, L.expo);
+        const float amp1 = spectrum_amp(L.k0sq + kx * kx + ky1 * ky1, L.expo);
+        const float2 g0 = box_muller(rnd.x, rnd.y), g1 = box_muller(rnd.z, rnd.w);
+        v[b] = make_float2(kRoot * amp0 * g0.x, kRoot * amp0 * g0.y);
+        v[b + 8] = make_float2(kRoot * amp1 * g1.x, kRoot * amp1 * g1.y);
+      }
+    }
+  }
+  fft_regs<RB>(v, ex1, ex2, t);
+  // the column in natural order for the stencil: ex1 is free again (its last readers are behind
+  // the transform's second barrier) and holds 17 T >= ny values
+#pragma unroll
+  for (int f = 0; f < 16; ++f) ex1[t + T * f] = v[dft16_pos(f)];
+  __syncthreads();
+  if (live) smooth_column_store(L, ex1, L.work + (size_t)ix * (ny + kPitchPad), t, T);
 }
 
 // pass 2: 2^LJ rows of one layer: fold the half spectra, batched inverse FFT of length
@@ -625,8 +691,28 @@ static int run_screen_passes(mrx_ctx* ctx, uint64_t seed, int ny, int nx, const 
       L.stream = d.stream;
       if (out_ny > max_out_ny) max_out_ny = out_ny;
     }
-    hipLaunchKernelGGL(screen_half_spectrum_fft_y, dim3(n2 + 1, nb), dim3(kBlock), lds1, ctx->stream,
-                       args, ny, nx, ly, key0, key1);
+    // the column transforms: in registers for ny = 1024, 2048, 4096 (the two self-mirrored columns
+    // through the Stockham kernel), MRX_OPT_SCREEN_STOCKHAM keeps the LDS form for all columns
+    const int rb = ctx->options[MRX_OPT_SCREEN_STOCKHAM] ? 0 : ny == 1024 ? 4 : ny == 2048 ? 8 : ny == 4096 ? 16 : 0;
+    if (rb && n2 > 1) {
+      // the two exchange images of the register form, or what the Stockham form of the edge columns needs
+      const size_t lds_r = std::max(2 * (size_t)kFft4096Pitch * kBlock * sizeof(float2), lds1);
+      const int cols = kBlock / (16 * rb);
+      const dim3 grid_r(mrx_ceil_div(n2 - 1, cols) + 2, nb);
+      if (rb == 4) {
+        MRX_LDS_CAP(ctx, screen_half_spectrum_regs<4>, lds_r);
+        hipLaunchKernelGGL(screen_half_spectrum_regs<4>, grid_r, dim3(kBlock), lds_r, ctx->stream, args, nx, key0, key1);
+      } else if (rb == 8) {
+        MRX_LDS_CAP(ctx, screen_half_spectrum_regs<8>, lds_r);
+        hipLaunchKernelGGL(screen_half_spectrum_regs<8>, grid_r, dim3(kBlock), lds_r, ctx->stream, args, nx, key0, key1);
+      } else {
+        MRX_LDS_CAP(ctx, screen_half_spectrum_regs<16>, lds_r);
+        hipLaunchKernelGGL(screen_half_spectrum_regs<16>, grid_r, dim3(kBlock), lds_r, ctx->stream, args, nx, key0, key1);
+      }
+    } else {
+      hipLaunchKernelGGL(screen_half_spectrum_fft_y, dim3(n2 + 1, nb), dim3(kBlock), lds1, ctx->stream,
+                         args, ny, nx, ly, key0, key1);
+    }
     MRX_CHECK_LAUNCH(ctx);
     const dim3 grid2(mrx_ceil_div(max_out_ny, 1 << lj), nb);
     if (lj == 2)

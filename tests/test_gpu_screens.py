@@ -187,6 +187,43 @@ def test_screen_batch_with_fused_smoothing(gpu_ctx, ny, nx):
         assert np.abs(g - ref).max() <= 1e-5 * np.abs(ref).max(), sp
 
 
+@pytest.mark.parametrize("ny,nx", [(1024, 512), (2048, 2048), (4096, 256), (2048, 1024)])
+def test_register_transforms_match_the_stockham_ones(gpu_ctx, ny, nx):
+    """Sides of 1024, 2048 and 4096 take the transforms in registers (fft_regs: 16 x RB x 16, the
+    spectrum cells drawn straight into the first pass's registers); MRX_OPT_SCREEN_STOCKHAM keeps
+    the LDS Stockham kernels.  Same Philox cells: the screens agree to float32 rounding -- plain,
+    smoothed, cropped -- and so do the planes of a 3-D volume (pass 1 fed from the work buffer).
+    One size also against numpy's irfft2 of the same spectrum."""
+    from maria_amd import _lib
+
+    base = dict(dy=5.0, dx=6.0, r0=800.0, nu=5.0 / 6.0)
+    specs = [dict(base, stream=0), dict(base, stream=1, sigma_y=4.25, sigma_x=3.5),
+             dict(base, stream=2, sigma_y=2.0, sigma_x=6.0, out_ny=ny - 37, out_nx=nx - 21)]
+    got = _generate_batch(gpu_ctx, 17, ny, nx, specs)
+    gpu_ctx.set_option(_lib.OPT_SCREEN_STOCKHAM, 1)
+    try:
+        ref = _generate_batch(gpu_ctx, 17, ny, nx, specs)
+    finally:
+        gpu_ctx.set_option(_lib.OPT_SCREEN_STOCKHAM, 0)
+    for g, r in zip(got, ref):
+        assert g.shape == r.shape and np.abs(r).max() > 1 and np.abs(g - r).max() <= 3e-6 * np.abs(r).max()
+    if (ny, nx) == (1024, 512):
+        from maria_amd._lib import philox4x32
+        from oracle import screens
+
+        want = screens.hermitian_philox_screen(philox4x32, 17, 0, ny, nx, 5.0, 6.0, 800.0, 5.0 / 6.0)
+        assert np.abs(got[0] - want).max() <= 2e-5 * np.abs(want).max()
+        args = (8, ny, nx, 30.0, 20.0, 25.0, 400.0, 1.0 / 3.0)
+        vol = _generate_3d(gpu_ctx, 5, 3, *args, [0.0, 2.5, 6.75], [1.0, 1.1, 0.9], sigma=2.0)
+        gpu_ctx.set_option(_lib.OPT_SCREEN_STOCKHAM, 1)
+        try:
+            vol_ref = _generate_3d(gpu_ctx, 5, 3, *args, [0.0, 2.5, 6.75], [1.0, 1.1, 0.9], sigma=2.0)
+        finally:
+            gpu_ctx.set_option(_lib.OPT_SCREEN_STOCKHAM, 0)
+        for g, r in zip(vol, vol_ref):
+            assert np.abs(g - r).max() <= 3e-6 * np.abs(r).max()
+
+
 def test_screen_statistics_match_matern(gpu_ctx):
     """Generator parity is statistical: unit variance and the
     Matern(nu=5/6, r0) covariance of functions/__init__.py:30-74 at a set of lags,
