@@ -76,7 +76,9 @@ def test_spectrum_matches_reference_model(gpu_ctx, T, fs, knee, generic):
         if m.sum() < 3:
             continue
         got, want = p[m].mean(), onoise.one_sided_psd_model(f[m], fs, knee).mean()
-        assert abs(got / want - 1) < 0.12, (lo, hi, got, want)
+        # 5 % per band; the lowest band (4-9 bins of the segment) reads 6 % high through the Hann
+        # window's leakage on the 1/f slope
+        assert abs(got / want - 1) < (0.10 if lo == edges[0] else 0.05), (lo, hi, got, want)
 
 
 @pytest.mark.parametrize("modes", [0, 2, 5])
@@ -257,10 +259,11 @@ def test_pink_part_has_zero_mean_and_no_power_below_the_tod(gpu_ctx, T, fs, knee
     """The mean of a detector's noise over the TOD is the mean of its white part: variance
     fs / T (generation.py:27-37 zeroes the f = 0 cell and the period is the TOD).  A pink
     part that kept periods longer than the TOD would add several times that."""
-    D = 256
-    x = _generate(gpu_ctx, D, T, fs, knee, seed=12).cpu().numpy().astype(np.float64)
-    m = x.mean(axis=1)
-    assert abs(m.var() / (fs / T) - 1) < 0.25, m.var() / (fs / T)
+    D = 4096  # the variance of 4096 means: 2.2 % sampling noise (256 detectors left 9 %)
+    x = _generate(gpu_ctx, D, T, fs, knee, seed=12, batch=1024)
+    m = x.double().mean(dim=1).cpu().numpy()
+    assert abs(m.var() / (fs / T) - 1) < 0.08, m.var() / (fs / T)
+    x = x[:256].cpu().numpy().astype(np.float64)
     # and the spectrum still follows 2 (1 + knee / f) from the second harmonic of the TOD on
     X = np.abs(np.fft.rfft(x, axis=1)) ** 2
     psd = 2 * X.mean(axis=0) / (fs * T)  # one-sided, per Hz: the white level is 2
