@@ -508,7 +508,8 @@ __device__ __forceinline__ void bin_corners(const MapArgs& g, const BucketArgs& 
 }
 
 template <bool kChain, bool kBil>
-__global__ __launch_bounds__(kBlock) void bin_bucket_kernel(MapArgs g, BinArgs b, BucketArgs k) {
+// (168 registers instead of 174: measured 21.3 -> 19.7 ms)
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) void bin_bucket_kernel(MapArgs g, BinArgs b, BucketArgs k) {
   using Tile = BinTile<kBil>;
   constexpr int kDet = Tile::kDet, kSpt = Tile::kSpt, kCorners = Tile::kCorners;
   __shared__ DetConst dets[kDet];
