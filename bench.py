@@ -316,8 +316,10 @@ def main():
         "second_kernel": {
             "kernel": "atm_sample_kernel",
             "bound": "valu + vector-memory issue (not hbm): see DESIGN 3.2 and profiles/r02_kernel_pmc.txt",
-            "ms_per_launch": sm_ms,
-            "bytes_per_launch": sm_bytes,
+            "ms_per_step": sm_ms,
+            "launches_per_step": n_launch,
+            "note": "sum over the step's block launches run back to back on one stream (serial breakdown)",
+            "bytes_per_step": sm_bytes,
             "achieved_GBps": sm_bytes / (sm_ms * 1e-3) / 1e9,
             "layer_samples_per_s": D * Ta * L / (sm_ms * 1e-3),
         },
