@@ -718,13 +718,15 @@ int ilog2(long long n) {
 extern "C" {
 
 int mrx_noise_period(int T, int* n1, int* n2) {
-  // smallest power of two N = n1*n2 >= max(T, 4096); n2 = min(8192, N/64) is the length of
-  // the first transform (one workgroup's LDS), n1 = N/n2 <= 1024 the second's
+  // smallest power of two N = n1*n2 >= max(T, 4096).  n2 is the length of the first transform (one
+  // workgroup), n1 = N/n2 <= 1024 the second's: N/64 up to 2^18; from there 4096 -- the length the
+  // register transform of pass 1 takes (the 8192-point Stockham pass spills: 69 against 200-300 G
+  // samples/s) -- and 8192 only for the longest period, 2^23
   if (T <= 0 || !n1 || !n2) return MRX_ERR_INVALID;
   int l = 12;
   while (l < 23 && (1LL << l) < (long long)T) ++l;
   if ((1LL << l) < (long long)T) return MRX_ERR_UNSUPPORTED;
-  const int l2 = l - 6 < 13 ? l - 6 : 13;
+  const int l2 = l <= 18 ? l - 6 : l <= 22 ? 12 : 13;
   *n2 = 1 << l2;
   *n1 = 1 << (l - l2);
   return MRX_OK;

@@ -34,9 +34,11 @@ def _generate(ctx, D, T, fs, knee, corr=0.0, basis=None, scale=None, seed=5, acc
 
 def test_period_helper(gpu_ctx):
     n1, n2 = C.c_int(), C.c_int()
-    for T, want in [(1, 4096), (3000, 4096), (4097, 8192), (240000, 262144), (1440000, 2097152), (1 << 23, 1 << 23)]:
+    for T, want in [(1, 4096), (3000, 4096), (4097, 8192), (240000, 262144), (400000, 1 << 19), (1440000, 2097152), (1 << 23, 1 << 23)]:
         assert gpu_ctx.lib.mrx_noise_period(T, C.byref(n1), C.byref(n2)) == 0
-        assert n1.value * n2.value == want and 64 <= n1.value <= 1024 and n2.value == min(8192, want // 64)
+        # first transform: N / 64 up to 2^18, then 4096 (the register transform's length), 8192 for 2^23 alone
+        first = want // 64 if want <= 1 << 18 else 4096 if want < 1 << 23 else 8192
+        assert n1.value * n2.value == want and 64 <= n1.value <= 1024 and n2.value == first
     assert gpu_ctx.lib.mrx_noise_period((1 << 23) + 1, C.byref(n1), C.byref(n2)) != 0  # unsupported length
 
 
