@@ -377,40 +377,43 @@ SpectrumKernel spectrum_kernel(int n2, int n_modes, int* threads) {
   }
 }
 
-// pass 1 for n2 = 4096 (periods of 2^18 samples: 131 072 < T <= 262 144): a thread builds its 16
-// cells k2 = t + 256 b in registers -- they are the inputs of the first radix-16 transform of
-// fft4096_workgroup -- so the spectrum never goes through LDS before the transform.  The cells of
-// all kPairsPerBlock series are built first, cell by cell, so that a cell's mode spectra are read
-// once and dropped (16 cells x kModes spectra do not fit the register file beside the data); then
-// the series are transformed one after the other.  Same draws, same cells as noise_spectrum_fft
-// (the two agree to rounding).
-template <int kModes>
+// pass 1 for n2 = 256 RB, RB = 4, 8, 16 (periods of 2^16, 2^17 and 2^18 ... 2^22 samples): a team of
+// T = 16 RB threads takes a series; a thread builds its 16 cells k2 = t + T b in registers -- they
+// are the inputs of the first radix-16 transform of fft_regs -- so the spectrum never goes through
+// LDS before the transform.  The cells of all kPairsPerBlock series of a team are built first, cell
+// by cell, so that a cell's mode spectra are read once and dropped (16 cells x kModes spectra do
+// not fit the register file beside the data); then the series are transformed one after the
+// other.  A workgroup holds 16 / RB teams on the same k1.  Same draws, same cells as
+// noise_spectrum_fft (the two agree to rounding).
+template <int kModes, int RB>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) void noise_spectrum_r16(
     float2* __restrict__ A, int n1, SpectrumArgs g, int pairs, uint32_t key0, uint32_t key1) {
   extern __shared__ float2 lds2[];
-  float2* ex1 = lds2;
-  float2* ex2 = lds2 + kFft4096Image;
-  constexpr int n2 = 4096, half = 2048;
-  const int t = threadIdx.x;
+  constexpr int T = 16 * RB, kTeams = kBlock / T, n2 = 256 * RB, half = n2 / 2;
+  const int team = threadIdx.x / T, t = threadIdx.x % T;
+  float2* ex1 = lds2 + (size_t)team * 2 * kFft4096Pitch * T;
+  float2* ex2 = ex1 + kFft4096Pitch * T;
   const int k1 = blockIdx.y;
   const int n = n1 * n2;
   const float amp = g.w_ind * sqrtf(g.knee);
   const float pink_var = amp * amp;
   const float sw = __builtin_sqrtf(g.white_var);
-  const int pair0 = blockIdx.x * kPairsPerBlock;
+  const int pair0 = (blockIdx.x * kTeams + team) * kPairsPerBlock;
   constexpr int kRegModes = kModes > 0 ? kModes : 1;
   // the pairs' mode coefficients sqrt(c) (B[a,m] + i B[b,m]) go through LDS: as scalar loads inside
   // the cell loop each is a stall of its full latency (four in a row per cell and pair: a quarter
   // of the kernel's time), and hoisted into registers they cost more than the file has left
-  __shared__ float2 coef[kPairsPerBlock][kMaxModes];
+  __shared__ float2 coef[kTeams][kPairsPerBlock][kMaxModes];
   if constexpr (kModes > 0) {
-    if (t < kPairsPerBlock * kModes) {
-      const int p = t / kModes, m = t - p * kModes;
-      const int pair = pair0 + p < pairs ? pair0 + p : pairs - 1;
+    if ((int)threadIdx.x < kTeams * kPairsPerBlock * kModes) {
+      const int q = threadIdx.x / kModes, m = threadIdx.x - q * kModes;  // q = team * kPairsPerBlock + p
+      const int want = blockIdx.x * kTeams * kPairsPerBlock + q;
+      const int pair = want < pairs ? want : pairs - 1;
       const int row_a = g.row0 + 2 * pair;
       const bool has_b = row_a + 1 < g.row0 + g.rows;
-      coef[p][m] = make_float2(g.w_corr * g.basis[(size_t)row_a * kModes + m],
-                               has_b ? g.w_corr * g.basis[(size_t)(row_a + 1) * kModes + m] : 0.0f);
+      coef[q / kPairsPerBlock][q % kPairsPerBlock][m] =
+          make_float2(g.w_corr * g.basis[(size_t)row_a * kModes + m],
+                      has_b ? g.w_corr * g.basis[(size_t)(row_a + 1) * kModes + m] : 0.0f);
     }
     __syncthreads();
   }
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   }
 #pragma unroll
   for (int b = 0; b < 8; ++b) {
-    const int k2 = t + 256 * b;
+    const int k2 = t + T * b;  // < n2 / 2 = 8 T
     const int ka = k1 + n1 * k2, kb = k1 + n1 * (k2 + half);
     const float am0 = merged_amp(ka, n, g.white_var, pink_var, g.win.k_min);
     const float am1 = merged_amp(kb, n, g.white_var, pink_var, g.win.k_min);
@@ -439,15 +442,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         f0[m] = nf0[m];
         f1[m] = nf1[m];
         if (b + 1 < 8) {
-          nf0[m] = Fk[(size_t)m * n + 256 * (b + 1)];
-          nf1[m] = Fk[(size_t)m * n + 256 * (b + 1) + half];
+          nf0[m] = Fk[(size_t)m * n + T * (b + 1)];
+          nf1[m] = Fk[(size_t)m * n + T * (b + 1) + half];
         }
       }
     }
 #pragma unroll
     for (int p = 0; p < kPairsPerBlock; ++p) {
+      // (this branch also keeps the scheduler from hoisting every cell's loads and draws to the top:
+      // without it the kernel spills 390 registers)
       const int pair = pair0 + p;
-      if (pair >= pairs) break;  // uniform
+      if (pair >= pairs) break;  // uniform over the team's waves; no barrier inside this loop
       const uint32_t series = g.series0 + pair;
       const U4 rnd = philox4x32_10(U4{(uint32_t)k1, (uint32_t)k2, series, kTagPink}, key0, key1);
       const float2 g0 = box_muller(rnd.x, rnd.y), g1 = box_muller(rnd.z, rnd.w);
@@ -468,8 +473,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
       if constexpr (kModes > 0) {
 #pragma unroll
         for (int m = 0; m < kModes; ++m) {
-          x0 = cfma(coef[p][m], f0[m], x0);
-          x1 = cfma(coef[p][m], f1[m], x1);
+          x0 = cfma(coef[team][p][m], f0[m], x0);
+          x1 = cfma(coef[team][p][m], f1[m], x1);
         }
       }
       v[p][b] = x0;
@@ -477,19 +482,19 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     }
   }
   const float inv_n = 1.0f / (float)n;
-  const float r0 = (float)(k1 * t) * inv_n, r1 = (float)(k1 * 256) * inv_n;  // k1 j < N <= 2^23: exact
+  const float r0 = (float)(k1 * t) * inv_n, r1 = (float)(k1 * T) * inv_n;  // k1 j < N <= 2^23: exact
   const float2 tw_first = make_float2(__builtin_amdgcn_cosf(r0), __builtin_amdgcn_sinf(r0));
   const float2 tw_step = make_float2(__builtin_amdgcn_cosf(r1), __builtin_amdgcn_sinf(r1));
 #pragma unroll
   for (int p = 0; p < kPairsPerBlock; ++p) {
     const int pair = pair0 + p;
-    if (pair >= pairs) break;  // uniform
-    fft4096_workgroup(v[p], ex1, ex2);
+    fft_regs<RB>(v[p], ex1, ex2, t);  // every thread of the workgroup reaches its barriers: a team past the end transforms leftovers
+    if (pair >= pairs) continue;
     float2* dst = A + ((size_t)pair * n1 + k1) * n2 + t;
     float2 w = tw_first;
 #pragma unroll
     for (int f = 0; f < 16; ++f) {
-      dst[256 * f] = cmul(v[p][dft16_pos(f)], w);
+      dst[T * f] = cmul(v[p][dft16_pos(f)], w);
       w = cmul(w, tw_step);
     }
   }
@@ -497,15 +502,26 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 
 typedef void (*SpectrumR16Kernel)(float2*, int, SpectrumArgs, int, uint32_t, uint32_t);
 
-SpectrumR16Kernel spectrum_r16_kernel(int n_modes) {
+template <int RB>
+SpectrumR16Kernel spectrum_r16_modes(int n_modes) {
   switch (n_modes) {
-    case 0: return noise_spectrum_r16<0>;
-    case 1: return noise_spectrum_r16<1>;
-    case 2: return noise_spectrum_r16<2>;
-    case 3: return noise_spectrum_r16<3>;
-    case 4: return noise_spectrum_r16<4>;
-    case 5: return noise_spectrum_r16<5>;
+    case 0: return noise_spectrum_r16<0, RB>;
+    case 1: return noise_spectrum_r16<1, RB>;
+    case 2: return noise_spectrum_r16<2, RB>;
+    case 3: return noise_spectrum_r16<3, RB>;
+    case 4: return noise_spectrum_r16<4, RB>;
+    case 5: return noise_spectrum_r16<5, RB>;
     default: return nullptr;  // more modes than registers: the Stockham kernel
+  }
+}
+
+// the register-transform instance for a first transform of n2 points, or null
+SpectrumR16Kernel spectrum_r16_kernel(int n2, int n_modes) {
+  switch (n2) {
+    case 1024: return spectrum_r16_modes<4>(n_modes);
+    case 2048: return spectrum_r16_modes<8>(n_modes);
+    case 4096: return spectrum_r16_modes<16>(n_modes);
+    default: return nullptr;
   }
 }
 
@@ -820,10 +836,10 @@ int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T
   // attribute belongs to the device)
   MRX_LDS_CAP(ctx, pass1, (2 * 8192 + 8192 / 4) * sizeof(float2));
   MRX_LDS_CAP(ctx, noise_fft_combine, lds2);
-  // periods of 2^18 samples: the register transform (option bit 1 keeps the Stockham kernel, for A/B runs)
+  // first transforms of 1024, 2048, 4096 points: the register transform (option bit 1 keeps the Stockham kernel, for A/B runs)
   const size_t lds_r16 = 2 * (size_t)kFft4096Image * sizeof(float2);
-  const SpectrumR16Kernel pass1_r16 =
-      n2 == 4096 && !(ctx->options[MRX_OPT_NOISE_GENERIC] & 2) ? spectrum_r16_kernel(n_modes) : nullptr;
+  const SpectrumR16Kernel pass1_r16 = !(ctx->options[MRX_OPT_NOISE_GENERIC] & 2) ? spectrum_r16_kernel(n2, n_modes) : nullptr;
+  const int pairs_per_wg = kPairsPerBlock * (n2 >= 1024 && n2 <= 4096 ? 4096 / n2 : 1);  // 16 / RB teams
   if (pass1_r16) MRX_LDS_CAP(ctx, pass1_r16, lds_r16);
 
   SpectrumArgs sp{};
@@ -881,7 +897,7 @@ int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T
     float2* Al = A + (size_t)lane * pairs_lane * n;
     hipLaunchKernelGGL(noise_pair_means, dim3(pairs), dim3(kBlock), 0, stream, n1, n2, sp, key0, key1);
     if (pass1_r16)
-      hipLaunchKernelGGL(pass1_r16, dim3(mrx_ceil_div(pairs, kPairsPerBlock), n1), dim3(kBlock), lds_r16,
+      hipLaunchKernelGGL(pass1_r16, dim3(mrx_ceil_div(pairs, pairs_per_wg), n1), dim3(kBlock), lds_r16,
                          stream, Al, n1, sp, pairs, key0, key1);
     else
       hipLaunchKernelGGL(pass1, dim3(mrx_ceil_div(pairs, kPairsPerBlock), n1), dim3(threads1), lds1,

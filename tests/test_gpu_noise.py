@@ -83,12 +83,14 @@ def test_spectrum_matches_reference_model(gpu_ctx, T, fs, knee, generic):
         assert abs(got / want - 1) < (0.10 if lo == edges[0] else 0.05), (lo, hi, got, want)
 
 
-@pytest.mark.parametrize("modes", [0, 2, 5])
-def test_register_first_pass_matches_the_stockham_one(gpu_ctx, modes):
-    """Periods of 2^18 samples build the spectrum in registers and transform it with three radix-16
-    register passes; option bit 1 keeps the LDS Stockham kernel.  Same draws, same cells: the two
-    series agree to float32 rounding (1/f noise: compared against the largest sample)."""
-    D, T, fs, knee = 11, 150000, 400.0, 3.0
+@pytest.mark.parametrize("modes,T", [(0, 150000), (2, 150000), (5, 150000), (5, 100000), (2, 50000), (0, 33000), (5, 300000)])
+def test_register_first_pass_matches_the_stockham_one(gpu_ctx, modes, T):
+    """First transforms of 1024, 2048 and 4096 points (periods of 2^16, 2^17 and 2^18 ... 2^22
+    samples) build the spectrum in registers and transform it with fft_regs (16 x RB x 16, 16 / RB
+    series side by side in a workgroup); option bit 1 keeps the LDS Stockham kernel.  Same draws,
+    same cells: the two series agree to float32 rounding (1/f noise: compared against the largest
+    sample).  11 detectors: an odd pair count, teams past the end."""
+    D, fs, knee = 11, 400.0, 3.0
     rng = np.random.default_rng(0)
     basis = None if modes == 0 else rng.normal(size=(D, modes)) / np.sqrt(modes)
     a = _generate(gpu_ctx, D, T, fs, knee, corr=0.4, basis=basis, seed=21).cpu().numpy()
