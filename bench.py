@@ -158,19 +158,24 @@ def main():
         import threading
 
         box = {}
+        try:  # the id travels over torch.distributed, from the thread that owns the group
+            unique_id = TodGather.exchange_unique_id(path.ctx, world, rank)
+        except Exception as exc:  # pragma: no cover - depends on the node
+            unique_id, box["note"] = None, f"{type(exc).__name__}: {exc}"[:300]
 
-        def make():
+        def make():  # ncclCommInitRank inside libmrx: the only part that can hang
             try:
                 torch.cuda.set_device(local_rank)  # the current device is per thread
-                box["gatherer"] = TodGather(path.ctx, n_total, world, rank)
+                box["gatherer"] = TodGather(path.ctx, n_total, world, rank, unique_id=unique_id)
             except Exception as exc:  # pragma: no cover - depends on the node
                 box["note"] = f"{type(exc).__name__}: {exc}"[:300]
 
-        th = threading.Thread(target=make, daemon=True)
-        th.start()
-        th.join(150.0)
-        if th.is_alive():
-            box["note"] = "the RCCL communicator did not come up within 150 s"
+        if unique_id is not None:
+            th = threading.Thread(target=make, daemon=True)
+            th.start()
+            th.join(150.0)
+            if th.is_alive():
+                box["note"] = "the RCCL communicator did not come up within 150 s"
         ok = torch.tensor([1 if "gatherer" in box else 0], dtype=torch.int32, device=red_device)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 1:

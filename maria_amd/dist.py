@@ -64,7 +64,21 @@ class TodGather:
     whole ``[world * rows_per_rank, T]`` array once, the writer puts the shard straight into
     this rank's rows (``my_rows``) and ``gather()`` completes the array in place: no staging."""
 
-    def __init__(self, ctx, n_det: int, world: int = None, rank: int = None, align: int = 16):
+    @staticmethod
+    def exchange_unique_id(ctx, world: int, rank: int) -> bytes:
+        """ncclGetUniqueId on rank 0, handed to every rank over the torch.distributed group (a
+        collective: call it from the thread that owns the group)."""
+        import ctypes as C
+
+        ident = C.create_string_buffer(128)
+        if rank == 0:
+            ctx.call("mrx_comm_unique_id", ident)
+        box = [ident.raw]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0)
+        return box[0]
+
+    def __init__(self, ctx, n_det: int, world: int = None, rank: int = None, align: int = 16, unique_id: bytes = None):
         import ctypes as C
 
         if world is None:
@@ -74,13 +88,9 @@ class TodGather:
         self.ctx, self.world, self.rank, self.n_det = ctx, int(world), int(rank), int(n_det)
         self.rows_per_rank = shard_bounds(n_det, world, 0, align)[1] if world > 1 else n_det
         self.lo, self.hi = shard_bounds(n_det, world, rank, align)
-        ident = C.create_string_buffer(128)
-        if self.rank == 0:
-            ctx.call("mrx_comm_unique_id", ident)
-        if self.world > 1:
-            box = [ident.raw]
-            dist.broadcast_object_list(box, src=0)
-            ident = C.create_string_buffer(box[0], 128)
+        if unique_id is None:
+            unique_id = self.exchange_unique_id(ctx, self.world, self.rank)
+        ident = C.create_string_buffer(unique_id, 128)
         comm = C.c_void_p()
         ctx.call("mrx_comm_create", ident, self.world, self.rank, C.byref(comm))
         self.comm = comm
