@@ -656,6 +656,105 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) 
   }
 }
 
+// pass 2 when n1 = 64 m, m = 2, 4, 8, 16 (periods of 2^19 ... 2^23): k1 = a + m b, sample block
+// mm = c + 64 d:  exp(2 pi i k1 mm / n1) = exp(2 pi i a c / n1) exp(2 pi i b c / 64) exp(2 pi i a d / m).
+//   stage a  per (j, a): the 64-point register transform over b of the rows a + m b, the twiddle
+//            exp(2 pi i a c / n1), back into the rows a + m c -- in place: a thread writes the rows
+//            it read, lanes are consecutive j (512 contiguous bytes per row and wave);
+//   stage b  per (j, c): the m-point transform over a of the rows a + m c (m consecutive rows),
+//            then the epilogue of noise_fft64_combine for the samples t = j + n2 (c + 64 d).
+// Three sweeps over the scratch instead of one, but every access whole lines: the LDS form's
+// tiles are 4096 / n1 adjacent j wide (64-byte rows at n1 = 512) and it took 72 % of the time.
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) void noise_fft64_rows(
+    float2* __restrict__ A, int n2, int m, int n1, int j_used) {
+  const int j = blockIdx.x * kBlock + threadIdx.x;
+  if (j >= j_used) return;
+  const int a = blockIdx.y;
+  float2* base = A + ((size_t)blockIdx.z * n1 + a) * n2 + j;
+  const size_t stride = (size_t)m * n2;
+  float re[64], im[64];
+#pragma unroll
+  for (int b = 0; b < 64; ++b) {
+    const vfloat2 v = *reinterpret_cast<const vfloat2*>(base + (size_t)b * stride);
+    re[b] = v[0];
+    im[b] = v[1];
+  }
+  fft64_inverse_reg(re, im);
+  const float step = (float)a / (float)n1;  // a c / n1 < 64 / 128: exact enough in float32 (a c < 2^10)
+#pragma unroll
+  for (int c = 0; c < 64; ++c) {
+    const float rev = (float)c * step;
+    const float2 w = make_float2(__builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
+    const float2 y = cmul(make_float2(re[fft64_pos(c)], im[fft64_pos(c)]), w);
+    *reinterpret_cast<vfloat2*>(base + (size_t)c * stride) = vfloat2{y.x, y.y};
+  }
+}
+
+template <int kM, bool kExtras>
+__global__ __launch_bounds__(kBlock) void noise_combine_rows(const float2* __restrict__ A, int n2, CombineArgs g) {
+  const int j = blockIdx.x * kBlock + threadIdx.x;
+  if (j >= n2 || j >= g.T) return;
+  const int c = blockIdx.y;
+  const float2* src = A + ((size_t)blockIdx.z * 64 * kM + (size_t)kM * c) * n2 + j;
+  float2 v[16];
+#pragma unroll
+  for (int a = 0; a < 16; ++a) v[a] = make_float2(0.f, 0.f);
+#pragma unroll
+  for (int a = 0; a < kM; ++a) {
+    const vfloat2 q = __builtin_nontemporal_load(reinterpret_cast<const vfloat2*>(src + (size_t)a * n2));
+    v[a] = make_float2(q[0], q[1]);
+  }
+  // the kM-point transform over a: output d at v[pos(d)]
+  if constexpr (kM == 16) {
+    dft16(v);
+  } else if constexpr (kM == 8) {
+    float2 u[8];
+#pragma unroll
+    for (int a = 0; a < 8; ++a) u[a] = v[a];
+    dft8(u);
+#pragma unroll
+    for (int a = 0; a < 8; ++a) v[a] = u[a];
+  } else if constexpr (kM == 4) {
+    radix4_inverse(v[0], v[1], v[2], v[3]);
+  } else {
+    const float2 s0 = cadd(v[0], v[1]), s1 = csub(v[0], v[1]);
+    v[0] = s0;
+    v[1] = s1;
+  }
+  const int row_a = g.row0 + 2 * blockIdx.z;
+  const bool has_b = row_a + 1 < g.row0 + g.rows;
+  const int row_b = has_b ? row_a + 1 : row_a;
+  const float sa = g.scale ? g.scale[row_a] : 1.0f, sb = g.scale ? g.scale[row_b] : 1.0f;
+  float* out_a = g.out + (size_t)row_a * g.ld;
+  float* out_b = g.out + (size_t)row_b * g.ld;
+  const float mean_a = g.mean ? (float)g.mean[blockIdx.z].x : 0.0f, mean_b = g.mean ? (float)g.mean[blockIdx.z].y : 0.0f;
+#pragma unroll
+  for (int d = 0; d < kM; ++d) {
+    const size_t t = (size_t)j + (size_t)n2 * (size_t)(c + 64 * d);
+    if (t >= (size_t)g.T) continue;
+    const float2 x = v[kM == 16 ? dft16_pos(d) : d];
+    float va = x.x - mean_a, vb = x.y - mean_b;
+    if (kExtras) {
+      float aa = sa, ab = sb;
+      if (g.loading) {
+        aa += g.per_loading * g.loading[(size_t)row_a * g.ld_loading + t];
+        ab += g.per_loading * g.loading[(size_t)row_b * g.ld_loading + t];
+      }
+      va *= aa;
+      vb *= ab;
+      if (g.accumulate) {
+        va += out_a[t];
+        vb += out_b[t];
+      }
+      out_a[t] = va;
+      if (has_b) out_b[t] = vb;
+    } else {
+      __builtin_nontemporal_store(sa * va, out_a + t);
+      if (has_b) __builtin_nontemporal_store(sb * vb, out_b + t);
+    }
+  }
+}
+
 // knee = 0: white noise only (generation.py:25), 4 samples per thread
 __global__ __launch_bounds__(kBlock) void noise_white_kernel(CombineArgs g, uint32_t key0, uint32_t key1) {
   const size_t t0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * 4;
@@ -908,6 +1007,22 @@ int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T
         hipLaunchKernelGGL(noise_fft64_combine<true>, grid, dim3(kBlock), 0, stream, Al, n2, h, key0, key1);
       else
         hipLaunchKernelGGL(noise_fft64_combine<false>, grid, dim3(kBlock), 0, stream, Al, n2, h, key0, key1);
+    } else if (n1 % 64 == 0 && n1 / 64 <= 16 && !(ctx->options[MRX_OPT_NOISE_GENERIC] & 1)) {
+      // n1 = 64 m: 64-point register transforms in place, then the m-point ones with the epilogue
+      const int m = n1 / 64;
+      const bool extras = h.loading || h.accumulate;
+      hipLaunchKernelGGL(noise_fft64_rows, dim3(mrx_ceil_div(j_used, kBlock), m, pairs), dim3(kBlock), 0, stream, Al, n2, m, n1, j_used);
+      const dim3 grid_b(mrx_ceil_div(j_used, kBlock), 64, pairs);
+#define MRX_COMBINE_ROWS(M)                                                                                   \
+  do {                                                                                                       \
+    if (extras) hipLaunchKernelGGL((noise_combine_rows<M, true>), grid_b, dim3(kBlock), 0, stream, Al, n2, h); \
+    else hipLaunchKernelGGL((noise_combine_rows<M, false>), grid_b, dim3(kBlock), 0, stream, Al, n2, h);       \
+  } while (0)
+      if (m == 2) MRX_COMBINE_ROWS(2);
+      else if (m == 4) MRX_COMBINE_ROWS(4);
+      else if (m == 8) MRX_COMBINE_ROWS(8);
+      else MRX_COMBINE_ROWS(16);
+#undef MRX_COMBINE_ROWS
     } else {
       hipLaunchKernelGGL(noise_fft_combine, dim3(mrx_ceil_div(j_used, 1 << lj), pairs), dim3(kBlock), lds2,
                          stream, Al, n1, n2, l1, lj, h, key0, key1);

@@ -102,6 +102,36 @@ def test_register_first_pass_matches_the_stockham_one(gpu_ctx, modes, T):
     assert np.abs(a).max() > 10 and np.abs(a - b).max() <= 2e-5 * np.abs(b).max()
 
 
+@pytest.mark.parametrize("T,modes", [(300000, 2), (600000, 5), (1500000, 0), (2200000, 3)])
+def test_register_second_pass_for_long_periods_matches_the_lds_one(gpu_ctx, T, modes):
+    """Periods of 2^19 ... 2^22 samples (n1 = 128 ... 1024 = 64 m): 64-point register transforms in
+    place over the scratch, then the m-point ones with the epilogue; option bit 0 keeps the LDS
+    tiles.  Same spectrum, same samples to float32 rounding; with a scale, a loading-dependent
+    level and accumulation into an existing TOD."""
+    import torch
+
+    D, fs, knee = 6, 400.0, 3.0
+    rng = np.random.default_rng(1)
+    basis = None if modes == 0 else rng.normal(size=(D, modes)) / np.sqrt(modes)
+    scale = np.linspace(0.5, 2.0, D)
+    a = _generate(gpu_ctx, D, T, fs, knee, corr=0.4, basis=basis, scale=scale, seed=33)
+    gpu_ctx.set_option(5, 1)
+    try:
+        b = _generate(gpu_ctx, D, T, fs, knee, corr=0.4, basis=basis, scale=scale, seed=33)
+    finally:
+        gpu_ctx.set_option(5, 0)
+    peak = float(b.abs().max())
+    assert peak > 10 and float((a - b).abs().max()) <= 2e-5 * peak
+    if modes == 2:  # the epilogue's other branch: loading-dependent level, accumulation
+        loading = torch.rand((D, T), dtype=torch.float32, device="cuda:0")
+        base = torch.full((D, T), 3.0, dtype=torch.float32, device="cuda:0")
+        c = _generate(gpu_ctx, D, T, fs, knee, corr=0.4, basis=basis, scale=scale, seed=33, loading=loading, per_loading=0.7,
+                      accumulate=1, out=base.clone())
+        want = 3.0 + a * (torch.as_tensor(scale, dtype=torch.float32, device="cuda:0")[:, None] + 0.7 * loading) / \
+            torch.as_tensor(scale, dtype=torch.float32, device="cuda:0")[:, None]
+        assert float((c - want).abs().max()) <= 3e-5 * peak
+
+
 def test_matches_oracle_generator_statistics(gpu_ctx):
     """Against the numpy restatement of the reference on the same parameters: equal band
     powers (three octaves below, at and above the knee) within sampling error."""
