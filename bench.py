@@ -173,9 +173,9 @@ def main():
         if unique_id is not None:
             th = threading.Thread(target=make, daemon=True)
             th.start()
-            th.join(150.0)
+            th.join(90.0)
             if th.is_alive():
-                box["note"] = "the RCCL communicator did not come up within 150 s"
+                box["note"] = "the RCCL communicator did not come up within 90 s"
         ok = torch.tensor([1 if "gatherer" in box else 0], dtype=torch.int32, device=red_device)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 1:
