@@ -6,8 +6,8 @@
 One step = one full pass of the path over one observation's worth of synthetic
 input for this rank's detectors: generate + smooth the turbulent screens
 (Philox / Hermitian FFT / fused Gaussian), fused pointing + layer gather + emission
-at the coarse rate, not-a-knot spline solve, cubic upsample to the sample rate ->
-float32 TOD in HBM.  All inputs are resident in HBM before the timed region.
+at the coarse rate, not-a-knot spline solve + cubic upsample to the sample rate (one
+kernel) -> float32 TOD in HBM.  All inputs are resident in HBM before the timed region.
 
 Metric (BASELINE.json): detector-samples/s = n_det x n_t x steps / time, summed
 over ranks.  N = 1 is the named configuration on one GPU.  N > 1:
@@ -21,7 +21,7 @@ over ranks.  N = 1 is the named configuration on one GPU.  N > 1:
     cannot be gathered onto one GPU).  --scaling overrides either default.
 
 Prints ONE JSON line on rank 0, including
-  roofline      : the dominant kernel (cubic upsample, HBM-bound streaming write),
+  roofline      : the dominant kernel (spline solve + cubic upsample, HBM-bound streaming write),
                   timed live with events on the launch stream
   second_kernel : the same for atm_sample_kernel (VALU / vector-memory-issue bound)
   cpu_baseline  : the numpy/scipy oracle on a detector subset, on this host's cores,
@@ -212,14 +212,12 @@ def main():
         if n_blocks > 1:
             path._run_pipelined(tod, n_blocks, serial_events=sev)
         else:
-            tev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+            tev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
             tev[0].record()
             path.sample()
             tev[1].record()
-            path.prepare()
+            path.upsample_fused(tod)
             tev[2].record()
-            path.upsample(tod)
-            tev[3].record()
             sev.append(tev)
 
     def barrier():
@@ -251,8 +249,8 @@ def main():
         serial_step(sev)
     torch.cuda.synchronize()
     # per stage: the sum over a step's block launches, averaged over the 3 passes
-    serial_ms = np.array([[t[i].elapsed_time(t[i + 1]) for i in range(3)] for t in sev]).sum(axis=0) / 3.0
-    serial_up_launch_ms = float(np.mean([t[2].elapsed_time(t[3]) for t in sev]))
+    serial_ms = np.array([[t[i].elapsed_time(t[i + 1]) for i in range(2)] for t in sev]).sum(axis=0) / 3.0
+    serial_up_launch_ms = float(np.mean([t[1].elapsed_time(t[2]) for t in sev]))
     step_ms = np.array([[ev[k][i].elapsed_time(ev[k][i + 1]) for i in range(2)] for k in range(args.steps)]).mean(axis=0)
     # the dominant kernel, timed live in the timed region on the stream it runs on: one launch
     # per detector block when the step is pipelined (its rows x T samples each)
@@ -262,9 +260,8 @@ def main():
         rows_per_launch = D / n_launch
     else:
         up_ms, rows_per_launch = serial_up_launch_ms, D / n_launch
-    up_bytes = 4.0 * rows_per_launch * T + 8.0 * rows_per_launch * Ta + 8.0 * T  # TOD write + (y,m) knots read + sample times read
+    up_bytes = 4.0 * rows_per_launch * T + 4.0 * rows_per_launch * Ta + 8.0 * T  # TOD write + coarse loading read + sample times read
     achieved = up_bytes / (up_ms * 1e-3) / 1e9
-    alone_bytes = 4.0 * D * T + 8.0 * D * Ta + 8.0 * T * n_launch
     alone = up_bytes / (serial_up_launch_ms * 1e-3) / 1e9
     # the sampler: 4 B/det-step written + each screen read once + inputs (it is not HBM-bound)
     sm_ms = float(serial_ms[0])
@@ -298,13 +295,13 @@ def main():
         "stage_ms": {
             "screens": float(step_ms[0]),
             "tod_synthesis_pipelined": float(step_ms[1]),
-            "serial_breakdown": {"sample": sm_ms, "spline_prepare": float(serial_ms[1]), "upsample": float(serial_ms[2]),
+            "serial_breakdown": {"sample": sm_ms, "upsample_with_spline_solve": float(serial_ms[1]),
                                  "note": "the same block launches back to back on one stream, outside the timed region; sums over the blocks"},
             "detector_blocks": n_launch,
         },
         "path_hbm_gbps": path.algorithmic_bytes() / (1e-3 * float(step_ms.sum())) / 1e9,
         "roofline": {
-            "kernel": "spline_upsample_kernel",
+            "kernel": "spline_upsample_fused_kernel",
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS,

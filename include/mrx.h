@@ -235,6 +235,20 @@ int mrx_spline_upsample(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
                         const float* d_scale, const int32_t* d_rows,
                         float* d_out, size_t ld_out);
 
+/* mrx_spline_prepare + mrx_spline_upsample in ONE kernel (sim/atmosphere.py:72-82): the
+ * writer reads the raw coarse samples d_y [Ta*D] f32 time-major -- mrx_atm_sample's
+ * d_loading as it is -- and solves the second derivatives of the knots its own tile of
+ * 1024 samples touches in the tile prologue (the same twisted factorisation, started
+ * 16 knots outside the tile or at the true not-a-knot end).  No (y, m) buffer, no solve
+ * launch.  Same result as the two-call form to float32 rounding of m (<= 1e-7 of y).
+ * Arguments as mrx_spline_upsample.  A tile whose samples span more knots than the LDS
+ * image holds (upsampling ratios T/Ta below ~4) is walked in segments: correct at any
+ * ratio, fastest from ~18 up (maria's ratios: 5 at 50 Hz, 40 at 400 Hz). */
+int mrx_spline_upsample_fused(mrx_ctx* ctx, const float* d_y, int D, int Ta,
+                              double ta0, double dta, const double* d_t, int T,
+                              const float* d_scale, const int32_t* d_rows,
+                              float* d_out, size_t ld_out);
+
 /* mrx_spline_upsample fused with TOD.to("K_RJ") (tod/tod.py:106-142): each sample
  * is divided by den_b(el) = (0.5 if polarized else 1) * k_B * 1e12 *
  * Int tau_b(nu) exp(-opacity(nu)) dnu (calibration/functions.py:73-90,

@@ -165,6 +165,7 @@ SIGNATURES = {
     "mrx_read_flags": (_i, [_vp, _vp, C.POINTER(C.c_uint32)]),
     "mrx_spline_prepare": (_i, [_vp, _vp, _i, _i, _vp]),
     "mrx_spline_upsample": (_i, [_vp, _vp, _i, _i, _d, _d, _vp, _i, _vp, _vp, _vp, _sz]),
+    "mrx_spline_upsample_fused": (_i, [_vp, _vp, _i, _i, _d, _d, _vp, _i, _vp, _vp, _vp, _sz]),
     "mrx_spline_upsample_krj": (_i, [_vp, _vp, _i, _i, _d, _d, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _sz]),
     "mrx_coarse_to_krj": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "mrx_tod_to_krj": (_i, [_vp, _vp, _sz, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i]),
@@ -274,6 +275,11 @@ class Context:
 
     def set_option(self, option: int, value: int):
         self.call("mrx_set_option", int(option), int(value))
+        self.__dict__.setdefault("_options", {})[int(option)] = int(value)
+
+    def get_option(self, option: int) -> int:
+        """The value this handle last set (0, the library default, if never set)."""
+        return self.__dict__.get("_options", {}).get(int(option), 0)
 
     def device_info(self) -> dict:
         n_cu, lds, hbm = _i(), _i(), _sz()

@@ -3,7 +3,7 @@
 ``DevicePath`` owns the device copies of one observation's inputs (as torch
 tensors: torch is the allocator and the stream owner, nothing else) and runs
 
-    mrx_atm_sample -> mrx_spline_prepare -> mrx_spline_upsample
+    mrx_atm_sample -> mrx_spline_upsample_fused
 
 for a contiguous block of detector rows.  The stages are the reference's
 ``Atmosphere.simulate_pwv`` (atmosphere/atmosphere.py:293-380) and
@@ -162,7 +162,7 @@ class DevicePath:
 
         self.d_flags = torch.zeros(1, dtype=torch.int32, device=dev)
         self.d_loading = torch.empty((self.Ta, self.D), dtype=torch.float32, device=dev)
-        self.d_ym = torch.empty((self.Ta, self.D, 2), dtype=torch.float32, device=dev)
+        self.d_ym = None  # (y, m) knots of the two-call spline form: allocated by prepare()
         self.d_pwv = torch.empty((self.Ta, self.D), dtype=torch.float64, device=dev) if keep_pwv else None
 
         self._layer_bufs = []
@@ -336,12 +336,23 @@ class DevicePath:
 
     def prepare(self, krj=False):
         """Second derivatives of the coarse loading (``krj``: of the coarse loading in K_RJ that
-        coarse_to_krj() made)."""
+        coarse_to_krj() made) for upsample() / upsample_krj(): the two-call form of the spline.
+        run() uses upsample_fused(), which needs neither this call nor its buffer."""
+        if self.d_ym is None:
+            self.d_ym = torch.empty((self.Ta, self.D, 2), dtype=torch.float32, device=self.device)
         self.ctx.call("mrx_spline_prepare", ptr(self.d_loading_krj if krj else self.d_loading), self.D, self.Ta, ptr(self.d_ym))
 
     def upsample(self, out):
         self.ctx.call(
             "mrx_spline_upsample", ptr(self.d_ym), self.D, self.Ta, self.ta0, self.dta,
+            ptr(self.d_t), self.T, ptr(self.d_gain), ptr(self.d_rows), ptr(out), out.stride(0),
+        )
+
+    def upsample_fused(self, out, krj=False):
+        """mrx_spline_upsample_fused: spline solve + evaluation of the coarse loading in one
+        kernel (no (y, m) buffer; ``krj``: of the coarse loading coarse_to_krj() made)."""
+        self.ctx.call(
+            "mrx_spline_upsample_fused", ptr(self.d_loading_krj if krj else self.d_loading), self.D, self.Ta, self.ta0, self.dta,
             ptr(self.d_t), self.T, ptr(self.d_gain), ptr(self.d_rows), ptr(out), out.stride(0),
         )
 
@@ -389,11 +400,8 @@ class DevicePath:
         with _range("Upsampling atmospheric loading"):
             if krj:
                 self.coarse_to_krj()
-            self.prepare(krj=krj)
-            self.upsample(out)
+            self.upsample_fused(out, krj=krj)
         return out
-
-    prepare_on_writer_stream = True
 
     def default_blocks(self):
         """Detector blocks of the pipelined run: 8 from 8192 rows up, 4 from 4096 (measured on
@@ -425,61 +433,55 @@ class DevicePath:
         ctx2.set_stream(side)
         st = dict(blocks=blocks, bounds=bounds, side=side, ctx2=ctx2,
                   ready=[torch.cuda.Event() for _ in bounds], start=torch.cuda.Event(),
-                  loading=[torch.empty((self.Ta, hi - lo), dtype=torch.float32, device=self.device) for lo, hi in bounds],
-                  ym=[torch.empty((self.Ta, hi - lo, 2), dtype=torch.float32, device=self.device) for lo, hi in bounds])
+                  loading=[torch.empty((self.Ta, hi - lo), dtype=torch.float32, device=self.device) for lo, hi in bounds])
         self._pipe = st
         return st
 
     def _run_pipelined(self, out, blocks, resident_wgs_per_cu=3, writer_events=None, serial_events=None, krj=False,
                        resident_times=2):
-        """sample + prepare of block b on the side stream, the writer of block b on the caller's
-        stream behind an event; block 0's sampler takes the whole chip (nothing to run beside).
+        """The sampler of block b on the side stream, the writer of block b (spline solve fused
+        in: mrx_spline_upsample_fused) on the caller's stream behind an event; block 0's sampler
+        takes the whole chip (nothing to run beside).
         ``writer_events``: a list that receives one (start, end) pair of timing events per writer
         launch, recorded on the stream the writer runs on (bench.py's live kernel timing).
         ``serial_events``: run the same block launches back to back on the caller's stream instead
-        (no overlap) and append (t0, t1, t2, t3) timing events per block around sample / prepare /
-        upsample: the per-stage breakdown of exactly the launches the pipelined step makes."""
+        (no overlap) and append (t0, t1, t2) timing events per block around sample / writer: the
+        per-stage breakdown of exactly the launches the pipelined step makes."""
         if self.plan is None:
             raise RuntimeError("no screens bound: call set_screens() or generate_screens() first")
         st = self._pipeline_state(blocks)
         main, side, ctx2 = torch.cuda.current_stream(self.device), st["side"], st["ctx2"]
+        # the writers go through self.ctx: its stream must be the one the events below are
+        # recorded on, whatever stream was current when this DevicePath was made
+        self.ctx.set_stream(main)
         serial = serial_events is not None
         if serial:
             side, ctx2 = main, self.ctx
         else:
             st["start"].record(main)  # screens (and the previous run's writers) come first
             side.wait_event(st["start"])
+        saved = (ctx2.get_option(_lib.OPT_SAMPLE_WGS_PER_CU), ctx2.get_option(_lib.OPT_SAMPLE_TIMES))
         sl = lambda t, lo, hi: None if t is None else ptr(t[lo:hi])  # noqa: E731
         for i, (lo, hi) in enumerate(st["bounds"]):
             n = hi - lo
             # beside a writer: a resident grid of 3 workgroups per CU, two time steps interleaved per
             # thread at 96 registers (measured: 2.62 ms against 2.73 for 4 per CU at 64 registers)
             alone = i == 0 or serial
-            ctx2.set_option(_lib.OPT_SAMPLE_WGS_PER_CU, 0 if alone else resident_wgs_per_cu)
-            ctx2.set_option(_lib.OPT_SAMPLE_TIMES, 0 if alone else resident_times)
+            ctx2.set_option(_lib.OPT_SAMPLE_WGS_PER_CU, saved[0] if alone else resident_wgs_per_cu)
+            ctx2.set_option(_lib.OPT_SAMPLE_TIMES, saved[1] if alone else resident_times)
             if serial:
-                tev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+                tev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
                 tev[0].record(main)
             ctx2.call(
                 "mrx_atm_sample", self.plan, ptr(self.d_az), ptr(self.d_el), self.Ta,
                 sl(self.d_dx, lo, hi), sl(self.d_dy, lo, hi), sl(self.d_band, lo, hi), sl(self.d_m00, lo, hi), n,
                 self.pwv0, None, ptr(st["loading"][i]), ptr(self.d_flags),
             )
-            if serial:
-                tev[1].record(main)
             if krj:  # TOD.to("K_RJ") on the coarse grid: the writer below then writes K_RJ at the pW writer's cost
                 self.coarse_to_krj(st["loading"][i], n, slice(lo, hi), ctx2)
-            prep_ctx = ctx2
-            if not serial and self.prepare_on_writer_stream:
-                # the sampler stream is the critical path while a writer streams beside it (it runs at
-                # half its stand-alone rate there): the spline solve goes in front of the writer instead
-                st["ready"][i].record(side)
-                main.wait_event(st["ready"][i])
-                prep_ctx = self.ctx
-            prep_ctx.call("mrx_spline_prepare", ptr(st["loading"][i]), n, self.Ta, ptr(st["ym"][i]))
             if serial:
-                tev[2].record(main)
-            elif not self.prepare_on_writer_stream:
+                tev[1].record(main)
+            else:
                 st["ready"][i].record(side)
                 main.wait_event(st["ready"][i])
             if self.d_rows is not None:
@@ -490,17 +492,17 @@ class DevicePath:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record(main)
             self.ctx.call(
-                "mrx_spline_upsample", ptr(st["ym"][i]), n, self.Ta, self.ta0, self.dta,
+                "mrx_spline_upsample_fused", ptr(st["loading"][i]), n, self.Ta, self.ta0, self.dta,
                 ptr(self.d_t), self.T, sl(self.d_gain, lo, hi), rows, ptr(dst), out.stride(0),
             )
             if writer_events is not None:
                 ev[1].record(main)
                 writer_events.append(ev)
             if serial:
-                tev[3].record(main)
+                tev[2].record(main)
                 serial_events.append(tev)
-        ctx2.set_option(_lib.OPT_SAMPLE_WGS_PER_CU, 0)
-        ctx2.set_option(_lib.OPT_SAMPLE_TIMES, 0)
+        ctx2.set_option(_lib.OPT_SAMPLE_WGS_PER_CU, saved[0])
+        ctx2.set_option(_lib.OPT_SAMPLE_TIMES, saved[1])
         self._pipelined = True
         return out
 

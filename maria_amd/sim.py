@@ -344,14 +344,12 @@ class Simulation:
                 # the conversion on the coarse grid, then the pW writer (HBM-bound): the two orders of
                 # "divide" and "interpolate" differ by less than a quarter of the parity tolerance here
                 path.coarse_to_krj()
-                path.prepare(krj=True)
-                path.upsample(out)
+                path.upsample_fused(out, krj=True)
             else:
                 path.prepare()
                 path.upsample_krj(out)
         else:
-            path.prepare()
-            path.upsample(out)
+            path.upsample_fused(out)
         return out
 
     def _sample_maps(self, obs, rows=None):

@@ -59,7 +59,7 @@ def test_act_like_three_bands(gpu_ctx):
 def test_atlast_50k_shard_time_chunked(gpu_ctx):
     """Config 5 on one GPU: a 1/8 detector shard (6250 rows), 16 layers of 4096^2
     screens, 3600 s at 400 Hz.  The 36 GB TOD is written in 600 s chunks through the
-    ld_out / d_t window of mrx_spline_upsample, as a consumer that cannot hold it would;
+    ld_out / d_t window of mrx_spline_upsample_fused, as a consumer that cannot hold it would;
     chunks must tile the un-chunked result exactly."""
     import torch
 
@@ -74,7 +74,6 @@ def test_atlast_50k_shard_time_chunked(gpu_ctx):
     path.generate_screens()
     assert path._layer_bufs[0][0].shape == (4096, 4096) and len(path._layer_bufs) == 16
     path.sample()
-    path.prepare()
     assert path.check_flags() == 0
     chunk = 240000  # 600 s
     buf = torch.empty((path.D, chunk), dtype=torch.float32, device="cuda:0")
@@ -84,7 +83,7 @@ def test_atlast_50k_shard_time_chunked(gpu_ctx):
     for s in range(0, path.T, chunk):
         d_t = path.d_t[s : s + chunk]
         path.ctx.call(
-            "mrx_spline_upsample", ptr(path.d_ym), path.D, path.Ta, path.ta0, path.dta,
+            "mrx_spline_upsample_fused", ptr(path.d_loading), path.D, path.Ta, path.ta0, path.dta,
             ptr(d_t), chunk, None, ptr(path.d_rows), ptr(buf), chunk,
         )
         assert bool(torch.isfinite(buf).all())

@@ -86,7 +86,6 @@ def test_pipelined_run_is_bit_identical_to_the_serial_one(full):
     assert path.check_flags() == 0
     del out
     path.sample()  # back to the serial state for the tests below
-    path.prepare()
 
 
 def test_gain_is_linear(full):
@@ -95,7 +94,7 @@ def test_gain_is_linear(full):
     p, path, tod = full
     path.set_gain(np.full(path.D, 2.0, np.float32))
     out = torch.empty_like(tod)
-    path.upsample(out)
+    path.upsample_fused(out)
     path.set_gain(None)
     assert torch.equal(out, 2.0 * tod)
 

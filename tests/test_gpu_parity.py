@@ -180,14 +180,30 @@ def test_full_path_matches_oracle(gpu_ctx):
     assert _fluct_err(tod, ref) <= 1e-3
 
 
-@pytest.mark.parametrize("Ta", [4, 5, 6, 7, 15, 16, 17, 31, 33, 48, 49, 100, 601])
-def test_spline_matches_scipy_all_lengths(gpu_ctx, Ta):
-    """mrx_spline_prepare + mrx_spline_upsample against scipy's not-a-knot cubic on
-    the same coarse samples, including the extrapolated tail (sim/atmosphere.py:72-82)
-    and samples before the first knot."""
+def _spline_upsample(gpu_ctx, form, d_y, D, Ta, ta0, dta, d_t, T, d_scale, d_out, ld):
+    """The two forms of the cubic upsample through the C ABI: "fused" = mrx_spline_upsample_fused (the
+    solve in the writer's tile prologue, what DevicePath.run launches), "two-call" = mrx_spline_prepare +
+    mrx_spline_upsample.  Returns the (y, m) knots of the two-call form (None for the fused one)."""
     import torch
 
     from maria_amd._lib import ptr
+
+    if form == "fused":
+        gpu_ctx.call("mrx_spline_upsample_fused", ptr(d_y), D, Ta, ta0, dta, ptr(d_t), T, ptr(d_scale), None, ptr(d_out), ld)
+        return None
+    d_ym = torch.empty((Ta, D, 2), dtype=torch.float32, device=d_y.device)
+    gpu_ctx.call("mrx_spline_prepare", ptr(d_y), D, Ta, ptr(d_ym))
+    gpu_ctx.call("mrx_spline_upsample", ptr(d_ym), D, Ta, ta0, dta, ptr(d_t), T, ptr(d_scale), None, ptr(d_out), ld)
+    return d_ym
+
+
+@pytest.mark.parametrize("form", ["fused", "two-call"])
+@pytest.mark.parametrize("Ta", [4, 5, 6, 7, 15, 16, 17, 31, 33, 48, 49, 100, 601])
+def test_spline_matches_scipy_all_lengths(gpu_ctx, Ta, form):
+    """Both forms of the cubic upsample against scipy's not-a-knot cubic on the same coarse
+    samples, including the extrapolated tail (sim/atmosphere.py:72-82) and samples before the
+    first knot."""
+    import torch
 
     rng = np.random.default_rng(Ta)
     D = 37
@@ -201,27 +217,24 @@ def test_spline_matches_scipy_all_lengths(gpu_ctx, Ta):
 
     dev = "cuda:0"
     d_y = torch.as_tensor(np.ascontiguousarray(y.T)).to(dev)
-    d_ym = torch.empty((Ta, D, 2), dtype=torch.float32, device=dev)
     d_t = torch.as_tensor(t).to(dev)
     ld = T + 3  # odd pitch: exercises the scalar-store path
     d_out = torch.full((D, ld), -7.0, dtype=torch.float32, device=dev)
-    gpu_ctx.call("mrx_spline_prepare", ptr(d_y), D, Ta, ptr(d_ym))
-    gpu_ctx.call("mrx_spline_upsample", ptr(d_ym), D, Ta, float(ta[0]), float(ta[1] - ta[0]), ptr(d_t), T, None, None, ptr(d_out), ld)
+    d_ym = _spline_upsample(gpu_ctx, form, d_y, D, Ta, float(ta[0]), float(ta[1] - ta[0]), d_t, T, None, d_out, ld)
     out = d_out.cpu().numpy()
     assert (out[:, T:] == -7.0).all(), "wrote past T"
     assert rel_err(out[:, :T], ref) <= 2e-6
-    # knots are reproduced (interpolation property)
-    ym = d_ym.cpu().numpy()
-    assert np.array_equal(ym[:, :, 0], y.T)
+    if d_ym is not None:  # knots are reproduced (interpolation property)
+        assert np.array_equal(d_ym.cpu().numpy()[:, :, 0], y.T)
 
 
-@pytest.mark.parametrize("ratio", [1.0, 2.5, 3.9, 8.0, 40.0, 400.0])
-def test_upsample_ratios(gpu_ctx, ratio):
-    """Every tile path of the evaluation kernel: ratios below ~4 take the global-load
-    path, the others stage knots through LDS."""
+@pytest.mark.parametrize("form", ["fused", "two-call"])
+@pytest.mark.parametrize("ratio", [1.0, 2.5, 3.9, 8.0, 17.0, 19.0, 40.0, 400.0])
+def test_upsample_ratios(gpu_ctx, ratio, form):
+    """Every tile path of the evaluation kernels.  Two-call form: ratios below ~4 take the
+    global-load path, the others stage knots through LDS.  Fused form: the 64-knot image (two row
+    groups per pass) from ~18 up, the 256-knot image down to ~4, segments of one tile below."""
     import torch
-
-    from maria_amd._lib import ptr
 
     rng = np.random.default_rng(3)
     D, Ta = 50, 700
@@ -233,14 +246,37 @@ def test_upsample_ratios(gpu_ctx, ratio):
     ref = scipy.interpolate.interp1d(ta, y, kind="cubic", bounds_error=False, fill_value="extrapolate", axis=-1)(t)
     dev = "cuda:0"
     d_y = torch.as_tensor(np.ascontiguousarray(y.T)).to(dev)
-    d_ym = torch.empty((Ta, D, 2), dtype=torch.float32, device=dev)
     d_t = torch.as_tensor(t).to(dev)
-    d_out = torch.empty((D, T), dtype=torch.float32, device=dev)
+    d_out = torch.full((D, T), float("nan"), dtype=torch.float32, device=dev)
     scale = rng.uniform(0.5, 2.0, D).astype(np.float32)
     d_scale = torch.as_tensor(scale).to(dev)
-    gpu_ctx.call("mrx_spline_prepare", ptr(d_y), D, Ta, ptr(d_ym))
-    gpu_ctx.call("mrx_spline_upsample", ptr(d_ym), D, Ta, float(ta[0]), 0.1, ptr(d_t), T, ptr(d_scale), None, ptr(d_out), T)
+    _spline_upsample(gpu_ctx, form, d_y, D, Ta, float(ta[0]), 0.1, d_t, T, d_scale, d_out, T)
     assert rel_err(d_out.cpu().numpy(), ref * scale[:, None]) <= 2e-6
+
+
+def test_fused_upsample_equals_the_two_call_form(gpu_ctx):
+    """The fused writer against prepare + upsample on white-noise knots (the hardest case for the
+    truncated sweeps: second differences as large as the values), 700 rows x 6000 knots x ratio 40, rows
+    through a destination permutation: equal to float32 rounding of m."""
+    import torch
+
+    from maria_amd._lib import ptr
+
+    rng = np.random.default_rng(11)
+    D, Ta, ratio = 700, 6000, 40
+    y = rng.standard_normal((Ta, D)).astype(np.float32)
+    T = Ta * ratio
+    t = 5.0 + np.arange(T) * (0.1 / ratio)
+    dev = "cuda:0"
+    d_y, d_t = torch.as_tensor(y).to(dev), torch.as_tensor(t).to(dev)
+    rows = torch.as_tensor(rng.permutation(D).astype(np.int32)).to(dev)
+    a = torch.empty((D, T), dtype=torch.float32, device=dev)
+    b = torch.empty_like(a)
+    d_ym = torch.empty((Ta, D, 2), dtype=torch.float32, device=dev)
+    gpu_ctx.call("mrx_spline_prepare", ptr(d_y), D, Ta, ptr(d_ym))
+    gpu_ctx.call("mrx_spline_upsample", ptr(d_ym), D, Ta, 5.0, 0.1, ptr(d_t), T, None, ptr(rows), ptr(a), T)
+    gpu_ctx.call("mrx_spline_upsample_fused", ptr(d_y), D, Ta, 5.0, 0.1, ptr(d_t), T, None, ptr(rows), ptr(b), T)
+    assert float((a - b).abs().max()) <= 2e-7 * float(a.abs().max())
 
 
 def test_linear_upsample(gpu_ctx):
@@ -294,6 +330,12 @@ def test_empty_shard_and_errors(gpu_ctx):
         gpu_ctx.call("mrx_spline_prepare", ptr(d), 4, 3, ptr(ym))
     with pytest.raises(MrxError, match="INVALID"):
         gpu_ctx.call("mrx_spline_prepare", None, 4, 8, ptr(ym))
+    t = torch.zeros(8, dtype=torch.float64, device="cuda:0")
+    o = torch.zeros((4, 8), dtype=torch.float32, device="cuda:0")
+    with pytest.raises(MrxError, match="UNSUPPORTED"):
+        gpu_ctx.call("mrx_spline_upsample_fused", ptr(d), 4, 3, 0.0, 0.1, ptr(t), 8, None, None, ptr(o), 8)
+    with pytest.raises(MrxError, match="INVALID"):
+        gpu_ctx.call("mrx_spline_upsample_fused", ptr(d), 4, 8, 0.0, 0.1, ptr(t), 8, None, None, ptr(o), 4)  # ld < T
 
 
 def test_shard_rows_are_bit_identical(gpu_ctx):
