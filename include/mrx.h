@@ -73,10 +73,11 @@ int mrx_synchronize(mrx_ctx* ctx);
  *    better conditioned near the zenith, and ~3x fewer instructions.
  *  MRX_OPT_AXIS_LITERAL = 1: mrx_atm_sample finds cell and weight on every screen axis with
  *    jax's float32 rule (searchsorted on the float32 nodes, weight (x - lo)/(hi - lo)), also on
- *    uniform axes.  The default computes the position in pixels in float64 on axes whose uniform
- *    hint verified: equal to the literal rule up to the float32 rounding of the reference's own
- *    coordinates (~1e-8 of the loading), at 3/4 of the instructions.  MRX_OPT_POINTING_CHAIN
- *    implies the literal rule.
+ *    uniform axes.  The default computes the position in pixels on axes whose uniform hint
+ *    verified (a float64 anchor per step and layer + the lane's float32 offset from it, good to
+ *    ~4e-6 pixel): equal to the literal rule up to the float32 rounding of the reference's own
+ *    coordinates (~2e-4 pixel, ~1e-8 of the loading), at a third of the instructions.
+ *    MRX_OPT_POINTING_CHAIN implies the literal rule.
  *  MRX_OPT_SAMPLE_TIMES = 1|2|4: coarse time steps per thread in mrx_atm_sample
  *    (tuning; 0 = library default). */
 enum {
@@ -91,8 +92,8 @@ enum {
                                 one applies (tests, A/B runs) */
   MRX_OPT_SAMPLE_WGS_PER_CU = 6, /* mrx_atm_sample runs as a resident grid of this many workgroups
                                     per CU that walk the work items (tuning; 0 = default, 8) */
-  MRX_OPT_SAMPLE_TILES = 7, /* 1: mrx_atm_sample stages each work item's screen windows in LDS
-                               (measured slower than the global gathers; off by default) */
+  MRX_OPT_RESERVED_7 = 7, /* (was MRX_OPT_SAMPLE_TILES: screen windows staged in LDS measured slower than
+                             the global gathers in round 2 and the kernel was removed; ignored) */
   MRX_OPT_NOISE_LANES = 8, /* streams mrx_noise_generate spreads its batches over (1..4; 0 = automatic:
                               up to 4, each with at least 128 detectors of the work buffer) */
   MRX_OPT_SCREEN_STOCKHAM = 9, /* 1: the screen generator's transforms as LDS Stockham passes even

@@ -70,6 +70,16 @@ struct alignas(64) mrx_layer_fast {
 };
 static_assert(sizeof(mrx_layer_fast) == 64, "one cache line per layer");
 
+// The float32 record of the pixel-coordinate kernel (atm_sample_px_kernel): one s_load_dwordx16.
+struct alignas(64) mrx_layer_px {
+  const float* values;
+  float pe_x, pe_y, pc_x, pc_y;
+  int n_e, n_c;
+  float pwv_rms;
+  int pad_[7];
+};
+static_assert(sizeof(mrx_layer_px) == 64, "one s_load_dwordx16 per layer");
+
 // Device-side band table descriptor: offsets (in floats) into the packed table
 // buffer, which is [values 2*np*ne][axis_pwv np][axis_el ne] per band.
 struct mrx_table_dev {
@@ -84,13 +94,15 @@ struct mrx_table_dev {
 struct mrx_atm_plan {
   mrx_layer_dev* d_layers = nullptr;
   mrx_layer_fast* d_fast = nullptr;
+  mrx_layer_px* d_px = nullptr;  // float32 records of the pixel-coordinate kernel
   double2* d_off = nullptr;  // [n_t][n_layers] (off_e, off_c)
   double2* d_offpx = nullptr;  // [n_t][n_layers] ((off_e - e0)/de, (off_c - c0)/dc): the same in pixels
   mrx_table_dev* d_tables = nullptr;
   float* d_table_data = nullptr;
   int n_layers = 0, n_tables = 0, n_t = 0;
   int table_floats = 0;
-  bool all_pixel = false;  // every layer passed the uniform check: the lean kernel instance applies
+  bool all_pixel = false;  // every layer passed the uniform check: atm_sample_px_kernel applies
+  bool any_cubic = false;  // a band table carries the bicubic cells of interpolation_method="cubic"
 };
 
 namespace {
@@ -129,6 +141,22 @@ __device__ __forceinline__ Cell find_cell(NodeFn node, int n, float x,
 }
 
 typedef __attribute__((address_space(1))) const float gfloat;  // global memory
+typedef __attribute__((address_space(1))) const char char_g;
+
+// v_cvt_flr_i32_f32: floor and convert in one instruction; saturates, NaN -> 0 (no undefined
+// conversion whatever the input)
+__device__ __forceinline__ int cvt_flr_i32(float x) {
+  int r;
+  asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+  return r;
+}
+
+// v_med3_i32: clamp x into [lo, hi] (lo <= hi) in one instruction
+__device__ __forceinline__ int med3_i32(int x, int lo, int hi) {
+  int r;
+  asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "s"(hi));
+  return r;
+}
 typedef float pair4 __attribute__((ext_vector_type(2), aligned(4)));
 typedef __attribute__((address_space(1))) const pair4 gpair;
 
@@ -182,6 +210,8 @@ __device__ __forceinline__ float bilinear(gfloat* values, int nc,
 // (sim/atmosphere.py:64-65): the float32 trilinear lookup in the reference's summation order,
 // or the float64 bicubic of interpolation_method="cubic".  `tdata` holds the band tables (LDS or
 // global).  in_t: the step exists (flags are only raised for real steps).
+// kCubicPath = false: a kernel instance for plans without cubic tables (the code is not compiled in).
+template <bool kCubicPath = true>
 __device__ __forceinline__ float band_loading(const mrx_table_dev& tb, const float* __restrict__ tdata, double pwv,
                                               float theta, float m00, bool in_t, uint32_t& iflags) {
   const float* __restrict__ ax_p = tdata + tb.off_pwv;
@@ -210,12 +240,12 @@ __device__ __forceinline__ float band_loading(const mrx_table_dev& tb, const flo
       }
     }
   }
-  if (!tb.cubic && (cp_.oob || cl.oob || tb.t_oob)) {
+  if ((!kCubicPath || !tb.cubic) && (cp_.oob || cl.oob || tb.t_oob)) {
     val = __builtin_nanf("");
     if (in_t) iflags |= MRX_FLAG_TABLE_OOB;
   }
   float out = m00 * val;
-  if (tb.cubic) {
+  if (kCubicPath && tb.cubic) {
     // interpolation_method="cubic" (band/band.py:288-300): scipy's tensor-product cubic
     // spline on (pwv, el) in float64, expanded by the host into a bicubic per cell; the
     // float64 product with the Mueller weight is rounded once (sim/atmosphere.py:64-65)
@@ -446,208 +476,193 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kT == 1 
 }
 
 
-// ---- the same sampling with the screens tiled in LDS ---------------------------------------
-// For plans whose layers are all uniform (pixel coordinates).  A work item is 256 detectors that
-// form a compact patch of the focal plane (the caller's Z-order) x `chunk` consecutive steps, so
-// on every layer its lines of sight stay inside a small window of the screen: the patch's
-// footprint plus what scan and wind move it in `chunk` steps (atlast_10k, 16 steps: 6 KB summed
-// over 8 layers in the median, 21 KB at the 99th percentile).  The item
-//   1. bounds (px, py) over its detectors and steps (one pass over the pointing, a workgroup
-//      min/max), maps that box through each layer's affine map: a window per layer;
-//   2. stages the windows that fit the LDS budget with coalesced row reads;
-//   3. samples: the 2x2 corners come from LDS.  A lane whose cell is not inside the window
-//      (a layer that did not fit, or rounding at the window's edge) reads global memory.
-// The divergent 8-byte global gathers are 0.2-0.37 ms of the kernel (a gather occupies the CU's
-// address unit ~17 cycles; a build without them runs in 0.65 ms).  MEASURED, this kernel does not
-// collect that: 1.05-1.15 ms against 0.86 ms for the global-gather kernel on atlast_10k, and
-// 3.17 against 2.79 ms when pipelined beside the writer -- the bound pass, four extra barriers per
-// item, the per-layer window record and the in-window test cost more than the gathers did.  It is
-// kept behind MRX_OPT_SAMPLE_TILES (off) with its parity test; DESIGN 3.2.
-constexpr int kWinBudgetFloats = 5120;  // 20 KiB of screen windows per workgroup
-constexpr int kMaxTiledLayers = 16;
+// ---- the pixel-coordinate kernel: float32 in the layer loop ----------------------------------
+// For plans whose layers all sit on verified-uniform axes (every generated screen does).  The
+// position of a line of sight on layer l at step t, in pixels, is affine in the unit-height
+// ground projection (px, py):   f = px pe_x + py pe_y + offpx(t, l).
+// At ~2000 pixels from the grid origin a float32 evaluation of that sum would be good to 2e-4
+// pixel (the reference's own rounding); round 2 therefore ran it in float64 -- four v_fma_f64,
+// four conversions and two v_add_f64 per layer-sample, 103 VALU instructions all told.  Here the
+// float64 part is paid once per (work item, step, layer) instead of once per lane:
+//   * ANCHOR.  For every step of the item and every layer, the pixel position of the boresight's
+//     own line of sight (pc_x, pc_y: float32 numbers, any point near the detectors would do) in
+//     float64, split into an integer cell and a float32 fraction in [0, 1): 16 bytes in LDS,
+//     computed by one thread each in the item's prologue;
+//   * DELTA.  A lane adds its float32 offset from the anchor, (px - pc_x) pe_x + (py - pc_y) pe_y:
+//     |delta| is the focal plane's footprint on the layer in pixels (<= ~40 at the top layer of
+//     atlast_10k), so its float32 rounding is <= 4e-6 pixel -- 50x below the reference's own
+//     coordinate rounding, and (px - pc_x), (py - pc_y) are shared by all layers.
+// Cell = anchor cell + floor(fraction + delta); weight = what is left.  The 2x2 blend is two
+// lerps along c and one along e (6 operations; jax's four weighted corners sum to the same value
+// to rounding), the layer's term is accumulated in float32 on the FLUCTUATION only
+// (sum_l rms_l y_l ~ 3 % of pwv0) and added to the float64 pwv0 once per step.
+constexpr int kMaxAnchors = 2048;  // (step, layer) pairs of one work item: 32 KiB of LDS at most
 
-struct TileWin {
-  int e_lo, c_lo;   // first row / column of the window on the screen
-  int we, wc;       // rows, columns (0 rows: the layer is not in LDS)
-  int off;          // float offset of the window in the LDS pool
-};
-
-template <bool kLdsTables>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) void atm_sample_tiled_kernel(
-    const mrx_layer_fast* __restrict__ fast, int n_layers, const double2* __restrict__ offpx,
-    const mrx_table_dev* __restrict__ tables, int n_tables, const float* __restrict__ table_data,
-    int table_floats, const float* __restrict__ az, const float* __restrict__ el, int Ta,
-    const float* __restrict__ dxs, const float* __restrict__ dys, const int32_t* __restrict__ band,
-    const float* __restrict__ mueller00, int D, double pwv0, double* __restrict__ pwv_out,
-    float* __restrict__ loading, uint32_t* __restrict__ flags, int chunk, int nbx, int n_items) {
-  extern __shared__ float lds_dyn[];  // [screen windows: kWinBudgetFloats][band tables]
-  __shared__ float4 bore[kMaxChunk];
-  __shared__ float red[4][4];        // per wave: px min, px max, py min, py max
-  __shared__ TileWin win[kMaxTiledLayers];
-  float* pool = lds_dyn;
-  float* lds_tables = lds_dyn + kWinBudgetFloats;
+template <bool kLdsTables, int kT, bool kPipe>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kT == 1 ? 8 : 5, kT == 1 ? 8 : 5))) void atm_sample_px_kernel(
+    const mrx_layer_fast* __restrict__ fast, const mrx_layer_px* __restrict__ lpx, int n_layers,
+    const double2* __restrict__ offpx, const mrx_table_dev* __restrict__ tables, int n_tables,
+    const float* __restrict__ table_data, int table_floats, const float* __restrict__ az,
+    const float* __restrict__ el, int Ta, const float* __restrict__ dxs, const float* __restrict__ dys,
+    const int32_t* __restrict__ band, const float* __restrict__ mueller00, int D, double pwv0,
+    double* __restrict__ pwv_out, float* __restrict__ loading, uint32_t* __restrict__ flags, int chunk,
+    int nbx, int n_items) {
+  extern __shared__ __align__(16) float4 lds_px[];  // [chunk * n_layers anchors][band tables]
+  __shared__ float4 bore[kMaxChunk];   // per step: cos/sin of (el - pi/2), cos/sin of az
+  __shared__ float2 borec[kMaxChunk];  // per step: unit-height projection of the boresight itself
+  float4* anchor = lds_px;
+  float* lds_tables = reinterpret_cast<float*>(lds_px + chunk * n_layers);
   if (kLdsTables)
     for (int i = threadIdx.x; i < table_floats; i += kBlock) lds_tables[i] = table_data[i];
   const float* __restrict__ tdata = kLdsTables ? lds_tables : table_data;
   uint32_t myflags = 0u;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
     const int t_first = (item / nbx) * chunk;
-    const int steps = min(chunk, Ta - t_first);
     uint32_t iflags = 0u;
-    __syncthreads();  // the previous item is done with bore[], win[] and the pool
+    __syncthreads();  // the previous item's readers of bore[] and anchor[] are done
     if ((int)threadIdx.x < chunk) {
       const int t = min(t_first + (int)threadIdx.x, Ta - 1);
       const float a = el[t] - kHalfPiF;  // transforms.py:22
       const float z = az[t];
-      bore[threadIdx.x] = make_float4(cosf(a), sinf(a), cosf(z), sinf(z));
+      const float ca = cosf(a), sa = sinf(a), cz = cosf(z), sz = sinf(z);
+      bore[threadIdx.x] = make_float4(ca, sa, cz, sz);
+      // the detector at the focal-plane centre: re = -sin a, im = cos a
+      borec[threadIdx.x] = make_float2((-sa * cz) / ca, (-sa * sz) / ca);
     }
     __syncthreads();
+    for (int k = threadIdx.x; k < chunk * n_layers; k += kBlock) {
+      const int it = k / n_layers, l = k - it * n_layers;
+      const int t = min(t_first + it, Ta - 1);
+      const mrx_layer_fast lf = fast[l];
+      const double2 o = offpx[(size_t)t * n_layers + l];
+      const float2 pc = borec[it];
+      const double Fe = fma((double)pc.x, lf.pe_x, fma((double)pc.y, lf.pe_y, o.x));
+      const double Fc = fma((double)pc.x, lf.pc_x, fma((double)pc.y, lf.pc_y, o.y));
+      // (a NaN position gives a finite cell and a NaN fraction: every lane then reads inside the
+      // screen and reports the line of sight as off it)
+      const double ce = floor(fmin(fmax(Fe, -1.0e9), 1.0e9)), cc = floor(fmin(fmax(Fc, -1.0e9), 1.0e9));
+      anchor[k] = make_float4(__int_as_float((int)ce), __int_as_float((int)cc), (float)(Fe - ce), (float)(Fc - cc));
+    }
 
     const int d = (item % nbx) * kBlock + threadIdx.x;
     const bool live = d < D;
-    const int dd = live ? d : D - 1;
-    // per-detector constants (coords/transforms.py:14-23), float32
+    const int dd = live ? d : D - 1;  // keep addresses valid; stores are masked
+    // ---- per-detector constants (coords/transforms.py:14-23), float32 ------
     const float dx = dxs[dd], dy = dys[dd];
     const float r = sqrtf(dx * dx + dy * dy);
     const float p = atan2f(-dx, -dy);
     const float sr = sinf(r), cr = cosf(r);
-    const float A = sr * cosf(p), Y = sr * sinf(p);
+    const float A = sr * cosf(p);  // sin(r) cos(p): real part before the tilt
+    const float Y = sr * sinf(p);  // sin(r) sin(p)
     const int b = band[dd];
     const float m00 = mueller00[dd];
     if (live && (b < 0 || b >= n_tables)) iflags |= MRX_FLAG_NAN;
     const mrx_table_dev tb = tables[min(max(b, 0), n_tables - 1)];
+    __syncthreads();  // anchors are in place
 
-    // ---- 1. bounds of the unit-height projection over the item ------------------------------
-    float pxl = 3.0e38f, pxh = -3.0e38f, pyl = 3.0e38f, pyh = -3.0e38f;
-    for (int it = 0; it < steps; ++it) {
-      const float4 bt = bore[it];
-      const float re = A * bt.x - cr * bt.y, im = A * bt.y + cr * bt.x;
-      const float inv_im = 1.0f / im;
-      const float fx = (re * bt.z - Y * bt.w) * inv_im, fy = (Y * bt.z + re * bt.w) * inv_im;
-      pxl = fminf(pxl, fx); pxh = fmaxf(pxh, fx);
-      pyl = fminf(pyl, fy); pyh = fmaxf(pyh, fy);
-    }
+    for (int it = 0; it < chunk && t_first + it < Ta; it += kT) {
+      float theta[kT], dpx[kT], dpy[kT], fl[kT], wlo[kT], whi[kT];
 #pragma unroll
-    for (int m = 32; m > 0; m >>= 1) {
-      pxl = fminf(pxl, __shfl_xor(pxl, m, 64)); pxh = fmaxf(pxh, __shfl_xor(pxh, m, 64));
-      pyl = fminf(pyl, __shfl_xor(pyl, m, 64)); pyh = fmaxf(pyh, __shfl_xor(pyh, m, 64));
-    }
-    if (lane == 0) {
-      red[wave][0] = pxl; red[wave][1] = pxh; red[wave][2] = pyl; red[wave][3] = pyh;
-    }
-    __syncthreads();
-    // ---- windows: one thread per layer; the pool is filled smallest window first ------------
-    if ((int)threadIdx.x < n_layers) {
-      const int l = threadIdx.x;
-      const double x0 = fminf(fminf(red[0][0], red[1][0]), fminf(red[2][0], red[3][0]));
-      const double x1 = fmaxf(fmaxf(red[0][1], red[1][1]), fmaxf(red[2][1], red[3][1]));
-      const double y0 = fminf(fminf(red[0][2], red[1][2]), fminf(red[2][2], red[3][2]));
-      const double y1 = fmaxf(fmaxf(red[0][3], red[1][3]), fmaxf(red[2][3], red[3][3]));
-      const mrx_layer_fast lf = fast[l];
-      // offsets over the item's steps (monotone in t for a steady wind; take both ends and the middle)
-      double oe0 = 1e300, oe1 = -1e300, oc0 = 1e300, oc1 = -1e300;
-      for (int it = 0; it < steps; ++it) {
-        const double2 o = offpx[(size_t)(t_first + it) * n_layers + l];
-        oe0 = fmin(oe0, o.x); oe1 = fmax(oe1, o.x); oc0 = fmin(oc0, o.y); oc1 = fmax(oc1, o.y);
+      for (int tt = 0; tt < kT; ++tt) {
+        // transforms.py:20-28 and the unit-height ground projection (see atm_sample_kernel)
+        const float4 bt = bore[it + tt];
+        const float2 pc = borec[it + tt];
+        const float re = A * bt.x - cr * bt.y;
+        const float im = A * bt.y + cr * bt.x;
+        theta[tt] = asinf(im);
+        const float inv_im = 1.0f / im;
+        dpx[tt] = (re * bt.z - Y * bt.w) * inv_im - pc.x;
+        dpy[tt] = (Y * bt.z + re * bt.w) * inv_im - pc.y;
+        fl[tt] = 0.0f;
+        wlo[tt] = 0.0f;  // smallest / largest interpolation weight met on the way through the layers
+        whi[tt] = 1.0f;
       }
-      // an affine map takes its extremes over a box at the box's corners
-      const double ea = lf.pe_x * (lf.pe_x >= 0 ? x0 : x1) + lf.pe_y * (lf.pe_y >= 0 ? y0 : y1) + oe0;
-      const double eb = lf.pe_x * (lf.pe_x >= 0 ? x1 : x0) + lf.pe_y * (lf.pe_y >= 0 ? y1 : y0) + oe1;
-      const double ca = lf.pc_x * (lf.pc_x >= 0 ? x0 : x1) + lf.pc_y * (lf.pc_y >= 0 ? y0 : y1) + oc0;
-      const double cb = lf.pc_x * (lf.pc_x >= 0 ? x1 : x0) + lf.pc_y * (lf.pc_y >= 0 ? y1 : y0) + oc1;
-      TileWin w;
-      // one pixel of margin each side against the float32 rounding of the bounds; cells i, i + 1
-      w.e_lo = min(max((int)fmax(fmin(ea, 2.0e9), -1.0) - 1, 0), lf.n_e - 2);
-      w.c_lo = min(max((int)fmax(fmin(ca, 2.0e9), -1.0) - 1, 0), lf.n_c - 2);
-      const int e_hi = min(max((int)fmax(fmin(eb, 2.0e9), -1.0) + 2, 1), lf.n_e - 1);
-      const int c_hi = min(max((int)fmax(fmin(cb, 2.0e9), -1.0) + 2, 1), lf.n_c - 1);
-      w.we = e_hi - w.e_lo + 1;
-      w.wc = c_hi - w.c_lo + 1;
-      w.off = 0;
-      if (!(ea == ea && eb == eb && ca == ca && cb == cb) || w.we < 2 || w.wc < 2 ||
-          (long long)w.we * w.wc > kWinBudgetFloats)
-        w.we = 0;
-      win[l] = w;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {  // pack: layers in order while they fit (lower layers are smaller and come first)
-      int used = 0;
-      for (int l = 0; l < n_layers; ++l) {
-        const int need = win[l].we * win[l].wc;
-        if (need > 0 && used + need <= kWinBudgetFloats) {
-          win[l].off = used;
-          used += need;
-        } else {
-          win[l].we = 0;
+      // ---- layer stack (atmosphere/atmosphere.py:317-373) ---------------------
+      // Software-pipelined by hand: the gathers of layer l + 1 are issued before layer l is blended, so
+      // that a wave has 4 kT loads in flight while it computes (the compiler, left alone, issues a
+      // layer's two loads and waits for them: at the 3 waves per SIMD this kernel gets beside the TOD
+      // writer that exposed the whole L2 latency 8 times per step).  sched_barrier pins the order.
+      const float4* an = anchor + it * n_layers;
+      struct Stage {  // one layer's gathers in flight, for the thread's kT steps
+        pair4 r0[kT], r1[kT];
+        float we[kT], wc[kT];
+        float rms;
+      };
+      auto issue = [&](int l, Stage& g) {
+        const mrx_layer_px lp = lpx[l];  // wave-uniform: one scalar load
+        const char_g* row0 = (const char_g*)lp.values;
+        const char_g* row1 = (const char_g*)(lp.values + lp.n_c);
+        const int ne2 = lp.n_e - 2, nc2 = lp.n_c - 2, nc4 = lp.n_c * 4;
+        g.rms = lp.pwv_rms;
+#pragma unroll
+        for (int tt = 0; tt < kT; ++tt) {
+          const float4 a4 = an[tt * n_layers + l];
+          const int ae = __float_as_int(a4.x), ac = __float_as_int(a4.y);
+          const float fe = a4.z + __builtin_fmaf(dpx[tt], lp.pe_x, dpy[tt] * lp.pe_y);
+          const float fc = a4.w + __builtin_fmaf(dpx[tt], lp.pc_x, dpy[tt] * lp.pc_y);
+          // cell = anchor cell + floor(f), clamped into the grid; weight relative to the clamped cell, so
+          // that a position outside shows as a weight outside [0, 1] (the last node belongs to the last cell)
+          const int ie = med3_i32(ae + cvt_flr_i32(fe), 0, ne2);
+          const int ic = med3_i32(ac + cvt_flr_i32(fc), 0, nc2);
+          g.we[tt] = fe - (float)(ie - ae);
+          g.wc[tt] = fc - (float)(ic - ac);
+          wlo[tt] = fminf(fminf(wlo[tt], g.we[tt]), g.wc[tt]);
+          whi[tt] = fmaxf(fmaxf(whi[tt], g.we[tt]), g.wc[tt]);
+          const uint32_t boff = __umul24(ie, nc4) + ((uint32_t)ic << 2);  // < 4 GiB: sides below 2^23 and the screen fits memory
+          g.r0[tt] = *(const gpair*)(row0 + boff);
+          g.r1[tt] = *(const gpair*)(row1 + boff);
+        }
+      };
+      auto blend = [&](const Stage& g) {
+#pragma unroll
+        for (int tt = 0; tt < kT; ++tt) {
+          const float y0 = __builtin_fmaf(g.wc[tt], g.r0[tt].y - g.r0[tt].x, g.r0[tt].x);
+          const float y1 = __builtin_fmaf(g.wc[tt], g.r1[tt].y - g.r1[tt].x, g.r1[tt].x);
+          fl[tt] = __builtin_fmaf(g.rms, __builtin_fmaf(g.we[tt], y1 - y0, y0), fl[tt]);
+        }
+      };
+      // two stages in turn, no copies: a stage's loads land while the other one is blended.  (The pass
+      // after the last layer fetches layer n - 1 once more -- same lines, its weights already counted --
+      // instead of branching around the issue.)
+      Stage ga, gb;
+      if (kPipe) {
+        if (n_layers > 0) issue(0, ga);
+        for (int l = 0; l < n_layers; l += 2) {
+          issue(min(l + 1, n_layers - 1), gb);
+          __builtin_amdgcn_sched_barrier(0);
+          blend(ga);
+          __builtin_amdgcn_sched_barrier(0);
+          issue(min(l + 2, n_layers - 1), ga);
+          __builtin_amdgcn_sched_barrier(0);
+          if (l + 1 < n_layers) blend(gb);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {  // alone on the chip at 8 waves per SIMD the occupancy hides the latency: the plain loop is 12 % faster there
+        for (int l = 0; l < n_layers; ++l) {
+          issue(l, ga);
+          blend(ga);
         }
       }
-    }
-    __syncthreads();
-    // ---- 2. stage the windows: a wave per row, lanes along the row ---------------------------
-    for (int l = 0; l < n_layers; ++l) {
-      const TileWin w = win[l];
-      if (w.we == 0) continue;  // uniform
-      const mrx_layer_fast lf = fast[l];
-      gfloat* src = (gfloat*)lf.values + (size_t)w.e_lo * lf.n_c + w.c_lo;
-      for (int rr = wave; rr < w.we; rr += kBlock / 64)
-        for (int cc = lane; cc < w.wc; cc += 64) pool[w.off + rr * w.wc + cc] = src[(size_t)rr * lf.n_c + cc];
-    }
-    __syncthreads();
-
-    // ---- 3. the steps ---------------------------------------------------------------------------
-    for (int it = 0; it < steps; ++it) {
-      const int t = t_first + it;
-      const float4 bt = bore[it];
-      const float re = A * bt.x - cr * bt.y, im = A * bt.y + cr * bt.x;
-      const float theta = asinf(im);
-      const float inv_im = 1.0f / im;
-      const double px = (double)((re * bt.z - Y * bt.w) * inv_im);
-      const double py = (double)((Y * bt.z + re * bt.w) * inv_im);
-      double pwv = pwv0;
-      for (int l = 0; l < n_layers; ++l) {
-        const mrx_layer_fast lf = fast[l];
-        const TileWin w = win[l];
-        const double2 o = offpx[(size_t)t * n_layers + l];
-        const double fe = fma(px, lf.pe_x, fma(py, lf.pe_y, o.x));
-        const double fc = fma(px, lf.pc_x, fma(py, lf.pc_y, o.y));
-        Cell ce, cc;
-        ce.i = min(max(__double2int_rz(fe), 0), lf.n_e - 2);
-        cc.i = min(max(__double2int_rz(fc), 0), lf.n_c - 2);
-        ce.w = (float)(fe - (double)ce.i);
-        cc.w = (float)(fc - (double)cc.i);
-        ce.oob = !(ce.w >= 0.0f && ce.w <= 1.0f);
-        cc.oob = !(cc.w >= 0.0f && cc.w <= 1.0f);
-        const int re_ = ce.i - w.e_lo, rc_ = cc.i - w.c_lo;
-        // (a layer that is not in LDS has we = 0: no cell is inside)
-        const bool inw = (unsigned)re_ < (unsigned)max(w.we - 1, 0) && (unsigned)rc_ < (unsigned)max(w.wc - 1, 0);
-        float yv;
-        if (__builtin_amdgcn_ballot_w64(!inw) == 0) {  // the whole wave inside the window
-          const float* q = pool + w.off + re_ * w.wc + rc_;
-          const float v00 = q[0], v01 = q[1], v10 = q[w.wc], v11 = q[w.wc + 1];
-          const float we0 = 1.0f - ce.w, we1 = ce.w, wc0 = 1.0f - cc.w, wc1 = cc.w;
-          float y = 0.0f;
-          y = y + v00 * (we0 * wc0);
-          y = y + v01 * (we0 * wc1);
-          y = y + v10 * (we1 * wc0);
-          y = y + v11 * (we1 * wc1);
-          yv = (ce.oob || cc.oob) ? __builtin_nanf("") : y;
-        } else {
-          yv = bilinear((gfloat*)lf.values, lf.n_c, ce, cc);
+      // ---- band emission (band/band.py:264-300) and Mueller weight -----------
+#pragma unroll
+      for (int tt = 0; tt < kT; ++tt) {
+        const int t = t_first + it + tt;
+        // a line of sight off a screen is jax's NaN fill (atmosphere.py:359-369): some weight left
+        // [0, 1], or a NaN position made the sum NaN (min / max skip NaN operands)
+        const bool off = !(wlo[tt] >= 0.0f && whi[tt] <= 1.0f) || fl[tt] != fl[tt];
+        const double pwv = off ? (double)__builtin_nanf("") : pwv0 + (double)fl[tt];
+        if (off && t < Ta) iflags |= MRX_FLAG_SCREEN_OOB;
+        const float out = band_loading<false>(tb, tdata, pwv, theta[tt], m00, t < Ta, iflags);
+        if (live && t < Ta) {
+          const size_t o = (size_t)t * D + d;
+          loading[o] = out;
+          if (pwv_out) pwv_out[o] = pwv;
         }
-        pwv += (double)(lf.pwv_rms * yv);
       }
-      if (pwv != pwv) iflags |= MRX_FLAG_SCREEN_OOB;  // only a line of sight off a screen makes it NaN
-      const float out = band_loading(tb, tdata, pwv, theta, m00, true, iflags);
-      if (live) {
-        const size_t oo = (size_t)t * D + d;
-        loading[oo] = out;
-        if (pwv_out) pwv_out[oo] = pwv;
-      }
-    }
+    }  // chunk loop
     if (live) myflags |= iflags;
-  }
+  }  // item loop
   if (myflags) atomicOr(flags, myflags);
 }
 
@@ -655,7 +670,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(6, 8))) 
 
 // Fills the axis-derived fields of each layer descriptor and checks whether
 // float32(g0 + i*dg) reproduces the axis arrays exactly.
-__global__ void plan_finish_layers(mrx_layer_dev* layers, mrx_layer_fast* fast, int n_layers) {
+__global__ void plan_finish_layers(mrx_layer_dev* layers, mrx_layer_fast* fast, mrx_layer_px* px, int n_layers) {
   const int l = blockIdx.x;
   mrx_layer_dev& ly = layers[l];
   __shared__ int ok_e, ok_c;
@@ -693,7 +708,13 @@ __global__ void plan_finish_layers(mrx_layer_dev* layers, mrx_layer_fast* fast, 
     f.pe_x = ly.pe_x; f.pe_y = ly.pe_y; f.pc_x = ly.pc_x; f.pc_y = ly.pc_y;
     f.n_e = ly.n_e; f.n_c = ly.n_c;
     f.pwv_rms = ly.pwv_rms;
-    f.pixel = ok_e && ok_c && ly.de > 0.0 && ly.dc > 0.0;
+    // (sides below 2^23: the pixel kernel forms cell indices with 24-bit multiplies)
+    f.pixel = ok_e && ok_c && ly.de > 0.0 && ly.dc > 0.0 && ly.n_e < (1 << 23) && ly.n_c < (1 << 23);
+    mrx_layer_px& q = px[l];
+    q.values = ly.values;
+    q.pe_x = (float)ly.pe_x; q.pe_y = (float)ly.pe_y; q.pc_x = (float)ly.pc_x; q.pc_y = (float)ly.pc_y;
+    q.n_e = ly.n_e; q.n_c = ly.n_c;
+    q.pwv_rms = ly.pwv_rms;
   }
 }
 
@@ -734,6 +755,7 @@ void plan_free(mrx_atm_plan* p) {
   if (p->d_off) (void)hipFree(p->d_off);
   if (p->d_offpx) (void)hipFree(p->d_offpx);
   if (p->d_fast) (void)hipFree(p->d_fast);
+  if (p->d_px) (void)hipFree(p->d_px);
   if (p->d_tables) (void)hipFree(p->d_tables);
   if (p->d_table_data) (void)hipFree(p->d_table_data);
   delete p;
@@ -785,6 +807,8 @@ int mrx_atm_plan_create(mrx_ctx* ctx, const mrx_layer* layers, int n_layers,
     h.cubic = t.d_cubic;
     MRX_REQUIRE(ctx, !t.d_cubic || (t.n_pwv >= 4 && t.n_el >= 4), "the cubic lookup needs >= 4 nodes per axis");
   }
+  bool any_cubic = false;
+  for (int b = 0; b < n_tables; ++b) any_cubic = any_cubic || tables[b].d_cubic != nullptr;
   std::vector<mrx_layer_dev> hlay((size_t)n_layers);
   for (int l = 0; l < n_layers; ++l) {
     const mrx_layer& y = layers[l];
@@ -813,6 +837,7 @@ int mrx_atm_plan_create(mrx_ctx* ctx, const mrx_layer* layers, int n_layers,
   p->n_tables = n_tables;
   p->n_t = n_t;
   p->table_floats = floats;
+  p->any_cubic = any_cubic;
   hipError_t e = hipSuccess;
   auto ok = [&]() { return e == hipSuccess; };
   if (n_layers > 0) {
@@ -820,6 +845,7 @@ int mrx_atm_plan_create(mrx_ctx* ctx, const mrx_layer* layers, int n_layers,
     if (ok()) e = hipMalloc(&p->d_off, sizeof(double2) * (size_t)n_layers * n_t);
     if (ok()) e = hipMalloc(&p->d_offpx, sizeof(double2) * (size_t)n_layers * n_t);
     if (ok()) e = hipMalloc(&p->d_fast, sizeof(mrx_layer_fast) * n_layers);
+    if (ok()) e = hipMalloc(&p->d_px, sizeof(mrx_layer_px) * n_layers);
     if (ok())
       e = hipMemcpyAsync(p->d_layers, hlay.data(),
                          sizeof(mrx_layer_dev) * n_layers,
@@ -833,7 +859,7 @@ int mrx_atm_plan_create(mrx_ctx* ctx, const mrx_layer* layers, int n_layers,
                        ctx->stream);
   if (ok() && n_layers > 0) {
     hipLaunchKernelGGL(plan_finish_layers, dim3(n_layers), dim3(256), 0,
-                       ctx->stream, p->d_layers, p->d_fast, n_layers);
+                       ctx->stream, p->d_layers, p->d_fast, p->d_px, n_layers);
     for (int l = 0; l < n_layers; ++l)
       hipLaunchKernelGGL(plan_pack_offsets, dim3(mrx_ceil_div(n_t, 256)),
                          dim3(256), 0, ctx->stream, p->d_off, p->d_offpx, p->d_layers,
@@ -928,20 +954,36 @@ int mrx_atm_sample(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d_az,
   // (an instance of the general kernel compiled without the literal path, for plans whose layers
   // are all uniform, measured SLOWER -- 1.27 vs 1.00 ms -- whatever the occupancy bound: kept out)
   const bool literal = ctx->options[MRX_OPT_AXIS_LITERAL] != 0 || chain;
-  if (plan->all_pixel && !literal && plan->n_layers <= kMaxTiledLayers && ctx->options[MRX_OPT_SAMPLE_TILES]) {
-    const size_t lds_t = sizeof(float) * ((size_t)kWinBudgetFloats + (lds ? (size_t)plan->table_floats : 0));
+  if (plan->all_pixel && !literal && !plan->any_cubic) {
+    // the pixel-coordinate kernel: anchors of one work item (chunk steps x layers) live in LDS
+    if (plan->n_layers * kt > kMaxAnchors) kt = 1;
+    while (chunk > kt && chunk * plan->n_layers > kMaxAnchors) chunk /= 2;
+    chunk = (chunk / kt) * kt;
+    const int nby = mrx_ceil_div(Ta, chunk);
+    const long long n_items = (long long)nbx * nby;
+    MRX_REQUIRE(ctx, n_items <= 0x7fffffffLL, "too many work items for one launch");
+    const dim3 gridp((unsigned)std::min(n_items, (long long)per_cu * (ctx->n_cu > 0 ? ctx->n_cu : 256)));
+    const size_t lds_p = sizeof(float4) * (size_t)chunk * plan->n_layers + lds_bytes;
+    // a small resident grid (beside the TOD writer) takes the software-pipelined layer loop
+    const bool pipe = ctx->options[MRX_OPT_SAMPLE_WGS_PER_CU] > 0 && ctx->options[MRX_OPT_SAMPLE_WGS_PER_CU] < 8;
+    if (kt == 4) kt = 2;  // (no instance: four interleaved steps spill at 96 registers)
+#define MRX_LAUNCH_PX(L, T, P)                                                                       \
+  do {                                                                                               \
+    MRX_LDS_CAP(ctx, (atm_sample_px_kernel<L, T, P>), lds_p);                                         \
+    hipLaunchKernelGGL((atm_sample_px_kernel<L, T, P>), gridp, dim3(kBlock), lds_p, ctx->stream,     \
+                       plan->d_fast, plan->d_px, plan->n_layers, plan->d_offpx, plan->d_tables,      \
+                       plan->n_tables, plan->d_table_data, plan->table_floats, d_az, d_el, Ta, d_dx, \
+                       d_dy, d_band, d_mueller00, D, pwv0, d_pwv, d_loading, d_flags, chunk, nbx,    \
+                       (int)n_items);                                                                \
+  } while (0)
+#define MRX_LAUNCH_PX_T(L, P) do { if (kt == 1) MRX_LAUNCH_PX(L, 1, P); else MRX_LAUNCH_PX(L, 2, P); } while (0)
     if (lds) {
-      MRX_LDS_CAP(ctx, atm_sample_tiled_kernel<true>, lds_t);
-      hipLaunchKernelGGL(atm_sample_tiled_kernel<true>, grid, dim3(kBlock), lds_t, ctx->stream, plan->d_fast,
-                         plan->n_layers, plan->d_offpx, plan->d_tables, plan->n_tables, plan->d_table_data,
-                         plan->table_floats, d_az, d_el, Ta, d_dx, d_dy, d_band, d_mueller00, D, pwv0, d_pwv,
-                         d_loading, d_flags, chunk, nbx, (int)items);
+      if (pipe) MRX_LAUNCH_PX_T(true, true); else MRX_LAUNCH_PX_T(true, false);
     } else {
-      hipLaunchKernelGGL(atm_sample_tiled_kernel<false>, grid, dim3(kBlock), lds_t, ctx->stream, plan->d_fast,
-                         plan->n_layers, plan->d_offpx, plan->d_tables, plan->n_tables, plan->d_table_data,
-                         plan->table_floats, d_az, d_el, Ta, d_dx, d_dy, d_band, d_mueller00, D, pwv0, d_pwv,
-                         d_loading, d_flags, chunk, nbx, (int)items);
+      if (pipe) MRX_LAUNCH_PX_T(false, true); else MRX_LAUNCH_PX_T(false, false);
     }
+#undef MRX_LAUNCH_PX_T
+#undef MRX_LAUNCH_PX
     MRX_CHECK_LAUNCH(ctx);
     return MRX_OK;
   }

@@ -404,8 +404,8 @@ class DevicePath:
         return out
 
     def default_blocks(self):
-        """Detector blocks of the pipelined run: 8 from 8192 rows up, 4 from 4096 (measured on
-        atlast_10k, several boxes: 8 blocks -7...-10 %, 4 blocks -4...-9 % against the serial path)."""
+        """Detector blocks of the pipelined run: 4 from 4096 rows up (round 3, atlast_10k: 2.12 ms with 4
+        blocks, 2.17 with 8, 2.24-2.34 with 12, 2.69 serial)."""
         if self.d_pwv is not None or self.D < 4096:
             return 1
         # screens that do not fit the Infinity Cache (atlast_50k: 16 x 4096^2 = 1.07 GB) make the
@@ -414,7 +414,7 @@ class DevicePath:
         screens_bytes = 4 * sum(len(l["extrusion"]) * len(l["cross_section"]) for l in self.problem["layers"])
         if screens_bytes > 256 << 20:
             return 1
-        return 8 if self.D >= 8192 else 4
+        return 4
 
     def _pipeline_state(self, blocks):
         st = getattr(self, "_pipe", None)
@@ -438,7 +438,7 @@ class DevicePath:
         return st
 
     def _run_pipelined(self, out, blocks, resident_wgs_per_cu=3, writer_events=None, serial_events=None, krj=False,
-                       resident_times=2):
+                       resident_times=1):
         """The sampler of block b on the side stream, the writer of block b (spline solve fused
         in: mrx_spline_upsample_fused) on the caller's stream behind an event; block 0's sampler
         takes the whole chip (nothing to run beside).
@@ -464,8 +464,9 @@ class DevicePath:
         sl = lambda t, lo, hi: None if t is None else ptr(t[lo:hi])  # noqa: E731
         for i, (lo, hi) in enumerate(st["bounds"]):
             n = hi - lo
-            # beside a writer: a resident grid of 3 workgroups per CU, two time steps interleaved per
-            # thread at 96 registers (measured: 2.62 ms against 2.73 for 4 per CU at 64 registers)
+            # beside a writer: a resident grid of 3 workgroups per CU at 64 registers, the layer loop
+            # software-pipelined (round 3, atlast_10k: 2.12 ms at 3 per CU, 2.15 at 4, 2.27 at 5, 2.44 at 2;
+            # two steps per thread at 96 registers: 2.18)
             alone = i == 0 or serial
             ctx2.set_option(_lib.OPT_SAMPLE_WGS_PER_CU, saved[0] if alone else resident_wgs_per_cu)
             ctx2.set_option(_lib.OPT_SAMPLE_TIMES, saved[1] if alone else resident_times)
