@@ -9,8 +9,14 @@ input for this rank's detectors: generate + smooth the turbulent screens
 at the coarse rate, not-a-knot spline solve + cubic upsample to the sample rate (one
 kernel) -> float32 TOD in HBM.  All inputs are resident in HBM before the timed region.
 
+Launch.  ``python bench.py --gpus N`` from a plain shell starts its own N ranks: the parent
+process -- before it touches a GPU -- runs ``python -m torch.distributed.run --nproc-per-node N
+bench.py ...`` as a CHILD, lets rank 0's JSON line through and exits with the child's status.
+Started by torch.distributed.run itself (WORLD_SIZE set) it is one of the ranks.
+
 Metric (BASELINE.json): detector-samples/s = n_det x n_t x steps / time, summed
-over ranks.  N = 1 is the named configuration on one GPU.  N > 1:
+over ranks.  N = 1 is the named configuration on one GPU (atlast_50k: its per-GPU share of an
+8-GPU run, 1/8 of the detectors -- ``config.weak_unit``).  N > 1:
   * atlast_10k (BASELINE config 4) is STRONG scaling: the configuration's 10 000
     detectors in total, sharded in contiguous row blocks; every rank
     regenerates the (small) screens from the same Philox key, so the data path has no
@@ -23,9 +29,11 @@ over ranks.  N = 1 is the named configuration on one GPU.  N > 1:
 Prints ONE JSON line on rank 0, including
   roofline      : the dominant kernel (spline solve + cubic upsample, HBM-bound streaming write),
                   timed live with events on the launch stream
-  second_kernel : the same for atm_sample_kernel (VALU / vector-memory-issue bound)
-  cpu_baseline  : the numpy/scipy oracle on a detector subset, on this host's cores,
-                  with one BLAS/OpenMP thread and with all of them
+  second_kernel : the same for the sampler (VALU / vector-memory-latency bound)
+  cpu_baseline  : the numpy/scipy oracle on a detector subset, on one host core and on
+                  min(64, physical cores) processes; parity of the GPU rows against it, on the
+                  loading and on the fluctuation alone (per-detector mean removed)
+  frontend      : wall time of what a user calls, Simulation(...).run(), set-up and run
 """
 
 from __future__ import annotations
@@ -41,10 +49,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak (spec); ~6300 achievable
-TRAFFIC_FILES = ("r02_traffic.json", "r01_traffic.json")  # newest first
+TRAFFIC_FILES = ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")  # newest first
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -54,18 +62,63 @@ def parse_args():
                     help="N > 1: strong = the named configuration's detectors in total (default for atlast_10k), "
                     "weak = the named configuration per GPU (default for atlast_50k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-dets", type=int, default=2048, help="detector rows of each CPU-baseline sample")
+    ap.add_argument("--cpu-dets", type=int, default=2048, help="detector rows of the one-core CPU-baseline sample")
+    ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the all-core CPU baseline (0 = min(64, physical cores))")
+    ap.add_argument("--no-frontend", action="store_true", help="skip the Simulation(...).run() wall-clock section")
     ap.add_argument("--no-screens-in-step", action="store_true", help="time TOD synthesis only (screens generated once)")
     ap.add_argument("--shard-screens", action="store_true",
                     help="N > 1: each rank generates its round-robin share of the layers and the owners broadcast them "
-                    "(default: every rank regenerates all layers, 0.28 ms, cheaper than any collective)")
+                    "(mrx_exchange_screens over RCCL; default: every rank regenerates all layers, 0.28 ms, cheaper than the exchange)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to rehearse the launch on one GPU)")
     ap.add_argument("--single-device", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--no-allgather", action="store_true", help="skip the separately timed all-gather at N > 1")
+    ap.add_argument("--gather-algo", choices=["allgather", "p2p", "both"], default="allgather",
+                    help="the separately timed gather: one ncclAllGather (default), direct sends/receives to every peer "
+                    "(mrx_allgather_tod_p2p), or both one after the other")
+    ap.add_argument("--nccl-algo", default=None, help="exported as NCCL_ALGO before the communicator is made (e.g. Ring, Tree)")
     ap.add_argument("--gather-reps", type=int, default=3)
     ap.add_argument("--blocks", type=int, default=None, help="detector blocks of the pipelined TOD synthesis (default: DevicePath.default_blocks(); 1 = serial)")
-    return ap.parse_args()
+    ap.add_argument("--print-launch", action="store_true", help="print the child launch command of --gpus N as JSON and exit (no GPU needed)")
+    return ap.parse_args(argv)
 
+
+# ---- self-launch -----------------------------------------------------------------------
+
+def _free_port():
+    import socket
+
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_command(n_gpus, argv, port):
+    """The child command of ``bench.py --gpus N`` started from a plain shell: one rank per GPU on this node."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_gpus}",
+            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def needs_launch(args, environ):
+    """N > 1 requested and this process is not already a rank of a torch.distributed.run job."""
+    return args.gpus > 1 and int(environ.get("WORLD_SIZE", "1")) == 1 and "TORCHELASTIC_RUN_ID" not in environ
+
+
+def launch(args, argv):
+    """Start the ranks as a child job; nothing here touches the GPU.  stdout is inherited, so rank 0's
+    JSON line is this process's output; returns the child's exit status."""
+    import subprocess
+
+    cmd = launch_command(args.gpus, [a for a in argv if a != "--print-launch"], _free_port())
+    if args.print_launch:
+        print(json.dumps({"launch": cmd}))
+        return 0
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ---- CPU baseline ----------------------------------------------------------------------
 
 def _cpu_model():
     try:
@@ -76,6 +129,27 @@ def _cpu_model():
     except OSError:
         pass
     return "unknown"
+
+
+def _physical_cores():
+    try:
+        cores = set()
+        phys = core = None
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("physical id"):
+                    phys = line.split(":")[1].strip()
+                elif line.startswith("core id"):
+                    core = line.split(":")[1].strip()
+                elif not line.strip():
+                    if phys is not None and core is not None:
+                        cores.add((phys, core))
+                    phys = core = None
+        if cores:
+            return len(cores)
+    except OSError:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
 
 
 def cpu_baseline(problem, screens, rows):
@@ -103,8 +177,102 @@ def cpu_baseline(problem, screens, rows):
     return tod, dt
 
 
-def main():
-    args = parse_args()
+def cpu_baseline_all_cores(config, n_total, screens, n_procs, rows_per_proc=512):
+    """The same oracle on ``n_procs`` processes at once, ``rows_per_proc`` detector rows each (rows taken
+    cyclically from the configuration), every process timing its own share behind a common barrier;
+    the aggregate rate is all rows over the slowest process.  The workers never touch the GPU."""
+    import multiprocessing as mp
+    import tempfile
+
+    import numpy as np
+
+    from oracle import cpu_pool
+
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else tempfile.gettempdir()
+    path = os.path.join(shm, f"mrx_bench_screens_{os.getpid()}.npy")
+    np.save(path, np.stack(screens))
+    ctx = mp.get_context("spawn")
+    barrier, queue = ctx.Barrier(n_procs), ctx.Queue()
+    procs = [ctx.Process(target=cpu_pool.worker, args=(config, n_total, w, rows_per_proc, path, barrier, queue), daemon=True)
+             for w in range(n_procs)]
+    t0 = time.perf_counter()
+    try:
+        for p in procs:
+            p.start()
+        got = [queue.get(timeout=600) for _ in procs]
+        for p in procs:
+            p.join(30)
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+        try:
+            os.remove(path)
+        except OSError:
+            pass
+    errors = [g for g in got if "error" in g]
+    if errors:
+        raise RuntimeError(errors[0]["error"])
+    slowest = max(g["seconds"] for g in got)
+    return {"rows": n_procs * rows_per_proc, "seconds_slowest_process": slowest, "seconds_with_startup": time.perf_counter() - t0,
+            "processes": n_procs}
+
+
+def fluct_err(a, b):
+    """max |fluctuation difference| / max |reference fluctuation|, per-detector mean removed."""
+    import numpy as np
+
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    fa, fb = a - a.mean(axis=-1, keepdims=True), b - b.mean(axis=-1, keepdims=True)
+    return float(np.abs(fa - fb).max() / max(np.abs(fb).max(), 1e-300))
+
+
+# ---- what a user calls -----------------------------------------------------------------
+
+def frontend_timing(device):
+    """Wall clock of Simulation(atlast_10k-shaped instrument, device_output=True): set-up (Atmosphere.initialize:
+    hull, rotation search, layer geometry, device upload -- atmosphere/atmosphere.py:81-281) and run()
+    (sim/simulation.py:201-272) atmosphere-only and with the detector noise, K_RJ (the reference's default units)."""
+    import numpy as np
+    import torch
+
+    from maria_amd.instrument import Band, Detectors, Instrument, Site
+    from maria_amd.sim import Plan, Simulation
+
+    band = Band(center=150e9, width=30e9, shape="top_hat", name="f150")
+    inst = Instrument(Detectors.hexagon(10000, 2.0, [band], primary_size=50.0))
+    plan = Plan.daisy(start_time=1.7e9, duration=600.0, sample_rate=400.0, scan_center=(45.0, 60.0), radius=0.5, speed=0.5)
+    out = {"instrument": f"{inst.dets.n} det hexagon, 2 deg field, 1 band; daisy 600 s @ 400 Hz; units K_RJ; device_output"}
+    for name, noise in (("atmosphere", False), ("atmosphere_noise", True)):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sim = Simulation(inst, plan, Site(altitude=5000.0), atmosphere="2d", noise=noise, device_output=True, noise_seed=1,
+                         progress_bars=False)
+        torch.cuda.synchronize()
+        init_s = time.perf_counter() - t0
+        walls, spans = [], []
+        for _ in range(9):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            e0.record()
+            (tod,) = sim.run()
+            e1.record()
+            torch.cuda.synchronize()
+            walls.append(time.perf_counter() - t0)
+            spans.append(e0.elapsed_time(e1))
+            del tod
+        # (median of 8 runs after the first; single runs show 50-80 ms host stalls on a shared box)
+        out[name] = {"init_s": init_s, "run_ms": 1e3 * float(np.median(walls[1:])), "run_ms_min": 1e3 * float(np.min(walls[1:])),
+                     "first_run_ms": 1e3 * walls[0], "gpu_span_ms": float(np.median(spans[1:]))}
+        del sim
+        torch.cuda.empty_cache()
+    return out
+
+
+# ---- the benchmark ---------------------------------------------------------------------
+
+def run(args):
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -113,13 +281,14 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start with `python bench.py --gpus N` or torch.distributed.run --nproc-per-node N")
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
     if args.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = f"cuda:{local_rank}"
+    if args.nccl_algo:
+        os.environ["NCCL_ALGO"] = args.nccl_algo
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.backend == "nccl":
@@ -129,15 +298,18 @@ def main():
     red_device = device if args.backend == "nccl" else "cpu"
 
     from maria_amd import synthetic
+    from maria_amd._lib import Context
     from maria_amd.dist import TodGather, exchange_layer_screens, layers_of_rank, shard_bounds
     from maria_amd.pipeline import DevicePath
 
     scaling = args.scaling or ("weak" if args.config == "atlast_50k" else "strong")
     n_config = synthetic.CONFIGS[args.config]["n_det"]
+    weak_unit = None
     if args.config == "atlast_50k" and scaling == "weak":
         # BASELINE config 5 is stated on 8 GPUs (6 250 detectors and a 36 GB TOD each; the whole 288 GB
         # TOD fits no single GPU): the weak-scaling unit is that per-GPU share, on any number of GPUs
         n_total = (n_config // 8) * world
+        weak_unit = "atlast_50k/8: 6250 detectors per GPU"
     else:
         n_total = n_config if (scaling == "strong" or world == 1) else n_config * world
     problem = synthetic.config_problem(args.config, n_det=n_total)
@@ -149,50 +321,64 @@ def main():
     # the output buffer: with the all-gather, the whole [n_det, T] TOD with this rank's shard
     # written straight into its rows; otherwise the shard alone
     gatherer, full = None, None
-    want_gather = world > 1 and not args.no_allgather and scaling == "strong" and args.backend == "nccl"
+    want_comm = world > 1 and args.backend == "nccl" and ((not args.no_allgather and scaling == "strong") or args.shard_screens)
     gather_note = None
-    if want_gather:
-        # The communicator comes up in a helper thread with a deadline: a rendezvous that never
-        # completes must cost the all-gather figure, not the benchmark line.  The ranks then agree
-        # (a torch.distributed reduction) on whether every one of them has it.
+    if want_comm:
+        # The communicator comes up in a helper thread with a deadline and a context of its own: a
+        # rendezvous that never completes must cost the all-gather figure, not the benchmark line.
+        # The ranks then agree (a torch.distributed reduction) on whether every one of them has it.
         import threading
 
         box = {}
+        comm_ctx = Context(local_rank)
         try:  # the id travels over torch.distributed, from the thread that owns the group
-            unique_id = TodGather.exchange_unique_id(path.ctx, world, rank)
+            unique_id = TodGather.exchange_unique_id(comm_ctx, world, rank)
         except Exception as exc:  # pragma: no cover - depends on the node
             unique_id, box["note"] = None, f"{type(exc).__name__}: {exc}"[:300]
 
         def make():  # ncclCommInitRank inside libmrx: the only part that can hang
             try:
                 torch.cuda.set_device(local_rank)  # the current device is per thread
-                box["gatherer"] = TodGather(path.ctx, n_total, world, rank, unique_id=unique_id)
+                box["gatherer"] = TodGather(comm_ctx, n_total, world, rank, unique_id=unique_id)
             except Exception as exc:  # pragma: no cover - depends on the node
                 box["note"] = f"{type(exc).__name__}: {exc}"[:300]
 
+        th = None
         if unique_id is not None:
             th = threading.Thread(target=make, daemon=True)
             th.start()
             th.join(90.0)
             if th.is_alive():
                 box["note"] = "the RCCL communicator did not come up within 90 s"
-        ok = torch.tensor([1 if "gatherer" in box else 0], dtype=torch.int32, device=red_device)
+        ok = torch.tensor([1 if ("gatherer" in box and not (th and th.is_alive())) else 0], dtype=torch.int32, device=red_device)
         dist.all_reduce(ok, op=dist.ReduceOp.MIN)
         if int(ok.item()) == 1:
             gatherer = box["gatherer"]
-            full = gatherer.full_buffer(T, device)
-            tod = gatherer.my_rows(full)
+            if not args.no_allgather and scaling == "strong":
+                full = gatherer.full_buffer(T, device)
+                tod = gatherer.my_rows(full)
         else:
             gather_note = box.get("note", "another rank could not create the communicator")
+            if "gatherer" in box and not (th and th.is_alive()):  # this rank has one the job cannot use
+                try:
+                    box["gatherer"].close()
+                except Exception:
+                    pass
             gatherer, full = None, None
     if full is None:
         tod = torch.empty((D, T), dtype=torch.float32, device=device)
     own_layers = layers_of_rank(L, world, rank) if (args.shard_screens and world > 1) else None
+    if own_layers is not None and args.backend == "nccl" and gatherer is None:
+        own_layers = None  # no communicator: fall back to regenerating every layer on every rank
 
     def screens():
         path.generate_screens(only=own_layers)
         if own_layers is not None:
-            exchange_layer_screens(path._gen_screens)
+            if gatherer is not None:  # RCCL through the C ABI, on the communicator's stream = the current one
+                gatherer.ctx.set_stream(torch.cuda.current_stream())
+                gatherer.exchange_screens(path._gen_screens)
+            else:  # gloo rehearsal
+                exchange_layer_screens(path._gen_screens)
 
     writer_events = []
     n_blocks = args.blocks if args.blocks is not None else path.default_blocks()
@@ -289,7 +475,7 @@ def main():
             "n_det_per_gpu": D,
             "n_samples": T,
             "screens_in_step": not args.no_screens_in_step,
-            "screens": "sharded by layer + broadcast" if own_layers is not None else "regenerated on every rank from the Philox key",
+            "screens": "sharded by layer + broadcast by the owners" if own_layers is not None else "regenerated on every rank from the Philox key",
             "parallelism": f"detector-sharded x{world}, no data-path collective",
         },
         "stage_ms": {
@@ -316,8 +502,8 @@ def main():
             "frac_alone": alone / HBM_PEAK_GBPS,
         },
         "second_kernel": {
-            "kernel": "atm_sample_kernel",
-            "bound": "valu + vector-memory issue (not hbm): see DESIGN 3.2 and profiles/r02_kernel_pmc.txt",
+            "kernel": "atm_sample_px_kernel",
+            "bound": "valu + vector-memory latency (not hbm): see DESIGN 3.2 and profiles/r03_kernel_pmc.txt",
             "ms_per_step": sm_ms,
             "launches_per_step": n_launch,
             "note": "sum over the step's block launches run back to back on one stream (serial breakdown)",
@@ -327,6 +513,8 @@ def main():
         },
         "flags": int(flags),
     }
+    if weak_unit:
+        result["config"]["weak_unit"] = weak_unit
 
     # HBM bytes per launch of the dominant kernel from the PMC counters: collected in
     # separate rocprofv3 --pmc passes (gpurun refuses --pmc inside an ordinary run), stored
@@ -341,7 +529,7 @@ def main():
             # per launch of the profiled run; scaled by rows when this run cuts the shard differently
             result["roofline"]["traffic"] = tr["hbm_bytes_per_launch"] * tr.get("launches_per_step", 1) / n_launch
             result["roofline"]["traffic_source"] = tr["source"]
-        break
+            break
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import threadpoolctl
@@ -352,9 +540,6 @@ def main():
             ref, cpu_s1 = cpu_baseline(problem, scr, slice(0, n_sub))
         got = tod[:n_sub].cpu().numpy()
         err = float(np.abs(got.astype(np.float64) - ref).max() / np.abs(ref).max())
-        threads = max([p["num_threads"] for p in threadpoolctl.threadpool_info()] or [1])
-        ref2, cpu_sn = cpu_baseline(problem, scr, slice(D - n_sub, D))  # library defaults: all cores
-        err2 = float(np.abs(tod[D - n_sub :].cpu().numpy().astype(np.float64) - ref2).max() / np.abs(ref2).max())
         result["cpu_baseline"] = {
             "value": n_sub * T / cpu_s1,
             "unit": "detector-samples/s",
@@ -362,15 +547,34 @@ def main():
             "kind": "port",
             "sample": f"first {n_sub} of {D} detector rows, full {T} samples, screens given (sampling + emission + cubic "
             f"upsample; numpy/scipy with BLAS/OpenMP pools limited to 1 thread): {cpu_s1:.2f} s",
-            "all_cores": {
-                "value": n_sub * T / cpu_sn, "threads": threads, "seconds": cpu_sn,
-                "sample": f"last {n_sub} rows, thread pools at the library default ({threads}); numpy fancy indexing and "
-                "scipy interp1d do not use them, so both timings agree",
-            },
             "host_cpus": os.cpu_count(),
+            "physical_cores": _physical_cores(),
             "cpu_model": _cpu_model(),
-            "parity_max_rel_err_vs_gpu": max(err, err2),
+            "parity_max_rel_err_vs_gpu": err,
+            # the turbulent signal alone: per-detector mean removed, relative to the largest fluctuation
+            "parity_fluct_rel_err": fluct_err(got, ref),
         }
+        del ref, got
+        try:
+            n_procs = args.cpu_procs or min(64, _physical_cores())
+            allc = cpu_baseline_all_cores(args.config, n_total, scr, n_procs)
+            result["cpu_baseline"]["all_cores"] = {
+                "value": allc["rows"] * T / allc["seconds_slowest_process"], "unit": "detector-samples/s", "cores": n_procs,
+                "seconds": allc["seconds_slowest_process"],
+                "sample": f"{n_procs} processes x 512 detector rows each (rows taken cyclically), full {T} samples, one "
+                "numpy/scipy thread per process, timed behind a common barrier; rate = all rows / slowest process",
+            }
+        except Exception as exc:  # pragma: no cover - depends on the host
+            result["cpu_baseline"]["all_cores"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+
+    if rank == 0 and world == 1 and not args.no_frontend and args.config == "atlast_10k":
+        del tod
+        path._pipe = None
+        torch.cuda.empty_cache()
+        try:
+            result["frontend"] = frontend_timing(device)
+        except Exception as exc:  # pragma: no cover
+            result["frontend"] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
 
     # The one all-gather of the final TOD over xGMI (north star / BASELINE config 4), through
     # the C ABI, on its own clock: reported beside `value`, never part of it.  A failure here
@@ -384,40 +588,49 @@ def main():
         def watchdog():
             if not finished.wait(180.0):
                 if rank == 0:
-                    result["allgather"] = {"error": "no completion within 180 s"}
+                    result.setdefault("allgather", {})["error"] = "no completion within 180 s"
                     print(json.dumps(result), flush=True)
                 os._exit(3)
 
         threading.Thread(target=watchdog, daemon=True).start()
         try:
-            if gatherer is not None:
-                times = []
-                for _ in range(max(1, args.gather_reps)):
-                    barrier()
-                    t0 = time.perf_counter()
-                    gathered = gatherer.gather(full)
-                    barrier()
-                    times.append(time.perf_counter() - t0)
-                # rows of another rank must have arrived: compare with what this rank would have produced there
-                other = (rank + 1) % world
-                olo, ohi = shard_bounds(n_total, world, other)
-                probe = DevicePath(problem, device=device, det_slice=slice(olo, min(olo + 16, ohi)))
-                probe.set_screens(path._gen_screens)
-                check = probe.run()
-                same = bool(torch.equal(check, gathered[olo : olo + check.shape[0]]))
-                dt = float(np.median(times))
-                nbytes = gatherer.bytes_received(T)
-                tmax = torch.tensor([dt], dtype=torch.float64, device=red_device)
-                dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-                dt = float(tmax.item())
-                result["allgather"] = {
-                    "ms": 1e3 * dt, "received_GB_per_rank": nbytes / 1e9, "GBps_per_rank": nbytes / dt / 1e9,
-                    "in_timed_region": False, "in_place": True, "reps": len(times),
-                    "transport": "RCCL ncclAllGather via libmrx mrx_allgather_tod",
-                    "rows_of_next_rank_bit_identical": same,
-                    "step_plus_gather_ms": 1e3 * elapsed / args.steps + 1e3 * dt,
-                    "value_with_gather": n_step * T / (elapsed / args.steps + dt),
-                }
+            if gatherer is not None and full is not None:
+                gatherer.ctx.set_stream(torch.cuda.current_stream())
+                algos = ["allgather", "p2p"] if args.gather_algo == "both" else [args.gather_algo]
+                for algo in algos:
+                    times = []
+                    for _ in range(max(1, args.gather_reps)):
+                        barrier()
+                        t0 = time.perf_counter()
+                        gathered = gatherer.gather(full, algo=algo)
+                        barrier()
+                        times.append(time.perf_counter() - t0)
+                    # rows of another rank must have arrived: compare with what this rank would have produced there
+                    other = (rank + 1) % world
+                    olo, ohi = shard_bounds(n_total, world, other)
+                    probe = DevicePath(problem, device=device, det_slice=slice(olo, min(olo + 16, ohi)))
+                    probe.set_screens(path._gen_screens)
+                    check = probe.run()
+                    same = bool(torch.equal(check, gathered[olo : olo + check.shape[0]]))
+                    dt = float(np.median(times))
+                    nbytes = gatherer.bytes_received(T)
+                    tmax = torch.tensor([dt], dtype=torch.float64, device=red_device)
+                    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+                    dt = float(tmax.item())
+                    entry = {
+                        "ms": 1e3 * dt, "received_GB_per_rank": nbytes / 1e9, "GBps_per_rank": nbytes / dt / 1e9,
+                        "in_timed_region": False, "in_place": True, "reps": len(times),
+                        "transport": {"allgather": "RCCL ncclAllGather via libmrx mrx_allgather_tod",
+                                      "p2p": "RCCL grouped ncclSend/ncclRecv to every peer via libmrx mrx_allgather_tod_p2p"}[algo],
+                        "NCCL_ALGO": os.environ.get("NCCL_ALGO"),
+                        "rows_of_next_rank_bit_identical": same,
+                        "step_plus_gather_ms": 1e3 * elapsed / args.steps + 1e3 * dt,
+                        "value_with_gather": n_step * T / (elapsed / args.steps + dt),
+                    }
+                    result["allgather" if algo == algos[0] else f"allgather_{algo}"] = entry
+                    if algo != algos[-1]:  # the next variant must move the rows again
+                        full.zero_()
+                        path.run(tod, blocks=n_blocks)
             elif args.backend != "nccl":
                 # rehearsal on one device: the torch.distributed fallback on a small CPU slice
                 from maria_amd.dist import all_gather_tod
@@ -445,5 +658,14 @@ def main():
         dist.destroy_process_group()
 
 
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.print_launch or needs_launch(args, os.environ):
+        return launch(args, argv)
+    run(args)
+    return 0
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -429,6 +429,23 @@ int mrx_comm_destroy(mrx_ctx* ctx, mrx_comm* comm);
 int mrx_allgather_tod(mrx_ctx* ctx, mrx_comm* comm, const float* d_shard, float* d_full,
                       size_t count);
 
+/* The same gather as world - 1 direct sends + world - 1 receives in one RCCL group instead of
+ * one ncclAllGather: every pair of the node's GPUs has its own xGMI link, so each rank pushes
+ * its shard to all peers at once (shard / link rate, against (world - 1) x that around a ring;
+ * SURVEY section 5).  Same arguments and result as mrx_allgather_tod; which of the two is
+ * faster on a given node is for the caller to measure (bench.py --gather-algo). */
+int mrx_allgather_tod_p2p(mrx_ctx* ctx, mrx_comm* comm, const float* d_shard, float* d_full,
+                          size_t count);
+
+/* Layer-sharded screen generation (strong scaling: the screens are replicated work): rank
+ * l % world generated layer l (mrx_screen_generate_batch with its own layers only); one
+ * ncclBroadcast per layer from its owner, all in one group, fills the other ranks' buffers in
+ * place.  Screens are functions of (seed, layer), so the result equals what every rank would
+ * have generated itself (atmosphere/process.py:191-209 has no counterpart: the reference is
+ * one process).  d_screens [n_layers] device pointers (host array), counts [n_layers] floats. */
+int mrx_exchange_screens(mrx_ctx* ctx, mrx_comm* comm, float* const* d_screens, const size_t* counts,
+                         int n_layers);
+
 /* ---- map sampling --------------------------------------------- */
 
 /* A celestial map as MapMixin._sample_maps sees it after smoothing, conversion to K_RJ and

@@ -179,6 +179,8 @@ SIGNATURES = {
     "mrx_comm_wrap": (_i, [_vp, _vp, _i, _i, C.POINTER(_vp)]),
     "mrx_comm_destroy": (_i, [_vp, _vp]),
     "mrx_allgather_tod": (_i, [_vp, _vp, _vp, _vp, _sz]),
+    "mrx_allgather_tod_p2p": (_i, [_vp, _vp, _vp, _vp, _sz]),
+    "mrx_exchange_screens": (_i, [_vp, _vp, _vp, _vp, _i]),
     "mrx_screen_work_floats": (_i, [_i, _i, _i, C.POINTER(_sz)]),
     "mrx_screen_generate_batch": (_i, [_vp, C.c_uint64, _i, _i, C.POINTER(MrxScreenDesc), _i, _vp, _sz]),
     "mrx_screen3d_work_floats": (_i, [_i, _i, _i, _i, C.POINTER(_sz)]),

@@ -32,6 +32,11 @@ struct Rccl {
   int (*CommInitRank)(void**, int, UniqueId, int) = nullptr;
   int (*CommDestroy)(void*) = nullptr;
   int (*AllGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
+  int (*Broadcast)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
   const char* (*GetErrorString)(int) = nullptr;
   bool ok = false;
 };
@@ -52,7 +57,13 @@ Rccl& rccl() {
     r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.handle, "ncclCommDestroy"));
     r.AllGather = reinterpret_cast<decltype(r.AllGather)>(dlsym(r.handle, "ncclAllGather"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.handle, "ncclGetErrorString"));
-    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather;
+    r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(dlsym(r.handle, "ncclBroadcast"));
+    r.Send = reinterpret_cast<decltype(r.Send)>(dlsym(r.handle, "ncclSend"));
+    r.Recv = reinterpret_cast<decltype(r.Recv)>(dlsym(r.handle, "ncclRecv"));
+    r.GroupStart = reinterpret_cast<decltype(r.GroupStart)>(dlsym(r.handle, "ncclGroupStart"));
+    r.GroupEnd = reinterpret_cast<decltype(r.GroupEnd)>(dlsym(r.handle, "ncclGroupEnd"));
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllGather && r.Broadcast && r.Send && r.Recv &&
+           r.GroupStart && r.GroupEnd;
   });
   return r;
 }
@@ -147,6 +158,55 @@ int mrx_allgather_tod(mrx_ctx* ctx, mrx_comm* comm, const float* d_shard, float*
               "d_shard must be this rank's slot of d_full (in place) or disjoint from it");
   const int nrc = rccl().AllGather(d_shard, d_full, count, kNcclFloat, comm->nccl, ctx->stream);
   if (nrc != 0) return nccl_fail(ctx, "ncclAllGather", nrc);
+  return MRX_OK;
+}
+
+int mrx_allgather_tod_p2p(mrx_ctx* ctx, mrx_comm* comm, const float* d_shard, float* d_full,
+                          size_t count) {
+  MRX_ENTER(ctx);
+  if (!ctx) return MRX_ERR_INVALID;
+  MRX_REQUIRE(ctx, comm != nullptr && comm->nccl != nullptr, "null communicator");
+  if (count == 0) return MRX_OK;
+  MRX_REQUIRE(ctx, d_shard && d_full, "null pointer");
+  float* slot = d_full + (size_t)comm->rank * count;
+  MRX_REQUIRE(ctx, d_shard == slot || d_shard + count <= d_full ||
+                       d_full + (size_t)comm->world * count <= d_shard,
+              "d_shard must be this rank's slot of d_full (in place) or disjoint from it");
+  // world - 1 sends and world - 1 receives in one group: every pair of GPUs has its own xGMI
+  // link, so all of them move data at once (shard / link rate, against
+  // (world - 1) x that for a ring)
+  int nrc = rccl().GroupStart();
+  if (nrc != 0) return nccl_fail(ctx, "ncclGroupStart", nrc);
+  for (int k = 1; k < comm->world && nrc == 0; ++k) {
+    const int to = (comm->rank + k) % comm->world, from = (comm->rank - k + comm->world) % comm->world;
+    nrc = rccl().Send(d_shard, count, kNcclFloat, to, comm->nccl, ctx->stream);
+    if (nrc == 0) nrc = rccl().Recv(d_full + (size_t)from * count, count, kNcclFloat, from, comm->nccl, ctx->stream);
+  }
+  const int erc = rccl().GroupEnd();
+  if (nrc != 0) return nccl_fail(ctx, "ncclSend/ncclRecv", nrc);
+  if (erc != 0) return nccl_fail(ctx, "ncclGroupEnd", erc);
+  if (d_shard != slot)
+    MRX_HIP(ctx, hipMemcpyAsync(slot, d_shard, count * sizeof(float), hipMemcpyDeviceToDevice, ctx->stream));
+  return MRX_OK;
+}
+
+int mrx_exchange_screens(mrx_ctx* ctx, mrx_comm* comm, float* const* d_screens, const size_t* counts,
+                         int n_layers) {
+  MRX_ENTER(ctx);
+  if (!ctx) return MRX_ERR_INVALID;
+  MRX_REQUIRE(ctx, comm != nullptr && comm->nccl != nullptr, "null communicator");
+  MRX_REQUIRE(ctx, n_layers >= 0, "negative layer count");
+  if (n_layers == 0) return MRX_OK;
+  MRX_REQUIRE(ctx, d_screens && counts, "null pointer");
+  for (int l = 0; l < n_layers; ++l) MRX_REQUIRE(ctx, d_screens[l] != nullptr || counts[l] == 0, "null screen pointer");
+  int nrc = rccl().GroupStart();
+  if (nrc != 0) return nccl_fail(ctx, "ncclGroupStart", nrc);
+  for (int l = 0; l < n_layers && nrc == 0; ++l)
+    if (counts[l] > 0)
+      nrc = rccl().Broadcast(d_screens[l], d_screens[l], counts[l], kNcclFloat, l % comm->world, comm->nccl, ctx->stream);
+  const int erc = rccl().GroupEnd();
+  if (nrc != 0) return nccl_fail(ctx, "ncclBroadcast", nrc);
+  if (erc != 0) return nccl_fail(ctx, "ncclGroupEnd", erc);
   return MRX_OK;
 }
 

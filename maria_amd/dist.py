@@ -102,17 +102,30 @@ class TodGather:
     def my_rows(self, full: torch.Tensor) -> torch.Tensor:
         return full[self.lo : self.hi]
 
-    def gather(self, full: torch.Tensor, shard: torch.Tensor = None):
+    def gather(self, full: torch.Tensor, shard: torch.Tensor = None, algo: str = "allgather"):
         """Complete ``full`` on every rank (enqueued on the context's stream).  ``shard``: a
-        separate contiguous [rows_per_rank, T] buffer to gather from; default in place."""
+        separate contiguous [rows_per_rank, T] buffer to gather from; default in place.
+        ``algo``: "allgather" (one ncclAllGather) or "p2p" (direct sends and receives to every
+        peer in one group: mrx_allgather_tod_p2p)."""
         from ._lib import ptr
 
         assert full.is_contiguous() and full.shape[0] == self.world * self.rows_per_rank
         count = self.rows_per_rank * full.shape[1]
         src = full[self.rank * self.rows_per_rank :] if shard is None else shard
         assert src.is_contiguous() and src.numel() >= count
-        self.ctx.call("mrx_allgather_tod", self.comm, ptr(src), ptr(full), count)
+        name = {"allgather": "mrx_allgather_tod", "p2p": "mrx_allgather_tod_p2p"}[algo]
+        self.ctx.call(name, self.comm, ptr(src), ptr(full), count)
         return full[: self.n_det]
+
+    def exchange_screens(self, screens):
+        """mrx_exchange_screens: layer l was generated by rank l % world; fill in the others' in place."""
+        import ctypes as C
+
+        assert all(t.is_contiguous() and t.dtype == torch.float32 for t in screens)
+        ptrs = (C.c_void_p * len(screens))(*[t.data_ptr() for t in screens])
+        counts = (C.c_size_t * len(screens))(*[t.numel() for t in screens])
+        self.ctx.call("mrx_exchange_screens", self.comm, ptrs, counts, len(screens))
+        return screens
 
     def bytes_received(self, T: int) -> int:
         return (self.world - 1) * self.rows_per_rank * T * 4
@@ -133,7 +146,8 @@ def layers_of_rank(n_layers: int, world_size: int = None, rank: int = None):
 
 
 def exchange_layer_screens(screens):
-    """Strong-scaling option: each rank generated only ``layers_of_rank`` into its (persistent,
+    """Strong-scaling option, torch.distributed form (any backend; the RCCL form through the C ABI is
+    ``TodGather.exchange_screens``): each rank generated only ``layers_of_rank`` into its (persistent,
     plan-bound) screen buffers; one broadcast per layer from its owner fills the rest in
     place.  Screens are functions of (seed, layer) only, so the result is bit for bit what every
     rank would have generated itself.  Layers may differ in shape, hence per-layer broadcasts."""

@@ -163,7 +163,12 @@ class DevicePath:
         self.d_flags = torch.zeros(1, dtype=torch.int32, device=dev)
         self.d_loading = torch.empty((self.Ta, self.D), dtype=torch.float32, device=dev)
         self.d_ym = None  # (y, m) knots of the two-call spline form: allocated by prepare()
+        # keep_pwv: every sample() also writes the float64 zenith-scaled pwv (the map mixin reads it) and
+        # run() keeps the stages serial; without it coarse_pwv() still works -- it re-runs the sampler on
+        # the bound screens into a buffer made on first use
+        self.keep_pwv = bool(keep_pwv)
         self.d_pwv = torch.empty((self.Ta, self.D), dtype=torch.float64, device=dev) if keep_pwv else None
+        self._pwv_stale = True
 
         self._layer_bufs = []
         self._table_bufs = []
@@ -324,15 +329,16 @@ class DevicePath:
         return self._gen_screens
 
     # -- hot path ------------------------------------------------------------
-    def sample(self):
+    def sample(self, want_pwv=False):
         self._pipelined = False
         if self.plan is None:
             raise RuntimeError("no screens bound: call set_screens() or generate_screens() first")
         self.ctx.call(
             "mrx_atm_sample", self.plan, ptr(self.d_az), ptr(self.d_el), self.Ta,
             ptr(self.d_dx), ptr(self.d_dy), ptr(self.d_band), ptr(self.d_m00), self.D,
-            self.pwv0, ptr(self.d_pwv), ptr(self.d_loading), ptr(self.d_flags),
+            self.pwv0, ptr(self.d_pwv) if (self.keep_pwv or want_pwv) else None, ptr(self.d_loading), ptr(self.d_flags),
         )
+        self._pwv_stale = not (self.keep_pwv or want_pwv)
 
     def prepare(self, krj=False):
         """Second derivatives of the coarse loading (``krj``: of the coarse loading in K_RJ that
@@ -367,7 +373,12 @@ class DevicePath:
         return self.d_loading.T.index_select(0, self._d_inverse)
 
     def coarse_pwv(self):
-        """[D, Ta] float64 zenith-scaled pwv in the caller's detector order."""
+        """[D, Ta] float64 zenith-scaled pwv in the caller's detector order (of the screens now bound:
+        without ``keep_pwv`` the sampler runs once more to produce it)."""
+        if self.d_pwv is None:
+            self.d_pwv = torch.empty((self.Ta, self.D), dtype=torch.float64, device=self.device)
+        if self._pwv_stale:
+            self.sample(want_pwv=True)
         return self.d_pwv.T.index_select(0, self._d_inverse)
 
     def run(self, out=None, blocks=None, writer_events=None, krj=False):
@@ -393,7 +404,7 @@ class DevicePath:
             self.prepare()
             self.upsample_krj(out)
             return out
-        if blocks > 1 and self.d_pwv is None:
+        if blocks > 1 and not self.keep_pwv:
             return self._run_pipelined(out, blocks, writer_events=writer_events, krj=krj)
         with _range("Sampling turbulence + Computing atmospheric emission"):
             self.sample()
@@ -406,7 +417,7 @@ class DevicePath:
     def default_blocks(self):
         """Detector blocks of the pipelined run: 4 from 4096 rows up (round 3, atlast_10k: 2.12 ms with 4
         blocks, 2.17 with 8, 2.24-2.34 with 12, 2.69 serial)."""
-        if self.d_pwv is not None or self.D < 4096:
+        if self.keep_pwv or self.D < 4096:
             return 1
         # screens that do not fit the Infinity Cache (atlast_50k: 16 x 4096^2 = 1.07 GB) make the
         # sampler memory-bound, and beside the writer it then loses more than the overlap gains
@@ -505,6 +516,7 @@ class DevicePath:
         ctx2.set_option(_lib.OPT_SAMPLE_WGS_PER_CU, saved[0])
         ctx2.set_option(_lib.OPT_SAMPLE_TIMES, saved[1])
         self._pipelined = True
+        self._pwv_stale = True
         return out
 
     # -- TOD.to("K_RJ") fused into the upsample -----------------------------------------

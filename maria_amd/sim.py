@@ -210,6 +210,7 @@ class Simulation:
         noise_seed: int = None,
         device_output: bool = False,
         shard=None,
+        device: str = "cuda:0",
     ):
         """sim/simulation.py:76-198.  ``device_output=True`` leaves the TOD on the GPU as
         a torch tensor (a 10 k x 240 k TOD is 9.6 GB; the PCIe copy dwarfs the synthesis).
@@ -243,6 +244,7 @@ class Simulation:
         self.noise, self.dtype = noise, dtype
         self.disable_progress_bars = not progress_bars
         self.device_output = device_output
+        self.device = device  # every observation of this Simulation runs on this GPU
         if shard == "auto":
             import torch.distributed as dist
 
@@ -266,8 +268,11 @@ class Simulation:
         self._noise_ctx = None
         self.obs_list = []
         for plan in self.plans:
-            obs = Observation(instrument, plan, site, atmosphere, self.atmosphere_kwargs)
+            obs = Observation(instrument, plan, site, atmosphere, {"device": device, **self.atmosphere_kwargs})
             if hasattr(obs, "atmosphere"):
+                # only the map mixin reads the coarse pwv (sim/map.py:117-135): without it the sampler and
+                # the TOD writer run pipelined in one call and the pwv is made if somebody asks for it
+                obs.atmosphere.keep_pwv = self.map is not None
                 obs.atmosphere.initialize(obs)
             self.obs_list.append(obs)
 
@@ -299,7 +304,11 @@ class Simulation:
     # -- sim/atmosphere.py:24-84 -------------------------------------------------------
     def _simulate_atmosphere(self, obs):
         lo, hi = self._rows(obs.instrument.dets.n)
-        obs.atmosphere.simulate_pwv(instrument=obs.instrument, det_slice=None if self.shard is None else slice(lo, hi))
+        det_slice = None if self.shard is None else slice(lo, hi)
+        if self.map is None:  # screens only: DevicePath.run() samples and writes in one pipelined call
+            obs.atmosphere.new_realisation(instrument=obs.instrument, det_slice=det_slice)
+        else:
+            obs.atmosphere.simulate_pwv(instrument=obs.instrument, det_slice=det_slice)
 
     def _gather(self, obs, tod):
         """All-gather a shard's TOD along the detector axis (equal row blocks, so the gathered
@@ -321,6 +330,10 @@ class Simulation:
         """Host part of ``TOD.to("K_RJ")`` (tod/tod.py:90-97): collapse the bands' transmission
         tables at the scalars the TOD metadata carries, rounded as run_obs stores them."""
         atm, dets = obs.atmosphere, obs.instrument.dets
+        key = (id(atm._device_path()), metadata["base_temperature"], metadata["pwv"])
+        if getattr(obs, "_cal_key", None) == key:  # same path, same scalars: the tables are on the device already
+            return
+        obs._cal_key = key
         sp = atm.spectrum
         tables = [{"T": sp.side_base_temperature, "pwv": sp.side_zenith_pwv, "el": sp.side_elevation,
                    "values": band.transmission_table(sp)} for band in dets.bands]
@@ -340,6 +353,11 @@ class Simulation:
         out = torch.empty((path.D, path.T), dtype=torch.float32, device=path.device)
         if units == "K_RJ":
             self._set_calibration(obs, metadata)
+        if self.map is None:  # nothing sampled yet (see _simulate_atmosphere)
+            path.run(out, krj=units == "K_RJ")
+            path.check_flags()  # RuntimeError "introduced nans" like atmosphere.py:368-369
+            return out
+        if units == "K_RJ":
             if path.coarse_krj_bound() <= path.COARSE_KRJ_LIMIT:
                 # the conversion on the coarse grid, then the pW writer (HBM-bound): the two orders of
                 # "divide" and "interpolate" differ by less than a quarter of the parity tolerance here
@@ -369,8 +387,8 @@ class Simulation:
             path = atm._device_path()
             ctx, device = path.ctx, path.device
         else:
-            device = torch.device("cuda:0")
-            self._noise_ctx = self._noise_ctx or Context(0)
+            device = torch.device(self.device)
+            self._noise_ctx = self._noise_ctx or Context(device.index or 0)
             ctx = self._noise_ctx
             ctx.set_stream(torch.cuda.current_stream(device))
         T = len(obs.coords.t)
@@ -432,9 +450,9 @@ class Simulation:
         if hasattr(obs, "atmosphere"):
             ctx, device = obs.atmosphere._device_path().ctx, obs.atmosphere._device_path().device
         else:
-            device = torch.device("cuda:0")
+            device = torch.device(self.device)
             if self._noise_ctx is None:
-                self._noise_ctx = Context(0)
+                self._noise_ctx = Context(device.index or 0)
             ctx = self._noise_ctx
             ctx.set_stream(torch.cuda.current_stream(device))
         t = obs.coords.t
@@ -463,7 +481,7 @@ class Simulation:
                     "latitude": obs.site.latitude, "longitude": obs.site.longitude,
                     "shard": None if rows is None else {"rank": self.shard[0], "world": self.shard[1], "rows": [lo, hi]}}
         has_atm = hasattr(obs, "atmosphere")
-        device = torch.device(obs.atmosphere.device) if has_atm else torch.device("cuda:0")
+        device = torch.device(obs.atmosphere.device) if has_atm else torch.device(self.device)
         # Bands whose NEP grows with the loading need the loadings in pW, WITHOUT the gain
         # error, before the noise is drawn (sim/noise.py:35-37 runs before simulation.py:239-247
         # multiplies the gain into the non-noise fields); gain and the K_RJ conversion are then
@@ -543,7 +561,7 @@ class Simulation:
                 self._set_calibration(obs, metadata)
                 device = path.device
             else:
-                device = torch.device("cuda:0")
+                device = torch.device(self.device)
                 den = self._band_denominators(obs.instrument.dets)[lo:hi]
             for name, field in data.items():
                 on_device = isinstance(field, torch.Tensor)

@@ -1,0 +1,64 @@
+"""bench.py's self-launch (CPU tier): `python bench.py --gpus N` from a plain shell must start N ranks as a
+CHILD job before touching a GPU, pass its arguments on and return the child's status."""
+
+from __future__ import annotations
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+
+
+def _clean_env():
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TORCHELASTIC_RUN_ID")}
+    env["MRX_TEST"] = "1"
+    return env
+
+
+def test_launch_command_carries_the_arguments():
+    argv = ["--gpus", "4", "--steps", "7", "--warmup", "2", "--backend", "gloo", "--single-device"]
+    cmd = bench.launch_command(4, argv, 29123)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29123"
+    k = cmd.index(os.path.join(ROOT, "bench.py"))
+    assert cmd[k + 1 :] == argv
+
+
+def test_needs_launch_only_from_a_plain_shell():
+    args = bench.parse_args(["--gpus", "8"])
+    assert bench.needs_launch(args, {})
+    assert bench.needs_launch(args, {"WORLD_SIZE": "1"})
+    assert not bench.needs_launch(args, {"WORLD_SIZE": "8", "RANK": "3"})  # already a rank of torch.distributed.run
+    assert not bench.needs_launch(args, {"WORLD_SIZE": "1", "TORCHELASTIC_RUN_ID": "x"})
+    assert not bench.needs_launch(bench.parse_args([]), {})  # N = 1 runs in this process
+
+
+def test_print_launch_from_the_command_line():
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--print-launch"],
+                         env=_clean_env(), capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    cmd = json.loads(out.stdout.strip().splitlines()[-1])["launch"]
+    assert "--nproc-per-node=2" in cmd and cmd[-4:] == ["--gpus", "2", "--steps", "3"]
+
+
+@pytest.mark.timeout(600)
+def test_the_parent_returns_the_childs_status():
+    """Without a GPU every rank stops at bench.py's own "needs a GPU" assertion: the launcher must have started
+    them (two ranks, gloo) and must hand their failure on as a non-zero status, not swallow it."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present: the ranks would run the benchmark")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--single-device",
+                          "--steps", "1", "--warmup", "0", "--no-cpu-baseline"],
+                         env=_clean_env(), capture_output=True, text=True, timeout=560)
+    assert out.returncode != 0
+    assert "bench.py needs a GPU" in out.stderr

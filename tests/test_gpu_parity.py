@@ -347,6 +347,17 @@ def test_allgather_through_the_c_abi_single_rank(gpu_ctx):
     torch.cuda.synchronize()
     assert torch.equal(out, shard)
     assert g.bytes_received(T) == 0
+    # the direct form (grouped sends / receives: none with one rank) and the layer exchange (one
+    # grouped broadcast per layer from its owner, here rank 0 itself) on the same communicator
+    shard2 = torch.rand((n_det, T), dtype=torch.float32, device="cuda:0")
+    out = g.gather(full, shard=shard2, algo="p2p")
+    torch.cuda.synchronize()
+    assert torch.equal(out, shard2)
+    screens = [torch.rand((64, 48 + l), dtype=torch.float32, device="cuda:0") for l in range(3)]
+    keep = [t.clone() for t in screens]
+    g.exchange_screens(screens)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(screens, keep))
     g.close()
 
 
