@@ -29,13 +29,19 @@ struct mrx_ctx {
     double* d_taps = nullptr;
   } taps[kTapSlots];
   int taps_next = 0;
-  // float32 taps of the fused screen smoothing, zero-padded to a fixed length
+  // float32 taps of the fused screen smoothing, zero-padded to a fixed length.  A batch of the screen
+  // generator pins the slots it has taken (pinned == ftaps_batch) so that a later miss of the SAME batch
+  // cannot evict them before the batch is launched; 128 slots hold the ~2 x 60 distinct taps of a
+  // model="3d" layer table without thrashing.
+  static constexpr int kFTapSlots = 128;
   struct FTapSlot {
     double sigma = -1.0;
     int radius = 0;
     float* d_taps = nullptr;
-  } ftaps[kTapSlots];
+    unsigned long long pinned = 0;
+  } ftaps[kFTapSlots];
   int ftaps_next = 0;
+  unsigned long long ftaps_batch = 0;
   int options[MRX_OPT_COUNT] = {0};
   // screen normalisations (sum of the PSD over the FFT grid), one device double
   // per distinct (grid, spectrum)

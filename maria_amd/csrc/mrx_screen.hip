@@ -527,6 +527,7 @@ __global__ void philox_normal_kernel(float* __restrict__ out, size_t n,
 int get_ftaps(mrx_ctx* ctx, double sigma, int radius, const float** d_out) {
   for (auto& slot : ctx->ftaps)
     if (slot.d_taps && slot.sigma == sigma && slot.radius == radius) {
+      slot.pinned = ctx->ftaps_batch;
       *d_out = slot.d_taps;
       return MRX_OK;
     }
@@ -537,8 +538,14 @@ int get_ftaps(mrx_ctx* ctx, double sigma, int radius, const float** d_out) {
     sum += k ? 2.0 * e[k] : e[k];
   }
   for (int k = 0; k <= radius; ++k) w[k] = (float)(e[k] / sum);
-  auto& slot = ctx->ftaps[ctx->ftaps_next];
-  ctx->ftaps_next = (ctx->ftaps_next + 1) % mrx_ctx::kTapSlots;
+  // round-robin eviction that skips the slots the batch under assembly already points at (a batch
+  // takes at most 2 kMaxBatch = 32 of the 128 slots, so the walk always ends)
+  int pick = ctx->ftaps_next;
+  for (int n = 0; n < mrx_ctx::kFTapSlots && ctx->ftaps[pick].d_taps && ctx->ftaps[pick].pinned == ctx->ftaps_batch; ++n)
+    pick = (pick + 1) % mrx_ctx::kFTapSlots;
+  auto& slot = ctx->ftaps[pick];
+  ctx->ftaps_next = (pick + 1) % mrx_ctx::kFTapSlots;
+  slot.pinned = ctx->ftaps_batch;
   if (slot.d_taps)  // a kernel in flight may still read the evicted taps
     MRX_HIP(ctx, hipDeviceSynchronize());
   else
@@ -650,6 +657,7 @@ static int run_screen_passes(mrx_ctx* ctx, uint64_t seed, int ny, int nx, const 
     ScreenBatchArgs args{};
     int max_out_ny = 0;
     bool late_smooth[kMaxBatch] = {false};
+    ++ctx->ftaps_batch;  // the tap slots taken from here on stay put until this batch is launched
     for (int i = 0; i < nb; ++i) {
       const mrx_screen_desc& d = screens[first + i];
       MRX_REQUIRE(ctx, d.d_out != nullptr, "null output pointer");

@@ -1299,8 +1299,9 @@ int mrx_spline_upsample_krj(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
   MRX_REQUIRE(ctx, d_bore_el && d_dx && d_dy && d_band && d_cal_axis_el &&
                        d_cal_values,
               "null calibration pointer");
-  MRX_REQUIRE(ctx, n_el >= 2 && n_bands >= 1 && (size_t)n_el * (1 + n_bands) <= 8192,
-              "calibration tables need 2 <= n_el and n_el*(1+n_bands) <= 8192");
+  // the cell table lives in LDS as one float4 per (band, cell): 96 KiB beside the kernels' static images
+  MRX_REQUIRE(ctx, n_el >= 2 && n_bands >= 1 && (size_t)(n_el - 1) * n_bands <= 6144,
+              "calibration tables need 2 <= n_el and (n_el-1)*n_bands <= 6144");
   MRX_REQUIRE(ctx, dta > 0.0, "coarse step must be positive");
   MRX_REQUIRE(ctx, ld_out >= (size_t)T, "ld_out smaller than T");
   if (Ta < 4)
@@ -1317,6 +1318,7 @@ int mrx_spline_upsample_krj(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
   const int vec_ok =
       (ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15u) == 0);
   const size_t lds = sizeof(float4) * (size_t)(n_el - 1) * n_bands;  // the cell table
+  MRX_LDS_CAP(ctx, spline_upsample_krj_kernel, lds);
   hipLaunchKernelGGL(spline_upsample_krj_kernel, grid, dim3(kBlock), lds,
                      ctx->stream, reinterpret_cast<const float2*>(d_ym), D, Ta,
                      ta0, 1.0 / dta, d_t, T, d_scale, d_rows, d_bore_el, d_dx,
@@ -1336,11 +1338,13 @@ int mrx_coarse_to_krj(mrx_ctx* ctx, const float* d_loading, int D, int Ta, const
   if (D == 0 || Ta == 0) return MRX_OK;
   MRX_REQUIRE(ctx, d_loading && d_out && d_bore_el_coarse && d_dx && d_dy && d_band && d_cal_axis_el && d_cal_values,
               "null pointer");
-  MRX_REQUIRE(ctx, n_el >= 2 && n_bands >= 1 && (size_t)n_el * (1 + n_bands) <= 8192,
-              "calibration tables need 2 <= n_el and n_el*(1+n_bands) <= 8192");
+  // the cell table lives in LDS as one float4 per (band, cell): 96 KiB beside the kernels' static images
+  MRX_REQUIRE(ctx, n_el >= 2 && n_bands >= 1 && (size_t)(n_el - 1) * n_bands <= 6144,
+              "calibration tables need 2 <= n_el and (n_el-1)*n_bands <= 6144");
   const dim3 grid(mrx_ceil_div(D, kBlock), mrx_ceil_div(Ta, kCoarseKrjSteps));
   MRX_REQUIRE(ctx, grid.y <= 65535u, "Ta too large for one launch");
   const size_t lds = sizeof(float4) * (size_t)(n_el - 1) * n_bands;
+  MRX_LDS_CAP(ctx, coarse_krj_kernel, lds);
   hipLaunchKernelGGL(coarse_krj_kernel, grid, dim3(kBlock), lds, ctx->stream, d_loading, D, Ta, d_bore_el_coarse,
                      d_dx, d_dy, d_band, d_cal_axis_el, d_cal_values, n_el, n_bands, d_out);
   MRX_CHECK_LAUNCH(ctx);
@@ -1357,13 +1361,15 @@ static int tod_convert(mrx_ctx* ctx, bool inverse, float* d_data, size_t ld, int
   if (D == 0 || T == 0) return MRX_OK;
   MRX_REQUIRE(ctx, d_data && d_bore_el && d_dx && d_dy && d_band && d_cal_axis_el && d_cal_values,
               "null pointer");
-  MRX_REQUIRE(ctx, n_el >= 2 && n_bands >= 1 && (size_t)n_el * (1 + n_bands) <= 8192,
-              "calibration tables need 2 <= n_el and n_el*(1+n_bands) <= 8192");
+  // the cell table lives in LDS as one float4 per (band, cell): 96 KiB beside the kernels' static images
+  MRX_REQUIRE(ctx, n_el >= 2 && n_bands >= 1 && (size_t)(n_el - 1) * n_bands <= 6144,
+              "calibration tables need 2 <= n_el and (n_el-1)*n_bands <= 6144");
   MRX_REQUIRE(ctx, ld >= (size_t)T, "ld smaller than T");
   dim3 grid(mrx_ceil_div(T, kTileSamples), mrx_ceil_div(D, kTileDet));
   MRX_REQUIRE(ctx, grid.y <= 65535u, "D too large for one launch");
   const int vec_ok = (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_data) & 15u) == 0);
   const size_t lds = sizeof(float4) * (size_t)(n_el - 1) * n_bands;  // the cell table
+  if (inverse) MRX_LDS_CAP(ctx, tod_krj_kernel<true>, lds); else MRX_LDS_CAP(ctx, tod_krj_kernel<false>, lds);
   if (inverse)
     hipLaunchKernelGGL(tod_krj_kernel<true>, grid, dim3(kBlock), lds, ctx->stream, d_data, ld, D, T,
                        d_scale, d_rows, d_bore_el, d_dx, d_dy, d_band, d_cal_axis_el,

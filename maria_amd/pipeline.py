@@ -157,7 +157,11 @@ class DevicePath:
         gain = problem.get("gain")
         self.d_gain = _dev(pick(gain), torch.float32, dev) if gain is not None else None
         self.ta0 = float(problem["ta"][0])
-        self.dta = float(problem["ta"][1] - problem["ta"][0])
+        # the coarse step from the grid's whole span: the difference of two neighbouring nodes carries the
+        # float64 rounding of a unix time (1e-7 s: 1e-6 of the step, 0.7 ms of time shift -- 1.3e-6 of the
+        # loading -- at the end of a 600 s scan)
+        ta = np.asarray(problem["ta"], float)
+        self.dta = float((ta[-1] - ta[0]) / (len(ta) - 1)) if len(ta) > 1 else float(problem.get("timestep", 1.0))
         self.pwv0 = float(problem["pwv0"])
 
         self.d_flags = torch.zeros(1, dtype=torch.int32, device=dev)

@@ -25,6 +25,17 @@ def _device_path(problem, **kw):
     return DevicePath(problem, device="cuda:0", **kw)
 
 
+# Fluctuation-only bounds (per-detector mean removed, relative to the largest fluctuation): 2x the largest
+# value measured on the GPU in round 3 (printed by the tests; pytest -s).  The loading is a float32 number
+# dominated by its mean, so its rounding (a few ulp, ~4e-7 of the value) is ~3e-5 of a 1.4 % fluctuation;
+# the TOD adds the spline's extrapolated tail, where knot differences grow ~3.5x.  Measured: coarse loading
+# 5.5e-5 ... 8.8e-5 (three shapes, both pointing modes), pixel rule vs literal rule 6.6e-5, TOD 2.4e-4.
+# (The float64 pwv -- the turbulent signal before the float32 emission lookup -- agrees to 3e-6 of its own
+# fluctuation at full size: tests/test_gpu_fullsize.py.)
+FLUCT_TOL_COARSE = 1.8e-4
+FLUCT_TOL_TOD = 5e-4
+
+
 def _fluct_err(a, b):
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
@@ -55,7 +66,9 @@ def test_sample_matches_oracle(gpu_ctx, n_det, n_layers, n_bands, chain):
     _, inter = hotpath.run_path(p, return_intermediates=True)
     assert rel_err(got_pwv, inter["pwv"]) <= 2e-6
     assert rel_err(got, inter["loading_a"]) <= TOL_TOD
-    assert _fluct_err(got, inter["loading_a"]) <= 1e-3
+    fe = _fluct_err(got, inter["loading_a"])
+    print(f"MEASURED sample fluct {n_det}/{n_layers}/{n_bands}/chain={chain}: {fe:.3e}")
+    assert fe <= FLUCT_TOL_COARSE
 
 
 def test_nonuniform_axes_take_the_array_path(gpu_ctx):
@@ -137,7 +150,9 @@ def test_pixel_coordinates_agree_with_the_literal_cell_search(gpu_ctx):
     b_load, b_pwv = path.d_loading, path.d_pwv
     assert rel_err(a_pwv.cpu().numpy(), b_pwv.cpu().numpy()) <= 2e-7
     assert rel_err(a_load.cpu().numpy(), b_load.cpu().numpy()) <= 1e-6
-    assert _fluct_err(a_load.cpu().numpy().T, b_load.cpu().numpy().T) <= 2e-4
+    fe = _fluct_err(a_load.cpu().numpy().T, b_load.cpu().numpy().T)
+    print(f"MEASURED pixel-vs-literal fluct: {fe:.3e}")
+    assert fe <= FLUCT_TOL_COARSE
     _, inter = hotpath.run_path(p, return_intermediates=True)
     for pwv in (a_pwv, b_pwv):
         assert rel_err(pwv.T.index_select(0, path._d_inverse).cpu().numpy(), inter["pwv"]) <= 2e-6
@@ -153,7 +168,9 @@ def test_full_path_matches_oracle(gpu_ctx):
     ref = hotpath.run_path(p)
     assert tod.shape == ref.shape and tod.dtype == np.float32
     assert rel_err(tod, ref) <= TOL_TOD
-    assert _fluct_err(tod, ref) <= 1e-3
+    fe = _fluct_err(tod, ref)
+    print(f"MEASURED full-path fluct: {fe:.3e}")
+    assert fe <= FLUCT_TOL_TOD
 
 
 def _spline_upsample(gpu_ctx, form, d_y, D, Ta, ta0, dta, d_t, T, d_scale, d_out, ld):

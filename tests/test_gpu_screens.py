@@ -187,6 +187,31 @@ def test_screen_batch_with_fused_smoothing(gpu_ctx, ny, nx):
         assert np.abs(g - ref).max() <= 1e-5 * np.abs(ref).max(), sp
 
 
+def test_tap_cache_eviction_spares_the_batch_under_assembly():
+    """The fused stencils' Gaussian taps are cached per (sigma, radius) in the context.  A batch whose
+    first layers HIT cached slots and whose later layers MISS must not have the hit slots evicted
+    before its single launch: fill and wrap the cache with 140 distinct sigmas, then
+    run a batch that mixes the oldest cached sigmas with new ones and compare every layer with the
+    same layer generated on its own."""
+    from maria_amd import Context
+
+    ctx = Context(0)  # a cache of its own
+    ny = nx = 128
+    base = dict(dy=5.0, dx=5.0, r0=300.0, nu=5.0 / 6.0)
+    sig = lambda k: 0.8 + 0.01 * k  # noqa: E731
+    for k0 in range(0, 140, 14):  # 140 distinct sigma_y (radius 3-9): the 128 slots wrap
+        _generate_batch(ctx, 3, ny, nx, [dict(base, stream=k, sigma_y=sig(k), sigma_x=0.0) for k in range(k0, k0 + 14)])
+    # now cached: sigmas 12 .. 139 (0 .. 11 were evicted).  The batch: 8 hits on the OLDEST cached slots -- the
+    # next to be evicted -- followed by 8 misses
+    specs = [dict(base, stream=100 + i, sigma_y=sig(12 + i), sigma_x=0.0) for i in range(8)]
+    specs += [dict(base, stream=200 + i, sigma_y=2.5 + 0.013 * i, sigma_x=0.0) for i in range(8)]
+    got = _generate_batch(ctx, 3, ny, nx, specs)
+    fresh = Context(0)
+    for sp, g in zip(specs, got):
+        alone = _generate_batch(fresh, 3, ny, nx, [sp])[0]
+        assert np.array_equal(g, alone), sp
+
+
 @pytest.mark.parametrize("ny,nx", [(1024, 512), (2048, 2048), (4096, 256), (2048, 1024)])
 def test_register_transforms_match_the_stockham_ones(gpu_ctx, ny, nx):
     """Sides of 1024, 2048 and 4096 take the transforms in registers (fft_regs: 16 x RB x 16, the
