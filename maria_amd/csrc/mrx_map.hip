@@ -30,6 +30,9 @@ constexpr int kTileDet = 16;
 constexpr int kSamplesPerThread = 4;
 constexpr int kTileSamples = kBlock * kSamplesPerThread;
 constexpr int kMaxStokes = 4;
+#ifndef MRX_MAP_WAVES
+#define MRX_MAP_WAVES 3  // (4 waves at 128 registers spill 119 values: 13.6 ms against 13.3)
+#endif
 constexpr float kHalfPiF = 1.57079637050628662109375f;
 constexpr float kTwoPiF = 6.283185482025146484375f;
 
@@ -40,7 +43,16 @@ typedef float vfloat4 __attribute__((ext_vector_type(4)));
 struct Axis {
   int n;
   double first, inv_step;
+  float lo, hi;  // float32 bounds just beyond the axis (one pixel either side): offsets are clamped into them first
 };
+
+__host__ __device__ inline Axis make_axis(int n, double first, double step) {
+  Axis a{n, first, 1.0 / step, 0.0f, 0.0f};
+  const double x0 = first - 1.5 * step, x1 = first + ((double)n + 0.5) * step;
+  a.lo = (float)(x0 < x1 ? x0 : x1);
+  a.hi = (float)(x0 < x1 ? x1 : x0);
+  return a;
+}
 
 struct MapArgs {
   const float* values;  // [C][S][n_eta][n_xi]
@@ -75,7 +87,7 @@ struct MapArgs {
 
 struct DetConst {
   float c_re, c_cr, c_im;  // sin(r)cos(p), cos(r), sin(r)sin(p)
-  double w[kMaxStokes];  // Mueller[d, 0, stokes]
+  double w[kMaxStokes];    // Mueller[d, 0, stokes]: float64 for the binning's float64 sums; map sampling rounds them to float32
 };
 
 struct SampleConst;
@@ -86,18 +98,25 @@ __device__ __forceinline__ int sc_index(const struct MapArgs& g, const SampleCon
 // (x - side[b-1]) / (side[b] - side[b-1]) is the fractional part of u; at a node the two
 // conventions (bin b with p = 0, bin b - 1 with p = 1) give the same interpolated value, so the
 // nodes themselves need not be read.
-__device__ __forceinline__ void axis_weights(const Axis& a, double x, bool bilinear, int& i0, int& i1, double& p) {
-  const double u = (x - a.first) * a.inv_step;
-  if (bilinear) {
+__device__ __forceinline__ void axis_weights(const Axis& a, float x, bool bilinear, int& i0, int& i1, float& p) {
+  // the position in pixels in float64 (a float32 product would be good to 6e-5 pixel only at pixel
+  // 1000); cell and weight leave it as an integer and a float32 fraction.  The offset is first clamped
+  // to one pixel beyond the axis (a NaN goes to the low end), so u is finite and converts safely;
+  // beyond the ends the reference's weights are (x + inf)/inf = nan -> 0 and finite/inf = 0: p = 0.
+  const double u = ((double)__builtin_amdgcn_fmed3f(x, a.lo, a.hi) - a.first) * a.inv_step;
+  if (bilinear) {  // workgroup-uniform
+    asm volatile("" ::: "memory");  // keep this a branch: if-converted, both arms' float64 work would run
     const double fl = floor(u);
-    const int b = (int)fmin(fmax(fl + 1.0, 0.0), (double)a.n);
-    p = (b == 0 || b == a.n) ? 0.0 : u - fl;  // beyond the ends: (x + inf)/inf = nan -> 0; finite/inf = 0
+    const int ifl = (int)fl;
+    const int b = min(max(ifl + 1, 0), a.n);
+    p = (b == 0 || b == a.n) ? 0.0f : (float)(u - fl);
     i0 = min(max(b - 1, 0), a.n - 1);
     i1 = min(b, a.n - 1);
   } else {
+    asm volatile("" ::: "memory");
     // np.digitize on the midpoints: the nearest node
-    i0 = i1 = (int)fmin(fmax(floor(u + 0.5), 0.0), (double)(a.n - 1));
-    p = 0.0;
+    i0 = i1 = min(max((int)floor(u + 0.5), 0), a.n - 1);
+    p = 0.0f;
   }
 }
 
@@ -137,7 +156,7 @@ __device__ __forceinline__ void rgi_axis(const RgiAxis& a, float x, int& i, floa
 struct SampleConst {
   float ca, sa;   // cos / sin of (el_bore - pi/2), float32 as the chain computes them
   float az;       // boresight azimuth
-  double G[6];    // direct mode: (dz_re, dz_im) = c @ G, c = (sin r cos p, cos r, sin r sin p)
+  float G[6];     // direct mode: (dz_re, dz_im) = c @ G, c = (sin r cos p, cos r, sin r sin p); composed in float64
   int jj;         // coarse interval of the sample time and the weight within it
   double u;
   int s;          // the (clamped) sample index
@@ -185,7 +204,7 @@ __device__ __forceinline__ void sample_const(const MapArgs& g, int s, bool chain
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-      for (int k = 0; k < 2; ++k) sc.G[i * 2 + k] = R[i][0] * P[0][k] + R[i][1] * P[1][k] + R[i][2] * P[2][k];
+      for (int k = 0; k < 2; ++k) sc.G[i * 2 + k] = (float)(R[i][0] * P[0][k] + R[i][1] * P[1][k] + R[i][2] * P[2][k]);
   }
 }
 
@@ -200,11 +219,13 @@ __device__ __forceinline__ float sample_value(const MapArgs& g, const CalLds& cl
                                               const DetConst& dc, int d, const SampleConst& sc, float ox,
                                               float oy, float el_d, double y0, double y1) {
   int e0, e1, x0, x1;
-  double pe, px;
-  axis_weights(ax_eta, (double)oy, g.bilinear, e0, e1, pe);
-  axis_weights(ax_xi, (double)ox, g.bilinear, x0, x1, px);
-  const double qe = 1.0 - pe, qx = 1.0 - px;
-  const double w00 = qe * qx, w10 = pe * qx, w01 = qe * px, w11 = pe * px;
+  float pe, px;
+  axis_weights(ax_eta, oy, g.bilinear, e0, e1, pe);
+  axis_weights(ax_xi, ox, g.bilinear, x0, x1, px);
+  // float32 weights and sums (round 3): the reference's float64 sparse product P @ map is rounded to
+  // float32 per channel anyway (map.py:155); a float32 evaluation is within 2e-7 of it
+  const float qe = 1.0f - pe, qx = 1.0f - px;
+  const float w00 = qe * qx, w10 = pe * qx, w01 = qe * px, w11 = pe * px;
   float cal_w_p = 0.f, cal_w_e = 0.f;
   int ip = 0, ie = 0;
   bool oob = false;
@@ -215,19 +236,25 @@ __device__ __forceinline__ float sample_value(const MapArgs& g, const CalLds& cl
     rgi_axis(cl.el, el_d, ie, cal_w_e, o2);
     oob = o1 || o2;
   }
-  const int plane = g.n_eta * g.n_xi;  // < 2^31: checked by the host
-  const int o00 = e0 * g.n_xi + x0, o10 = e1 * g.n_xi + x0, o01 = e0 * g.n_xi + x1, o11 = e1 * g.n_xi + x1;
-  const float* m = g.values;
+  const int plane = g.n_eta * g.n_xi;  // < 2^29: checked by the host (byte offsets in 32 bits)
+  // byte offsets of the four corners inside a plane as unsigned 32-bit numbers: the loads then take the
+  // plane's base from scalar registers (no 64-bit vector address arithmetic)
+  const uint32_t r0 = (uint32_t)(e0 * g.n_xi) << 2, r1 = (uint32_t)(e1 * g.n_xi) << 2;
+  const uint32_t c0 = (uint32_t)x0 << 2, c1 = (uint32_t)x1 << 2;
+  const uint32_t o00 = r0 + c0, o10 = r1 + c0, o01 = r0 + c1, o11 = r1 + c1;
+  typedef __attribute__((address_space(1))) const char gchar;
+  typedef __attribute__((address_space(1))) const float gfl;
+  gchar* m = (gchar*)g.values;
   float acc = 0.0f;
   for (int c = 0; c < g.C; ++c) {
-    double val = 0.0;
+    float val = 0.0f;
 #pragma unroll
     for (int k = 0; k < kS; ++k) {
-      const double v = fma(w00, (double)m[o00], fma(w10, (double)m[o10], fma(w01, (double)m[o01], w11 * (double)m[o11])));
-      val = fma(dc.w[k], v, val);
-      m += plane;
+      const float v = fmaf(w00, *(gfl*)(m + o00), fmaf(w10, *(gfl*)(m + o10), fmaf(w01, *(gfl*)(m + o01), w11 * *(gfl*)(m + o11))));
+      val = fmaf((float)dc.w[k], v, val);
+      m += (size_t)plane * 4;
     }
-    double pw_per_k;
+    float pw_per_k;
     if (kCal) {
       const float* tab = cl.tab + c * g.n_pwv * g.n_el + ip * g.n_el + ie;
       // float32 corner sum in product order, weights built as (1 * w_pwv) * w_el
@@ -237,11 +264,11 @@ __device__ __forceinline__ float sample_value(const MapArgs& g, const CalLds& cl
       v = __fadd_rn(v, __fmul_rn(tab[g.n_el], __fmul_rn(cal_w_p, we0)));
       v = __fadd_rn(v, __fmul_rn(tab[g.n_el + 1], __fmul_rn(cal_w_p, cal_w_e)));
       if (oob) v = __builtin_nanf("");
-      pw_per_k = (double)__fmul_rn(1.380649e-11f, v);  // 1e12 k_B as a weak scalar on a float32 array
+      pw_per_k = __fmul_rn(1.380649e-11f, v);  // 1e12 k_B as a weak scalar on a float32 array
     } else {
-      pw_per_k = 1.380649e-11 * g.scalar[c];
+      pw_per_k = (float)(1.380649e-11 * g.scalar[c]);
     }
-    acc = (float)fma(pw_per_k, val, (double)acc);  // float32 accumulator (map.py:155)
+    acc = fmaf(pw_per_k, val, acc);  // float32 accumulator (map.py:155)
   }
   return acc;
 }
@@ -260,11 +287,6 @@ __device__ __forceinline__ float asin_poly(float x) {
   p = fmaf(p, a, 1.5707963050f);
   const float r = 1.57079632679f - sqrtf(fmaxf(1.0f - a, 0.0f)) * p;
   return copysignf(r, x);
-}
-
-__device__ __noinline__ double asin_over_r(double r2) {
-  const double r = sqrt(r2);
-  return asin(fmin(r, 1.0)) / r;
 }
 
 // raw (unconvolved) map loading of one detector at one sample, float32.
@@ -308,15 +330,22 @@ __device__ __forceinline__ void sample_offsets(const MapArgs& g, const DetConst&
     ox = -__fmul_rn(dz_re, f);
     oy = -__fmul_rn(dz_im, f);
   } else {
-    const double c0 = (double)dc.c_re, c1 = (double)dc.c_cr, c2 = (double)dc.c_im;
-    const double dz_re = fma(c0, sc.G[0], fma(c1, sc.G[2], c2 * sc.G[4]));
-    const double dz_im = fma(c0, sc.G[1], fma(c1, sc.G[3], c2 * sc.G[5]));
-    const double r2 = fma(dz_re, dz_re, dz_im * dz_im);
-    // asin(r)/r: the series to r^12 below 0.3 rad (error < 1e-9), the function beyond
-    double f = fma(r2, fma(r2, fma(r2, fma(r2, fma(r2, fma(r2, 10395.0 / 599040.0, 945.0 / 42240.0), 105.0 / 3456.0), 15.0 / 336.0), 3.0 / 40.0), 1.0 / 6.0), 1.0);
-    if (__builtin_expect(r2 >= 0.09, 0)) f = asin_over_r(r2);
-    ox = (float)(-dz_re * f);
-    oy = (float)(-dz_im * f);
+    // float32 (round 3): the offsets are float32 numbers in the reference (transforms.py:36-53); with the
+    // composed rotation rounded to float32 every term below is good to 6e-8 of ~1e-2 rad, i.e. to the
+    // spacing of the float32 result itself
+    const float dz_re = fmaf(dc.c_re, sc.G[0], fmaf(dc.c_cr, sc.G[2], dc.c_im * sc.G[4]));
+    const float dz_im = fmaf(dc.c_re, sc.G[1], fmaf(dc.c_cr, sc.G[3], dc.c_im * sc.G[5]));
+    const float r2 = fmaf(dz_re, dz_re, dz_im * dz_im);
+    // asin(r)/r: the series to r^8 below 0.1 rad (error < 3e-10), the function beyond
+    float f = fmaf(r2, fmaf(r2, fmaf(r2, fmaf(r2, 35.0f / 1152.0f, 15.0f / 336.0f), 3.0f / 40.0f), 1.0f / 6.0f), 1.0f);
+    if (__builtin_amdgcn_ballot_w64(r2 >= 0.01f) != 0) {
+      if (r2 >= 0.01f) {
+        const float r = sqrtf(r2);
+        f = asinf(fminf(r, 1.0f)) / r;
+      }
+    }
+    ox = -dz_re * f;
+    oy = -dz_im * f;
     if (kNeedEl) el_d = asin_poly(im);
   }
 }
@@ -411,9 +440,10 @@ __global__ __launch_bounds__(kBlock) void bin_map_kernel(MapArgs g, BinArgs b) {
       float ox, oy, el_d;
       sample_offsets<kChain, false>(g, dc, sc[q], ox, oy, el_d);
       int e0, e1, x0, x1;
-      double pe, px;
-      axis_weights(ax_eta, (double)oy, g.bilinear, e0, e1, pe);
-      axis_weights(ax_xi, (double)ox, g.bilinear, x0, x1, px);
+      float pef, pxf;
+      axis_weights(ax_eta, oy, g.bilinear, e0, e1, pef);
+      axis_weights(ax_xi, ox, g.bilinear, x0, x1, pxf);
+      const double pe = (double)pef, px = (double)pxf;
       const double W = b.weight ? (double)b.weight[(size_t)d * b.ld_w + sb + q] : 1.0;
       const double WD = W * (double)b.tod[(size_t)d * b.ld_tod + sb + q];
       const double w[4] = {(1.0 - pe) * (1.0 - px), pe * (1.0 - px), (1.0 - pe) * px, pe * px};
@@ -488,9 +518,10 @@ __device__ __forceinline__ void bin_corners(const MapArgs& g, const BucketArgs& 
                                             float ox, float oy, int chan, uint32_t (&word)[BinTile<kBil>::kCorners],
                                             double (&wc)[BinTile<kBil>::kCorners]) {
   int e0, e1, x0, x1;
-  double pe, px;
-  axis_weights(ax_eta, (double)oy, kBil, e0, e1, pe);
-  axis_weights(ax_xi, (double)ox, kBil, x0, x1, px);
+  float pef, pxf;
+  axis_weights(ax_eta, oy, kBil, e0, e1, pef);
+  axis_weights(ax_xi, ox, kBil, x0, x1, pxf);
+  const double pe = (double)pef, px = (double)pxf;  // the products below in float64, as bin_map_kernel forms them
   auto pixel = [&](int e, int x) {
     const uint32_t r = (uint32_t)((chan * k.nby + (e >> 5)) * k.nbx + (x >> 6));
     return (r << 11) | (uint32_t)(((e & 31) << 6) | (x & 63));
@@ -718,7 +749,7 @@ __global__ __launch_bounds__(kBlock) void bin_accumulate_kernel(MapArgs g, BinAr
 template <bool kChain, bool kCal, int kS>
 // without the per-sample atmospheric calibration the kernel fits 168 registers (three waves per
 // SIMD: 16.8 -> 14.8 ms at 10 000 x 240 000); with it the cap costs spills (26.8 -> 34.4 ms)
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kCal ? 2 : 3, kCal ? 2 : 3))) void map_sample_kernel(MapArgs g) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kCal ? 2 : MRX_MAP_WAVES, kCal ? 2 : MRX_MAP_WAVES))) void map_sample_kernel(MapArgs g, int groups) {
   __shared__ DetConst dets[kTileDet];
   __shared__ float2 edge[2][kBlock];  // (first, last) raw value of every thread, double-buffered
   extern __shared__ float cal_lds[];   // calibration axes and tables (a few KB)
@@ -728,12 +759,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kCal ? 2
     for (int i = threadIdx.x; i < g.n_el; i += kBlock) cal_lds[g.n_pwv + i] = g.cal_el[i];
     for (int i = threadIdx.x; i < g.C * g.n_pwv * g.n_el; i += kBlock) cal_lds[g.n_pwv + g.n_el + i] = g.cal[i];
   }
-  const int d0 = blockIdx.y * kTileDet;
   const int s_tile = blockIdx.x * kTileSamples;
   const int sb = s_tile + threadIdx.x * kSamplesPerThread;
-  const int nd = min(kTileDet, g.D - d0);
-  if ((int)threadIdx.x < nd) dets[threadIdx.x] = make_det_const(g, d0 + threadIdx.x);
   const Axis ax_eta = g.eta, ax_xi = g.xi;
+  // the per-sample part (float64 composition of the three rotations, ~500 instruction slots a sample)
+  // is shared by the `groups` x 16 detector rows this workgroup walks
   SampleConst sc[kSamplesPerThread], sc_halo;
 #pragma unroll
   for (int q = 0; q < kSamplesPerThread; ++q) {
@@ -753,6 +783,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kCal ? 2
     cl.tab = cal_lds + g.n_pwv + g.n_el;
   }
   const bool full = (sb + kSamplesPerThread <= g.T) && g.vec_ok;
+  for (int grp = 0; grp < groups; ++grp) {
+  const int d0 = (blockIdx.y * groups + grp) * kTileDet;
+  if (d0 >= g.D) break;
+  const int nd = min(kTileDet, g.D - d0);
+  __syncthreads();  // the previous group is done with dets[] and edge[]
+  if ((int)threadIdx.x < nd) dets[threadIdx.x] = make_det_const(g, d0 + threadIdx.x);
+  __syncthreads();
   for (int dl = 0; dl < nd; ++dl) {
     const DetConst dc = dets[dl];
     const int d = d0 + dl;
@@ -772,13 +809,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kCal ? 2
     __syncthreads();
     const float left = first ? halo : edge[dl & 1][threadIdx.x - 1].y;
     const float right = last ? halo : edge[dl & 1][threadIdx.x + 1].x;
-    // scipy.ndimage.convolve1d, symmetric 3-tap kernel, double accumulation (map.py:170)
+    // scipy.ndimage.convolve1d, symmetric 3-tap kernel (map.py:170): 0.5 r + 0.25 (prev + next); the
+    // float32 form differs from scipy's float64 accumulation by one rounding of the float32 result
     float o[kSamplesPerThread];
 #pragma unroll
     for (int q = 0; q < kSamplesPerThread; ++q) {
-      const double prev = (double)(q == 0 ? left : r[q - 1]);
-      const double next = (double)(q == kSamplesPerThread - 1 ? right : r[q + 1]);
-      o[q] = (float)((double)r[q] * 0.5 + (prev + next) * 0.25);
+      const float prev = q == 0 ? left : r[q - 1];
+      const float next = q == kSamplesPerThread - 1 ? right : r[q + 1];
+      o[q] = fmaf(r[q], 0.5f, (prev + next) * 0.25f);
     }
     float* dst = g.out + (size_t)d * g.ld + sb;
     if (full) {
@@ -789,6 +827,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kCal ? 2
       for (int q = 0; q < kSamplesPerThread; ++q)
         if (sb + q < g.T) dst[q] = o[q];
     }
+  }
   }
 }
 
@@ -820,8 +859,8 @@ int mrx_map_sample(mrx_ctx* ctx, const mrx_sky_map* map, const mrx_map_cal* cal,
   }
   MapArgs g{};
   g.values = map->d_values;
-  g.eta = Axis{map->n_eta, map->eta0, 1.0 / map->deta};
-  g.xi = Axis{map->n_xi, map->xi0, 1.0 / map->dxi};
+  g.eta = make_axis(map->n_eta, map->eta0, map->deta);
+  g.xi = make_axis(map->n_xi, map->xi0, map->dxi);
   g.C = map->n_channels;
   g.S = map->n_stokes;
   g.n_eta = map->n_eta;
@@ -860,17 +899,21 @@ int mrx_map_sample(mrx_ctx* ctx, const mrx_sky_map* map, const mrx_map_cal* cal,
   g.out = d_out;
   g.ld = ld_out;
   g.vec_ok = (ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15u) == 0);
-  dim3 grid(mrx_ceil_div(T, kTileSamples), mrx_ceil_div(D, kTileDet));
+  // detector tiles per workgroup (they share the per-sample constants): 4 while that leaves >= 16
+  // workgroups per CU in the grid
+  int groups = 4;
+  while (groups > 1 && (long long)mrx_ceil_div(T, kTileSamples) * mrx_ceil_div(D, kTileDet * groups) < 16LL * 256) groups /= 2;
+  dim3 grid(mrx_ceil_div(T, kTileSamples), mrx_ceil_div(D, kTileDet * groups));
   MRX_REQUIRE(ctx, grid.y <= 65535u, "D too large for one launch");
   size_t lds = 0;
   if (cal->d_table) {
     lds = sizeof(float) * ((size_t)cal->n_pwv + cal->n_el + (size_t)map->n_channels * cal->n_pwv * cal->n_el);
     MRX_REQUIRE(ctx, lds <= 48 * 1024, "calibration tables of all channels must fit in 48 KiB");
   }
-  MRX_REQUIRE(ctx, (long long)map->n_eta * map->n_xi < (1LL << 31), "a map plane must hold fewer than 2^31 pixels");
+  MRX_REQUIRE(ctx, (long long)map->n_eta * map->n_xi < (1LL << 29), "a map plane must hold fewer than 2^29 pixels");
   const bool chain = ctx->options[MRX_OPT_POINTING_CHAIN] != 0, has_cal = cal->d_table != nullptr;
 #define MRX_LAUNCH_MAP(CH, CA, S) \
-  hipLaunchKernelGGL((map_sample_kernel<CH, CA, S>), grid, dim3(kBlock), lds, ctx->stream, g)
+  hipLaunchKernelGGL((map_sample_kernel<CH, CA, S>), grid, dim3(kBlock), lds, ctx->stream, g, groups)
 #define MRX_LAUNCH_MAP_S(CH, CA)                    \
   switch (map->n_stokes) {                          \
     case 1: MRX_LAUNCH_MAP(CH, CA, 1); break;       \
@@ -902,8 +945,8 @@ static int bin_map_args(mrx_ctx* ctx, const mrx_sky_map* map, const float* d_tod
   MRX_REQUIRE(ctx, (long long)map->n_eta * map->n_xi < (1LL << 31), "a map plane must hold fewer than 2^31 pixels");
   MRX_REQUIRE(ctx, ld_tod >= (size_t)T && (!d_weight || ld_weight >= (size_t)T), "leading dimension smaller than T");
   g = MapArgs{};
-  g.eta = Axis{map->n_eta, map->eta0, 1.0 / map->deta};
-  g.xi = Axis{map->n_xi, map->xi0, 1.0 / map->dxi};
+  g.eta = make_axis(map->n_eta, map->eta0, map->deta);
+  g.xi = make_axis(map->n_xi, map->xi0, map->dxi);
   g.C = map->n_channels;
   g.S = map->n_stokes;
   g.n_eta = map->n_eta;
