@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copy the summaries of gpurun_out/<tag> (scripts/profile_round.sh) into profiles/<tag>_*.
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 SRC=$ROOT/gpurun_out/$TAG
 cp $SRC/stats/run_kernel_stats.csv $ROOT/profiles/${TAG}_kernel_stats.csv
@@ -25,6 +25,6 @@ for k in sorted(tot):
     if k.startswith("noise"):
         print(f"{k:40s} launches {max(cnt[(k, c)] for c in tot[k]):4d} " + " ".join(f"{c}={v / cnt[(k, c)]:.4g}" for c, v in sorted(tot[k].items())))
 PY
-grep -h "^bin_map" $SRC/bin_bench.log > $ROOT/profiles/${TAG}_bin_bench.txt
+grep -h "^bin" $SRC/bin_bench.log > $ROOT/profiles/${TAG}_bin_bench.txt
 grep -h "^map_sample" $SRC/map_bench.log > $ROOT/profiles/${TAG}_map_bench.txt
 ls -la $ROOT/profiles | grep $TAG

@@ -36,9 +36,9 @@ def main():
         f.write("kernel,launches,FETCH_SIZE_KB_per_launch,WRITE_SIZE_KB_per_launch,fetch_bytes_corrected,write_bytes,hbm_bytes_per_launch\n")
         for r in rows:
             f.write(",".join(str(x) for x in r) + "\n")
-    up = [r for r in rows if r[0] == "spline_upsample_kernel"][0]
+    up = [r for r in rows if r[0] in ("spline_upsample_fused_kernel", "spline_upsample_kernel")][0]
     with open(f"{prefix}_traffic.json", "w") as f:
-        json.dump({"config": "atlast_10k", "kernel": "spline_upsample_kernel", "hbm_bytes_per_launch": up[6], "fetch_bytes_corrected": up[4],
+        json.dump({"config": "atlast_10k", "kernel": up[0], "hbm_bytes_per_launch": up[6], "fetch_bytes_corrected": up[4],
                    "launches_per_step": int(sys.argv[3]) if len(sys.argv) > 3 else 4,
                    "write_bytes": up[5],
                    "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes with --kernel-trace only (KB units x1024); "
@@ -60,7 +60,7 @@ def main():
                     cnt[(name, row["Counter_Name"])] += 1
         except OSError:
             continue
-        lines.append(f"# pass {sub}: rocprofv3 --kernel-trace --pmc <counters below> -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline")
+        lines.append(f"# pass {sub}: rocprofv3 --kernel-trace --pmc <counters below> -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-frontend")
         for k in sorted(tot):
             if k.startswith("__amd") or k.startswith("at::") or k.startswith("plan_"):
                 continue

@@ -4,12 +4,12 @@
 # follow-on rows' kernel stats.
 # Usage (from the repo root, under gpurun): bash scripts/profile_round.sh <tag>
 set -o pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-B="python3 $ROOT/bench.py --no-cpu-baseline"
+B="python3 $ROOT/bench.py --no-cpu-baseline --no-frontend"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o run -- $B --steps 10 --warmup 3 > $OUT/bench_under_rocprof.json 2> $OUT/stats.log
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o run -- $B --steps 3 --warmup 1 > $OUT/pmc_fetch.json 2> $OUT/pmc_fetch.log
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -o run -- $B --steps 3 --warmup 1 > $OUT/pmc_write.json 2> $OUT/pmc_write.log
@@ -20,7 +20,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/krj -o run -- pytho
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/noise -o run -- python3 $ROOT/scripts/noise_bench.py 10000 240000 3 > $OUT/noise_bench.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/noise_pmc -o run -- python3 $ROOT/scripts/noise_bench.py 10000 240000 1 > $OUT/noise_pmc.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/map -o run -- python3 $ROOT/scripts/map_bench.py 10000 240000 2 > $OUT/map_bench.log 2>&1
-MRX_BENCH_BIN=1 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bin -o run -- python3 $ROOT/scripts/map_bench.py 10000 240000 > $OUT/bin_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bin -o run -- python3 $ROOT/scripts/bin_bench.py 1024 1 3 > $OUT/bin_bench.log 2>&1
 cd $ROOT
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.log
 tail -c 400 $OUT/bench.json
