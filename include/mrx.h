@@ -334,6 +334,16 @@ int mrx_gauss_smooth2d(mrx_ctx* ctx, const float* d_in, float* d_out,
                        float* d_tmp, int ny, int nx, double sigma_y,
                        double sigma_x, double truncate);
 
+/* Linear resampling of every row of a screen onto new column positions:
+ *   d_out[e * ld_out + j] = d_scale[j] * ((1 - d_w[j]) * d_in[e * ld_in + d_idx[j]] + d_w[j] * d_in[e * ld_in + d_idx[j] + 1]).
+ * model="3d": every layer of the one process has its own cross-section grid, coarser with height
+ * (atmosphere/atmosphere.py:208-219, extrusion.py:20-22), while the layers are planes of one volume
+ * generated on one grid; the host gives the bracketing column, the weight and a variance factor
+ * (1 / sqrt((1-w)^2 + w^2 + 2 w (1-w) rho(step)): a linear blend of two unit-variance samples has
+ * less than unit variance) per output column.  0 <= d_idx[j] <= n_in - 2. */
+int mrx_resample_columns(mrx_ctx* ctx, const float* d_in, int n_e, int n_in, size_t ld_in, const int32_t* d_idx,
+                         const float* d_w, const float* d_scale, int n_out, float* d_out, size_t ld_out);
+
 /* ProjectionMap.smooth (map/projection.py:485-504): numer = G(data*weight),
  * denom = G(weight), out = denom > 0 ? numer/denom : 0; d_weight may be NULL
  * (weight == 1).  d_denom_out may be NULL.  d_tmp: 2*ny*nx floats. */

@@ -172,6 +172,7 @@ SIGNATURES = {
     "mrx_pointing_broadcast": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _sz]),
     "mrx_linear_upsample": (_i, [_vp, _vp, _i, _i, _d, _d, _vp, _i, _vp, _sz]),
     "mrx_gauss_smooth2d": (_i, [_vp, _vp, _vp, _vp, _i, _i, _d, _d, _d]),
+    "mrx_resample_columns": (_i, [_vp, _vp, _i, _i, _sz, _vp, _vp, _vp, _i, _vp, _sz]),
     "mrx_map_smooth": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _d, _d]),
     "mrx_screen_generate": (_i, [_vp, C.c_uint64, C.c_uint32, _i, _i, _d, _d, _d, _d, _vp, _vp]),
     "mrx_comm_unique_id": (_i, [_vp, _vp]),

@@ -290,19 +290,48 @@ class DevicePath:
                 _lib.load().mrx_screen3d_work_floats(nh, fe, fc, len(members), C.byref(n))
                 need = max(need, n.value)
             self._gen_work = torch.empty(need, dtype=torch.float32, device=dev)
+            # model="3d" with per-layer cross-section grids (layer["gen"]): the volume's planes are generated on
+            # the process's generation grid, then resampled onto each layer's own grid and smoothed there
+            self._gen_fine = {}
+            for l, layer in enumerate(layers):
+                g = layer.get("gen")
+                if g is not None:
+                    ne, n_l = shapes[l]
+                    self._gen_fine[l] = dict(
+                        plane=torch.empty((ne, len(g["cross"])), dtype=torch.float32, device=dev),
+                        idx=_dev(g["idx"], torch.int32, dev), w=_dev(g["w"], torch.float32, dev), scale=_dev(g["scale"], torch.float32, dev))
+            if self._gen_fine:
+                ne = max(shapes[l][0] for l in self._gen_fine)
+                nc = max(shapes[l][1] for l in self._gen_fine)
+                self._gen_tmp = torch.empty((2, ne * nc), dtype=torch.float32, device=dev)
             self.set_screens(self._gen_screens)
+
+        def pixel_sigmas(layer):
+            """(sigma_e, sigma_c) of the beam in pixels as the reference forms them (atmosphere.py:338-339):
+            beam sigma / mean extrusion step and beam sigma / layer.res -- the layer's RESOLUTION, which the
+            step of its linspace grid exceeds slightly (synthetic layers without a "res": the grid step)."""
+            de = float(layer["extrusion"][1] - layer["extrusion"][0])
+            dc = float(layer["cross_section"][1] - layer["cross_section"][0])
+            sigma = float(layer.get("beam_sigma", 0) or 0) if smooth else 0.0
+            return sigma / de, sigma / float(layer.get("res") or dc)
 
         def describe(members):
             descs = (_lib.MrxScreenDesc * len(members))()
             for d, l in zip(descs, members):
-                layer, out = layers[l], self._gen_screens[l]
+                layer = layers[l]
                 de = float(layer["extrusion"][1] - layer["extrusion"][0])
-                dc = float(layer["cross_section"][1] - layer["cross_section"][0])
-                sigma = float(layer.get("beam_sigma", 0) or 0) if smooth else 0.0
+                fine = self._gen_fine.get(l)
+                if fine is None:
+                    out = self._gen_screens[l]
+                    dc = float(layer["cross_section"][1] - layer["cross_section"][0])
+                    d.sigma_y, d.sigma_x = pixel_sigmas(layer)
+                else:  # unsmoothed, on the generation grid
+                    out = fine["plane"]
+                    dc = float(layer["gen"]["cross"][1] - layer["gen"]["cross"][0])
+                    d.sigma_y = d.sigma_x = 0.0
                 d.d_out, d.stream = out.data_ptr(), l
                 d.out_ny, d.out_nx, d.ld_out = out.shape[0], out.shape[1], out.stride(0)
                 d.dy, d.dx, d.r0, d.nu = de, dc, float(layer["r0"]), float(layer["nu"])
-                d.sigma_y, d.sigma_x = sigma / de, sigma / dc
             return descs
 
         with _range("Generating turbulence"):
@@ -322,7 +351,8 @@ class DevicePath:
                 first = layers[members[0]]
                 vol = first["volume"]
                 de = float(first["extrusion"][1] - first["extrusion"][0])
-                dc = float(first["cross_section"][1] - first["cross_section"][0])
+                cross = first["gen"]["cross"] if first.get("gen") is not None else first["cross_section"]
+                dc = float(cross[1] - cross[0])
                 pos = (C.c_double * len(members))(*[layers[l]["volume"]["pos"] for l in members])
                 scl = (C.c_double * len(members))(*[layers[l]["volume"]["scale"] for l in members])
                 self.ctx.call(
@@ -330,6 +360,18 @@ class DevicePath:
                     float(first["r0"]), float(first["nu"]), pos, scl, describe(members), len(members),
                     ptr(self._gen_work), self._gen_work.numel(),
                 )
+                for l in members:  # onto the layer's own grid, then the beam on that grid (atmosphere.py:341-344)
+                    fine = self._gen_fine.get(l)
+                    if fine is None:
+                        continue
+                    out, plane = self._gen_screens[l], fine["plane"]
+                    ne, n_l = out.shape
+                    sy, sx = pixel_sigmas(layers[l])
+                    dst = out if (sy <= 1e-15 and sx <= 1e-15) else self._gen_tmp[0]
+                    self.ctx.call("mrx_resample_columns", ptr(plane), ne, plane.shape[1], plane.stride(0), ptr(fine["idx"]), ptr(fine["w"]),
+                                  ptr(fine["scale"]), n_l, ptr(dst), n_l)
+                    if dst is not out:
+                        self.ctx.call("mrx_gauss_smooth2d", ptr(dst), ptr(out), ptr(self._gen_tmp[1]), ne, n_l, sy, sx, 4.0)
         return self._gen_screens
 
     # -- hot path ------------------------------------------------------------

@@ -293,3 +293,47 @@ def test_simulation_3d_model(gpu_ctx):
     assert 0.3 * want_near < near < 1.5 * want_near and 0.5 * want_far < far < 1.6 * want_far, (near, want_near, far, want_far)
     with pytest.raises(ValueError, match="Invalid model"):
         Simulation(inst, plan, Site(altitude=1800.0), atmosphere="5d", noise=False)
+
+
+def test_3d_layers_on_their_own_grids(gpu_ctx):
+    """model="3d" with a resolution that grows with height (extrusion.py:56-60): every layer's screen lives on its own
+    cross-section grid (atmosphere.py:208-219).  The chain behind it -- the volume's planes on one generation grid,
+    mrx_resample_columns onto the layer's nodes, the beam smoothing ON THAT GRID with sigma / layer.res pixels
+    (atmosphere.py:338-344) -- is checked layer by layer against numpy / scipy on the downloaded generation planes,
+    and the TOD against the oracle chain on the downloaded screens."""
+    import scipy.ndimage
+
+    from maria_amd.instrument import Band, Detectors, Instrument, Site
+    from maria_amd.sim import Plan, Simulation
+    from oracle import hotpath
+
+    bands = [Band(center=150e9, width=30e9, name="f150")]
+    inst = Instrument(Detectors.hexagon(37, 3.0, bands, primary_size=25.0))
+    plan = Plan.daisy(start_time=1.7e9, duration=20.0, sample_rate=20.0, scan_center=(130.0, 52.0), radius=0.3, speed=0.3)
+    sim = Simulation(inst, plan, Site(altitude=1800.0), atmosphere="3d", noise=False,
+                     atmosphere_kwargs={"weather": {"pwv": 1.2}, "max_height": 3000.0, "seed": 5})
+    (tod,) = sim.run(units="pW")
+    obs = sim.obs_list[0]
+    atm = obs.atmosphere
+    layers = atm._layer_list()
+    counts = [len(l["cross_section"]) for l in layers]
+    assert len(set(counts)) > 1 and counts[0] > counts[-1]
+    path = atm._device_path()
+    screens = [b[0].cpu().numpy() for b in path._layer_bufs]
+    for l in (0, len(layers) // 2, len(layers) - 1):
+        layer, g = layers[l], layers[l]["gen"]
+        plane = path._gen_fine[l]["plane"].cpu().numpy().astype(np.float64)
+        assert np.isfinite(plane).all() and 0.05 < (plane**2).mean() < 20.0  # (a patch smaller than the 1 km outer scale: no tighter claim)
+        coarse = (g["scale"] * ((1 - g["w"]) * plane[:, g["idx"]] + g["w"] * plane[:, g["idx"] + 1])).astype(np.float32)
+        de = layer["extrusion"][1] - layer["extrusion"][0]
+        ref = scipy.ndimage.gaussian_filter(coarse, sigma=(layer["beam_sigma"] / de, layer["beam_sigma"] / layer["res"]))
+        assert screens[l].shape == ref.shape == (len(layer["extrusion"]), counts[l])
+        assert np.abs(screens[l] - ref).max() <= 1e-5 * np.abs(ref).max(), l
+    prob = dict(
+        t=obs.coords.t, ta=atm.boresight.t, az_a=atm.boresight.az, el_a=atm.boresight.el,
+        offsets=inst.dets.offsets, band_index=inst.dets.band_index, m00=inst.dets.mueller00(),
+        layers=[dict(l, values=s) for l, s in zip(layers, screens)],
+        tables=atm._tables(inst.dets), T0=float(atm.weather.temperature[0]), pwv0=float(atm.weather.pwv),
+        timestep=float(atm.timestep), gain=None,
+    )
+    assert rel_err(tod.data["atmosphere"], hotpath.run_path(prob)) <= 1e-5

@@ -247,13 +247,60 @@ def test_am_spectrum_loader_interpolates_to_the_site_altitude(tmp_path):
 # ---- model="3d" (extrusion.py:69-77, atmosphere.py:141-279) ----------------------------------
 
 
-def _sim3d(max_height=400.0):
+def _sim3d(max_height=400.0, fov=0.3, primary=25.0, n=37):
     bands = [Band(center=150e9, width=30e9, name="f150")]
-    inst = Instrument(Detectors.hexagon(37, 0.3, bands, primary_size=25.0))
+    inst = Instrument(Detectors.hexagon(n, fov, bands, primary_size=primary))
     plan = Plan.daisy(start_time=1.7e9, duration=30.0, sample_rate=20.0, scan_center=(130.0, 52.0), radius=0.3, speed=0.3)
     site = Site(altitude=1800.0)
     kw = dict(weather={"pwv": 1.2}, max_height=max_height)
     return Simulation(inst, plan, site, atmosphere="3d", atmosphere_kwargs=kw, noise=False), inst, plan, site
+
+
+def _check_layer_grids(proc, ref, want, same_extent=True):
+    """Every layer of the one process has its own cross-section grid at its own resolution over the process's
+    extent (atmosphere.py:208-219): n = int((ptp + 2 res) / res) nodes from ymin - res to ymax + res.  The product's
+    rotation minimises the extent (section 4 of DESIGN.md), so its extent is the oracle's or slightly less."""
+    for l, layer in enumerate(proc["layers"]):
+        cs, cr, res = layer["cross_section"], want["cross_sections"][l], float(ref["res"][l])
+        assert layer["res"] == pytest.approx(res, rel=1e-12)
+        width, width_ref = cs[-1] - cs[0] - 2 * res, cr[-1] - cr[0] - 2 * res
+        assert width <= width_ref * (1 + 1e-4) + 1e-3
+        if same_extent:  # (with layers kilometres apart the oracle's hull-area search may stop at a far wider ribbon)
+            assert width >= 0.98 * width_ref - 0.05 and abs(len(cs) - len(cr)) <= 1 + int(0.02 * width_ref / res)
+        assert len(cs) == int(max(2, (width + 2 * res) / res))
+        assert cs[1] - cs[0] == pytest.approx((width + 2 * res) / (len(cs) - 1), rel=1e-9)
+        # the generation grid brackets every node; weights in [0, 1); a linear blend of two unit-variance samples
+        # is rescaled to unit variance
+        g = layer["gen"]
+        gx = g["cross"]
+        assert gx[0] < cs[0] and gx[-1] > cs[-1] and np.allclose(np.diff(gx), gx[1] - gx[0], rtol=1e-9)
+        assert gx[1] - gx[0] <= (cs[1] - cs[0]) * (1 + 1e-12)
+        assert g["idx"].min() >= 0 and g["idx"].max() <= len(gx) - 2 and (g["w"] >= 0).all() and (g["w"] < 1 + 1e-6).all()
+        np.testing.assert_allclose(gx[g["idx"]] + g["w"] * (gx[1] - gx[0]), cs, atol=1e-3 * (gx[1] - gx[0]))
+        assert (g["scale"] >= 1 - 1e-6).all() and (g["scale"] < 1.05).all()
+
+
+def test_3d_layers_have_their_own_cross_section_resolution():
+    """A wide field makes the resolution grow with height (extrusion.py:56-60: 0.1 z fov): the layers' grids then
+    differ in step and node count, all over the same extent, all resampled from one generation grid."""
+    sim, inst, plan, site = _sim3d(max_height=6000.0, fov=3.0, primary=25.0, n=61)
+    obs = sim.obs_list[0]
+    atm = obs.atmosphere
+    ref = geometry.generate_layers(
+        inst.dets.field_of_view, [(25.0, b.center) for b in inst.dets.bands], float(obs.boresight.el.min()),
+        _weather_dict(atm.weather), site.altitude, pwv=atm.weather.pwv, mode="3d", max_height=6000.0,
+    )
+    np.testing.assert_allclose(atm.layers["res"], ref["res"], rtol=1e-12)
+    assert ref["res"].max() > 1.2 * ref["res"].min()
+    proc = atm.processes[0]
+    ta, az_a, el_a = hotpath.downsample(plan.time, plan.phi, plan.theta, atm.timestep)
+    outer_pp = hotpath.project_unit(*hotpath.broadcast(inst.dets.outer().offsets, az_a, el_a))
+    np.random.seed(3)
+    want = geometry.process_geometry_multi(ref, np.arange(len(ref["h"])), ref["res"].min(), outer_pp, atm.timestep, len(ta))
+    _check_layer_grids(proc, ref, want, same_extent=False)
+    counts = [len(l["cross_section"]) for l in proc["layers"]]
+    assert len(set(counts)) > 1 and counts[0] >= counts[-1]  # coarser with height
+    assert len({id(l["gen"]["cross"]) for l in proc["layers"]}) == 1  # one generation grid for the volume
 
 
 def test_3d_layer_table_and_process_equal_the_oracle():
@@ -282,11 +329,7 @@ def test_3d_layer_table_and_process_equal_the_oracle():
     assert len(proc["layers"]) == len(ref["h"])
     ex, er = proc["extrusion"], want["extrusion"]
     assert ex[1] - ex[0] == pytest.approx(ref["res"].min(), rel=1e-12) and abs(len(ex) - len(er)) <= 2
-    cs = proc["cross_section"]
-    width = cs[-1] - cs[0] - 2 * proc["layers"][0]["res"]
-    assert width <= want["cross_extent"] * (1 + 1e-4) + 1e-3 and width >= 0.98 * want["cross_extent"] - 0.05
-    # the product keeps ONE cross grid at the finest layer's resolution (the reference: one per layer)
-    assert cs[1] - cs[0] <= min(np.diff(c)[0] for c in want["cross_sections"].values()) * (1 + 1e-9)
+    _check_layer_grids(proc, ref, want)
     # the layers are planes of one volume: positions in units of the thinnest slab, variance scales >= 1
     vol = proc["volume"]
     pos = np.array([l["volume"]["pos"] for l in proc["layers"]])
