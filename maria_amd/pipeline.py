@@ -52,6 +52,7 @@ def morton_order(offsets):
     off = np.asarray(offsets, float)
     if len(off) < 2:
         return np.arange(len(off))
+    off = np.where(np.isfinite(off), off, 0.0)  # (a NaN offset sorts anywhere; its samples are NaN whatever its place)
     lo, span = off.min(axis=0), np.maximum(np.ptp(off, axis=0), 1e-300)
     q = np.minimum(((off - lo) / span * 65535.0).astype(np.uint64), 65535)
 

@@ -305,6 +305,43 @@ def test_out_of_screen_raises_like_reference(gpu_ctx):
     assert np.isnan(path.d_loading.cpu().numpy()).any()
 
 
+@pytest.mark.parametrize("literal", [0, 1], ids=["pixel", "literal"])
+def test_degenerate_pointing_is_flagged_not_faulted(gpu_ctx, literal):
+    """Lines of sight at or below the horizon (the reference refuses such observations up front,
+    sim/observation.py:61-71; the C ABI has no such guard) and NaN pointing: the ground projection is
+    infinite or NaN, every cell index is clamped into its screen, the samples come out NaN with
+    MRX_FLAG_SCREEN_OOB -- and detectors with a sane pointing in the same launch keep their values."""
+    from maria_amd import _lib
+
+    p = small_problem(n_det=70, n_layers=3, n_bands=1)
+    good = _device_path(p, ctx=gpu_ctx)
+    gpu_ctx.set_option(_lib.OPT_AXIS_LITERAL, literal)
+    try:
+        good.sample()
+    finally:
+        gpu_ctx.set_option(_lib.OPT_AXIS_LITERAL, 0)
+    want = good.coarse_loading().cpu().numpy()
+    assert good.check_flags() == 0
+    q = dict(p)
+    off = np.array(p["offsets"], float)
+    off[3] = [0.0, -np.radians(70.0)]   # 70 degrees below the boresight: under the horizon
+    off[11] = [np.nan, 0.0]
+    q["offsets"] = off
+    path = _device_path(q, ctx=gpu_ctx)
+    path.clear_flags()
+    gpu_ctx.set_option(_lib.OPT_AXIS_LITERAL, literal)
+    try:
+        path.sample()
+    finally:
+        gpu_ctx.set_option(_lib.OPT_AXIS_LITERAL, 0)
+    with pytest.raises(RuntimeError, match="introduced nans"):
+        path.check_flags()
+    got = path.coarse_loading().cpu().numpy()
+    assert np.isnan(got[11]).all() and np.isnan(got[3]).any()
+    keep = np.setdiff1d(np.arange(70), [3, 11])
+    assert np.array_equal(got[keep], want[keep])
+
+
 def test_empty_shard_and_errors(gpu_ctx):
     import torch
 
