@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define MRX_VERSION 111 /* 0.1.1: mrx_band_table.d_cubic, screen batches, communicator, bucketed binning */
+#define MRX_VERSION 120 /* 0.2.0: mrx_spline_upsample_fused, mrx_allgather_tod_p2p, mrx_exchange_screens, mrx_resample_columns;
+                           MRX_OPT_SAMPLE_TILES retired */
 
 typedef enum mrx_status {
   MRX_OK = 0,
