@@ -30,9 +30,6 @@ constexpr int kTileDet = 16;
 constexpr int kSamplesPerThread = 4;
 constexpr int kTileSamples = kBlock * kSamplesPerThread;
 constexpr int kMaxStokes = 4;
-#ifndef MRX_MAP_WAVES
-#define MRX_MAP_WAVES 3  // (4 waves at 128 registers spill 119 values: 13.6 ms against 13.3)
-#endif
 constexpr float kHalfPiF = 1.57079637050628662109375f;
 constexpr float kTwoPiF = 6.283185482025146484375f;
 
@@ -224,8 +221,7 @@ __device__ __forceinline__ float sample_value(const MapArgs& g, const CalLds& cl
   axis_weights(ax_xi, ox, g.bilinear, x0, x1, px);
   // float32 weights and sums (round 3): the reference's float64 sparse product P @ map is rounded to
   // float32 per channel anyway (map.py:155); a float32 evaluation is within 2e-7 of it
-  const float qe = 1.0f - pe, qx = 1.0f - px;
-  const float w00 = qe * qx, w10 = pe * qx, w01 = qe * px, w11 = pe * px;
+  const float qe = 1.0f - pe;
   float cal_w_p = 0.f, cal_w_e = 0.f;
   int ip = 0, ie = 0;
   bool oob = false;
@@ -237,20 +233,25 @@ __device__ __forceinline__ float sample_value(const MapArgs& g, const CalLds& cl
     oob = o1 || o2;
   }
   const int plane = g.n_eta * g.n_xi;  // < 2^29: checked by the host (byte offsets in 32 bits)
-  // byte offsets of the four corners inside a plane as unsigned 32-bit numbers: the loads then take the
-  // plane's base from scalar registers (no 64-bit vector address arithmetic)
-  const uint32_t r0 = (uint32_t)(e0 * g.n_xi) << 2, r1 = (uint32_t)(e1 * g.n_xi) << 2;
-  const uint32_t c0 = (uint32_t)x0 << 2, c1 = (uint32_t)x1 << 2;
-  const uint32_t o00 = r0 + c0, o10 = r1 + c0, o01 = r0 + c1, o11 = r1 + c1;
+  // The two corners of a row as ONE 8-byte load (x, x + 1): x is moved to n_xi - 2 when the sample sits in the
+  // last column or beyond (both indices n_xi - 1), where the upper weight 1 selects that column.  Byte offsets
+  // inside a plane as unsigned 32-bit numbers: the loads take the plane's base from scalar registers.
+  const bool at_end = x0 > g.n_xi - 2;
+  const int xa = at_end ? g.n_xi - 2 : x0;
+  const float pxa = at_end ? 1.0f : (x1 > x0 ? px : 0.0f);
+  const float w0a = qe * (1.0f - pxa), w0b = qe * pxa, w1a = pe * (1.0f - pxa), w1b = pe * pxa;
+  const uint32_t o0 = ((uint32_t)(e0 * g.n_xi) + (uint32_t)xa) << 2, o1 = ((uint32_t)(e1 * g.n_xi) + (uint32_t)xa) << 2;
   typedef __attribute__((address_space(1))) const char gchar;
-  typedef __attribute__((address_space(1))) const float gfl;
+  typedef float pair4 __attribute__((ext_vector_type(2), aligned(4)));
+  typedef __attribute__((address_space(1))) const pair4 gpair;
   gchar* m = (gchar*)g.values;
   float acc = 0.0f;
   for (int c = 0; c < g.C; ++c) {
     float val = 0.0f;
 #pragma unroll
     for (int k = 0; k < kS; ++k) {
-      const float v = fmaf(w00, *(gfl*)(m + o00), fmaf(w10, *(gfl*)(m + o10), fmaf(w01, *(gfl*)(m + o01), w11 * *(gfl*)(m + o11))));
+      const pair4 r0 = *(gpair*)(m + o0), r1 = *(gpair*)(m + o1);
+      const float v = fmaf(w0a, r0.x, fmaf(w0b, r0.y, fmaf(w1a, r1.x, w1b * r1.y)));
       val = fmaf((float)dc.w[k], v, val);
       m += (size_t)plane * 4;
     }
@@ -749,7 +750,7 @@ __global__ __launch_bounds__(kBlock) void bin_accumulate_kernel(MapArgs g, BinAr
 template <bool kChain, bool kCal, int kS>
 // without the per-sample atmospheric calibration the kernel fits 168 registers (three waves per
 // SIMD: 16.8 -> 14.8 ms at 10 000 x 240 000); with it the cap costs spills (26.8 -> 34.4 ms)
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kCal ? 2 : MRX_MAP_WAVES, kCal ? 2 : MRX_MAP_WAVES))) void map_sample_kernel(MapArgs g, int groups) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kChain ? (kCal ? 2 : 3) : (kCal ? 3 : 5), kChain ? (kCal ? 2 : 3) : 8))) void map_sample_kernel(MapArgs g, int groups) {
   __shared__ DetConst dets[kTileDet];
   __shared__ float2 edge[2][kBlock];  // (first, last) raw value of every thread, double-buffered
   extern __shared__ float cal_lds[];   // calibration axes and tables (a few KB)
@@ -763,18 +764,39 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kCal ? 2
   const int sb = s_tile + threadIdx.x * kSamplesPerThread;
   const Axis ax_eta = g.eta, ax_xi = g.xi;
   // the per-sample part (float64 composition of the three rotations, ~500 instruction slots a sample)
-  // is shared by the `groups` x 16 detector rows this workgroup walks
+  // is shared by the `groups` x 16 detector rows this workgroup walks.  Without the literal chain and
+  // the per-sample calibration a sample's record is its six float32 matrix entries: it then lives in LDS
+  // (slot 0 / 1025: the halo samples of the 3-tap kernel) and the row loop fetches it with three 8-byte
+  // reads, instead of five records held in 65 registers per thread (168 -> 63 registers).
+  constexpr bool kLdsSc = !kChain;
+  constexpr int kRec = kCal ? 10 : 6;  // + cos / sin of the boresight elevation, coarse interval and weight
+  __shared__ __align__(16) float sc_lds[kLdsSc ? kRec * (kTileSamples + 2) : 8];
   SampleConst sc[kSamplesPerThread], sc_halo;
-#pragma unroll
-  for (int q = 0; q < kSamplesPerThread; ++q) {
-    sample_const(g, sb + q, kChain, sc[q]);
-    sc[q].s = min(max(sb + q, 0), g.T - 1);
-  }
   const bool first = threadIdx.x == 0, last = threadIdx.x == kBlock - 1;
-  if (first || last) {
-    const int sh = first ? s_tile - 1 : s_tile + kTileSamples;
-    sample_const(g, sh, kChain, sc_halo);
-    sc_halo.s = min(max(sh, 0), g.T - 1);
+  if (kLdsSc) {
+    for (int i = threadIdx.x; i < kTileSamples + 2; i += kBlock) {
+      SampleConst one;
+      sample_const(g, s_tile - 1 + i, false, one);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) sc_lds[kRec * i + k] = one.G[k];
+      if (kCal) {
+        sc_lds[kRec * i + 6] = one.ca;
+        sc_lds[kRec * i + 7] = one.sa;
+        sc_lds[kRec * i + 8] = __int_as_float(one.jj);
+        sc_lds[kRec * i + 9] = (float)one.u;  // (the interpolated pwv is rounded to float32 anyway)
+      }
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < kSamplesPerThread; ++q) {
+      sample_const(g, sb + q, kChain, sc[q]);
+      sc[q].s = min(max(sb + q, 0), g.T - 1);
+    }
+    if (first || last) {
+      const int sh = first ? s_tile - 1 : s_tile + kTileSamples;
+      sample_const(g, sh, kChain, sc_halo);
+      sc_halo.s = min(max(sh, 0), g.T - 1);
+    }
   }
   __syncthreads();
   if (kCal) {
@@ -782,6 +804,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kCal ? 2
     cl.el = make_rgi_axis(cal_lds + g.n_pwv, g.n_el);
     cl.tab = cal_lds + g.n_pwv + g.n_el;
   }
+  // slot of a sample's record: the thread's q-th sample, or its halo sample
+  auto record = [&](int slot) {
+    SampleConst one{};
+    const float2* rec = reinterpret_cast<const float2*>(sc_lds + kRec * slot);
+    const float2 a = rec[0], b = rec[1], c = rec[2];
+    one.G[0] = a.x; one.G[1] = a.y; one.G[2] = b.x; one.G[3] = b.y; one.G[4] = c.x; one.G[5] = c.y;
+    if (kCal) {
+      const float2 d = rec[3], e = rec[4];
+      one.ca = d.x; one.sa = d.y;
+      one.jj = __float_as_int(e.x);
+      one.u = (double)e.y;
+    }
+    return one;
+  };
   const bool full = (sb + kSamplesPerThread <= g.T) && g.vec_ok;
   for (int grp = 0; grp < groups; ++grp) {
   const int d0 = (blockIdx.y * groups + grp) * kTileDet;
@@ -794,7 +830,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kCal ? 2
     const DetConst dc = dets[dl];
     const int d = d0 + dl;
     float r[kSamplesPerThread];
-    const int jj0 = kCal ? sc[0].jj : 0;
+    const int jj0 = kCal ? (kLdsSc ? __float_as_int(sc_lds[kRec * (1 + threadIdx.x * kSamplesPerThread) + 8]) : sc[0].jj) : 0;
     double y0 = 0.0, y1 = 0.0;
     if (kCal) {
       y0 = g.pwv[(size_t)jj0 * g.D + d];
@@ -802,9 +838,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kCal ? 2
     }
 #pragma unroll
     for (int q = 0; q < kSamplesPerThread; ++q)
-      r[q] = raw_sample<kChain, kCal, kS>(g, cl, ax_eta, ax_xi, dc, d, sc[q], jj0, y0, y1);
+      r[q] = raw_sample<kChain, kCal, kS>(g, cl, ax_eta, ax_xi, dc, d, kLdsSc ? record(1 + threadIdx.x * kSamplesPerThread + q) : sc[q], jj0, y0, y1);
     float halo = 0.0f;
-    if (first || last) halo = raw_sample<kChain, kCal, kS>(g, cl, ax_eta, ax_xi, dc, d, sc_halo, jj0, y0, y1);
+    if (first || last)
+      halo = raw_sample<kChain, kCal, kS>(g, cl, ax_eta, ax_xi, dc, d, kLdsSc ? record(first ? 0 : kTileSamples + 1) : sc_halo, jj0, y0, y1);
     edge[dl & 1][threadIdx.x] = make_float2(r[0], r[kSamplesPerThread - 1]);
     __syncthreads();
     const float left = first ? halo : edge[dl & 1][threadIdx.x - 1].y;
@@ -912,8 +949,15 @@ int mrx_map_sample(mrx_ctx* ctx, const mrx_sky_map* map, const mrx_map_cal* cal,
   }
   MRX_REQUIRE(ctx, (long long)map->n_eta * map->n_xi < (1LL << 29), "a map plane must hold fewer than 2^29 pixels");
   const bool chain = ctx->options[MRX_OPT_POINTING_CHAIN] != 0, has_cal = cal->d_table != nullptr;
-#define MRX_LAUNCH_MAP(CH, CA, S) \
-  hipLaunchKernelGGL((map_sample_kernel<CH, CA, S>), grid, dim3(kBlock), lds, ctx->stream, g, groups)
+  // (the kernel's static LDS -- sample records, edge exchange -- is up to 46 KiB: with large calibration
+  // tables the sum passes the 64 KiB a launch gets by default)
+#define MRX_LAUNCH_MAP(CH, CA, S)                                                                              \
+  do {                                                                                                         \
+    if (lds + 47 * 1024 > 64 * 1024)                                                                           \
+      MRX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(map_sample_kernel<CH, CA, S>),           \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
+    hipLaunchKernelGGL((map_sample_kernel<CH, CA, S>), grid, dim3(kBlock), lds, ctx->stream, g, groups);       \
+  } while (0)
 #define MRX_LAUNCH_MAP_S(CH, CA)                    \
   switch (map->n_stokes) {                          \
     case 1: MRX_LAUNCH_MAP(CH, CA, 1); break;       \
