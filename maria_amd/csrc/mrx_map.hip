@@ -496,12 +496,36 @@ struct BinTile {
   static constexpr int kEntries = kDet * kSamples * kCorners;  // 16 384 / 8 192 contributions per tile at most
 };
 
-struct BinEntry {
+// A routed contribution.  Bilinear: pixel, signal, sample weight x corner weight in float64 (16 bytes).
+// Nearest pixel (the mapper's default; corner weight 1): the sample weight as the float32 it is (12 bytes), or
+// nothing at all when the caller passed no weights (8 bytes: pass A writes and pass B reads half the bytes).
+template <int kBytes>
+struct BinEntryT;
+template <>
+struct BinEntryT<16> {
   uint32_t local;  // pixel inside the region, (eta & 31) << 6 | (xi & 63), | detector within the tile << 11
   float d;         // signal
   double ww;       // sample weight x corner weight
+  __device__ __forceinline__ double weight() const { return ww; }
+  __device__ __forceinline__ void set_weight(double w) { ww = w; }
 };
-static_assert(sizeof(BinEntry) == 16, "BinEntry is one 16-byte store");
+template <>
+struct BinEntryT<12> {
+  uint32_t local;
+  float d;
+  float w;
+  __device__ __forceinline__ double weight() const { return (double)w; }
+  __device__ __forceinline__ void set_weight(double x) { w = (float)x; }
+};
+template <>
+struct BinEntryT<8> {
+  uint32_t local;
+  float d;
+  __device__ __forceinline__ double weight() const { return 1.0; }
+  __device__ __forceinline__ void set_weight(double) {}
+};
+static_assert(sizeof(BinEntryT<16>) == 16 && sizeof(BinEntryT<12>) == 12 && sizeof(BinEntryT<8>) == 8, "entry sizes");
+constexpr int bin_entry_bytes(bool bilinear, bool weights) { return bilinear ? 16 : weights ? 12 : 8; }
 
 struct BucketArgs {
   int nbx, nby, R;     // regions per row / per column of a plane, in all (channels x nby x nbx)
@@ -510,7 +534,7 @@ struct BucketArgs {
   int n_tiles;
   int tile_det, tile_entries;  // BinTile<>::kDet, kEntries of the form in use
   uint32_t* tab;       // [R][n_tiles]: (first entry of the region in the tile's slot) << 16 | count
-  BinEntry* entries;   // [n_tiles][tile_entries]
+  void* entries;       // [n_tiles][tile_entries] BinEntryT<entry_bytes>
 };
 
 // the contributions of one sample: pixel (region << 11 | local) and weight per corner
@@ -539,10 +563,11 @@ __device__ __forceinline__ void bin_corners(const MapArgs& g, const BucketArgs& 
   }
 }
 
-template <bool kChain, bool kBil>
+template <bool kChain, bool kBil, bool kW>
 // (168 registers instead of 174: measured 21.3 -> 19.7 ms)
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) void bin_bucket_kernel(MapArgs g, BinArgs b, BucketArgs k) {
   using Tile = BinTile<kBil>;
+  using Entry = BinEntryT<bin_entry_bytes(kBil, kW)>;
   constexpr int kDet = Tile::kDet, kSpt = Tile::kSpt, kCorners = Tile::kCorners;
   __shared__ DetConst dets[kDet];
   __shared__ uint32_t part[kBlock];
@@ -614,7 +639,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) 
   }
   __syncthreads();
   // sweep 2: every contribution to its place
-  BinEntry* slot = k.entries + (size_t)tile * Tile::kEntries;
+  Entry* slot = reinterpret_cast<Entry*>(k.entries) + (size_t)tile * Tile::kEntries;
   for (int dl = 0; dl < nd; ++dl) {
     const int d = d0 + dl;
     const int chan = b.channel ? min(max(b.channel[d], 0), g.C - 1) : 0;
@@ -629,17 +654,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) 
       } else {
         wc[0] = 1.0;
       }
-      const double W = b.weight ? (double)b.weight[(size_t)d * b.ld_w + sb + q] : 1.0;
+      const double W = (kW || kBil) && b.weight ? (double)b.weight[(size_t)d * b.ld_w + sb + q] : 1.0;
       const float D = b.tod[(size_t)d * b.ld_tod + sb + q];
 #pragma unroll
       for (int c = 0; c < kCorners; ++c) {
         const uint32_t wd = words[((dl * kBlock + threadIdx.x) * kSpt + q) * kCorners + c];
         if (wd == kBinNone) continue;
         const uint32_t pos = atomicAdd(&cursor[wd >> 11], 1u);
-        BinEntry en;
+        Entry en;
         en.local = (wd & (uint32_t)(kBinRegionPx - 1)) | ((uint32_t)dl << 11);
         en.d = D;
-        en.ww = W * wc[c];
+        en.set_weight(W * wc[c]);
         slot[pos] = en;
       }
     }
@@ -648,7 +673,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) 
 
 // pass B: block (region, split): the region's segments of the split's tiles into LDS, then the
 // block of 64 x 32 pixels into the map
+template <int kEntryBytes>
 __global__ __launch_bounds__(kBlock) void bin_accumulate_kernel(MapArgs g, BinArgs b, BucketArgs k, int splits) {
+  using Entry = BinEntryT<kEntryBytes>;
+  const Entry* entries = reinterpret_cast<const Entry*>(k.entries);
   extern __shared__ double bin_acc[];  // [S][2][kBinRegionPx]: sum, weight
   __shared__ uint32_t seg_cnt[kBlock];   // a batch's non-empty segments: count,
   __shared__ uint32_t seg_base[kBlock];  // index of the first entry in the work buffer minus its place in the batch's list,
@@ -702,7 +730,7 @@ __global__ __launch_bounds__(kBlock) void bin_accumulate_kernel(MapArgs g, BinAr
     constexpr int kPer = 4;
     int cur = 0;
     for (int j0 = threadIdx.x; j0 < total; j0 += kBlock * kPer) {
-      BinEntry en[kPer];
+      Entry en[kPer];
       int det[kPer];
 #pragma unroll
       for (int i = 0; i < kPer; ++i) {
@@ -711,7 +739,7 @@ __global__ __launch_bounds__(kBlock) void bin_accumulate_kernel(MapArgs g, BinAr
         det[i] = 0;
         if (j < total) {
           while (j >= seg_end[cur]) ++cur;
-          en[i] = k.entries[seg_base[cur] + (uint32_t)j];
+          en[i] = entries[seg_base[cur] + (uint32_t)j];
           det[i] = seg_d0[cur] + (int)(en[i].local >> 11);
         }
       }
@@ -723,8 +751,9 @@ __global__ __launch_bounds__(kBlock) void bin_accumulate_kernel(MapArgs g, BinAr
         for (int i = 0; i < kPer; ++i) {
           if (m[i] == 0.0) continue;  // zero weight: nothing to add (np.abs(P) entries that are 0); padding
           const uint32_t px = en[i].local & (uint32_t)(kBinRegionPx - 1);
-          atomicAdd(&bin_acc[(s * 2) * kBinRegionPx + px], m[i] * (en[i].ww * (double)en[i].d));
-          atomicAdd(&bin_acc[(s * 2 + 1) * kBinRegionPx + px], fabs(m[i]) * en[i].ww);
+          const double ww = en[i].weight();
+          atomicAdd(&bin_acc[(s * 2) * kBinRegionPx + px], m[i] * (ww * (double)en[i].d));
+          atomicAdd(&bin_acc[(s * 2 + 1) * kBinRegionPx + px], fabs(m[i]) * ww);
         }
       }
     }
@@ -1077,7 +1106,8 @@ int mrx_bin_map_work_bytes(const mrx_sky_map* map, int D, int T, size_t* min_byt
   if (!R || D < 1 || T < 1 || !min_bytes || !full_bytes) return R ? MRX_ERR_INVALID : MRX_ERR_UNSUPPORTED;
   const BinGeometry q = bin_geometry(map->bilinear != 0, R);
   // one column of tiles (all detectors x one tile of samples): its slots and its words of the table
-  const size_t col = (size_t)mrx_ceil_div(D, q.tile_det) * ((size_t)q.tile_entries * sizeof(BinEntry) + (size_t)R * sizeof(uint32_t));
+  // (sized for the largest entry: the nearest-pixel forms need 12 or 8 of the 16 bytes)
+  const size_t col = (size_t)mrx_ceil_div(D, q.tile_det) * ((size_t)q.tile_entries * 16 + (size_t)R * sizeof(uint32_t));
   *min_bytes = col;
   *full_bytes = col * (size_t)mrx_ceil_div(T, q.tile_samples);
   return MRX_OK;
@@ -1108,20 +1138,27 @@ int mrx_bin_map_bucketed(mrx_ctx* ctx, const mrx_sky_map* map, const float* d_to
   k.tile_entries = q.tile_entries;
   const int tiles_y = mrx_ceil_div(D, q.tile_det);
   MRX_REQUIRE(ctx, tiles_y <= 65535, "D too large for one launch");
-  const size_t col = (size_t)tiles_y * ((size_t)q.tile_entries * sizeof(BinEntry) + (size_t)k.R * sizeof(uint32_t));
+  const int entry_bytes = bin_entry_bytes(bil, d_weight != nullptr);
+  const size_t col = (size_t)tiles_y * ((size_t)q.tile_entries * entry_bytes + (size_t)k.R * sizeof(uint32_t));
   MRX_REQUIRE(ctx, d_work && (reinterpret_cast<uintptr_t>(d_work) & 15u) == 0 && work_bytes >= col,
               "work buffer: 16-byte aligned, at least mrx_bin_map_work_bytes' minimum");
   const int cols_total = mrx_ceil_div(T, q.tile_samples);
-  int cols = (int)(work_bytes / col < (size_t)cols_total ? work_bytes / col : (size_t)cols_total);
+  const size_t usable = work_bytes - 16;  // the table behind the entries is moved up to a 16-byte boundary
+  int cols = (int)(usable / col < (size_t)cols_total ? usable / col : (size_t)cols_total);
+  if (cols < 1) cols = 1;  // (work_bytes >= the 16-byte-entry minimum: one column of 8- or 12-byte entries fits)
   // pass B indexes the entries of a chunk with 32 bits
   while ((long long)cols * tiles_y * q.tile_entries > (1LL << 32) - 1) cols = (cols + 1) / 2;
   const size_t lds_b = (size_t)g.S * 2 * kBinRegionPx * sizeof(double);
   const bool chain = ctx->options[MRX_OPT_POINTING_CHAIN] != 0;
   typedef void (*BucketKernel)(MapArgs, BinArgs, BucketArgs);
-  const BucketKernel pass_a = bil ? (chain ? bin_bucket_kernel<true, true> : bin_bucket_kernel<false, true>)
-                                  : (chain ? bin_bucket_kernel<true, false> : bin_bucket_kernel<false, false>);
+  typedef void (*AccKernel)(MapArgs, BinArgs, BucketArgs, int);
+  const bool wts = d_weight != nullptr;
+  const BucketKernel pass_a = bil ? (chain ? bin_bucket_kernel<true, true, true> : bin_bucket_kernel<false, true, true>)
+                              : wts ? (chain ? bin_bucket_kernel<true, false, true> : bin_bucket_kernel<false, false, true>)
+                                    : (chain ? bin_bucket_kernel<true, false, false> : bin_bucket_kernel<false, false, false>);
+  const AccKernel pass_b = bil ? bin_accumulate_kernel<16> : wts ? bin_accumulate_kernel<12> : bin_accumulate_kernel<8>;
   MRX_LDS_CAP(ctx, pass_a, q.lds_a);
-  MRX_LDS_CAP(ctx, bin_accumulate_kernel, lds_b);
+  MRX_LDS_CAP(ctx, pass_b, lds_b);
   // enough workgroups per region to fill the chip: the regions under the scan hold most samples
   // (the time does not depend on the number from 8192 items up: measured)
   int splits = 32768 / k.R;
@@ -1132,12 +1169,13 @@ int mrx_bin_map_bucketed(mrx_ctx* ctx, const mrx_sky_map* map, const float* d_to
     k.n_tiles = nc * tiles_y;
     k.s0 = c0 * q.tile_samples;
     k.s1 = (long long)(c0 + nc) * q.tile_samples < (long long)T ? (c0 + nc) * q.tile_samples : T;
-    k.entries = reinterpret_cast<BinEntry*>(d_work);
-    k.tab = reinterpret_cast<uint32_t*>(k.entries + (size_t)k.n_tiles * q.tile_entries);
+    k.entries = d_work;
+    // (the table behind the entries, 16-byte aligned whatever the entry size)
+    k.tab = reinterpret_cast<uint32_t*>(static_cast<char*>(d_work) + (((size_t)k.n_tiles * q.tile_entries * entry_bytes + 15) & ~(size_t)15));
     MRX_HIP(ctx, hipMemsetAsync(k.tab, 0, (size_t)k.R * k.n_tiles * sizeof(uint32_t), ctx->stream));
     hipLaunchKernelGGL(pass_a, dim3(nc, tiles_y), dim3(kBlock), q.lds_a, ctx->stream, g, b, k);
     const int sp = splits < k.n_tiles ? splits : k.n_tiles;
-    hipLaunchKernelGGL(bin_accumulate_kernel, dim3(k.R, sp), dim3(kBlock), lds_b, ctx->stream, g, b, k, sp);
+    hipLaunchKernelGGL(pass_b, dim3(k.R, sp), dim3(kBlock), lds_b, ctx->stream, g, b, k, sp);
     MRX_CHECK_LAUNCH(ctx);
   }
   return MRX_OK;
