@@ -394,6 +394,9 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_kernel(
 // The sweeps cost latency in one wave (~50 dependent float64 steps), not
 // throughput: the other workgroups of the CU keep the store pipeline busy.
 constexpr int kFHalo = 16;
+#ifndef MRX_WRITER_WAVES
+#define MRX_WRITER_WAVES 5  // occupancy target of the fused writer (see the kernel): 6 -> 80 registers, 2 spilled
+#endif
 
 template <int kMaxKnots, int kG>
 struct FusedLds {
@@ -403,9 +406,12 @@ struct FusedLds {
 };
 
 template <bool kHasScale, int kMaxKnots, int kG>
-// <= 72 registers: beside the resident sampler (3 x 96 registers per lane and SIMD) the writer must
-// still fit 3 waves per SIMD -- with 2 it loses a fifth of its rate
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7))) void spline_upsample_fused_kernel(
+// 5 waves per SIMD = up to 96 registers (the kernel takes 94, nothing spilled).  Beside the resident sampler
+// (3 workgroups per CU x 64 registers) 3 writer waves per SIMD still fit (192 + 288 <= 512); with 2 the writer
+// loses a fifth of its rate.  The first fused version was capped at 72 registers (the round-2
+// sampler took 3 x 96) and spilled 10 values: 44 bytes of scratch per lane = 11 KB per workgroup against the
+// 128 KB it writes -- the 8 % of extra WRITE_SIZE in profiles/r03_traffic.json, and 3 % of the step.
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_WRITER_WAVES))) void spline_upsample_fused_kernel(
     const float* __restrict__ y, int D, int n, double ta0, double inv_dta,
     const double* __restrict__ t, int T, const float* __restrict__ scale,
     const int32_t* __restrict__ rows, float* __restrict__ out, size_t ld,
