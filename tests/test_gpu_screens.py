@@ -420,3 +420,32 @@ def test_screen_3d_statistics_match_matern(gpu_ctx):
     a = _generate_3d(gpu_ctx, 77, 0, nh, ny, nx, d, d, d, r0, nu, pos[:2])
     b = _generate_3d(gpu_ctx, 77, 0, nh, ny, nx, d, d, d, r0, nu, pos[:2])
     assert all(np.array_equal(x, y) for x, y in zip(a, b))
+
+
+def test_resample_columns_matches_numpy(gpu_ctx):
+    """mrx_resample_columns (model="3d": a layer's own cross-section nodes from the generation grid): the scaled
+    linear blend of the two bracketing columns, rows with a pitch, first and last columns, and its argument checks."""
+    import torch
+
+    from maria_amd import MrxError
+    from maria_amd._lib import ptr
+
+    rng = np.random.default_rng(8)
+    n_e, n_in, ld_in, n_out, ld_out = 300, 41, 45, 29, 33
+    src = rng.standard_normal((n_e, ld_in)).astype(np.float32)
+    u = np.sort(rng.uniform(0, n_in - 1, n_out))
+    u[0], u[-1] = 0.0, n_in - 1.0
+    idx = np.clip(np.floor(u).astype(np.int32), 0, n_in - 2)
+    w = (u - idx).astype(np.float32)
+    scale = rng.uniform(1.0, 1.05, n_out).astype(np.float32)
+    want = scale * ((1 - w) * src[:, idx] + w * src[:, idx + 1])
+    dev = "cuda:0"
+    d_src, d_idx, d_w, d_s = (torch.as_tensor(a).to(dev) for a in (src, idx, w, scale))
+    d_out = torch.full((n_e, ld_out), -3.0, dtype=torch.float32, device=dev)
+    gpu_ctx.call("mrx_resample_columns", ptr(d_src), n_e, n_in, ld_in, ptr(d_idx), ptr(d_w), ptr(d_s), n_out, ptr(d_out), ld_out)
+    got = d_out.cpu().numpy()
+    assert (got[:, n_out:] == -3.0).all()
+    assert np.abs(got[:, :n_out] - want).max() <= 3e-7 * np.abs(want).max()
+    with pytest.raises(MrxError, match="INVALID"):
+        gpu_ctx.call("mrx_resample_columns", ptr(d_src), n_e, n_in, ld_in, ptr(d_idx), ptr(d_w), ptr(d_s), n_out, ptr(d_out), n_out - 1)
+    gpu_ctx.call("mrx_resample_columns", ptr(d_src), 0, n_in, ld_in, ptr(d_idx), ptr(d_w), ptr(d_s), n_out, ptr(d_out), ld_out)  # empty: no-op
