@@ -1272,6 +1272,8 @@ int mrx_spline_upsample_fused(mrx_ctx* ctx, const float* d_y, int D, int Ta,
   // rows per workgroup and occupancy do not matter (round 3, 10 000 x 240 000 alone: 1.77-1.79 ms = 5.35-5.41 TB/s
   // for 1, 2 or 4 batches at 5, 4 or 3 workgroups per CU; 5.5 at 2 per CU): the kernel sits on the chip's
   // store ceiling (5.5-5.8 TB/s, scripts/exp_upsample.hip)
+  // (alone 1, 2 and 4 batches run alike; beside the sampler one is best: pipelined TOD synthesis 2.10 / 2.14 / 2.19 ms,
+  // scripts/exp_writer_batches.py)
   if (batches <= 0) batches = 1;
   while (batches > 1 && (long long)mrx_ceil_div(T, kTileSamples) *
                                 mrx_ceil_div(D, rows_per_batch * batches) < 4LL * 256 * 4)
