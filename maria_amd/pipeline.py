@@ -481,7 +481,7 @@ class DevicePath:
         # whole sampler workgroups (and writer tiles) per block.  The first block's sampler has
         # nothing to run beside, so that block is half as long as the others: the writer starts sooner
         units = -(-self.D // 256)
-        share = [1] + [2] * (blocks - 1) if blocks > 1 else [1]
+        share = getattr(self, "block_shares", None) or ([1] + [2] * (blocks - 1) if blocks > 1 else [1])
         cuts = np.floor(np.cumsum(share) / float(sum(share)) * units + 0.5).astype(int)
         edges = [0] + [min(int(c) * 256, self.D) for c in cuts]
         edges[-1] = self.D
