@@ -31,8 +31,9 @@
 extern "C" {
 #endif
 
-#define MRX_VERSION 120 /* 0.2.0: mrx_spline_upsample_fused, mrx_allgather_tod_p2p, mrx_exchange_screens, mrx_resample_columns;
-                           MRX_OPT_SAMPLE_TILES retired */
+#define MRX_VERSION 130 /* 0.2.0 (120): mrx_spline_upsample_fused, mrx_allgather_tod_p2p, mrx_exchange_screens,
+                           mrx_resample_columns; MRX_OPT_SAMPLE_TILES retired.  130: mrx_screen_amplitudes,
+                           mrx_screen_desc.d_amp, mrx_screen_generate_3d(..., d_amp) */
 
 typedef enum mrx_status {
   MRX_OK = 0,
@@ -382,6 +383,8 @@ typedef struct mrx_screen_desc {
   double dy, dx;           /* grid steps (m)                                         */
   double r0, nu;           /* outer scale (m), Matern smoothness                     */
   double sigma_y, sigma_x; /* beam sigma in pixels along y / x; 0 = no smoothing     */
+  const float* d_amp;      /* amplitude table of mrx_screen_amplitudes for this FFT domain
+                              (dy, dx, r0, nu are then ignored), or NULL: the power law */
 } mrx_screen_desc;
 /* floats of scratch for n_screens screens: 2 * n_screens * (nx/2 + 1) * (ny + 16) */
 int mrx_screen_work_floats(int ny, int nx, int n_screens, size_t* floats);
@@ -403,7 +406,35 @@ int mrx_screen_generate_3d(mrx_ctx* ctx, uint64_t seed, uint32_t stream, int nh,
                            double dh, double dy, double dx, double r0, double nu,
                            const double* plane_pos, const double* plane_scale,
                            const mrx_screen_desc* planes, int n_planes, float* d_work,
-                           size_t work_floats);
+                           size_t work_floats, const float* d_amp);
+
+/* Covariance-matched amplitudes (circulant embedding) for the generators above.  The power law is
+ * the continuous transform of the Matern covariance cut at the grid's Nyquist wavenumber; for rough
+ * fields (nu = 1/3 in three dimensions, atmosphere/atmosphere.py:249) most of the one-pixel structure
+ * lies beyond it.  This table holds sqrt(max(lambda, 0)) with lambda the eigenvalues of the
+ * covariance ITSELF on the periodic nh x ny x nx grid (nh = 0: two dimensions),
+ *     lambda[k] = sum_d rho_per(d) cos(2 pi k.d / N),   rho_per(d) = sum over images n of rho(|d + n L| / r0)
+ * (images summed, not the distance wrapped: the periodic covariance stays positive definite; images
+ * beyond x_cut outer scales -- where rho < 1e-10 -- are skipped), so that the structure function of the
+ * screens is Matern's from one pixel up.  The header of the table normalises the screens by
+ * sum(lambda) / rho_per(0): their variance is rho_per(0) = 1 + the images' share (1.01 at L = 5 r0) and
+ * their structure function 2 (rho_per(0) - rho_per(d)), in which the images cancel to second order.
+ * rho is the exact Matern correlation (functions/__init__.py:30-39) read from the caller's HOST tables
+ * log_cov[i] = log rho(x_i), log_sf[i] = log(1 - rho(x_i)) at log x_i = log_first + i log_step, x = r / r0
+ * (8192 nodes from 1e-6 to 1e3: four-point Lagrange interpolation in log x is then good to 1e-11; finite
+ * values only): rho(0) = 1 and, with x = max(|r| / r0, x_first), t = 1/(1 + x^2), rho = t (1 - exp(LSF(x))) +
+ * (1 - t) exp(LCOV(x)), the blend of functions/__init__.py:70-73.  (The reference's
+ * approximate_normalized_matern itself -- 1024 nodes, linear, good to 1e-5 -- is no longer positive
+ * definite on a grid at that accuracy: its clipped eigenvalues come back as 50 % too much structure at
+ * one pixel.)  float64 on the device, direct
+ * cosine sums over the even half axes: a set-up step, once per geometry (8 x 2048^2 layers of two
+ * outer scales: milliseconds; a 64 x 4096 x 512 volume: about a second).  d_table
+ * (mrx_screen_amp_floats' table_floats; 16-byte aligned) is then passed as mrx_screen_desc.d_amp
+ * (nh = 0) or mrx_screen_generate_3d's d_amp. */
+int mrx_screen_amp_floats(int nh, int ny, int nx, int n_radial, size_t* table_floats, size_t* work_floats);
+int mrx_screen_amplitudes(mrx_ctx* ctx, int nh, int ny, int nx, double dh, double dy, double dx, double r0,
+                          const double* log_cov, const double* log_sf, int n_radial, double log_first,
+                          double log_step, double x_cut, float* d_table, float* d_work, size_t work_floats);
 
 /* One unsmoothed screen over the whole domain.  d_work: mrx_screen_work_floats(ny, nx, 1)
  * floats (a buffer of 2*ny*nx float2, the size earlier versions asked for, is ample). */

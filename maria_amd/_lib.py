@@ -101,6 +101,7 @@ class MrxScreenDesc(C.Structure):
         ("nu", C.c_double),
         ("sigma_y", C.c_double),
         ("sigma_x", C.c_double),
+        ("d_amp", C.c_void_p),
     ]
 
 
@@ -186,7 +187,9 @@ SIGNATURES = {
     "mrx_screen_generate_batch": (_i, [_vp, C.c_uint64, _i, _i, C.POINTER(MrxScreenDesc), _i, _vp, _sz]),
     "mrx_screen3d_work_floats": (_i, [_i, _i, _i, _i, C.POINTER(_sz)]),
     "mrx_screen_generate_3d": (_i, [_vp, C.c_uint64, C.c_uint32, _i, _i, _i, _d, _d, _d, _d, _d, C.POINTER(_d), C.POINTER(_d),
-                                    C.POINTER(MrxScreenDesc), _i, _vp, _sz]),
+                                    C.POINTER(MrxScreenDesc), _i, _vp, _sz, _vp]),
+    "mrx_screen_amp_floats": (_i, [_i, _i, _i, _i, C.POINTER(_sz), C.POINTER(_sz)]),
+    "mrx_screen_amplitudes": (_i, [_vp, _i, _i, _i, _d, _d, _d, _d, C.POINTER(_d), C.POINTER(_d), _i, _d, _d, _d, _vp, _vp, _sz]),
     "mrx_screen_psd_sum": (_i, [_vp, _i, _i, _d, _d, _d, _d, C.POINTER(_d)]),
     "mrx_map_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _sz]),
     "mrx_bin_map": (_i, [_vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),

@@ -25,6 +25,7 @@
 // kx, ky), so every GPU regenerates bit-identical screens with no broadcast.
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 #include <vector>
 
 #include "mrx_internal.h"
@@ -57,6 +58,7 @@ struct ScreenLayerArgs {
   const double* psd_sum;  // device scalar: sum of the PSD over the grid
   const float* taps_y;    // [kMaxFusedRadius + 1] normalised Gaussian taps, zero beyond the radius
   const float* taps_x;
+  const float* amp;       // [nx/2 + 1][ny/2 + 1] amplitudes of mrx_screen_amplitudes (even in ky), or null: the power law
   int from_work;          // 1: the half spectrum of this plane already sits in `work` (3-D generator,
                           // written by screen3d_fft_h); pass 1 transforms it in place instead of drawing
   double dy, dx, k0sq;
@@ -209,9 +211,16 @@ __device__ __forceinline__ void half_spectrum_column_stockham(const ScreenLayerA
   } else
   for (int iy = threadIdx.x; iy < half; iy += kBlock) {
     const U4 rnd = philox4x32_10(U4{(uint32_t)ix, (uint32_t)iy, L.stream, 0u}, key0, key1);
-    const double ky0 = wavenumber(iy, ny, L.dy), ky1 = wavenumber(iy + half, ny, L.dy);
-    const float amp0 = spectrum_amp(L.k0sq + kx * kx + ky0 * ky0, L.expo);
-    const float amp1 = spectrum_amp(L.k0sq + kx * kx + ky1 * ky1, L.expo);
+    float amp0, amp1;
+    if (L.amp) {  // tabulated, even in ky: cell iy + ny/2 is the mirror of ny/2 - iy
+      const float* A = L.amp + (size_t)ix * (half + 1);
+      amp0 = A[iy];
+      amp1 = A[half - iy];
+    } else {
+      const double ky0 = wavenumber(iy, ny, L.dy), ky1 = wavenumber(iy + half, ny, L.dy);
+      amp0 = spectrum_amp(L.k0sq + kx * kx + ky0 * ky0, L.expo);
+      amp1 = spectrum_amp(L.k0sq + kx * kx + ky1 * ky1, L.expo);
+    }
     const float2 g0 = box_muller(rnd.x, rnd.y), g1 = box_muller(rnd.z, rnd.w);
     if (!edge) {
       data[iy] = make_float2(kRoot * amp0 * g0.x, kRoot * amp0 * g0.y);
@@ -272,17 +281,35 @@ __global__ __launch_bounds__(kBlock) void screen_half_spectrum_regs(const Screen
     } else {
       constexpr float kRoot = 0.70710678118654752f;
       const double kx = wavenumber(ix, nx, L.dx);
+      auto draw = [&](auto tabulated) {
+        float a0[8], a1[8];
+        if constexpr (decltype(tabulated)::value) {  // all 16 loads in flight before the first draw
+          const float* A = L.amp + (size_t)ix * (half + 1);
 #pragma unroll
-      for (int b = 0; b < 8; ++b) {  // one Philox call feeds two cells: ky index iy and iy + ny/2 (T * 8 = ny/2)
-        const int iy = t + T * b;
-        const U4 rnd = philox4x32_10(U4{(uint32_t)ix, (uint32_t)iy, L.stream, 0u}, key0, key1);
-        const double ky0 = wavenumber(iy, ny, L.dy), ky1 = wavenumber(iy + half, ny, L.dy);
-        const float amp0 = spectrum_amp(L.k0sq + kx * kx + ky0 * ky0, L.expo);
-        const float amp1 = spectrum_amp(L.k0sq + kx * kx + ky1 * ky1, L.expo);
-        const float2 g0 = box_muller(rnd.x, rnd.y), g1 = box_muller(rnd.z, rnd.w);
-        v[b] = make_float2(kRoot * amp0 * g0.x, kRoot * amp0 * g0.y);
-        v[b + 8] = make_float2(kRoot * amp1 * g1.x, kRoot * amp1 * g1.y);
-      }
+          for (int b = 0; b < 8; ++b) {
+            a0[b] = A[t + T * b];
+            a1[b] = A[half - (t + T * b)];
+          }
+        }
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {  // one Philox call feeds two cells: ky index iy and iy + ny/2 (T * 8 = ny/2)
+          const int iy = t + T * b;
+          const U4 rnd = philox4x32_10(U4{(uint32_t)ix, (uint32_t)iy, L.stream, 0u}, key0, key1);
+          float amp0, amp1;
+          if constexpr (decltype(tabulated)::value) {
+            amp0 = a0[b];
+            amp1 = a1[b];
+          } else {
+            const double ky0 = wavenumber(iy, ny, L.dy), ky1 = wavenumber(iy + half, ny, L.dy);
+            amp0 = spectrum_amp(L.k0sq + kx * kx + ky0 * ky0, L.expo);
+            amp1 = spectrum_amp(L.k0sq + kx * kx + ky1 * ky1, L.expo);
+          }
+          const float2 g0 = box_muller(rnd.x, rnd.y), g1 = box_muller(rnd.z, rnd.w);
+          v[b] = make_float2(kRoot * amp0 * g0.x, kRoot * amp0 * g0.y);
+          v[b + 8] = make_float2(kRoot * amp1 * g1.x, kRoot * amp1 * g1.y);
+        }
+      };
+      if (L.amp) draw(std::true_type{}); else draw(std::false_type{});
     }
   }
   fft_regs<RB>(v, ex1, ex2, t);
@@ -422,6 +449,7 @@ struct Screen3dPlane {
 
 struct Screen3dArgs {
   const Screen3dPlane* planes;  // device array [n_planes]
+  const float* amp;             // [nx/2 + 1][nh/2 + 1][ny/2 + 1] amplitudes (even in kz and ky), or null: the power law
   int n_planes;
   double dh, dy, dx, k0sq;
   float expo;
@@ -446,11 +474,19 @@ __global__ __launch_bounds__(kBlock) void screen3d_fft_h(const Screen3dArgs g, i
     const int iz = e >> lj, b = e & (J - 1);
     const int iy = iy0 + b;
     const U4 rnd = philox4x32_10(U4{(uint32_t)ix, (uint32_t)iy, (g.stream << 16) | (uint32_t)iz, kTag3d}, key0, key1);
-    const double ky = wavenumber(iy, ny, g.dy);
-    const double kz0 = wavenumber(iz, nh, g.dh), kz1 = wavenumber(iz + half, nh, g.dh);
-    const double kk = g.k0sq + kx * kx + ky * ky;
-    const float amp0 = kRoot * spectrum_amp(kk + kz0 * kz0, g.expo);
-    const float amp1 = kRoot * spectrum_amp(kk + kz1 * kz1, g.expo);
+    float amp0, amp1;
+    if (g.amp) {
+      const int my = (ny >> 1) + 1, fy = iy <= (ny >> 1) ? iy : ny - iy;
+      const float* A = g.amp + (size_t)ix * (half + 1) * my + fy;
+      amp0 = kRoot * A[(size_t)iz * my];
+      amp1 = kRoot * A[(size_t)(half - iz) * my];
+    } else {
+      const double ky = wavenumber(iy, ny, g.dy);
+      const double kz0 = wavenumber(iz, nh, g.dh), kz1 = wavenumber(iz + half, nh, g.dh);
+      const double kk = g.k0sq + kx * kx + ky * ky;
+      amp0 = kRoot * spectrum_amp(kk + kz0 * kz0, g.expo);
+      amp1 = kRoot * spectrum_amp(kk + kz1 * kz1, g.expo);
+    }
     const float2 g0 = box_muller(rnd.x, rnd.y), g1 = box_muller(rnd.z, rnd.w);
     data[(iz << lj) | b] = make_float2(amp0 * g0.x, amp0 * g0.y);
     data[((iz + half) << lj) | b] = make_float2(amp1 * g1.x, amp1 * g1.y);
@@ -511,6 +547,153 @@ __global__ __launch_bounds__(kBlock) void psd_sum_kernel(
     atomicAdd(sum, s);
   }
 }
+
+// ---- covariance-matched amplitudes (circulant embedding) ----
+// The power law above is the continuous transform of the Matern covariance cut at the grid's Nyquist
+// wavenumber: for rough fields (nu = 1/3 in three dimensions) much of the small-scale variance lies
+// beyond it and the structure function at one pixel comes out several times low.  The eigenvalues of
+// the covariance itself, sampled on the periodic grid,
+//     lambda[k] = sum_d rho_per(d) cos(2 pi k d / N)   per axis, separable,
+// carry the aliased power: a field drawn with amplitudes sqrt(lambda) has EXACTLY the covariance
+// rho_per between any two pixels.  rho is the exact Matern correlation (functions/__init__.py:30-39)
+// from a dense log-log table the host supplies (it needs a Bessel function).  The reference's own
+// approximate_normalized_matern (:42-74, a 1024-node log-log table good to 1e-5) will not do here: at
+// that accuracy the function is no longer positive definite on the grid, and the eigenvalues clipped
+// at zero come back as 50 % too much structure at one pixel.  float64 throughout: the eigenvalues
+// span ten decades.  Real and even along every axis, so only the non-negative half of each axis is
+// stored and transformed -- by direct cosine sums (a set-up step, run once per geometry).
+struct RadialTable {
+  const double* log_cov;  // [n] log rho at the nodes
+  const double* log_sf;   // [n] log (1 - rho)
+  int n;
+  double log_first, inv_dlog;  // uniform grid in log(r / r0)
+  double r_min, r_max;
+};
+
+// four-point Lagrange interpolation on the uniform grid (exact for cubics: with 8192 nodes over nine
+// decades the correlation is good to ~1e-11 of its value out to 30 outer scales)
+__device__ __forceinline__ double lagrange4(const double* __restrict__ f, int i, double u) {
+  const double a = u + 1.0, b = u, c = u - 1.0, d = u - 2.0;
+  return f[i - 1] * (-b * c * d * (1.0 / 6.0)) + f[i] * (a * c * d * 0.5) + f[i + 1] * (-a * b * d * 0.5) +
+         f[i + 2] * (a * b * c * (1.0 / 6.0));
+}
+
+__device__ double radial_correlation(const RadialTable& t, double r_eff) {
+  if (r_eff == 0.0) return 1.0;
+  const double re = fmax(fabs(r_eff), t.r_min);
+  if (!(re < t.r_max)) return 0.0;
+  const double u = (log(re) - t.log_first) * t.inv_dlog;
+  const int i = min(max((int)u, 1), t.n - 3);
+  const double w = u - (double)i;
+  const double sf = exp(lagrange4(t.log_sf, i, w));
+  const double cov = exp(lagrange4(t.log_cov, i, w));
+  const double tt = 1.0 / (1.0 + re * re);  // the complement where it is small, the correlation where it is
+  return tt * (1.0 - sf) + (1.0 - tt) * cov;
+}
+
+// R[iz][iy][ix] = sum over the periodic images n of rho(|offset (iz, iy, ix) + n L|), 0 <= i <= n/2 per
+// axis.  Summing the images (instead of wrapping the distance) keeps the periodic covariance positive
+// definite -- its eigenvalues are the continuous spectrum sampled on the reciprocal lattice plus the
+// grid's aliases, all >= 0 -- whereas the wrapped distance has a crease at half a period whose
+// negative eigenvalues, once clipped, come back as spurious small-scale power.  Images farther than
+// x_cut outer scales (rho < 1e-10) are skipped.
+struct ImageSum {
+  double Lz, Ly, Lx;  // periods (m)
+  int iz, iy, ix;     // images -i .. i per axis
+  double x_cut;       // in units of r0
+};
+
+__global__ __launch_bounds__(kBlock) void cov_grid_kernel(double* __restrict__ R, int mz, int my, int mx, double dh,
+                                                          double dy, double dx, double inv_r0, RadialTable t, ImageSum g) {
+  const size_t n = (size_t)mz * my * mx;
+  const double cut2 = g.x_cut * g.x_cut;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const int ix = (int)(i % mx), iy = (int)((i / mx) % my), iz = (int)(i / ((size_t)mx * my));
+    const double z0 = iz * dh, y0 = iy * dy, x0 = ix * dx;
+    double acc = 0.0;
+    for (int nz = -g.iz; nz <= g.iz; ++nz) {
+      const double z = (z0 + nz * g.Lz) * inv_r0;
+      if (z * z >= cut2) continue;
+      for (int ny_ = -g.iy; ny_ <= g.iy; ++ny_) {
+        const double y = (y0 + ny_ * g.Ly) * inv_r0;
+        const double zy = z * z + y * y;
+        if (zy >= cut2) continue;
+        for (int nx_ = -g.ix; nx_ <= g.ix; ++nx_) {
+          const double x = (x0 + nx_ * g.Lx) * inv_r0;
+          const double r2 = zy + x * x;
+          if (r2 < cut2) acc += radial_correlation(t, sqrt(r2));
+        }
+      }
+    }
+    R[i] = acc;
+  }
+}
+
+// one line per workgroup: the n-point transform of the even sequence held as its first n/2 + 1 values
+__global__ __launch_bounds__(kBlock) void even_dft_axis_kernel(double* __restrict__ R, int n, int n_inner,
+                                                               size_t outer_stride, size_t inner_stride, size_t stride) {
+  extern __shared__ __align__(16) double lds_d[];
+  const int m = n / 2 + 1;
+  double* line = lds_d;
+  double* ctab = lds_d + m;
+  const size_t base = (size_t)(blockIdx.x / n_inner) * outer_stride + (size_t)(blockIdx.x % n_inner) * inner_stride;
+  for (int d = threadIdx.x; d < m; d += kBlock) line[d] = R[base + (size_t)d * stride];
+  for (int j = threadIdx.x; j < n; j += kBlock) ctab[j] = cospi(2.0 * (double)j / (double)n);
+  __syncthreads();
+  for (int k = threadIdx.x; k < m; k += kBlock) {
+    double acc0 = 0.0, acc1 = 0.0;
+    int idx = 0;
+    int d = 1;
+    for (; d + 1 < n / 2; d += 2) {
+      idx += k;
+      if (idx >= n) idx -= n;
+      acc0 = fma(line[d], ctab[idx], acc0);
+      idx += k;
+      if (idx >= n) idx -= n;
+      acc1 = fma(line[d + 1], ctab[idx], acc1);
+    }
+    for (; d < n / 2; ++d) {
+      idx += k;
+      if (idx >= n) idx -= n;
+      acc0 = fma(line[d], ctab[idx], acc0);
+    }
+    const double ends = line[0] + ((k & 1) ? -line[n / 2] : line[n / 2]);
+    R[base + (size_t)k * stride] = ends + 2.0 * (acc0 + acc1);
+  }
+}
+
+// amp[kx][kz][ky] = sqrt(max(lambda, 0)) in float32, and the sum of amp^2 over the FULL grid
+// divided by the zero-lag value of the image sum (rho0[0], kept from before the transform): the screens are
+// normalised so that their STRUCTURE FUNCTION is Matern's -- their variance is then 1 + the images' share
+__global__ __launch_bounds__(kBlock) void amp_table_kernel(const double* __restrict__ R, int mz, int my, int mx,
+                                                           float* __restrict__ amp, double* __restrict__ sum,
+                                                           const double* __restrict__ rho0) {
+  __shared__ double part[kBlock / 64];
+  double acc = 0.0;
+  const size_t n = (size_t)mz * my * mx;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const int ky = (int)(i % my), kz = (int)((i / my) % mz), kx = (int)(i / ((size_t)my * mz));
+    const double lam = R[((size_t)kz * my + ky) * mx + kx];
+    const float a = (float)sqrt(fmax(lam, 0.0));
+    amp[i] = a;
+    // a cell of the half axes stands for itself and its mirror, but for 0 and n/2
+    const int mult = ((ky == 0 || ky == my - 1) ? 1 : 2) * ((kx == 0 || kx == mx - 1) ? 1 : 2) *
+                     ((mz == 1 || kz == 0 || kz == mz - 1) ? 1 : 2);
+    acc += (double)mult * (double)a * (double)a;
+  }
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double s = 0.0;
+    for (int w = 0; w < kBlock / 64; ++w) s += part[w];
+    atomicAdd(sum, s / rho0[0]);
+  }
+}
+
+__global__ void keep_first_kernel(const double* __restrict__ R, double* __restrict__ rho0) { rho0[0] = R[0]; }
+
+constexpr size_t kAmpHeader = 4;  // floats before the amplitudes: the float64 sum, then padding to 16 bytes
 
 __global__ void philox_normal_kernel(float* __restrict__ out, size_t n,
                                      uint32_t key0, uint32_t key1,
@@ -661,7 +844,7 @@ static int run_screen_passes(mrx_ctx* ctx, uint64_t seed, int ny, int nx, const 
     for (int i = 0; i < nb; ++i) {
       const mrx_screen_desc& d = screens[first + i];
       MRX_REQUIRE(ctx, d.d_out != nullptr, "null output pointer");
-      MRX_REQUIRE(ctx, from_work || (d.dy > 0 && d.dx > 0 && d.r0 > 0 && d.nu > 0),
+      MRX_REQUIRE(ctx, from_work || d.d_amp || (d.dy > 0 && d.dx > 0 && d.r0 > 0 && d.nu > 0),
                   "steps, r0 and nu must be positive");
       const int out_ny = d.out_ny > 0 ? d.out_ny : ny, out_nx = d.out_nx > 0 ? d.out_nx : nx;
       MRX_REQUIRE(ctx, out_ny <= ny && out_nx <= nx, "written block larger than the FFT domain");
@@ -671,7 +854,12 @@ static int run_screen_passes(mrx_ctx* ctx, uint64_t seed, int ny, int nx, const 
       ScreenLayerArgs& L = args.l[i];
       const double* d_sum = d_sum3d;
       int rc = MRX_OK;
-      if (!from_work) {
+      L.amp = nullptr;
+      if (!from_work && d.d_amp) {  // tabulated amplitudes: the table's header is their sum
+        MRX_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(d.d_amp) & 15u) == 0, "d_amp must be 16-byte aligned");
+        d_sum = reinterpret_cast<const double*>(d.d_amp);
+        L.amp = d.d_amp + kAmpHeader;
+      } else if (!from_work) {
         rc = psd_sum_slot(ctx, ny, nx, d.dy, d.dx, d.r0, d.nu, &d_sum);
         if (rc != MRX_OK) return rc;
       }
@@ -776,13 +964,14 @@ int mrx_screen_generate_3d(mrx_ctx* ctx, uint64_t seed, uint32_t stream, int nh,
                            double dh, double dy, double dx, double r0, double nu,
                            const double* plane_pos, const double* plane_scale,
                            const mrx_screen_desc* planes, int n_planes, float* d_work,
-                           size_t work_floats) {
+                           size_t work_floats, const float* d_amp) {
   MRX_ENTER(ctx);
   if (!ctx) return MRX_ERR_INVALID;
   MRX_REQUIRE(ctx, n_planes >= 0, "negative count");
   if (n_planes == 0) return MRX_OK;
   MRX_REQUIRE(ctx, planes && plane_pos && d_work, "null pointer");
-  MRX_REQUIRE(ctx, dh > 0 && dy > 0 && dx > 0 && r0 > 0 && nu > 0, "steps, r0 and nu must be positive");
+  MRX_REQUIRE(ctx, d_amp || (dh > 0 && dy > 0 && dx > 0 && r0 > 0 && nu > 0), "steps, r0 and nu must be positive");
+  MRX_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(d_amp) & 15u) == 0, "d_amp must be 16-byte aligned");
   MRX_REQUIRE(ctx, stream < 65536u, "the 3-D generator takes streams below 65536");
   const int lh = ilog2_exact(nh), ly = ilog2_exact(ny), lx = ilog2_exact(nx);
   if (lh < 0 || ly < 0 || lx < 0 || nh < 8 || nh > 2048 || ny < 64 || nx < 64 || ny > 8192 || nx > 8192)
@@ -810,11 +999,14 @@ int mrx_screen_generate_3d(mrx_ctx* ctx, uint64_t seed, uint32_t stream, int nh,
   MRX_HIP(ctx, hipMemcpyAsync(d_table, table.data(), sizeof(Screen3dPlane) * (size_t)n_planes, hipMemcpyHostToDevice,
                               ctx->stream));
   MRX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the host table goes out of scope
-  const double* d_sum = nullptr;
-  int rc = psd_sum_slot(ctx, ny, nx, dy, dx, r0, nu, &d_sum, nh, dh);
-  if (rc != MRX_OK) return rc;
+  const double* d_sum = reinterpret_cast<const double*>(d_amp);
+  if (!d_amp) {
+    int rc = psd_sum_slot(ctx, ny, nx, dy, dx, r0, nu, &d_sum, nh, dh);
+    if (rc != MRX_OK) return rc;
+  }
 
   Screen3dArgs g{};
+  g.amp = d_amp ? d_amp + kAmpHeader : nullptr;
   g.planes = d_table;
   g.n_planes = n_planes;
   g.dh = dh;
@@ -831,6 +1023,86 @@ int mrx_screen_generate_3d(mrx_ctx* ctx, uint64_t seed, uint32_t stream, int nh,
                      (uint32_t)seed, (uint32_t)(seed >> 32));
   MRX_CHECK_LAUNCH(ctx);
   return run_screen_passes(ctx, seed, ny, nx, planes, n_planes, d_work, true, d_sum);
+}
+
+int mrx_screen_amp_floats(int nh, int ny, int nx, int n_radial, size_t* table_floats, size_t* work_floats) {
+  if (nh < 0 || ny <= 0 || nx <= 0 || n_radial < 0) return MRX_ERR_INVALID;
+  const size_t m = (size_t)(nh > 0 ? nh / 2 + 1 : 1) * ((size_t)ny / 2 + 1) * ((size_t)nx / 2 + 1);
+  if (table_floats) *table_floats = kAmpHeader + ((m + 3) & ~(size_t)3);
+  if (work_floats) *work_floats = 2 * (m + 2 * (size_t)n_radial + 1) + 4;
+  return MRX_OK;
+}
+
+int mrx_screen_amplitudes(mrx_ctx* ctx, int nh, int ny, int nx, double dh, double dy, double dx, double r0,
+                          const double* log_cov, const double* log_sf, int n_radial, double log_first,
+                          double log_step, double x_cut, float* d_table, float* d_work, size_t work_floats) {
+  MRX_ENTER(ctx);
+  if (!ctx) return MRX_ERR_INVALID;
+  MRX_REQUIRE(ctx, log_cov && log_sf && d_table && d_work, "null pointer");
+  MRX_REQUIRE(ctx, n_radial >= 4 && n_radial <= (1 << 20) && log_step > 0, "the radial table needs 4 .. 2^20 nodes on an increasing log grid");
+  MRX_REQUIRE(ctx, dy > 0 && dx > 0 && r0 > 0 && (nh == 0 || dh > 0), "steps and r0 must be positive");
+  MRX_REQUIRE(ctx, x_cut > 0, "x_cut must be positive");
+  const int lh = nh ? ilog2_exact(nh) : 0, ly = ilog2_exact(ny), lx = ilog2_exact(nx);
+  if (lh < 0 || ly < 0 || lx < 0 || (nh && (nh < 8 || nh > 2048)) || ny < 64 || nx < 64 || ny > 8192 || nx > 8192)
+    return mrx_fail(ctx, MRX_ERR_UNSUPPORTED,
+                    "amplitude table: ny and nx powers of two in [64, 8192], nh 0 or in [8, 2048] (got %d x %d x %d)", nh, ny, nx);
+  size_t need = 0;
+  mrx_screen_amp_floats(nh, ny, nx, n_radial, nullptr, &need);
+  MRX_REQUIRE(ctx, work_floats >= need, "work buffer smaller than mrx_screen_amp_floats()");
+  MRX_REQUIRE(ctx, ((reinterpret_cast<uintptr_t>(d_work) | reinterpret_cast<uintptr_t>(d_table)) & 15u) == 0,
+              "d_table and d_work must be 16-byte aligned");
+  const int mz = nh ? nh / 2 + 1 : 1, my = ny / 2 + 1, mx = nx / 2 + 1;
+  const size_t m = (size_t)mz * my * mx;
+  double* R = reinterpret_cast<double*>(d_work);
+  double* d_cov = R + m;
+  double* d_sf = d_cov + n_radial;
+  double* d_rho0 = d_sf + n_radial;
+  MRX_HIP(ctx, hipMemcpyAsync(d_cov, log_cov, sizeof(double) * (size_t)n_radial, hipMemcpyHostToDevice, ctx->stream));
+  MRX_HIP(ctx, hipMemcpyAsync(d_sf, log_sf, sizeof(double) * (size_t)n_radial, hipMemcpyHostToDevice, ctx->stream));
+  MRX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the caller's host arrays may go away
+  RadialTable t{};
+  t.log_cov = d_cov;
+  t.log_sf = d_sf;
+  t.n = n_radial;
+  t.log_first = log_first;
+  t.inv_dlog = 1.0 / log_step;
+  t.r_min = std::exp(log_first);
+  t.r_max = std::exp(log_first + log_step * (double)(n_radial - 1));
+  const int blocks = (int)std::min<size_t>((m + kBlock - 1) / kBlock, 4096);
+  ImageSum g{};
+  g.Lz = nh ? nh * dh : 1.0;
+  g.Ly = ny * dy;
+  g.Lx = nx * dx;
+  g.x_cut = x_cut;
+  // an offset of the half grid is at most half a period from the origin: images up to x_cut r0 + L/2 away
+  auto images = [&](double L) { return (int)std::ceil(x_cut * r0 / L + 0.5); };
+  g.iz = nh ? images(g.Lz) : 0;
+  g.iy = images(g.Ly);
+  g.ix = images(g.Lx);
+  MRX_REQUIRE(ctx, (double)(2 * g.iz + 1) * (2 * g.iy + 1) * (2 * g.ix + 1) <= 1.0e6,
+              "the periodic domain is too small against x_cut r0 (more than 1e6 images per grid point)");
+  hipLaunchKernelGGL(cov_grid_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, R, mz, my, mx, nh ? dh : 0.0, dy, dx,
+                     1.0 / r0, t, g);
+  MRX_CHECK_LAUNCH(ctx);
+  hipLaunchKernelGGL(keep_first_kernel, dim3(1), dim3(1), 0, ctx->stream, R, d_rho0);
+  MRX_CHECK_LAUNCH(ctx);
+  auto axis = [&](int n, int lines, int n_inner, size_t outer_stride, size_t inner_stride, size_t stride) -> int {
+    const size_t lds = (size_t)(n / 2 + 1 + n) * sizeof(double);
+    MRX_LDS_CAP(ctx, even_dft_axis_kernel, lds);
+    hipLaunchKernelGGL(even_dft_axis_kernel, dim3(lines), dim3(kBlock), lds, ctx->stream, R, n, n_inner, outer_stride,
+                       inner_stride, stride);
+    MRX_CHECK_LAUNCH(ctx);
+    return MRX_OK;
+  };
+  int rc = axis(nx, mz * my, 1, (size_t)mx, 0, 1);                                  // along x: lines (iz, iy)
+  if (rc == MRX_OK) rc = axis(ny, mz * mx, mx, (size_t)my * mx, 1, (size_t)mx);      // along y: lines (iz, ix)
+  if (rc == MRX_OK && nh) rc = axis(nh, my * mx, my * mx, 0, 1, (size_t)my * mx);    // along h: lines (iy, ix)
+  if (rc != MRX_OK) return rc;
+  MRX_HIP(ctx, hipMemsetAsync(d_table, 0, sizeof(float) * kAmpHeader, ctx->stream));
+  hipLaunchKernelGGL(amp_table_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, R, mz, my, mx, d_table + kAmpHeader,
+                     reinterpret_cast<double*>(d_table), d_rho0);
+  MRX_CHECK_LAUNCH(ctx);
+  return MRX_OK;
 }
 
 int mrx_screen_generate(mrx_ctx* ctx, uint64_t seed, uint32_t stream, int ny,

@@ -44,6 +44,26 @@ def _dev(a, dtype, device):
     return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(device)
 
 
+def matern_log_tables(nu, n=8192, lo=1e-6, hi=1e3, eps=1e-10):
+    """log of the exact Matern correlation (functions/__init__.py:30-39) and of its complement at ``n``
+    log-spaced r / r0 -- the construction of the reference's ``approximate_normalized_matern`` (:42-74), eight
+    times denser because the device interpolates it to 1e-11 (``mrx_screen_amplitudes``).  Returns
+    (log_first, log_step, log_cov, log_sf, x_cut); values the float64 range cannot hold (rho underflows
+    beyond r ~ 700 r0) are pinned at log(1e-300); ``x_cut``: the first node where the correlation has fallen
+    below ``eps`` (periodic images farther away are not summed)."""
+    import scipy.special
+
+    x = np.geomspace(lo, hi, n)
+    z = np.sqrt(2 * nu) * x + 1e-16
+    cov = 2 ** (1 - nu) / scipy.special.gamma(nu) * scipy.special.kv(nu, z) * z**nu
+    with np.errstate(divide="ignore"):
+        log_cov = np.maximum(np.log(cov), np.log(1e-300))
+        log_sf = np.maximum(np.log(1 - cov), np.log(1e-300))
+    lx = np.log(x)
+    x_cut = float(x[np.argmax(cov < eps)]) if (cov < eps).any() else float(hi)
+    return float(lx[0]), float((lx[-1] - lx[0]) / (n - 1)), np.ascontiguousarray(log_cov), np.ascontiguousarray(log_sf), x_cut
+
+
 def morton_order(offsets):
     """Permutation that sorts focal-plane offsets along a Z-order curve, so that
     consecutive detectors (the lanes of a wave, the 256 rows of a workgroup) form a
@@ -256,6 +276,31 @@ class DevicePath:
         self.ctx.call("mrx_atm_plan_info", self.plan, C.byref(ua), C.byref(tl))
         return ua.value, bool(tl.value)
 
+    @staticmethod
+    def _grid_steps(layer):
+        """(extrusion step, cross-section step) of the grid a layer's screen is GENERATED on."""
+        de = float(layer["extrusion"][1] - layer["extrusion"][0])
+        cross = layer["gen"]["cross"] if layer.get("gen") is not None else layer["cross_section"]
+        return de, float(cross[1] - cross[0])
+
+    def _amplitude_table(self, nh, ny, nx, dh, dy, dx, r0, nu):
+        """The device table of ``mrx_screen_amplitudes`` for one periodic domain, built on first use; None when the
+        path was asked for the power-law spectrum."""
+        if getattr(self, "_amp", None) is None or self.problem.get("turbulence_spectrum", "covariance") != "covariance":
+            return None
+        key = (nh, ny, nx, dh, dy, dx, r0, nu)
+        if key not in self._amp:
+            log_first, log_step, log_cov, log_sf, x_cut = matern_log_tables(nu)
+            n_t, n_w = C.c_size_t(), C.c_size_t()
+            _lib.load().mrx_screen_amp_floats(nh, ny, nx, len(log_cov), C.byref(n_t), C.byref(n_w))
+            table = torch.empty(n_t.value, dtype=torch.float32, device=self.device)
+            work = torch.empty(n_w.value, dtype=torch.float32, device=self.device)
+            as_d = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+            self.ctx.call("mrx_screen_amplitudes", nh, ny, nx, dh, dy, dx, r0, as_d(log_cov), as_d(log_sf), len(log_cov),
+                          log_first, log_step, x_cut, ptr(table), ptr(work), work.numel())
+            self._amp[key] = table
+        return self._amp[key]
+
     def generate_screens(self, smooth=True, only=None):
         """Philox + k-space filter + complex-to-real iFFT on the device with the beam
         smoothing (atmosphere/atmosphere.py:328-344) folded into the two FFT passes
@@ -291,6 +336,19 @@ class DevicePath:
                 _lib.load().mrx_screen3d_work_floats(nh, fe, fc, len(members), C.byref(n))
                 need = max(need, n.value)
             self._gen_work = torch.empty(need, dtype=torch.float32, device=dev)
+            # amplitude tables (mrx_screen_amplitudes: the eigenvalues of the Matern covariance on the periodic
+            # grid), one per distinct (domain, steps, r0, nu); problem["turbulence_spectrum"] = "power_law" keeps the
+            # closed-form spectrum
+            self._amp = {}
+            if self.problem.get("turbulence_spectrum", "covariance") == "covariance":
+                for (fe, fc), members in self._gen_groups.items():
+                    for l in members:
+                        de, dc = self._grid_steps(layers[l])
+                        self._amplitude_table(0, fe, fc, 0.0, de, dc, float(layers[l]["r0"]), float(layers[l]["nu"]))
+                for (_, nh, (fe, fc)), members in self._gen_volumes.items():
+                    first = layers[members[0]]
+                    de, dc = self._grid_steps(first)
+                    self._amplitude_table(nh, fe, fc, float(first["volume"]["dh"]), de, dc, float(first["r0"]), float(first["nu"]))
             # model="3d" with per-layer cross-section grids (layer["gen"]): the volume's planes are generated on
             # the process's generation grid, then resampled onto each layer's own grid and smoothed there
             self._gen_fine = {}
@@ -333,6 +391,9 @@ class DevicePath:
                 d.d_out, d.stream = out.data_ptr(), l
                 d.out_ny, d.out_nx, d.ld_out = out.shape[0], out.shape[1], out.stride(0)
                 d.dy, d.dx, d.r0, d.nu = de, dc, float(layer["r0"]), float(layer["nu"])
+                if layer.get("volume") is None:
+                    amp = self._amplitude_table(0, *fft_shapes[l], 0.0, de, dc, d.r0, d.nu)
+                    d.d_amp = amp.data_ptr() if amp is not None else None
             return descs
 
         with _range("Generating turbulence"):
@@ -356,10 +417,11 @@ class DevicePath:
                 dc = float(cross[1] - cross[0])
                 pos = (C.c_double * len(members))(*[layers[l]["volume"]["pos"] for l in members])
                 scl = (C.c_double * len(members))(*[layers[l]["volume"]["scale"] for l in members])
+                amp = self._amplitude_table(nh, fe, fc, float(vol["dh"]), de, dc, float(first["r0"]), float(first["nu"]))
                 self.ctx.call(
                     "mrx_screen_generate_3d", self.problem["seed"], int(vid) & 0xFFFF, nh, fe, fc, float(vol["dh"]), de, dc,
                     float(first["r0"]), float(first["nu"]), pos, scl, describe(members), len(members),
-                    ptr(self._gen_work), self._gen_work.numel(),
+                    ptr(self._gen_work), self._gen_work.numel(), ptr(amp) if amp is not None else None,
                 )
                 for l in members:  # onto the layer's own grid, then the beam on that grid (atmosphere.py:341-344)
                     fine = self._gen_fine.get(l)

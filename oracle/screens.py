@@ -21,6 +21,38 @@ def psd_amplitude(ny, nx, dy, dx, r0, nu):
     return (k0sq + kx**2 + ky**2) ** (-(nu + 1.0) / 2.0)
 
 
+def periodic_covariance(shape, steps, r0, nu, x_cut=30.0):
+    """The exact Matern correlation (functions/__init__.py:30-39) summed over the periodic images of the
+    grid ``shape`` (2 or 3 axes) that lie within ``x_cut`` outer scales: the covariance of the field
+    mrx_screen_amplitudes defines, on the full grid."""
+    from itertools import product
+
+    from .functions import normalized_matern
+
+    half = [np.arange(n // 2 + 1) * float(d) for n, d in zip(shape, steps)]
+    periods = [n * float(d) for n, d in zip(shape, steps)]
+    reach = [int(np.ceil(x_cut * r0 / L + 0.5)) for L in periods]
+    acc = np.zeros([len(h) for h in half])
+    for image in product(*[range(-m, m + 1) for m in reach]):
+        axes = [(h + k * L) ** 2 for h, k, L in zip(half, image, periods)]
+        if sum(a.min() for a in axes) >= (x_cut * r0) ** 2:
+            continue
+        r = np.sqrt(sum(np.meshgrid(*axes, indexing="ij"))) / r0
+        near = r < x_cut
+        acc[near] += normalized_matern(r[near], nu)
+    fold = [np.minimum(np.arange(n), n - np.arange(n)) for n in shape]
+    return acc[np.ix_(*fold)]
+
+
+def covariance_amplitude(shape, steps, r0, nu, x_cut=30.0):
+    """sqrt of the eigenvalues of periodic_covariance, scaled so that a field drawn with them has Matern's
+    STRUCTURE FUNCTION (variance = the zero-lag image sum): the table mrx_screen_amplitudes builds by
+    cosine sums, here by numpy's FFT.  Returns (amp, sum of amp^2 / zero-lag value)."""
+    rho = periodic_covariance(shape, steps, r0, nu, x_cut)
+    amp = np.sqrt(np.maximum(np.fft.fftn(rho).real, 0.0))
+    return amp, rho.reshape(-1)[0]
+
+
 def numpy_screen(ny, nx, dy, dx, r0, nu, rng):
     amp = psd_amplitude(ny, nx, dy, dx, r0, nu)
     noise = rng.standard_normal((ny, nx)) + 1j * rng.standard_normal((ny, nx))
@@ -28,11 +60,13 @@ def numpy_screen(ny, nx, dy, dx, r0, nu, rng):
     return (field / np.sqrt((amp**2).sum())).astype(np.float32)
 
 
-def hermitian_philox_screen(philox4x32, seed, stream, ny, nx, dy, dx, r0, nu):
+def hermitian_philox_screen(philox4x32, seed, stream, ny, nx, dy, dx, r0, nu, amp=None):
     """The screen mrx_screen_generate defines (include/mrx.h): the Hermitian half spectrum
     rebuilt cell by cell from the library's own Philox routine, then numpy's irfft2.
-    ``philox4x32(seed, counter) -> 4 words`` (maria_amd._lib.philox4x32, host-evaluated)."""
-    amp = psd_amplitude(ny, nx, dy, dx, r0, nu)
+    ``philox4x32(seed, counter) -> 4 words`` (maria_amd._lib.philox4x32, host-evaluated).
+    ``amp``: [ny, nx] amplitudes (covariance_amplitude) instead of the power law."""
+    if amp is None:
+        amp = psd_amplitude(ny, nx, dy, dx, r0, nu)
     half = ny // 2
     H = np.zeros((ny, nx // 2 + 1), complex)
 
@@ -66,11 +100,12 @@ def psd_amplitude_3d(nh, ny, nx, dh, dy, dx, r0, nu):
     return (2.0 * nu / r0**2 + kx**2 + ky**2 + kz**2) ** (-(nu + 1.5) / 2.0)
 
 
-def hermitian_philox_screens_3d(philox4x32, seed, stream, nh, ny, nx, dh, dy, dx, r0, nu, plane_pos, plane_scale=None):
+def hermitian_philox_screens_3d(philox4x32, seed, stream, nh, ny, nx, dh, dy, dx, r0, nu, plane_pos, plane_scale=None, amp=None):
     """The height planes mrx_screen_generate_3d defines (include/mrx.h), rebuilt on the host:
     independent cells on kx <= nx/2, inverse FFT along h, linear interpolation to the planes,
     Hermitian symmetrisation of the two self-mirrored columns, numpy's irfft2 per plane."""
-    amp = psd_amplitude_3d(nh, ny, nx, dh, dy, dx, r0, nu)
+    if amp is None:
+        amp = psd_amplitude_3d(nh, ny, nx, dh, dy, dx, r0, nu)
     H = np.zeros((nh, ny, nx // 2 + 1), complex)
 
     def normal_pair(a, b):

@@ -154,6 +154,7 @@ def _generate_batch(ctx, seed, ny, nx, specs):
         d.out_ny, d.out_nx, d.ld_out = sp.get("out_ny", 0), sp.get("out_nx", 0), 0
         d.dy, d.dx, d.r0, d.nu = sp["dy"], sp["dx"], sp["r0"], sp["nu"]
         d.sigma_y, d.sigma_x = sp.get("sigma_y", 0.0), sp.get("sigma_x", 0.0)
+        d.d_amp = sp["amp"].data_ptr() if sp.get("amp") is not None else None
     n = C.c_size_t()
     _lib.load().mrx_screen_work_floats(ny, nx, len(specs), C.byref(n))
     work = torch.empty(n.value, dtype=torch.float32, device="cuda:0")
@@ -341,7 +342,7 @@ def test_lds_fft_matches_numpy(gpu_ctx, n, lj):
     assert np.abs(got - ref).max() <= 1e-6 * np.log2(n) * np.abs(ref).max()
 
 
-def _generate_3d(ctx, seed, stream, nh, ny, nx, dh, dy, dx, r0, nu, plane_pos, plane_scale=None, sigma=0.0, out_shape=None):
+def _generate_3d(ctx, seed, stream, nh, ny, nx, dh, dy, dx, r0, nu, plane_pos, plane_scale=None, sigma=0.0, out_shape=None, amp=None):
     import ctypes as C
 
     import torch
@@ -361,7 +362,7 @@ def _generate_3d(ctx, seed, stream, nh, ny, nx, dh, dy, dx, r0, nu, plane_pos, p
     work = torch.empty(need.value, dtype=torch.float32, device="cuda:0")
     pos = (C.c_double * n)(*plane_pos)
     scl = (C.c_double * n)(*plane_scale) if plane_scale is not None else None
-    ctx.call("mrx_screen_generate_3d", seed, stream, nh, ny, nx, dh, dy, dx, r0, nu, pos, scl, descs, n, ptr(work), work.numel())
+    ctx.call("mrx_screen_generate_3d", seed, stream, nh, ny, nx, dh, dy, dx, r0, nu, pos, scl, descs, n, ptr(work), work.numel(), ptr(amp))
     return [o.cpu().numpy() for o in outs]
 
 
@@ -449,3 +450,175 @@ def test_resample_columns_matches_numpy(gpu_ctx):
     with pytest.raises(MrxError, match="INVALID"):
         gpu_ctx.call("mrx_resample_columns", ptr(d_src), n_e, n_in, ld_in, ptr(d_idx), ptr(d_w), ptr(d_s), n_out, ptr(d_out), n_out - 1)
     gpu_ctx.call("mrx_resample_columns", ptr(d_src), 0, n_in, ld_in, ptr(d_idx), ptr(d_w), ptr(d_s), n_out, ptr(d_out), ld_out)  # empty: no-op
+
+
+# ---- covariance-matched amplitudes (mrx_screen_amplitudes) --------------------------------
+
+
+def _amp_table(ctx, nh, ny, nx, dh, dy, dx, r0, nu):
+    import ctypes as C
+
+    import torch
+
+    from maria_amd import _lib
+    from maria_amd._lib import ptr
+    from maria_amd.pipeline import matern_log_tables
+
+    log_first, log_step, log_cov, log_sf, x_cut = matern_log_tables(nu)
+    n_t, n_w = C.c_size_t(), C.c_size_t()
+    _lib.load().mrx_screen_amp_floats(nh, ny, nx, len(log_cov), C.byref(n_t), C.byref(n_w))
+    table = torch.empty(n_t.value, dtype=torch.float32, device="cuda:0")
+    work = torch.empty(n_w.value, dtype=torch.float32, device="cuda:0")
+    as_d = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    ctx.call("mrx_screen_amplitudes", nh, ny, nx, dh, dy, dx, r0, as_d(log_cov), as_d(log_sf), len(log_cov), log_first, log_step,
+             x_cut, ptr(table), ptr(work), work.numel())
+    return table
+
+
+def _unfold(table, nh, ny, nx):
+    """The device table [kx][kz][ky] over the half axes -> (sum, full [nh or 1, ny, nx] amplitudes)."""
+    host = table.cpu().numpy()
+    mz, my, mx = (nh // 2 + 1 if nh else 1), ny // 2 + 1, nx // 2 + 1
+    total = float(host[:2].view(np.float64)[0])
+    half = host[4 : 4 + mx * mz * my].reshape(mx, mz, my).transpose(1, 2, 0)  # [kz][ky][kx]
+    fold = lambda n: np.minimum(np.arange(n), n - np.arange(n))  # noqa: E731
+    full = half[np.ix_(fold(nh) if nh else np.zeros(1, int), fold(ny), fold(nx))]
+    return total, full
+
+
+@pytest.mark.parametrize("nh,ny,nx,nu,r0", [(0, 128, 64, 5 / 6, 300.0), (0, 256, 1024, 5 / 6, 300.0), (0, 2048, 64, 1 / 3, 100.0),
+                                            (8, 64, 128, 1 / 3, 40.0), (32, 128, 64, 1 / 3, 60.0)])
+def test_amplitude_table_matches_numpy_fft(gpu_ctx, nh, ny, nx, nu, r0):
+    """The table of mrx_screen_amplitudes (periodic images summed, float64 cosine sums over the even half
+    axes, the radial correlation by Lagrange interpolation of the host's log-log table) against numpy's FFT
+    of scipy's exact Matern correlation summed over the same images; the header normalises the screens to
+    Matern's structure function.  Boxes of 1 ... 30 outer scales a side: up to 59 images per axis."""
+    from maria_amd.pipeline import matern_log_tables
+    from oracle import functions, screens
+
+    dh, dy, dx = 40.0, 5.0, 7.0
+    table = _amp_table(gpu_ctx, nh, ny, nx, dh, dy, dx, r0, nu)
+    total, got = _unfold(table, nh, ny, nx)
+    shape, steps = ((nh, ny, nx), (dh, dy, dx)) if nh else ((ny, nx), (dy, dx))
+    ref, rho0 = screens.covariance_amplitude(shape, steps, r0, nu, x_cut=matern_log_tables(nu)[4])
+    ref = ref.reshape(got.shape)
+    assert np.abs(got - ref).max() <= 2e-6 * ref.max()
+    big = ref > 1e-3 * ref.max()
+    assert np.abs(got[big] / ref[big] - 1).max() <= 1e-5
+    assert abs(total / ((ref.astype(np.float32).astype(np.float64) ** 2).sum() / rho0) - 1) <= 1e-6
+    # positive definite: next to nothing is clipped
+    assert (got == 0).mean() < 1e-3
+    # what the table is for: the structure function of the field it defines, from one pixel up
+    cov = np.fft.ifftn(got.astype(np.float64) ** 2).real.reshape(-1) * got.size / total
+    lags = np.array([1, 2, 5])
+    want = functions.normalized_matern(lags * dx / r0, nu)
+    # (the images' curvature enters at second order in lag / period: 4e-3 in a box of 4.5 outer scales, 10 % in the
+    # first case's 1.5)
+    assert np.abs((cov[0] - cov[lags]) / (1 - want) - 1).max() < (5e-3 if min(ny * dy, nx * dx) > 4 * r0 else 0.15)
+
+
+@pytest.mark.parametrize("ny,nx", [(64, 128), (1024, 64), (2048, 64)])
+def test_screen_with_amplitude_table_matches_numpy_irfft(gpu_ctx, ny, nx):
+    """Both column forms (LDS and register transforms) read the table for the cells they draw: the screen
+    equals numpy's irfft2 of the same Philox cells times the oracle's amplitudes."""
+    from maria_amd._lib import philox4x32
+    from oracle import screens
+
+    dy, dx, r0, nu = 5.0, 7.0, 300.0, 5.0 / 6.0
+    seed, stream = 99, 2
+    table = _amp_table(gpu_ctx, 0, ny, nx, 0.0, dy, dx, r0, nu)
+    got = _generate_batch(gpu_ctx, seed, ny, nx, [dict(stream=stream, dy=dy, dx=dx, r0=r0, nu=nu, amp=table)])[0]
+    from maria_amd.pipeline import matern_log_tables
+
+    amp, rho0 = screens.covariance_amplitude((ny, nx), (dy, dx), r0, nu, x_cut=matern_log_tables(nu)[4])
+    ref = screens.hermitian_philox_screen(philox4x32, seed, stream, ny, nx, dy, dx, r0, nu, amp=amp) * np.sqrt(rho0)
+    assert np.abs(got - ref).max() <= 2e-5 * np.abs(ref).max()
+
+
+def test_screen_3d_with_amplitude_table_matches_numpy(gpu_ctx):
+    from maria_amd._lib import philox4x32
+    from oracle import screens
+
+    nh, ny, nx = 8, 64, 64
+    args = (nh, ny, nx, 30.0, 20.0, 25.0, 400.0, 1.0 / 3.0)
+    pos, scale = [0.0, 2.5, 6.0, 6.75], [1.0, 1.1, 1.0, 0.9]
+    table = _amp_table(gpu_ctx, *args)
+    got = _generate_3d(gpu_ctx, 5, 3, *args, pos, scale, amp=table)
+    from maria_amd.pipeline import matern_log_tables
+
+    amp, rho0 = screens.covariance_amplitude((nh, ny, nx), (30.0, 20.0, 25.0), 400.0, 1.0 / 3.0, x_cut=matern_log_tables(1.0 / 3.0)[4])
+    ref = screens.hermitian_philox_screens_3d(philox4x32, 5, 3, *args, pos, scale, amp=amp)
+    for g, r in zip(got, ref):
+        assert np.abs(g - np.sqrt(rho0) * r).max() <= 3e-5 * np.abs(r).max()
+
+
+def test_screen_statistics_with_amplitude_table_are_matern(gpu_ctx):
+    """With the covariance-matched amplitudes the generator's target IS the reference's covariance
+    (functions/__init__.py:42-74), so the measured structure function is held against it directly --
+    from ONE pixel up, for the smooth 2-D field (nu = 5/6) and the rough 3-D one (nu = 1/3), where the
+    power law is several times low at one pixel."""
+    from oracle import functions, screens
+
+    # two dimensions
+    ny = nx = 1024
+    d, r0, nu = 5.0, 1000.0, 5.0 / 6.0
+    lags = np.array([0, 1, 2, 4, 8, 16, 32, 64, 128])
+    table = _amp_table(gpu_ctx, 0, ny, nx, 0.0, d, d, r0, nu)
+    acc = np.zeros((2, len(lags)))
+    nrep = 48
+    for rep in range(0, nrep, 16):
+        specs = [dict(stream=rep + i, dy=d, dx=d, r0=r0, nu=nu, amp=table) for i in range(16)]
+        for s in _generate_batch(gpu_ctx, 20260612, ny, nx, specs):
+            (_, cy), (_, cx) = screens.radial_covariance(s, d, d, lags)
+            acc += np.array([cy, cx]) / nrep
+    sf_got = 2 * (acc[:, :1] - acc[:, 1:])
+    target = functions.approximate_normalized_matern(lags * d, nu=nu, r0=r0)
+    sf_ref = 2 * (target[0] - target[1:])
+    assert np.abs(sf_got / sf_ref[None] - 1).max() < 0.05, (sf_got, sf_ref)
+    assert np.abs(sf_got[:, :3] / sf_ref[None, :3] - 1).max() < 0.01, (sf_got, sf_ref)  # 1, 2, 4 pixels: little sampling noise
+
+    # three dimensions, nu = 1/3
+    nh, ny, nx = 256, 256, 256
+    d, r0, nu = 20.0, 600.0, 1.0 / 3.0
+    pos = [40.0, 41.0, 42.0, 44.0, 48.0, 56.0, 72.0]
+    lags = np.array([1, 2, 4, 8, 16, 32])
+    table = _amp_table(gpu_ctx, nh, ny, nx, d, d, d, r0, nu)
+    var, sf_v, sf_x = [], np.zeros(len(pos) - 1), np.zeros(len(lags))
+    nrep = 6
+    for rep in range(nrep):
+        planes = _generate_3d(gpu_ctx, 77, rep, nh, ny, nx, d, d, d, r0, nu, pos, amp=table)
+        base = planes[0].astype(np.float64)
+        var.append(np.mean([np.mean(p.astype(np.float64) ** 2) for p in planes]))
+        sf_v += np.array([np.mean((base - p) ** 2) for p in planes[1:]]) / nrep
+        sf_x += np.array([np.mean((base - np.roll(base, -k, axis=1)) ** 2) for k in lags]) / nrep
+    assert abs(np.mean(var) - 1) < 0.08, var
+    ref = lambda r: functions.normalized_matern(np.asarray(r, float) / r0, nu)  # noqa: E731
+    dz = (np.array(pos[1:]) - pos[0]) * d
+    # measured 0.1 % at one pixel (the power law: 4x low there), 1 % up to 16, 8 % at 32 pixels = one outer scale,
+    # where six realisations of 256^2 hold few independent patches
+    err_v, err_x = np.abs(sf_v / (2 * (1 - ref(dz))) - 1), np.abs(sf_x / (2 * (1 - ref(lags * d))) - 1)
+    assert err_v.max() < 0.12 and err_v[dz <= 8 * d].max() < 0.03, (sf_v, 2 * (1 - ref(dz)))
+    assert err_x.max() < 0.12 and err_x[lags <= 8].max() < 0.03, (sf_x, 2 * (1 - ref(lags * d)))
+
+
+def test_amplitude_table_errors(gpu_ctx):
+    import ctypes as C
+
+    import torch
+
+    from maria_amd._lib import MrxError, ptr
+    from maria_amd.pipeline import matern_log_tables
+
+    log_first, log_step, log_cov, log_sf, x_cut = matern_log_tables(5 / 6)
+    as_d = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+    table = torch.empty(1 << 16, dtype=torch.float32, device="cuda:0")
+    work = torch.empty(1 << 10, dtype=torch.float32, device="cuda:0")
+    with pytest.raises(MrxError, match="work buffer"):
+        gpu_ctx.call("mrx_screen_amplitudes", 0, 64, 64, 0.0, 5.0, 5.0, 300.0, as_d(log_cov), as_d(log_sf), len(log_cov), log_first,
+                     log_step, x_cut, ptr(table), ptr(work), work.numel())
+    with pytest.raises(MrxError, match="powers of two"):
+        gpu_ctx.call("mrx_screen_amplitudes", 0, 96, 64, 0.0, 5.0, 5.0, 300.0, as_d(log_cov), as_d(log_sf), len(log_cov), log_first,
+                     log_step, x_cut, ptr(table), ptr(table), table.numel())
+    with pytest.raises(MrxError, match="too small against x_cut"):
+        gpu_ctx.call("mrx_screen_amplitudes", 0, 64, 64, 0.0, 0.01, 0.01, 3000.0, as_d(log_cov), as_d(log_sf), len(log_cov), log_first,
+                     log_step, x_cut, ptr(table), ptr(table), table.numel())
