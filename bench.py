@@ -78,6 +78,7 @@ def parse_args(argv=None):
     ap.add_argument("--nccl-algo", default=None, help="exported as NCCL_ALGO before the communicator is made (e.g. Ring, Tree)")
     ap.add_argument("--gather-reps", type=int, default=3)
     ap.add_argument("--blocks", type=int, default=None, help="detector blocks of the pipelined TOD synthesis (default: DevicePath.default_blocks(); 1 = serial)")
+    ap.add_argument("--block-shares", default=None, help="A/B: relative sizes of the detector blocks, e.g. 1,2,2,2 (default: equal blocks)")
     ap.add_argument("--print-launch", action="store_true", help="print the child launch command of --gpus N as JSON and exit (no GPU needed)")
     return ap.parse_args(argv)
 
@@ -382,6 +383,9 @@ def run(args):
 
     writer_events = []
     n_blocks = args.blocks if args.blocks is not None else path.default_blocks()
+    if args.block_shares:
+        path.block_shares = [int(x) for x in args.block_shares.split(",")]
+        n_blocks = len(path.block_shares)
 
     def step(ev=None):
         """One pass: screens, then the TOD synthesis -- detector blocks pipelined on two streams

@@ -148,6 +148,7 @@ class MrxMapCal(C.Structure):
 _vp, _i, _d, _sz = C.c_void_p, C.c_int, C.c_double, C.c_size_t
 SIGNATURES = {
     "mrx_version": (_i, []),
+    "mrx_streams_concurrent": (_i, [_vp, _vp, C.POINTER(_i)]),
     "mrx_init": (_i, [_i, C.POINTER(_vp)]),
     "mrx_destroy": (_i, [_vp]),
     "mrx_set_stream": (_i, [_vp, _vp]),
@@ -281,6 +282,13 @@ class Context:
     def set_option(self, option: int, value: int):
         self.call("mrx_set_option", int(option), int(value))
         self.__dict__.setdefault("_options", {})[int(option)] = int(value)
+
+    def streams_concurrent(self, other) -> bool:
+        """mrx_streams_concurrent: does ``other`` (a torch stream) run beside this context's stream, or do the two
+        share a hardware queue and take turns?"""
+        flag = _i()
+        self.call("mrx_streams_concurrent", _vp(other.cuda_stream), C.byref(flag))
+        return bool(flag.value)
 
     def get_option(self, option: int) -> int:
         """The value this handle last set (0, the library default, if never set)."""

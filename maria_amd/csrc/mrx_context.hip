@@ -1,9 +1,85 @@
 // Context, stream binding, flags and the HIP-event timer of libmrx.
 #include "mrx_internal.h"
 
+namespace {
+
+// busy for `ticks` of the 100 MHz constant clock; every wave leaves once the time has passed
+__global__ void spin_kernel(long long ticks) {
+  const long long t0 = wall_clock64();
+  while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+}
+
+}  // namespace
+
+int mrx_probe_concurrent(mrx_ctx* ctx, hipStream_t a, hipStream_t b, bool* concurrent) {
+  *concurrent = true;
+  if (a == b) {
+    *concurrent = false;
+    return MRX_OK;
+  }
+  constexpr long long kTicks = 15000;  // 150 us
+  hipEvent_t e0 = nullptr, e1 = nullptr, eb = nullptr;
+  MRX_HIP(ctx, hipEventCreate(&e0));
+  MRX_HIP(ctx, hipEventCreate(&e1));
+  MRX_HIP(ctx, hipEventCreateWithFlags(&eb, hipEventDisableTiming));
+  float best = 1e30f;
+  for (int rep = 0; rep < 2; ++rep) {  // the first launch on a new stream pays for its queue
+    MRX_HIP(ctx, hipStreamSynchronize(a));
+    MRX_HIP(ctx, hipStreamSynchronize(b));
+    MRX_HIP(ctx, hipEventRecord(e0, a));
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, a, kTicks);
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, b, kTicks);
+    MRX_HIP(ctx, hipEventRecord(eb, b));
+    MRX_HIP(ctx, hipStreamWaitEvent(a, eb, 0));
+    MRX_HIP(ctx, hipEventRecord(e1, a));
+    MRX_HIP(ctx, hipEventSynchronize(e1));
+    float ms = 0.f;
+    MRX_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
+    if (ms < best) best = ms;
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  (void)hipEventDestroy(eb);
+  *concurrent = best < 1.6f * (float)kTicks * 1e-5f;  // one spin is 0.15 ms, two in a row 0.30
+  return MRX_OK;
+}
+
+int mrx_side_streams(mrx_ctx* ctx, int n) {
+  if (n > mrx_ctx::kSideStreams) return mrx_fail(ctx, MRX_ERR_INVALID, "at most %d side streams", mrx_ctx::kSideStreams);
+  if (!ctx->side_ev[0]) MRX_HIP(ctx, hipEventCreateWithFlags(&ctx->side_ev[0], hipEventDisableTiming));
+  // (re)check the streams against the context's current stream: one that shares its hardware queue would
+  // run its batches behind the main lane's instead of beside them
+  const bool recheck = !ctx->side_checked || ctx->side_probed != ctx->stream;
+  for (int i = 0; i < n; ++i) {
+    if (!ctx->side_ev[1 + i]) MRX_HIP(ctx, hipEventCreateWithFlags(&ctx->side_ev[1 + i], hipEventDisableTiming));
+    if (ctx->side_streams[i] && !recheck) continue;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+      if (!ctx->side_streams[i]) MRX_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_streams[i], hipStreamNonBlocking));
+      bool ok = true;
+      const int rc = mrx_probe_concurrent(ctx, ctx->stream, ctx->side_streams[i], &ok);
+      if (rc != MRX_OK) return rc;
+      if (ok || attempt == 5) break;  // (a device with a single queue: keep what there is)
+      (void)hipStreamDestroy(ctx->side_streams[i]);
+      ctx->side_streams[i] = nullptr;
+    }
+  }
+  ctx->side_probed = ctx->stream;
+  ctx->side_checked = true;
+  return MRX_OK;
+}
+
 extern "C" {
 
 int mrx_version(void) { return MRX_VERSION; }
+
+int mrx_streams_concurrent(mrx_ctx* ctx, void* other_stream, int* concurrent) {
+  MRX_ENTER(ctx);
+  if (!ctx || !concurrent) return MRX_ERR_INVALID;
+  bool ok = true;
+  const int rc = mrx_probe_concurrent(ctx, ctx->stream, (hipStream_t)other_stream, &ok);
+  *concurrent = ok ? 1 : 0;
+  return rc;
+}
 
 int mrx_init(int device, mrx_ctx** out) {
   if (!out) return MRX_ERR_INVALID;

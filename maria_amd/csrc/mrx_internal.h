@@ -68,10 +68,16 @@ struct mrx_ctx {
   static constexpr int kSideStreams = 3;
   hipStream_t side_streams[kSideStreams] = {nullptr};
   hipEvent_t side_ev[kSideStreams + 1] = {nullptr};  // [0]: fork, [1 + i]: join of side stream i
+  hipStream_t side_probed = nullptr;  // the context stream the side streams were last checked against
+  bool side_checked = false;
 };
 
-// the first n side streams (n <= kSideStreams) and their events exist after this returns MRX_OK
-inline int mrx_side_streams(mrx_ctx* ctx, int n);
+// the first n side streams (n <= kSideStreams) and their events exist after this returns MRX_OK,
+// each on a hardware queue of its own beside the context's stream (mrx_context.hip)
+int mrx_side_streams(mrx_ctx* ctx, int n);
+// do kernels on streams a and b run side by side?  (HIP spreads streams round-robin over a few hardware
+// queues -- four by default -- and two streams that land on one queue take turns.)  Synchronises both.
+int mrx_probe_concurrent(mrx_ctx* ctx, hipStream_t a, hipStream_t b, bool* concurrent);
 
 inline int mrx_fail(mrx_ctx* ctx, int code, const char* fmt, ...) {
   if (ctx) {
@@ -104,16 +110,6 @@ inline int mrx_fail(mrx_ctx* ctx, int code, const char* fmt, ...) {
       return mrx_fail((ctx), MRX_ERR_HIP, "kernel launch failed: %s (%s:%d)", \
                       hipGetErrorString(e__), __FILE__, __LINE__);           \
   } while (0)
-
-inline int mrx_side_streams(mrx_ctx* ctx, int n) {
-  if (n > mrx_ctx::kSideStreams) return mrx_fail(ctx, MRX_ERR_INVALID, "at most %d side streams", mrx_ctx::kSideStreams);
-  if (!ctx->side_ev[0]) MRX_HIP(ctx, hipEventCreateWithFlags(&ctx->side_ev[0], hipEventDisableTiming));
-  for (int i = 0; i < n; ++i) {
-    if (!ctx->side_streams[i]) MRX_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_streams[i], hipStreamNonBlocking));
-    if (!ctx->side_ev[1 + i]) MRX_HIP(ctx, hipEventCreateWithFlags(&ctx->side_ev[1 + i], hipEventDisableTiming));
-  }
-  return MRX_OK;
-}
 
 // Entry points that launch or allocate run on the context's own device, whatever the
 // calling thread's current device is; the caller's device is restored on return.

@@ -536,22 +536,40 @@ class DevicePath:
             return 1
         return 4
 
-    def _pipeline_state(self, blocks):
+    def _side_stream(self, main):
+        """A stream that really runs beside ``main``: HIP spreads streams round-robin over four hardware queues,
+        and one new stream in four lands on the caller's -- the two then take turns and the pipelined step is as
+        slow as the serial one (mrx_streams_concurrent)."""
+        self.ctx.set_stream(main)
+        side = None
+        for _ in range(6):
+            side = torch.cuda.Stream(device=self.device)
+            if self.ctx.streams_concurrent(side):
+                break
+        return side
+
+    def _pipeline_state(self, blocks, main=None):
         st = getattr(self, "_pipe", None)
+        main = main if main is not None else torch.cuda.current_stream(self.device)
         if st is not None and st["blocks"] == blocks:
+            if st["main"] != main.cuda_stream:  # another caller's stream: the side stream must be checked against it
+                st["side"] = self._side_stream(main)
+                st["ctx2"].set_stream(st["side"])
+                st["main"] = main.cuda_stream
             return st
-        # whole sampler workgroups (and writer tiles) per block.  The first block's sampler has
-        # nothing to run beside, so that block is half as long as the others: the writer starts sooner
+        # whole sampler workgroups (and writer tiles) per block, equal blocks (measured on two boxes against a
+        # first block half as long as the others, whose writer then waits for the second sampler: 2.02-2.05 ms
+        # against 2.07-2.12 at four blocks; scripts/exp_block_shares.py)
         units = -(-self.D // 256)
-        share = getattr(self, "block_shares", None) or ([1] + [2] * (blocks - 1) if blocks > 1 else [1])
+        share = getattr(self, "block_shares", None) or [1] * blocks
         cuts = np.floor(np.cumsum(share) / float(sum(share)) * units + 0.5).astype(int)
         edges = [0] + [min(int(c) * 256, self.D) for c in cuts]
         edges[-1] = self.D
         bounds = [(lo, hi) for lo, hi in zip(edges[:-1], edges[1:]) if hi > lo]
-        side = torch.cuda.Stream(device=self.device)
+        side = self._side_stream(main)
         ctx2 = Context(self.ctx.device)
         ctx2.set_stream(side)
-        st = dict(blocks=blocks, bounds=bounds, side=side, ctx2=ctx2,
+        st = dict(blocks=blocks, bounds=bounds, side=side, ctx2=ctx2, main=main.cuda_stream,
                   ready=[torch.cuda.Event() for _ in bounds], start=torch.cuda.Event(),
                   loading=[torch.empty((self.Ta, hi - lo), dtype=torch.float32, device=self.device) for lo, hi in bounds])
         self._pipe = st
@@ -569,8 +587,9 @@ class DevicePath:
         per-stage breakdown of exactly the launches the pipelined step makes."""
         if self.plan is None:
             raise RuntimeError("no screens bound: call set_screens() or generate_screens() first")
-        st = self._pipeline_state(blocks)
-        main, side, ctx2 = torch.cuda.current_stream(self.device), st["side"], st["ctx2"]
+        main = torch.cuda.current_stream(self.device)
+        st = self._pipeline_state(blocks, main)
+        side, ctx2 = st["side"], st["ctx2"]
         # the writers go through self.ctx: its stream must be the one the events below are
         # recorded on, whatever stream was current when this DevicePath was made
         self.ctx.set_stream(main)

@@ -11,7 +11,7 @@ path = DevicePath(p, device="cuda:0")
 path.generate_screens()
 tod = torch.empty((path.D, path.T), dtype=torch.float32, device="cuda:0")
 for rep in range(2):
-    for share in ([1, 2, 2, 2], [1, 3, 3, 3], [2, 3, 3, 3], [1, 1, 1, 1], [1, 2, 3, 3], [1, 2, 2, 2, 2], [2, 3, 3], [1, 4, 4, 4]):
+    for share in ([1, 2, 2, 2], [1, 1, 1, 1], [1, 2, 2, 2, 2], [1] * 6, [1, 2, 2, 2, 2, 2, 2], [1] * 8, [1] + [2] * 7 + [1], [1] * 10, [1] * 12, [1, 2, 3, 3, 3, 2, 1], [1, 2, 2, 2, 1]):
         path._pipe = None
         path.block_shares = share
         med, mn = timeit(lambda: path.run(tod, blocks=len(share)), 20)

@@ -443,3 +443,29 @@ def test_cubic_emission_lookup_matches_scipy(gpu_ctx):
         bad.check_flags()
     with pytest.raises(ValueError):
         DevicePath(dict(p, T0=100.0), device="cuda:0", ctx=gpu_ctx)  # interp1d refuses a T0 off the axis
+
+
+@pytest.mark.gpu
+def test_side_streams_are_chosen_off_the_callers_hardware_queue(gpu_ctx):
+    """HIP spreads streams round-robin over four hardware queues: one new stream in four shares the caller's
+    and would run the pipelined step's sampler behind the writer instead of beside it (2.9 instead of 2.1 ms at
+    the headline size).  mrx_streams_concurrent sees it (two spin kernels, timed); DevicePath takes a stream
+    that passes, whichever stream is current."""
+    import torch
+
+    from maria_amd import synthetic
+    from maria_amd.pipeline import DevicePath
+
+    main = torch.cuda.current_stream()
+    gpu_ctx.set_stream(main)
+    assert not gpu_ctx.streams_concurrent(main)  # a stream is not beside itself
+    verdicts = [gpu_ctx.streams_concurrent(torch.cuda.Stream()) for _ in range(8)]
+    assert any(verdicts)  # (on the default four queues: six of eight)
+    p = synthetic.make_problem(n_det=64, n_bands=1, fov_deg=0.5, fs=50.0, duration=20.0, n_layers=2, side=128)
+    path = DevicePath(p, device="cuda:0", ctx=gpu_ctx)
+    for cur in (main, torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()):
+        with torch.cuda.stream(cur):
+            side = path._side_stream(cur)
+            gpu_ctx.set_stream(cur)
+            assert gpu_ctx.streams_concurrent(side)
+    gpu_ctx.set_stream(main)
