@@ -39,6 +39,14 @@ for name, opts in (("pixel (default)", {}), ("axis literal", {1: 1}), ("pointing
     for k in opts:
         path.ctx.set_option(k, 0)
     out[name] = (got, coarse)
+    if not opts:
+        # the spline alone: scipy's float64 spline of the GPU's OWN coarse loading, in float64 and rounded to float32
+        import scipy.interpolate
+        own64 = scipy.interpolate.interp1d(p["ta"], coarse.astype(np.float64), kind="cubic", axis=-1, fill_value="extrapolate")(p["t"])
+        print(f"{name:18s} GPU TOD vs scipy spline of the GPU's coarse loading: fluct {fluct(got, own64):.3e} (float32 of it: {fluct(got, own64.astype(np.float32)):.3e}; "
+              f"float32 rounding alone: {fluct(own64.astype(np.float32), own64):.3e})")
+        ref64 = scipy.interpolate.interp1d(p["ta"], inter["loading_a"].astype(np.float64), kind="cubic", axis=-1, fill_value="extrapolate")(p["t"])
+        print(f"{name:18s} scipy spline of GPU coarse vs of oracle coarse (float64): fluct {fluct(own64, ref64):.3e}")
     print(f"{name:18s} vs oracle: TOD rel {rel(got, ref):.3e} fluct {fluct(got, ref):.3e} | coarse rel {rel(coarse, inter['loading_a']):.3e} fluct {fluct(coarse, inter['loading_a']):.3e}")
 a, b = out["pixel (default)"], out["axis literal"]
 print(f"pixel vs axis literal: TOD rel {rel(a[0], b[0]):.3e} fluct {fluct(a[0], b[0]):.3e}")

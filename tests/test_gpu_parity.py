@@ -216,7 +216,8 @@ def test_spline_matches_scipy_all_lengths(gpu_ctx, Ta, form):
     d_ym = _spline_upsample(gpu_ctx, form, d_y, D, Ta, float(ta[0]), float(ta[1] - ta[0]), d_t, T, None, d_out, ld)
     out = d_out.cpu().numpy()
     assert (out[:, T:] == -7.0).all(), "wrote past T"
-    assert rel_err(out[:, :T], ref) <= 2e-6
+    # measured 4e-8 ... 9e-8: the float32 rounding of the value itself (round 2's evaluation form: 1e-6)
+    assert rel_err(out[:, :T], ref) <= 2e-7
     if d_ym is not None:  # knots are reproduced (interpolation property)
         assert np.array_equal(d_ym.cpu().numpy()[:, :, 0], y.T)
 
@@ -244,7 +245,7 @@ def test_upsample_ratios(gpu_ctx, ratio, form):
     scale = rng.uniform(0.5, 2.0, D).astype(np.float32)
     d_scale = torch.as_tensor(scale).to(dev)
     _spline_upsample(gpu_ctx, form, d_y, D, Ta, float(ta[0]), 0.1, d_t, T, d_scale, d_out, T)
-    assert rel_err(d_out.cpu().numpy(), ref * scale[:, None]) <= 2e-6
+    assert rel_err(d_out.cpu().numpy(), ref * scale[:, None]) <= 2e-7  # measured 9e-8: the value's rounding and the gain's
 
 
 def test_fused_upsample_equals_the_two_call_form(gpu_ctx):
