@@ -729,9 +729,7 @@ __global__ __launch_bounds__(kBlock) void bin_accumulate_kernel(MapArgs g, BinAr
     // memory latency, not by bytes
     constexpr int kPer = 4;
     int cur = 0;
-    for (int j0 = threadIdx.x; j0 < total; j0 += kBlock * kPer) {
-      Entry en[kPer];
-      int det[kPer];
+    auto fetch = [&](int j0, Entry (&en)[kPer], int (&det)[kPer]) {
 #pragma unroll
       for (int i = 0; i < kPer; ++i) {
         const int j = j0 + i * kBlock;
@@ -743,19 +741,50 @@ __global__ __launch_bounds__(kBlock) void bin_accumulate_kernel(MapArgs g, BinAr
           det[i] = seg_d0[cur] + (int)(en[i].local >> 11);
         }
       }
-      for (int s = 0; s < g.S; ++s) {
-        double m[kPer];
+    };
+    auto weights = [&](const Entry (&en)[kPer], const int (&det)[kPer], int s, double (&m)[kPer]) {
 #pragma unroll
-        for (int i = 0; i < kPer; ++i) m[i] = en[i].local != kBinNone ? g.stokes_w[(size_t)det[i] * g.S + s] : 0.0;
+      for (int i = 0; i < kPer; ++i) m[i] = en[i].local != kBinNone ? g.stokes_w[(size_t)det[i] * g.S + s] : 0.0;
+    };
+    auto add = [&](const Entry (&en)[kPer], int s, const double (&m)[kPer]) {
 #pragma unroll
-        for (int i = 0; i < kPer; ++i) {
-          if (m[i] == 0.0) continue;  // zero weight: nothing to add (np.abs(P) entries that are 0); padding
-          const uint32_t px = en[i].local & (uint32_t)(kBinRegionPx - 1);
-          const double ww = en[i].weight();
-          atomicAdd(&bin_acc[(s * 2) * kBinRegionPx + px], m[i] * (ww * (double)en[i].d));
-          atomicAdd(&bin_acc[(s * 2 + 1) * kBinRegionPx + px], fabs(m[i]) * ww);
-        }
+      for (int i = 0; i < kPer; ++i) {
+        if (m[i] == 0.0) continue;  // zero weight: nothing to add (np.abs(P) entries that are 0); padding
+        const uint32_t px = en[i].local & (uint32_t)(kBinRegionPx - 1);
+        const double ww = en[i].weight();
+        atomicAdd(&bin_acc[(s * 2) * kBinRegionPx + px], m[i] * (ww * (double)en[i].d));
+        atomicAdd(&bin_acc[(s * 2 + 1) * kBinRegionPx + px], fabs(m[i]) * ww);
       }
+    };
+    // Two trips in flight.  An entry needs a second, dependent load (its detector's Stokes weight); loads return
+    // in order, so the weights of this trip are requested FIRST and the next trip's entries after them: waiting
+    // for the weights then leaves the entries in flight (14.1 -> 12.6 ms at 10 000 x 240 000; the other order,
+    // or one trip at a time, gains nothing).
+    auto trip = [&](const Entry (&en)[kPer], const int (&det)[kPer], bool more, int j_next, Entry (&en_n)[kPer], int (&det_n)[kPer]) {
+      double m[kPer];
+      weights(en, det, 0, m);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) fetch(j_next, en_n, det_n);
+      __builtin_amdgcn_sched_barrier(0);
+      add(en, 0, m);
+      for (int s = 1; s < g.S; ++s) {
+        weights(en, det, s, m);
+        add(en, s, m);
+      }
+    };
+    Entry ea[kPer], eb[kPer];
+    int da[kPer], db[kPer];
+    constexpr int kTrip = kBlock * kPer;
+    int j0 = threadIdx.x;
+    if (j0 < total) fetch(j0, ea, da);
+    while (j0 < total) {
+      const bool more_b = j0 + kTrip < total;
+      trip(ea, da, more_b, j0 + kTrip, eb, db);
+      if (!more_b) break;
+      const bool more_a = j0 + 2 * kTrip < total;
+      trip(eb, db, more_a, j0 + 2 * kTrip, ea, da);
+      if (!more_a) break;
+      j0 += 2 * kTrip;
     }
     __syncthreads();
   }
