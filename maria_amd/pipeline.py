@@ -692,8 +692,10 @@ class DevicePath:
         )
 
     # the coarse-grid form of the K_RJ conversion is taken when this estimate of its deviation from the
-    # per-sample form stays below a third of the parity tolerance (1e-5)
-    COARSE_KRJ_LIMIT = 3.0e-6
+    # per-sample form stays below 0.4 of the parity tolerance (1e-5): the float32 path itself takes 3e-6 of it
+    # at full size, which leaves a quarter of the tolerance unspent
+    COARSE_KRJ_LIMIT = 4.0e-6
+    SPLINE_KINK = 0.1708  # max |spline - f| / (slope jump x knot spacing) for a kink between uniform knots
 
     def coarse_krj_bound(self):
         """Estimate of max |S[y/g] - S[y]/g| / |S[y]/g| (S: the spline in time, g: the K_RJ
@@ -702,8 +704,10 @@ class DevicePath:
         (mrx_spline_upsample_krj, the reference's order, tod/tod.py:106-142).  Both are the same
         linear functional of y but for the spline's interpolation error on g(t) = den(el(t)):
         (a) where a detector's elevation crosses a node of the table's axis between two knots g has
-        a kink, and an interpolant misses a kink by at most 0.25 x (slope jump) x (knot spacing) --
-        0.3 here for the spline's ringing; measured on the daisy scan: 0.15;
+        a kink, and the not-a-knot cubic spline through uniform knots misses a kink by at most 0.1708 x
+        (slope jump) x (knot spacing) -- the kink in the middle of a knot interval; 0.085 on a knot; a
+        linear interpolant: 0.25 -- (tests/test_host_geometry.py::test_spline_error_at_a_kink computes it);
+        measured on the daisy scan: 0.15;
         (b) inside a cell g is linear in el, so the error is the spline's error on el(t),
         (5/384) h^4 d4el/dt4 -- estimated from fourth differences of the coarse boresight.
         inf when the form does not apply: a NaN in the collapsed table, a detector that may leave
@@ -730,7 +734,7 @@ class DevicePath:
         d4 = np.abs(np.diff(el, n=4)).max()
         # + 4e-7: the two forms round differently in float32 (and the per-sample writer interpolates
         # the reciprocal over 4 samples)
-        return float(1.1 * (0.3 * rel_jump * step + (5.0 / 384.0) * rel_slope * d4) + 4e-7)
+        return float(1.1 * (self.SPLINE_KINK * rel_jump * step + (5.0 / 384.0) * rel_slope * d4) + 4e-7)
 
     def coarse_to_krj(self, loading=None, n=None, rows=slice(None), ctx=None):
         """mrx_coarse_to_krj on the coarse loading (``loading``: a block's [Ta, n] buffer, in

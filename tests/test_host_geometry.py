@@ -337,3 +337,20 @@ def test_3d_layer_table_and_process_equal_the_oracle():
     assert vol["nh"] >= pos.max() + 1 and (vol["nh"] & (vol["nh"] - 1)) == 0
     assert all(1.0 <= l["volume"]["scale"] < 1.2 for l in proc["layers"])
     assert [l["layer_index"] for l in atm._layer_list()] == list(range(len(ref["h"])))
+
+
+def test_spline_error_at_a_kink():
+    """DevicePath.coarse_krj_bound prices a kink of the K_RJ denominator (a detector's elevation crossing a node of
+    the table's axis between two coarse samples) with the not-a-knot cubic spline's worst miss of a unit slope jump
+    between uniform knots: 0.1708 of the knot spacing, kink in the middle of an interval."""
+    import scipy.interpolate
+
+    from maria_amd.pipeline import DevicePath
+
+    x = np.arange(-40.0, 41.0)
+    xs = np.linspace(-5, 5, 20001)
+    worst = 0.0
+    for a in np.linspace(0, 1, 101):
+        f = lambda t: np.maximum(t - a, 0.0)  # noqa: E731
+        worst = max(worst, np.abs(scipy.interpolate.CubicSpline(x, f(x), bc_type="not-a-knot")(xs) - f(xs)).max())
+    assert 0.170 < worst <= DevicePath.SPLINE_KINK
