@@ -62,3 +62,33 @@ def test_the_parent_returns_the_childs_status():
                          env=_clean_env(), capture_output=True, text=True, timeout=560)
     assert out.returncode != 0
     assert "bench.py needs a GPU" in out.stderr
+
+
+def test_recorded_bench_lines_carry_the_contract_fields():
+    """The lines bench.py printed on the GPU box (profiles/: N = 1 under the defaults, and the two-rank rehearsal) hold
+    every field of the driver's contract, the roofline and CPU-baseline objects, and consistent arithmetic."""
+    for name in ("r03_bench.json", "r03_bench_gloo2.json"):
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            line = json.loads(f.read().strip().splitlines()[-1])
+        for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                    "dtype", "data", "config", "roofline"):
+            assert key in line, (name, key)
+        assert line["unit"] == "detector-samples/s" and line["higher_is_better"] is True and line["vs_baseline"] is None
+        assert line["dtype"] == "f32" and line["data"] == "synthetic" and "workload" in line["config"] and "model" not in line["config"]
+        assert line["scaling"] in ("weak", "strong")
+        # value = whole-job samples per second: all detectors x samples x steps over the timed region
+        per_step = line["config"]["n_det_total"] * line["config"]["n_samples"]
+        assert abs(line["value"] / (per_step / (line["ms_per_step"] * 1e-3)) - 1) < 1e-6
+        roof = line["roofline"]
+        for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+            assert key in roof, (name, key)
+        assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0
+        assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-9 and 0.3 < roof["frac"] < 1.0
+        if line["n_gpus"] == 1:
+            cpu = line["cpu_baseline"]
+            for key in ("value", "unit", "cores", "kind", "sample"):
+                assert key in cpu, key
+            assert cpu["kind"] == "port" and cpu["cores"] == 1 and cpu["unit"] == line["unit"]
+            assert cpu["parity_max_rel_err_vs_gpu"] <= 1e-5 and cpu["parity_fluct_rel_err"] <= 5e-4
+            # the kernel's measured HBM traffic stays near its algorithmic bytes (re-reads would show here first)
+            assert 1.0 <= roof["traffic"] / roof["bytes_per_launch"] < 1.15
