@@ -102,13 +102,28 @@ def test_screen_statistics_through_the_front_end(gpu_ctx):
     # a ribbon spans about one outer scale, so a single realisation is nearly one draw of the
     # large-scale modes: the second moment about ZERO (not the ribbon's own mean) is what
     # averages to the field's unit variance, over realisations
+    from oracle import functions
+
     msq = []
-    for _ in range(12):
+    lags = np.array([1, 2, 4, 8])
+    sf = np.zeros((2, len(lags)))
+    n_real = 96  # (a ribbon of 750 x 4 pixels holds few independent increments: 12 realisations scatter by 10 %)
+    for _ in range(n_real):
         atm.simulate_pwv(instrument=None)  # no smoothing
         raw = [b[0].cpu().numpy() for b in atm._device_path()._layer_bufs]
         assert all(np.isfinite(s).all() for s in raw)
         msq.append([float((s.astype(np.float64) ** 2).mean()) for s in raw])
+        for i, s in enumerate(raw):  # structure function along the extrusion axis (differences: the large modes cancel)
+            s = s.astype(np.float64)
+            sf[i] += [np.mean((s[k:] - s[:-k]) ** 2) / n_real for k in lags]
     assert 0.4 < np.mean(msq) < 1.9, msq
+    # ... and the small-scale structure is Matern's (functions/__init__.py:30-39) from ONE pixel of the ribbon up: the
+    # generator's amplitudes are the covariance's own eigenvalues on the padded periodic domain (mrx_screen_amplitudes)
+    for i, l in enumerate(sorted(atm.processes)):
+        pr = atm.processes[l]
+        de = float(pr["extrusion"][1] - pr["extrusion"][0])
+        want = 2 * (1 - functions.normalized_matern(lags * de / pr["r0"], pr["nu"]))
+        assert np.abs(sf[i] / want - 1).max() < 0.03, (sf[i], want)  # measured 0.2 ... 1.0 %
     atm._realisation -= 1  # same realisation, smoothed
     atm.simulate_pwv(instrument=inst)
     smooth = [b[0].cpu().numpy() for b in atm._device_path()._layer_bufs]
