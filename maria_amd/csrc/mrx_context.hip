@@ -18,7 +18,14 @@ int mrx_probe_concurrent(mrx_ctx* ctx, hipStream_t a, hipStream_t b, bool* concu
     return MRX_OK;
   }
   constexpr long long kTicks = 15000;  // 150 us
-  hipEvent_t e0 = nullptr, e1 = nullptr, eb = nullptr;
+  struct Events {  // released on every way out
+    hipEvent_t e0 = nullptr, e1 = nullptr, eb = nullptr;
+    ~Events() {
+      for (hipEvent_t e : {e0, e1, eb})
+        if (e) (void)hipEventDestroy(e);
+    }
+  } ev;
+  hipEvent_t &e0 = ev.e0, &e1 = ev.e1, &eb = ev.eb;
   MRX_HIP(ctx, hipEventCreate(&e0));
   MRX_HIP(ctx, hipEventCreate(&e1));
   MRX_HIP(ctx, hipEventCreateWithFlags(&eb, hipEventDisableTiming));
@@ -37,9 +44,6 @@ int mrx_probe_concurrent(mrx_ctx* ctx, hipStream_t a, hipStream_t b, bool* concu
     MRX_HIP(ctx, hipEventElapsedTime(&ms, e0, e1));
     if (ms < best) best = ms;
   }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  (void)hipEventDestroy(eb);
   *concurrent = best < 1.6f * (float)kTicks * 1e-5f;  // one spin is 0.15 ms, two in a row 0.30
   return MRX_OK;
 }
