@@ -525,8 +525,10 @@ class DevicePath:
 
     def default_blocks(self):
         """Detector blocks of the pipelined run: 4 from 4096 rows up (round 3, atlast_10k: 2.12 ms with 4
-        blocks, 2.17 with 8, 2.24-2.34 with 12, 2.69 serial)."""
-        if self.keep_pwv or self.D < 4096:
+        blocks, 2.17 with 8, 2.24-2.34 with 12, 2.69 serial), 2 from 2048 (the shard of a 4-GPU run, 2 512 rows:
+        0.63 ms against 0.66 serial and 0.69 with 4), 1 below (1 264 rows: 0.35 against 0.37;
+        scripts/exp_small_blocks.py)."""
+        if self.keep_pwv or self.D < 2048:
             return 1
         # screens that do not fit the Infinity Cache (atlast_50k: 16 x 4096^2 = 1.07 GB) make the
         # sampler memory-bound, and beside the writer it then loses more than the overlap gains
@@ -534,7 +536,7 @@ class DevicePath:
         screens_bytes = 4 * sum(len(l["extrusion"]) * len(l["cross_section"]) for l in self.problem["layers"])
         if screens_bytes > 256 << 20:
             return 1
-        return 4
+        return 4 if self.D >= 4096 else 2
 
     def _side_stream(self, main):
         """A stream that really runs beside ``main``: HIP spreads streams round-robin over four hardware queues,
