@@ -487,6 +487,7 @@ def _unfold(table, nh, ny, nx):
 
 
 @pytest.mark.parametrize("nh,ny,nx,nu,r0", [(0, 128, 64, 5 / 6, 300.0), (0, 256, 1024, 5 / 6, 300.0), (0, 2048, 64, 1 / 3, 100.0),
+                                            (0, 8192, 64, 5 / 6, 150.0),  # the longest axis: 98 KB of LDS for its cosine sums
                                             (8, 64, 128, 1 / 3, 40.0), (32, 128, 64, 1 / 3, 60.0)])
 def test_amplitude_table_matches_numpy_fft(gpu_ctx, nh, ny, nx, nu, r0):
     """The table of mrx_screen_amplitudes (periodic images summed, float64 cosine sums over the even half
