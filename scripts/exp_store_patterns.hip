@@ -21,6 +21,7 @@ typedef float vfloat4 __attribute__((ext_vector_type(4)));
 // tiles are numbered along the time axis first (order 0) or along the detector axis first (order 1)
 __global__ __launch_bounds__(256) void fill(float* out, int D, int T, size_t ld, int rows, int span, int tiles_t, int tiles_d, int order,
                                             int nt) {
+  extern __shared__ float occupancy_pad[];  // dynamic LDS only caps the workgroups per CU
   const int id = blockIdx.x;
   const int tt = order == 0 ? id % tiles_t : id / tiles_d, td = order == 0 ? id / tiles_t : id % tiles_d;
   const vfloat4 v = {1.f, 2.f, 3.f, (float)threadIdx.x};
@@ -78,6 +79,16 @@ int main(int argc, char** argv) {
     for (int order = 0; order < 2; ++order) {
       const float ms = time_ms([&] { hipLaunchKernelGGL(fill, dim3(tiles_t * tiles_d), dim3(256), 0, 0, out, D, T, (size_t)T, rows, span, tiles_t, tiles_d, order, 1); });
       printf("%2d rows x %5d samples, %s first: %.3f ms %.0f GB/s\n", rows, span, order == 0 ? "time" : "detector", ms, gb / ms * 1e3);
+    }
+  }
+  // the writer's tile (32 rows x 1024 samples, time first) under an occupancy cap
+  CK(hipFuncSetAttribute(reinterpret_cast<const void*>(fill), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  for (int rows : {32, 16}) {
+    const int span = 1024, tiles_t = (T + span - 1) / span, tiles_d = (D + rows - 1) / rows;
+    for (int kb : {0, 20, 30, 40, 53, 64, 80, 150}) {
+      const float ms = time_ms([&] { hipLaunchKernelGGL(fill, dim3(tiles_t * tiles_d), dim3(256), (size_t)kb * 1024, 0, out, D, T, (size_t)T, rows, span, tiles_t, tiles_d, 0, 1); });
+      printf("%2d rows x 1024 samples, time first, %3d KB LDS per workgroup (%s per CU): %.3f ms %.0f GB/s\n", rows, kb,
+             kb == 0 ? "8" : kb <= 20 ? "8" : kb <= 30 ? "5" : kb <= 40 ? "4" : kb <= 53 ? "3" : kb <= 80 ? "2" : "1", ms, gb / ms * 1e3);
     }
   }
   return 0;
