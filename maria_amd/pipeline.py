@@ -601,6 +601,12 @@ class DevicePath:
         else:
             st["start"].record(main)  # screens (and the previous run's writers) come first
             side.wait_event(st["start"])
+        if not serial:
+            # the sampler runs through the side context: what the caller set on this path's context (the cell rule, the
+            # pointing chain: MRX_OPT_AXIS_LITERAL, MRX_OPT_POINTING_CHAIN) applies there too
+            for opt in (_lib.OPT_POINTING_CHAIN, _lib.OPT_AXIS_LITERAL):
+                if ctx2.get_option(opt) != self.ctx.get_option(opt):
+                    ctx2.set_option(opt, self.ctx.get_option(opt))
         saved = (ctx2.get_option(_lib.OPT_SAMPLE_WGS_PER_CU), ctx2.get_option(_lib.OPT_SAMPLE_TIMES))
         sl = lambda t, lo, hi: None if t is None else ptr(t[lo:hi])  # noqa: E731
         for i, (lo, hi) in enumerate(st["bounds"]):

@@ -83,6 +83,51 @@ for trial in range(max(4, trials // 4)):
     bad += not ok
     print(f"sampler n_det={n_det} layers={n_layers} T={a.shape[1]}: vs oracle {e1:.2e}, vs literal rule {e2:.2e} {'ok' if ok else 'BAD'}", flush=True)
 
+# 2b. sampler variants: stretched axes (array search), cubic emission tables, the float32 pointing chain, gains, row
+# order, the pipelined run in 2-5 blocks against the serial one (bit for bit) -- all against the oracle
+for trial in range(max(6, trials // 4)):
+    n_det = int(rng.integers(600, 2200))
+    cubic = bool(rng.random() < 0.35)
+    p = synthetic.make_problem(n_det=n_det, n_bands=int(rng.integers(1, 4)), fov_deg=float(rng.uniform(0.1, 1.5)), fs=float(rng.choice([20.0, 50.0])),
+                               duration=float(rng.uniform(8.0, 30.0)), n_layers=int(rng.integers(1, 6)), side=int(rng.choice([128, 256])),
+                               seed=int(rng.integers(1, 1 << 30)))
+    if cubic:
+        p["interpolation_method"] = "cubic"
+    if rng.random() < 0.5:
+        p["gain"] = rng.uniform(0.8, 1.2, n_det)
+    path = DevicePath(p, device=dev, ctx=ctx)
+    path.generate_screens()
+    stretched = False
+    if rng.random() < 0.5 and not cubic:  # stretch one axis of one layer smoothly: the plan then searches the axis array
+        scr = [s.clone() for s in path._gen_screens]
+        l = int(rng.integers(0, len(p["layers"])))
+        key = "cross_section" if rng.random() < 0.5 else "extrusion"
+        ax = p["layers"][l][key]
+        mid = 0.5 * (ax[0] + ax[-1])
+        p["layers"][l][key] = mid + (ax - mid) * (1.0 + 0.2 * ((ax - mid) / (ax[-1] - mid)) ** 2)
+        for layer, s_ in zip(p["layers"], scr):
+            layer["values"] = s_.cpu().numpy()
+        path = DevicePath(p, device=dev, ctx=ctx)
+        path.set_screens(scr)
+        stretched = True
+    chain = bool(rng.random() < 0.3)
+    ctx.set_option(_lib.OPT_POINTING_CHAIN, 1 if chain else 0)
+    serial = path.run(blocks=1).clone()
+    flags = path.check_flags()
+    blocks = int(rng.integers(2, 6))
+    piped = path.run(blocks=blocks).clone()
+    ctx.set_option(_lib.OPT_POINTING_CHAIN, 0)
+    if not stretched:
+        for layer, s_ in zip(p["layers"], path._gen_screens):
+            layer["values"] = s_.cpu().numpy()
+    ref = hotpath.run_path(p)
+    e1 = rel(serial.cpu().numpy(), ref)
+    same = bool(torch.equal(serial, piped))
+    ok = e1 <= 1e-5 and same and flags == 0
+    bad += not ok
+    print(f"variants n_det={n_det} cubic={cubic} stretched={stretched} chain={chain} gain={p.get('gain') is not None} blocks={blocks}: vs oracle {e1:.2e}, "
+          f"pipelined == serial {same} {'ok' if ok else 'BAD'}", flush=True)
+
 # 3. amplitude tables
 for trial in range(max(4, trials // 6)):
     nh = int(rng.choice([0, 0, 8, 16]))

@@ -72,7 +72,7 @@ def test_runs_are_deterministic_and_shards_bit_identical(full):
 
 def test_pipelined_run_is_bit_identical_to_the_serial_one(full):
     """DevicePath.run() cuts the shard into detector blocks and runs the sampler of block b+1
-    beside the writer of block b on two streams (the default from 4096 rows up; the first block is half as long as the others so that the writer starts early): same kernels,
+    beside the writer of block b on two streams (the default from 2048 rows up, equal blocks): same kernels,
     same rows, same bits -- for several block counts, and twice in a row (buffer reuse)."""
     import torch
 
@@ -84,6 +84,22 @@ def test_pipelined_run_is_bit_identical_to_the_serial_one(full):
         assert torch.equal(out, tod), blocks
         assert torch.equal(path.coarse_loading(), path.coarse_loading())  # assembled from the block buffers
     assert path.check_flags() == 0
+    # the sampler's rule set on the path's context reaches the side context of the pipelined run too
+    # (a randomised sweep found the pipelined run on the default rule whatever the caller had set)
+    from maria_amd import _lib
+
+    for option in (_lib.OPT_AXIS_LITERAL, _lib.OPT_POINTING_CHAIN):
+        path.ctx.set_option(option, 1)
+        try:
+            serial = path.run(torch.empty_like(tod), blocks=1)
+            piped = path.run(out, blocks=4)
+            assert torch.equal(serial, piped), option
+            assert not torch.equal(serial, tod)  # it IS another rule
+        finally:
+            path.ctx.set_option(option, 0)
+        del serial
+    path.run(out, blocks=4)
+    assert torch.equal(out, tod)  # and it is gone again
     del out
     path.sample()  # back to the serial state for the tests below
 
