@@ -783,7 +783,7 @@ __device__ __forceinline__ float den_lookup(float el, const float4* C, int n_el,
 struct KrjSamples {
   float eb0, eb3;  // boresight elevation of the thread's first and last sample
   float x0, x3;    // the same minus the tile's reference elevation (CalDet::ebm)
-  float ca0, sa0, ca3, sa3;
+  int curved;      // some thread of the workgroup: its four boresight elevations are NOT linear in the sample index to 1e-6 rad
 };
 
 // The K_RJ values of a thread's 4 consecutive samples of one detector.  den is piecewise
@@ -794,15 +794,48 @@ struct KrjSamples {
 // apart, the value jax computes); otherwise -- a node between them, a guess that missed, an
 // elevation off the axis -- every sample is looked up on its own at the interpolated
 // elevation.  `sv` already carries the detector's scale.
-template <bool kInverse = false>
+template <bool kInverse = false, bool kCurved = false>
 __device__ __forceinline__ void krj_row(const CalDet& c, const float4* C, int n_el, float el_first,
                                         float el_last, float el_inv, const KrjSamples& k,
-                                        const float (&sv)[kSamplesPerThread], float (&o)[kSamplesPerThread]) {
+                                        const float (&sv)[kSamplesPerThread], float (&o)[kSamplesPerThread],
+                                        const float* __restrict__ bore_el, int sb, int T) {
   constexpr int kL = kSamplesPerThread - 1;
+  if constexpr (kCurved) {
+    // Low sample rates or tight fast scans (20 Hz, a 0.1 deg daisy at 0.8 deg/s: 3e-4 rad of curvature over a thread's
+    // four samples, 1e-4 of den) -- every sample at its own boresight elevation.  The workgroup takes this instance of
+    // its row loop when any of its threads sees more than 1e-6 rad (KrjSamples::curved); never at the rates the
+    // interpolation below was built for (400 Hz: 6e-8 rad).
+    // (one sample at a time, its elevation reloaded: unrolled, or with the four values kept in registers, this
+    // instance would set the kernel's register count -- 98 instead of 96 costs a wave per SIMD and 12 %)
+#pragma unroll 1
+    for (int q = 0; q < kSamplesPerThread; ++q) {
+      const float ebq = bore_el[min(sb + q, T - 1)];
+      float el;
+      if (c.exact) {
+        // (the hardware sine and cosine, in revolutions: 1e-6 rad here, where den hardly moves with the elevation;
+        // cosf / sinf inlined would set the kernel's register count)
+        const float rev = (ebq - 1.57079637050628662109375f) * 0.15915494309189535f;
+        el = det_elevation(c, ebq, __builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
+      } else {
+        el = fmaf(c.slope, ebq - c.ebm, ebq + c.dm);
+      }
+      const float den = den_lookup(el, C, n_el, el_first, el_last, el_inv);
+      const float val = kInverse ? sv[q] * den : sv[q] * __builtin_amdgcn_rcpf(den);
+      o[0] = q == 0 ? val : o[0];
+      o[1] = q == 1 ? val : o[1];
+      o[2] = q == 2 ? val : o[2];
+      o[3] = q == 3 ? val : o[3];
+    }
+    return;
+  }
   float e0, e3;
   if (c.exact) {  // uniform over the workgroup (one detector row at a time), and rare
-    e0 = det_elevation(c, k.eb0, k.ca0, k.sa0);
-    e3 = det_elevation(c, k.eb3, k.ca3, k.sa3);
+    // (sine and cosine of the boresight elevation on the spot, by the hardware instructions in revolutions -- 1e-6 rad,
+    // where den hardly moves with the elevation: kept per thread for every row they were four registers of a kernel
+    // that sits at a wave-per-SIMD boundary)
+    const float r0 = (k.eb0 - 1.57079637050628662109375f) * 0.15915494309189535f, r3 = (k.eb3 - 1.57079637050628662109375f) * 0.15915494309189535f;
+    e0 = det_elevation(c, k.eb0, __builtin_amdgcn_cosf(r0), __builtin_amdgcn_sinf(r0));
+    e3 = det_elevation(c, k.eb3, __builtin_amdgcn_cosf(r3), __builtin_amdgcn_sinf(r3));
   } else {
     e0 = fmaf(c.slope, k.x0, k.eb0 + c.dm);
     e3 = fmaf(c.slope, k.x3, k.eb3 + c.dm);
@@ -842,15 +875,6 @@ __device__ __forceinline__ void krj_row(const CalDet& c, const float4* C, int n_
   }
 }
 
-// the trigonometry the exact path needs
-__device__ __forceinline__ void krj_exact_trig(KrjSamples& k) {
-  const float a0 = k.eb0 - 1.57079637050628662109375f, a3 = k.eb3 - 1.57079637050628662109375f;
-  k.ca0 = cosf(a0);  // = sin(el_bore) up to the rounding of float32(pi/2)
-  k.sa0 = sinf(a0);  // = -cos(el_bore)
-  k.ca3 = cosf(a3);
-  k.sa3 = sinf(a3);
-}
-
 // Shared prologue of the two K_RJ kernels, per workgroup: stage the cell table, reduce the
 // boresight elevation range of the tile's 1024 samples (red[8] = lo, red[9] = hi) and return
 // this thread's sample constants.  Ends with a barrier.
@@ -860,9 +884,18 @@ __device__ __forceinline__ KrjSamples krj_prologue(float4* cells, float* red, co
   KrjSamples k;
   k.eb0 = bore_el[min(sb, T - 1)];
   k.eb3 = bore_el[min(sb + kSamplesPerThread - 1, T - 1)];
+  float eb_lo, eb_hi;
+  {
+    static_assert(kSamplesPerThread == 4, "the curvature check below is written for four samples");
+    const float eb1 = bore_el[min(sb + 1, T - 1)], eb2 = bore_el[min(sb + 2, T - 1)];
+    const float third = (k.eb3 - k.eb0) * (1.0f / 3.0f);
+    k.curved = !(fabsf(eb1 - (k.eb0 + third)) <= 1.0e-6f && fabsf(eb2 - (k.eb0 + 2.0f * third)) <= 1.0e-6f);  // (a NaN: per sample too)
+    eb_lo = fminf(fminf(k.eb0, eb1), fminf(eb2, k.eb3));
+    eb_hi = fmaxf(fmaxf(k.eb0, eb1), fmaxf(eb2, k.eb3));
+  }
   // (the samples are monotone enough that the ends of the threads' 4-sample runs bound the
   // range to ~1e-7 rad): lanes -> waves -> workgroup
-  float lo = fminf(k.eb0, k.eb3), hi = fmaxf(k.eb0, k.eb3);
+  float lo = eb_lo, hi = eb_hi;
 #pragma unroll
   for (int m = 32; m > 0; m >>= 1) {
     lo = fminf(lo, __shfl_xor(lo, m, 64));
@@ -879,12 +912,11 @@ __device__ __forceinline__ KrjSamples krj_prologue(float4* cells, float* red, co
   const float ebm = 0.5f * (lo + hi);
   k.x0 = k.eb0 - ebm;
   k.x3 = k.eb3 - ebm;
-  krj_exact_trig(k);  // few tiles need it, but computing it under a (uniform) branch costs more than it saves
   if (threadIdx.x == 0) {
     red[8] = lo;
     red[9] = hi;
   }
-  __syncthreads();
+  k.curved = __syncthreads_or(k.curved);  // (the barrier this prologue ends with)
   return k;
 }
 
@@ -912,7 +944,19 @@ __device__ __forceinline__ void krj_stage_rows(CalDet* cdet, float* red, const f
   }
 }
 
-__global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
+// the static part of the K_RJ writer's LDS, carved from the dynamic buffer behind the cell table (with a static size the
+// compiler derives the occupancy from it and ignores the register bound below, as for the fused writer)
+struct KrjWriterLds {
+  static constexpr int kMaxKnots = 64, kPitch = kMaxKnots + 1;
+  float2 tile[kTileDet * kPitch];
+  CalDet cdet[kTileDet];
+  float red[12];
+  int row_lds[kTileDet];
+};
+
+// 5 waves per SIMD = 96 registers: the evaluation loop needs 95; the per-sample instance of the loop (KrjSamples::curved,
+// rare) would take the kernel to 98 and a wave per SIMD away (K_RJ writer 2.6 -> 3.0 ms), so it spills what is over
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) void spline_upsample_krj_kernel(
     const float2* __restrict__ ym, int D, int n, double ta0, double inv_dta,
     const double* __restrict__ t, int T, const float* __restrict__ scale,
     const int32_t* __restrict__ rows, const float* __restrict__ bore_el,
@@ -920,13 +964,14 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
     const int32_t* __restrict__ band, const float* __restrict__ cal_axis,
     const float* __restrict__ cal_values, int n_el, int n_bands,
     float* __restrict__ out, size_t ld, int vec_ok, int groups) {
-  constexpr int kMaxKnots = 64;  // 8 KiB image: the arithmetic of this writer wants the occupancy
-  constexpr int kPitch = kMaxKnots + 1;
-  extern __shared__ __align__(16) float4 cal_cells[];  // [n_bands][n_el - 1], see stage_cal_cells
-  __shared__ float2 tile[kTileDet * kPitch];
-  __shared__ CalDet cdet[kTileDet];
-  __shared__ float red[12];
-  __shared__ int row_lds[kTileDet];  // destination rows of the group (see spline_upsample_kernel)
+  constexpr int kMaxKnots = KrjWriterLds::kMaxKnots;  // 8 KiB image: the arithmetic of this writer wants the occupancy
+  constexpr int kPitch = KrjWriterLds::kPitch;
+  extern __shared__ __align__(16) float4 cal_cells[];  // [n_bands][n_el - 1], see stage_cal_cells; then KrjWriterLds
+  KrjWriterLds& L = *reinterpret_cast<KrjWriterLds*>(cal_cells + (size_t)n_bands * (n_el - 1));
+  float2* tile = L.tile;
+  CalDet* cdet = L.cdet;
+  float* red = L.red;
+  int* row_lds = L.row_lds;  // destination rows of the group (see spline_upsample_kernel)
   auto row_of = [&](int dl, int d) -> size_t { return rows ? (size_t)row_lds[dl] : (size_t)d; };
 
   const int s_tile = blockIdx.x * kTileSamples;
@@ -969,7 +1014,7 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
     __syncthreads();
     // the loop body is instantiated once per knot source so that each instance
     // addresses one memory space (a runtime select would force flat loads)
-    auto body = [&](auto from_lds) {
+    auto body = [&](auto from_lds, auto curved) {
     for (int dl = 0; dl < nd; ++dl) {
       const CalDet c = cdet[dl];
       const float4* C = cal_cells + c.band * (n_el - 1);
@@ -986,7 +1031,7 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
         }
         sv[q] = c.scale * spline_eval(w, q, k0, k1);
       }
-      krj_row(c, C, n_el, el_first, el_last, el_inv, ks, sv, o);
+      krj_row<false, decltype(curved)::value>(c, C, n_el, el_first, el_last, el_inv, ks, sv, o, bore_el, sb, T);
       float* dst = out + row_of(dl, d0 + dl) * ld + sb;
       if (full) {
         const vfloat4 v = {o[0], o[1], o[2], o[3]};
@@ -998,7 +1043,11 @@ __global__ __launch_bounds__(kBlock) void spline_upsample_krj_kernel(
       }
     }
     };
-    if (use_lds) body(std::true_type{}); else body(std::false_type{});
+    if (ks.curved) {  // (uniform)
+      if (use_lds) body(std::true_type{}, std::true_type{}); else body(std::false_type{}, std::true_type{});
+    } else {
+      if (use_lds) body(std::true_type{}, std::false_type{}); else body(std::false_type{}, std::false_type{});
+    }
   }
 }
 
@@ -1066,6 +1115,7 @@ __global__ __launch_bounds__(kBlock) void tod_krj_kernel(
   const float el_first = cal_cells[0].x, el_last = cal_axis[n_el - 1];
   const float el_inv = cal_cells[0].z;
   const bool full = (sb + kSamplesPerThread <= T) && vec_ok;
+  auto rows_loop = [&](auto curved) {
   for (int dl = 0; dl < nd; ++dl) {
     const CalDet c = cdet[dl];
     const float4* C = cal_cells + c.band * (n_el - 1);
@@ -1081,7 +1131,7 @@ __global__ __launch_bounds__(kBlock) void tod_krj_kernel(
     float sv[kSamplesPerThread];
 #pragma unroll
     for (int q = 0; q < kSamplesPerThread; ++q) sv[q] = c.scale * v[q];
-    krj_row<kInverse>(c, C, n_el, el_first, el_last, el_inv, ks, sv, v);
+    krj_row<kInverse, decltype(curved)::value>(c, C, n_el, el_first, el_last, el_inv, ks, sv, v, bore_el, sb, T);
     if (full) {
       const vfloat4 x = {v[0], v[1], v[2], v[3]};
       __builtin_nontemporal_store(x, reinterpret_cast<vfloat4*>(row));
@@ -1091,6 +1141,8 @@ __global__ __launch_bounds__(kBlock) void tod_krj_kernel(
         if (sb + q < T) row[q] = v[q];
     }
   }
+  };
+  if (ks.curved) rows_loop(std::true_type{}); else rows_loop(std::false_type{});  // (uniform)
 }
 
 
@@ -1328,7 +1380,7 @@ int mrx_spline_upsample_krj(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
   MRX_REQUIRE(ctx, grid.y <= 65535u, "D too large for one launch");
   const int vec_ok =
       (ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15u) == 0);
-  const size_t lds = sizeof(float4) * (size_t)(n_el - 1) * n_bands;  // the cell table
+  const size_t lds = sizeof(float4) * (size_t)(n_el - 1) * n_bands + sizeof(KrjWriterLds);  // the cell table, the knot image
   MRX_LDS_CAP(ctx, spline_upsample_krj_kernel, lds);
   hipLaunchKernelGGL(spline_upsample_krj_kernel, grid, dim3(kBlock), lds,
                      ctx->stream, reinterpret_cast<const float2*>(d_ym), D, Ta,

@@ -465,10 +465,42 @@ class DevicePath:
 
     def upsample_fused(self, out, krj=False):
         """mrx_spline_upsample_fused: spline solve + evaluation of the coarse loading in one
-        kernel (no (y, m) buffer; ``krj``: of the coarse loading coarse_to_krj() made)."""
+        kernel (no (y, m) buffer; ``krj``: of the coarse loading coarse_to_krj() made -- up to the last
+        knot; the samples the reference extrapolates beyond it are divided one by one, _krj_tail)."""
+        n_main = self._krj_split() if krj else self.T
         self.ctx.call(
             "mrx_spline_upsample_fused", ptr(self.d_loading_krj if krj else self.d_loading), self.D, self.Ta, self.ta0, self.dta,
-            ptr(self.d_t), self.T, ptr(self.d_gain), ptr(self.d_rows), ptr(out), out.stride(0),
+            ptr(self.d_t), n_main, ptr(self.d_gain), ptr(self.d_rows), ptr(out), out.stride(0),
+        )
+        if krj and n_main < self.T:
+            k = self._krj_tail_knots()
+            self._krj_tail(self.d_loading[self.Ta - k :], self.D, slice(0, self.D), out, ptr(self.d_rows), self.ctx)
+
+    def _krj_split(self):
+        """Samples up to the last coarse knot.  Past it the reference EXTRAPOLATES its spline of the loading and divides
+        by the true denominator; the coarse-grid form would extrapolate loading / denominator instead, and an extrapolated
+        cubic misses the denominator's motion by 50x what an interior interval does (9e-5 in the last four samples of a
+        tight fast scan, found by the randomised front-end sweep) -- so those samples, at most one coarse step of them,
+        take the per-sample form: the two-call spline of the last knots and mrx_spline_upsample_krj on that window."""
+        if getattr(self, "_n_main", None) is None:
+            self._n_main = int(np.searchsorted(np.asarray(self.problem["t"], float)[: self.T], float(self.problem["ta"][-1]), side="right"))
+        return self._n_main
+
+    def _krj_tail_knots(self):
+        return min(self.Ta, 48)  # the end of the spline forgets knots farther back as 0.268^k
+
+    def _krj_tail(self, y_tail, n, rows, out, d_rows, ctx):
+        """The samples past the last knot in K_RJ, per sample: ``y_tail`` the last _krj_tail_knots() knots of the coarse
+        loading in pW ([k, n], contiguous) of the detector rows ``rows`` (internal order)."""
+        c = self._cal
+        k, s0 = self._krj_tail_knots(), self._krj_split()
+        ym = torch.empty((k, n, 2), dtype=torch.float32, device=self.device)
+        ctx.call("mrx_spline_prepare", ptr(y_tail), n, k, ptr(ym))
+        dst = out[:, s0:] if d_rows.value else out[rows, s0:]
+        ctx.call(
+            "mrx_spline_upsample_krj", ptr(ym), n, k, float(self.problem["ta"][self.Ta - k]), self.dta, ptr(self.d_t[s0:]), self.T - s0,
+            None if self.d_gain is None else ptr(self.d_gain[rows]), d_rows, ptr(c["bore_el"][s0:]), ptr(c["dx"][rows]), ptr(c["dy"][rows]),
+            ptr(self.d_band[rows]), ptr(c["axis"]), ptr(c["values"]), c["n_el"], c["n_bands"], ptr(dst), out.stride(0),
         )
 
     def set_gain(self, gain):
@@ -625,7 +657,12 @@ class DevicePath:
                 sl(self.d_dx, lo, hi), sl(self.d_dy, lo, hi), sl(self.d_band, lo, hi), sl(self.d_m00, lo, hi), n,
                 self.pwv0, None, ptr(st["loading"][i]), ptr(self.d_flags),
             )
-            if krj:  # TOD.to("K_RJ") on the coarse grid: the writer below then writes K_RJ at the pW writer's cost
+            if krj and krj != "sample":  # TOD.to("K_RJ") on the coarse grid: the writer below then writes K_RJ at the pW writer's cost
+                if self._krj_split() < self.T:  # (the samples past the last knot: per sample, from the loading in pW,
+                    if "tail" not in st:        #  in one pass over all rows after the last block)
+                        st["tail"] = torch.empty((self._krj_tail_knots(), self.D), dtype=torch.float32, device=self.device)
+                    with torch.cuda.stream(side):
+                        st["tail"][:, lo:hi].copy_(st["loading"][i][self.Ta - self._krj_tail_knots() :])
                 self.coarse_to_krj(st["loading"][i], n, slice(lo, hi), ctx2)
             if serial:
                 tev[1].record(main)
@@ -641,8 +678,9 @@ class DevicePath:
                 ev[0].record(main)
             self.ctx.call(
                 "mrx_spline_upsample_fused", ptr(st["loading"][i]), n, self.Ta, self.ta0, self.dta,
-                ptr(self.d_t), self.T, sl(self.d_gain, lo, hi), rows, ptr(dst), out.stride(0),
+                ptr(self.d_t), self._krj_split() if krj else self.T, sl(self.d_gain, lo, hi), rows, ptr(dst), out.stride(0),
             )
+
             if writer_events is not None:
                 ev[1].record(main)
                 writer_events.append(ev)
@@ -651,6 +689,9 @@ class DevicePath:
                 serial_events.append(tev)
         ctx2.set_option(_lib.OPT_SAMPLE_WGS_PER_CU, saved[0])
         ctx2.set_option(_lib.OPT_SAMPLE_TIMES, saved[1])
+        if krj and krj != "sample" and self._krj_split() < self.T:
+            # (the copies into st["tail"] precede each block's ready event on the side stream, and main has waited for every one)
+            self._krj_tail(st["tail"], self.D, slice(0, self.D), out, ptr(self.d_rows), self.ctx)
         self._pipelined = True
         self._pwv_stale = True
         return out
@@ -740,9 +781,20 @@ class DevicePath:
         rel_slope = (np.abs(slope[:, cells]) / np.minimum(np.abs(den[:, 1:]), np.abs(den[:, :-1]))[:, cells]).max()
         step = np.abs(np.diff(el)).max()
         d4 = np.abs(np.diff(el, n=4)).max()
+        # Samples BEFORE the first knot (none in the reference, whose coarse grid starts at the first sample) would be
+        # EXTRAPOLATED by both forms, and the cubic's error on g at a distance
+        # delta h beyond the end is delta (delta+1) (delta+2) (delta+3) / 24 times h^4 d4g/dt4 -- 0.95 at delta = 1
+        # against the 5/384 of an interior interval -- and a kink there is missed by delta x (slope jump) x h.  (A
+        # randomised sweep found the form 9e-5 off in the last four samples of a tight, fast scan: a 0.13 deg daisy
+        # at 0.6 deg/s, 12 knots per turn.)
+        t, ta = np.asarray(self.problem["t"], float), np.asarray(self.problem["ta"], float)
+        h = (ta[-1] - ta[0]) / max(len(ta) - 1, 1)
+        delta = max(0.0, (ta[0] - t.min()) / h) if len(t) else 0.0  # (past the last knot the samples are divided one by one)
+        smooth = max(5.0 / 384.0, delta * (delta + 1) * (delta + 2) * (delta + 3) / 24.0)
+        kink = max(self.SPLINE_KINK, delta)
         # + 4e-7: the two forms round differently in float32 (and the per-sample writer interpolates
         # the reciprocal over 4 samples)
-        return float(1.1 * (self.SPLINE_KINK * rel_jump * step + (5.0 / 384.0) * rel_slope * d4) + 4e-7)
+        return float(1.1 * (kink * rel_jump * step + smooth * rel_slope * d4) + 4e-7)
 
     def coarse_to_krj(self, loading=None, n=None, rows=slice(None), ctx=None):
         """mrx_coarse_to_krj on the coarse loading (``loading``: a block's [Ta, n] buffer, in

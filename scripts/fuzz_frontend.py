@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Development aid: randomised instruments, scans and atmospheres through Simulation.run() against the oracle chain on the
+downloaded screens (pW and K_RJ, gains, detector shards, both turbulence spectra, 1-6 layers).
+Usage: python scripts/fuzz_frontend.py [seed] [trials]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from maria_amd.instrument import Band, Detectors, Instrument, Site
+from maria_amd.sim import Plan, Simulation
+from oracle import hotpath
+
+seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
+trials = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+rng = np.random.default_rng(seed)
+bad = 0
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - np.asarray(b, np.float64)).max() / max(np.abs(b).max(), 1e-300))
+
+
+for trial in range(trials):
+    n_bands = int(rng.integers(1, 3))
+    centers = [93e9, 150e9, 220e9]
+    bands = [Band(center=centers[b], width=0.25 * centers[b], shape="top_hat", name=f"b{b}", gain_error=float(rng.choice([0.0, 0.05]))) for b in range(n_bands)]
+    n = int(rng.integers(7, 400))
+    inst = Instrument(Detectors.hexagon(n, float(rng.uniform(0.05, 1.0)), bands, primary_size=float(rng.uniform(3.0, 30.0))))
+    plan = Plan.daisy(start_time=1.7e9, duration=float(rng.uniform(8.0, 60.0)), sample_rate=float(rng.choice([20.0, 50.0, 100.0])),
+                      scan_center=(float(rng.uniform(0, 360)), float(rng.uniform(30.0, 70.0))), radius=float(rng.uniform(0.1, 0.8)), speed=float(rng.uniform(0.2, 0.8)))
+    units = str(rng.choice(["pW", "K_RJ"]))
+    spectrum = str(rng.choice(["covariance", "power_law"]))
+    kw = {"n_layers": int(rng.integers(1, 7)), "seed": int(rng.integers(1, 1 << 30)), "weather": {"pwv": float(rng.uniform(0.3, 3.0))}, "turbulence_spectrum": spectrum}
+    try:
+        sim = Simulation(inst, plan, Site(altitude=float(rng.uniform(0.0, 5000.0)), region="synthetic"), atmosphere="2d", atmosphere_kwargs=kw, noise=False,
+                         gain_seed=int(rng.integers(1, 1000)))
+        (tod,) = sim.run(units=units)
+    except Exception as exc:  # noqa: BLE001
+        bad += 1
+        print(f"trial {trial}: n={inst.dets.n} bands={n_bands} {units} {spectrum} layers={kw['n_layers']}: {type(exc).__name__}: {exc} BAD", flush=True)
+        continue
+    data = tod.data["atmosphere"]
+    obs = sim.obs_list[0]
+    atm, dets = obs.atmosphere, inst.dets
+    path = atm._device_path()
+    layers = [dict(atm.processes[l], values=bufs[0].cpu().numpy()) for l, bufs in zip(sorted(atm.processes), path._layer_bufs)]
+    p = dict(t=obs.coords.t, ta=atm.boresight.t, az_a=atm.boresight.az, el_a=atm.boresight.el, offsets=dets.offsets, band_index=dets.band_index,
+             m00=dets.mueller00(), layers=layers, tables=atm._tables(dets), T0=float(atm.weather.temperature[0]), pwv0=float(atm.weather.pwv),
+             timestep=float(atm.timestep), gain=None)
+    ref = hotpath.run_path(p)
+    if units == "K_RJ":
+        sp = atm.spectrum
+        tables = [{"T": sp.side_base_temperature, "pwv": sp.side_zenith_pwv, "el": sp.side_elevation,
+                   "values": hotpath.transmission_integral_grid(b.passband, sp.side_nu, sp._opacity)} for b in dets.bands]
+        _, el_det = hotpath.broadcast(obs.coords.offsets, obs.boresight.az, obs.boresight.el)
+        ref = hotpath.calibrate_to_krj(ref, dets.band_index, tables, tod.metadata["base_temperature"], tod.metadata["pwv"], el_det)
+    T = data.shape[1]
+    gain = np.median(data / ref, axis=1)  # the per-detector gain error, exp(0.05 N(0,1)) or 1
+    err = rel(data, ref * gain[:, None])
+    ok = err <= 2e-5 and np.isfinite(data).all() and 0.7 < gain.min() and gain.max() < 1.4
+    bad += not ok
+    if not ok and units == "K_RJ":  # which form of the conversion it was
+        bound = path.coarse_krj_bound()
+        print(f"   coarse-form bound {bound:.2e} (limit {path.COARSE_KRJ_LIMIT:.0e}: {'coarse grid' if bound <= path.COARSE_KRJ_LIMIT else 'per sample'}); "
+              f"elevation step per knot {np.abs(np.diff(atm.boresight.el)).max():.2e} rad, scan el range {np.ptp(atm.boresight.el):.3f} rad", flush=True)
+    print(f"trial {trial}: n={dets.n} bands={n_bands} T={T} Ta={len(atm.boresight.t)} layers={kw['n_layers']} {units} {spectrum}: {err:.2e} "
+          f"gain {gain.min():.3f}..{gain.max():.3f} {'ok' if ok else 'BAD'}", flush=True)
+    del sim, tod
+print("BAD" if bad else "all ok", bad)

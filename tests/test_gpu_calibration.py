@@ -152,6 +152,14 @@ def test_coarse_krj_form_stays_within_its_bound(gpu_ctx):
     dev = float(((got - ref).abs() / ref.abs()).max())
     assert dev <= bound, (dev, bound)
     assert dev > 0  # it IS another order of operations: not bit-identical
+    # past the last knot the reference extrapolates its spline and divides by the true denominator: the coarse form does
+    # NOT extrapolate loading / denominator there (an extrapolated cubic misses the denominator 50x worse than an
+    # interior interval: 9e-5 in the last samples of a tight fast scan, found by scripts/fuzz_frontend.py) but divides
+    # those samples one by one -- the per-sample writer on the last knots' window: the same values to rounding
+    s0 = path._krj_split()
+    assert 0 < s0 < path.T
+    tail = float(((got[:, s0:] - ref[:, s0:]).abs() / ref[:, s0:].abs()).max())
+    assert tail <= 5e-7, tail  # (measured 2e-7: a float32 ulp or two)
     # refused: a table whose axis the focal plane may leave, the zenith, an elevation slew of 1 deg per knot
     low = [dict(t, el=np.radians(np.linspace(59.5, 90.1, 33))) for t in tables]
     path.set_calibration(low, 273.15, 1.0, el_full, p["offsets"] @ R.T, [False, True])
