@@ -53,8 +53,9 @@ def simulate_noise(ctx, dets, T, sample_rate, seed, noise_kwargs=None, device="c
     ``dets`` is a ``maria_amd.instrument.Detectors``; bands carry ``NEP`` (W sqrt(s)), ``knee``
     (Hz) and ``NEP_per_loading``; ``loading`` is the [ndet, T] float32 device tensor of the summed
     loadings in pW, needed only by bands whose NEP grows with it (noise.py:35-37).
-    ``det_slice``: generate only these rows of every band-major table (a detector shard, even
-    start): a shard's rows equal the same rows of the unsharded call, modes included."""
+    ``det_slice``: generate only these rows of every band-major table (a detector shard; it may
+    begin or end inside a detector pair): a shard's rows equal the same rows of the unsharded call,
+    modes included."""
     kw = dict(DEFAULT_NOISE_SIM_KWARGS)
     kw.update(noise_kwargs or {})
     dev = torch.device(device)
@@ -72,8 +73,6 @@ def simulate_noise(ctx, dets, T, sample_rate, seed, noise_kwargs=None, device="c
         if last <= first:
             continue
         offset = first - int(idx[0])  # index within the band: what the draws are keyed by
-        if offset % 2:
-            raise ValueError("a detector shard must start at an even row of each band (the pink series come in pairs)")
         per_loading = float(getattr(band, "NEP_per_loading", 0.0))
         if per_loading and loading is None:
             raise ValueError(f"band {band.name} has NEP_per_loading != 0: pass the summed loading (sim/noise.py:35-37)")
@@ -90,20 +89,46 @@ def simulate_noise(ctx, dets, T, sample_rate, seed, noise_kwargs=None, device="c
             else:
                 basis = np.ones((len(idx), 1))
             cache[key] = basis
-        basis = basis[offset : offset + last - first]
         count = last - first
-        d_basis = torch.as_tensor(np.ascontiguousarray(basis, np.float32)).to(dev)
-        d_scale = torch.full((count,), float(1e12 * band.NEP), dtype=torch.float32, device=dev)  # noise.py:62
         n_modes = basis.shape[1]
         need = C.c_size_t()
         ctx.lib.mrx_noise_work_floats(int(T), int(n_modes), int(min(batch, count)), C.byref(need))
         work = torch.empty(need.value, dtype=torch.float32, device=dev)
+
+        def generate(row0, n_rows, dst, dst_loading):
+            """rows row0 .. row0 + n_rows - 1 of the band (row0 even: the pink series come in pairs) into ``dst``"""
+            d_basis = torch.as_tensor(np.ascontiguousarray(basis[row0 : row0 + n_rows], np.float32)).to(dev)
+            d_scale = torch.full((n_rows,), float(1e12 * band.NEP), dtype=torch.float32, device=dev)  # noise.py:62
+            ctx.call(
+                "mrx_noise_generate", int(seed) + 7919 * b, n_rows, row0, int(T), float(sample_rate), float(band.knee),
+                float(kw.get("correlated_noise_proportion", 0)), ptr(d_basis), int(n_modes), ptr(d_scale),
+                ptr(dst_loading) if per_loading else None, dst_loading.stride(0) if per_loading else 0,
+                1e12 * per_loading, ptr(dst), dst.stride(0), 0, ptr(work), need.value,
+            )
+
         view = out[first - lo : last - lo]
-        ctx.call(
-            "mrx_noise_generate", int(seed) + 7919 * b, count, offset, int(T), float(sample_rate), float(band.knee),
-            float(kw.get("correlated_noise_proportion", 0)), ptr(d_basis), int(n_modes), ptr(d_scale),
-            ptr(loading[first - lo : last - lo]) if per_loading else None, loading.stride(0) if per_loading else 0,
-            1e12 * per_loading, ptr(view), out.stride(0), 0, ptr(work), need.value,
-        )
+        lview = loading[first - lo : last - lo] if per_loading else None
+        start = 0
+        if offset % 2:
+            # the shard begins on the second detector of a pair: that pair is drawn whole into two scratch rows (its first
+            # detector belongs to the neighbouring shard, which draws the same pair) and the second row kept
+            pair = torch.empty((2, T), dtype=torch.float32, device=dev)
+            pl = None
+            if per_loading:  # the first row's loading is not ours: any finite values do for a row that is dropped
+                pl = torch.stack([lview[0], lview[0]])
+            generate(offset - 1, 2, pair, pl)
+            view[0].copy_(pair[1])
+            start = 1
+        # ... and likewise when it ends on the FIRST detector of a pair whose second one exists (in the next shard): drawn
+        # alone, that row would get the same draws but another rounding (the pair's two rows share one complex transform)
+        stop = count
+        if (offset + count) % 2 and offset + count < len(idx) and count > start:
+            pair = torch.empty((2, T), dtype=torch.float32, device=dev)
+            pl = torch.stack([lview[count - 1], lview[count - 1]]) if per_loading else None
+            generate(offset + count - 1, 2, pair, pl)
+            view[count - 1].copy_(pair[0])
+            stop = count - 1
+        if stop > start:
+            generate(offset + start, stop - start, view[start:stop], None if lview is None else lview[start:stop])
         del work
     return out

@@ -737,7 +737,9 @@ class DevicePath:
             axis=_dev(el_axis, torch.float32, dev), values=_dev(dens, torch.float32, dev), n_el=len(el_axis), n_bands=nb,
             bore_el=_dev(bore_el, torch.float32, dev), dx=_dev(off[:, 0], torch.float32, dev), dy=_dev(off[:, 1], torch.float32, dev),
             axis_np=el_axis.astype(np.float32).astype(np.float64), values_np=dens.astype(np.float64),
-            radius=float(np.hypot(off[:, 0], off[:, 1]).max()) if len(off) else 0.0,
+            # (of the WHOLE focal plane, not of this shard's rows: which form of the conversion a run takes must not
+            # depend on how its detectors are sharded -- shards are bit-identical to the unsharded rows)
+            radius=float(np.hypot(*np.asarray(coords_offsets, float).T).max()) if len(coords_offsets) else 0.0,
         )
 
     # the coarse-grid form of the K_RJ conversion is taken when this estimate of its deviation from the

@@ -65,5 +65,32 @@ for trial in range(trials):
               f"elevation step per knot {np.abs(np.diff(atm.boresight.el)).max():.2e} rad, scan el range {np.ptp(atm.boresight.el):.3f} rad", flush=True)
     print(f"trial {trial}: n={dets.n} bands={n_bands} T={T} Ta={len(atm.boresight.t)} layers={kw['n_layers']} {units} {spectrum}: {err:.2e} "
           f"gain {gain.min():.3f}..{gain.max():.3f} {'ok' if ok else 'BAD'}", flush=True)
+    # a detector shard of the same simulation, with the noise on: every field the same rows bit for bit, and the
+    # round trip through the other unit within float32
+    if rng.random() < 0.5 and dets.n >= 48:
+        from maria_amd.dist import shard_bounds
+
+        world = int(rng.integers(2, 5))
+        rank = int(rng.integers(0, world))
+        common = dict(atmosphere="2d", atmosphere_kwargs=kw, noise=True, gain_seed=7, noise_seed=int(rng.integers(1, 1000)))
+        try:
+            (full,) = Simulation(inst, plan, sim.site, **common).run(units=units)
+            (part,) = Simulation(inst, plan, sim.site, shard=(rank, world), **common).run(units=units)
+            lo, hi = shard_bounds(dets.n, world, rank)
+            same = [f for f in ("atmosphere", "noise") if not np.array_equal(part.data[f], full.data[f][lo:hi])] or True
+            other = "pW" if units == "K_RJ" else "K_RJ"
+            back = part.to(other).to(units)
+            rt = max(rel(back.data[f], part.data[f]) for f in ("atmosphere", "noise"))
+            ok2 = same is True and rt < 2e-6 and np.isfinite(full.data["noise"]).all()
+        except Exception as exc:  # noqa: BLE001
+            ok2, same, rt = False, f"{type(exc).__name__}: {exc}", float("nan")
+        bad += not ok2
+        print(f"   shard {rank}/{world} with noise: rows identical {same}, unit round trip {rt:.1e} {'ok' if ok2 else 'BAD'}", flush=True)
+        if not ok2 and same is not True and not isinstance(same, str):
+            starts = [int(np.nonzero(dets.band_index == b)[0][0]) for b in range(n_bands)]
+            d = np.abs(part.data["noise"] - full.data["noise"][lo:hi])
+            rows_bad = np.nonzero(d.max(axis=1) > 0)[0]
+            print(f"      {units}; rows [{lo}, {hi}); bands start at {starts}, n = {dets.n}; differing shard rows {rows_bad[:8]} ... ({len(rows_bad)}), "
+                  f"max |diff| / max |noise| {d.max() / np.abs(full.data['noise']).max():.2e}", flush=True)
     del sim, tod
 print("BAD" if bad else "all ok", bad)

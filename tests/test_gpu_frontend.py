@@ -183,16 +183,19 @@ def test_reference_atmosphere_test_case_zenith_stare(gpu_ctx):
     assert rel_err(k, ref) <= 1e-5
 
 
-@pytest.mark.parametrize("units", ["pW", "K_RJ"])
-def test_sharded_simulation_rows_equal_the_unsharded_run(gpu_ctx, units):
+@pytest.mark.parametrize("units,n", [("pW", 64), ("K_RJ", 64), ("K_RJ", 61)])
+def test_sharded_simulation_rows_equal_the_unsharded_run(gpu_ctx, units, n):
     """Simulation(shard=(rank, world)) simulates its block of detector rows only: atmosphere, map
     and noise fields of every shard are the same rows of the unsharded run, bit for bit (no
-    cross-detector term: atmosphere/atmosphere.py:346-373; draws keyed by the global row)."""
+    cross-detector term: atmosphere/atmosphere.py:346-373; draws keyed by the global row).
+    n = 61: bands of odd size, so that shards begin and end inside the detector pairs that share a noise
+    transform (the straddling pair is drawn whole on both sides: a randomised sweep found the lone row
+    1e-7 off), and the choice between the two K_RJ forms must not depend on the shard's own detectors."""
     from maria_amd import map as mmap
     from maria_amd.dist import shard_bounds
     from maria_amd.sim import Simulation
 
-    inst, plan, site = _setup(n=64, duration=20.0)  # 2 bands x 64: shards cut through band 1 and 2
+    inst, plan, site = _setup(n=n, duration=20.0)  # 2 bands x n: shards cut through band 1 and 2
     X, Y = np.meshgrid(np.linspace(-1, 1, 48), np.linspace(-1, 1, 48))
     sky = mmap.ProjectionMap(0.02 * np.exp(-(X**2 + Y**2) / 0.05).astype(np.float32), nu=120e9, width=1.5, center=(45.0, 55.0), frame="az/el")
     kw = dict(atmosphere="2d", atmosphere_kwargs={"seed": 3, "n_layers": 3}, map=sky, noise=True, gain_seed=11, noise_seed=77)
