@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Development aid: randomised instruments, scans and atmospheres through Simulation.run() against the oracle chain on the
-downloaded screens (pW and K_RJ, gains, detector shards, both turbulence spectra, 1-6 layers).
+downloaded screens (pW and K_RJ, gains, detector shards with the noise on, both turbulence spectra, 1-6 layers or the 3-D model, both
+interpolation methods).
 Usage: python scripts/fuzz_frontend.py [seed] [trials]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -30,23 +31,29 @@ for trial in range(trials):
                       scan_center=(float(rng.uniform(0, 360)), float(rng.uniform(30.0, 70.0))), radius=float(rng.uniform(0.1, 0.8)), speed=float(rng.uniform(0.2, 0.8)))
     units = str(rng.choice(["pW", "K_RJ"]))
     spectrum = str(rng.choice(["covariance", "power_law"]))
-    kw = {"n_layers": int(rng.integers(1, 7)), "seed": int(rng.integers(1, 1 << 30)), "weather": {"pwv": float(rng.uniform(0.3, 3.0))}, "turbulence_spectrum": spectrum}
+    model = "3d" if rng.random() < 0.3 else "2d"
+    method = "cubic" if rng.random() < 0.25 else "linear"
+    kw = {"seed": int(rng.integers(1, 1 << 30)), "weather": {"pwv": float(rng.uniform(0.3, 3.0))}, "turbulence_spectrum": spectrum, "interpolation_method": method}
+    if model == "3d":  # (a few hundred thin layers of one volume: kept low and short)
+        kw["max_height"] = float(rng.uniform(300.0, 2500.0))
+    else:
+        kw["n_layers"] = int(rng.integers(1, 7))
     try:
-        sim = Simulation(inst, plan, Site(altitude=float(rng.uniform(0.0, 5000.0)), region="synthetic"), atmosphere="2d", atmosphere_kwargs=kw, noise=False,
+        sim = Simulation(inst, plan, Site(altitude=float(rng.uniform(0.0, 5000.0)), region="synthetic"), atmosphere=model, atmosphere_kwargs=kw, noise=False,
                          gain_seed=int(rng.integers(1, 1000)))
         (tod,) = sim.run(units=units)
     except Exception as exc:  # noqa: BLE001
         bad += 1
-        print(f"trial {trial}: n={inst.dets.n} bands={n_bands} {units} {spectrum} layers={kw['n_layers']}: {type(exc).__name__}: {exc} BAD", flush=True)
+        print(f"trial {trial}: n={inst.dets.n} bands={n_bands} {units} {spectrum} {model} {method}: {type(exc).__name__}: {exc} BAD", flush=True)
         continue
     data = tod.data["atmosphere"]
     obs = sim.obs_list[0]
     atm, dets = obs.atmosphere, inst.dets
     path = atm._device_path()
-    layers = [dict(atm.processes[l], values=bufs[0].cpu().numpy()) for l, bufs in zip(sorted(atm.processes), path._layer_bufs)]
+    layers = [dict(l, values=bufs[0].cpu().numpy()) for l, bufs in zip(atm._layer_list(), path._layer_bufs)]
     p = dict(t=obs.coords.t, ta=atm.boresight.t, az_a=atm.boresight.az, el_a=atm.boresight.el, offsets=dets.offsets, band_index=dets.band_index,
              m00=dets.mueller00(), layers=layers, tables=atm._tables(dets), T0=float(atm.weather.temperature[0]), pwv0=float(atm.weather.pwv),
-             timestep=float(atm.timestep), gain=None)
+             timestep=float(atm.timestep), gain=None, interpolation_method=method)
     ref = hotpath.run_path(p)
     if units == "K_RJ":
         sp = atm.spectrum
@@ -63,7 +70,7 @@ for trial in range(trials):
         bound = path.coarse_krj_bound()
         print(f"   coarse-form bound {bound:.2e} (limit {path.COARSE_KRJ_LIMIT:.0e}: {'coarse grid' if bound <= path.COARSE_KRJ_LIMIT else 'per sample'}); "
               f"elevation step per knot {np.abs(np.diff(atm.boresight.el)).max():.2e} rad, scan el range {np.ptp(atm.boresight.el):.3f} rad", flush=True)
-    print(f"trial {trial}: n={dets.n} bands={n_bands} T={T} Ta={len(atm.boresight.t)} layers={kw['n_layers']} {units} {spectrum}: {err:.2e} "
+    print(f"trial {trial}: n={dets.n} bands={n_bands} T={T} Ta={len(atm.boresight.t)} {model} layers={len(layers)} {method} {units} {spectrum}: {err:.2e} "
           f"gain {gain.min():.3f}..{gain.max():.3f} {'ok' if ok else 'BAD'}", flush=True)
     # a detector shard of the same simulation, with the noise on: every field the same rows bit for bit, and the
     # round trip through the other unit within float32
@@ -72,7 +79,7 @@ for trial in range(trials):
 
         world = int(rng.integers(2, 5))
         rank = int(rng.integers(0, world))
-        common = dict(atmosphere="2d", atmosphere_kwargs=kw, noise=True, gain_seed=7, noise_seed=int(rng.integers(1, 1000)))
+        common = dict(atmosphere=model, atmosphere_kwargs=kw, noise=True, gain_seed=7, noise_seed=int(rng.integers(1, 1000)))
         try:
             (full,) = Simulation(inst, plan, sim.site, **common).run(units=units)
             (part,) = Simulation(inst, plan, sim.site, shard=(rank, world), **common).run(units=units)
