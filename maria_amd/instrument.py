@@ -92,7 +92,7 @@ class Detectors:
         self.band_index = np.zeros(self.n, np.int32) if band_index is None else np.asarray(band_index, np.int32)
         self.primary_size = np.broadcast_to(np.asarray(primary_size, float), (self.n,)).copy()
         self.gamma = np.full(self.n, np.nan) if gamma is None else np.asarray(gamma, float)
-        if self.band_index.shape != (self.n,) or self.band_index.min() < 0 or self.band_index.max() >= len(self.bands):
+        if self.band_index.shape != (self.n,) or (self.n and (self.band_index.min() < 0 or self.band_index.max() >= len(self.bands))):
             raise ValueError("band_index must map every detector to one of the bands")
 
     @classmethod

@@ -482,6 +482,19 @@ class Simulation:
                     "shard": None if rows is None else {"rank": self.shard[0], "world": self.shard[1], "rows": [lo, hi]}}
         has_atm = hasattr(obs, "atmosphere")
         device = torch.device(obs.atmosphere.device) if has_atm else torch.device(self.device)
+        if hi <= lo:
+            # a rank past the last block of rows (dist.shard_bounds cuts blocks of 16: 144 detectors on 4 ranks are
+            # 48 + 48 + 48 + 0): fields of no rows, and the random streams kept in step with the other ranks
+            if has_atm:
+                metadata.update(atmosphere=True, pwv=float(np.round(obs.atmosphere.weather.pwv, 3)),
+                                base_temperature=float(np.round(obs.atmosphere.weather.temperature[0], 3)))
+                obs.atmosphere._realisation += 1
+            names = [n for n, on in (("atmosphere", has_atm), ("map", self.map is not None), ("noise", self.noise)) if on]
+            empty = torch.empty((0, len(obs.coords.t)), dtype=torch.float32, device=device)
+            obs.loading = {n: (empty.clone() if self.device_output else empty.cpu().numpy()) for n in names}
+            tod = TOD(data=obs.loading, dets=dets, coords=obs.boresight.broadcast(obs.coords.offsets[lo:hi]), units=units, metadata=metadata)
+            tod._calibrator = lambda data, to_krj: {k: (v.clone() if isinstance(v, torch.Tensor) else v.copy()) for k, v in data.items()}
+            return tod
         # Bands whose NEP grows with the loading need the loadings in pW, WITHOUT the gain
         # error, before the noise is drawn (sim/noise.py:35-37 runs before simulation.py:239-247
         # multiplies the gain into the non-noise fields); gain and the K_RJ conversion are then

@@ -27,8 +27,25 @@ for trial in range(trials):
     bands = [Band(center=centers[b], width=0.25 * centers[b], shape="top_hat", name=f"b{b}", gain_error=float(rng.choice([0.0, 0.05]))) for b in range(n_bands)]
     n = int(rng.integers(7, 400))
     inst = Instrument(Detectors.hexagon(n, float(rng.uniform(0.05, 1.0)), bands, primary_size=float(rng.uniform(3.0, 30.0))))
-    plan = Plan.daisy(start_time=1.7e9, duration=float(rng.uniform(8.0, 60.0)), sample_rate=float(rng.choice([20.0, 50.0, 100.0])),
-                      scan_center=(float(rng.uniform(0, 360)), float(rng.uniform(30.0, 70.0))), radius=float(rng.uniform(0.1, 0.8)), speed=float(rng.uniform(0.2, 0.8)))
+    duration, fs = float(rng.uniform(8.0, 60.0)), float(rng.choice([20.0, 50.0, 100.0]))
+    az0 = float(rng.choice([0.0, 359.95, 180.0])) if rng.random() < 0.25 else float(rng.uniform(0, 360))  # (the wrap of the azimuth)
+    el0 = float(rng.uniform(25.0, 84.0))
+    pattern = str(rng.choice(["daisy", "daisy", "triangle", "lissajous", "stare"]))
+    if pattern == "daisy":
+        plan = Plan.daisy(start_time=1.7e9, duration=duration, sample_rate=fs, scan_center=(az0, min(el0, 70.0)), radius=float(rng.uniform(0.1, 0.8)), speed=float(rng.uniform(0.2, 0.8)))
+    else:  # boresight tracks given sample by sample (radians): a constant-elevation sweep with sharp turns, a Lissajous box, a stare
+        t = np.arange(1.7e9, 1.7e9 + duration, 1.0 / fs)
+        s_, A, B = t - t[0], np.radians(rng.uniform(0.1, 1.0)), np.radians(rng.uniform(0.05, 0.5))
+        if pattern == "triangle":
+            period = float(rng.uniform(4.0, 20.0))
+            az = np.radians(az0) + A * (2 * np.abs(2 * ((s_ / period) % 1.0) - 1) - 1) / np.cos(np.radians(el0))
+            el = np.full_like(t, np.radians(el0))
+        elif pattern == "lissajous":
+            az = np.radians(az0) + A * np.sin(2 * np.pi * s_ / rng.uniform(3.0, 15.0)) / np.cos(np.radians(el0))
+            el = np.radians(el0) + B * np.sin(2 * np.pi * s_ / rng.uniform(3.0, 15.0) + rng.uniform(0, 6.28))
+        else:
+            az, el = np.full_like(t, np.radians(az0)), np.full_like(t, np.radians(el0))
+        plan = Plan(t, az, el)
     units = str(rng.choice(["pW", "K_RJ"]))
     spectrum = str(rng.choice(["covariance", "power_law"]))
     model = "3d" if rng.random() < 0.3 else "2d"
@@ -38,13 +55,19 @@ for trial in range(trials):
         kw["max_height"] = float(rng.uniform(300.0, 2500.0))
     else:
         kw["n_layers"] = int(rng.integers(1, 7))
+    altitude = float(rng.uniform(0.0, 5000.0))
+    if rng.random() < 0.5:  # another wind (drift direction, ribbon length, time step) and ground temperature
+        from maria_amd.atmosphere import SyntheticWeather
+
+        kw["weather_profile"] = SyntheticWeather(base_altitude=altitude, pwv=kw["weather"]["pwv"], base_temperature=float(rng.uniform(270.0, 290.0)),
+                                                 wind_speed=float(rng.uniform(2.0, 30.0)), wind_direction_deg=float(rng.uniform(0, 360)))
     try:
-        sim = Simulation(inst, plan, Site(altitude=float(rng.uniform(0.0, 5000.0)), region="synthetic"), atmosphere=model, atmosphere_kwargs=kw, noise=False,
+        sim = Simulation(inst, plan, Site(altitude=altitude, region="synthetic"), atmosphere=model, atmosphere_kwargs=kw, noise=False,
                          gain_seed=int(rng.integers(1, 1000)))
         (tod,) = sim.run(units=units)
     except Exception as exc:  # noqa: BLE001
         bad += 1
-        print(f"trial {trial}: n={inst.dets.n} bands={n_bands} {units} {spectrum} {model} {method}: {type(exc).__name__}: {exc} BAD", flush=True)
+        print(f"trial {trial}: n={inst.dets.n} bands={n_bands} {units} {spectrum} {model} {method} {pattern} az {az0:.1f} el {el0:.1f}: {type(exc).__name__}: {exc} BAD", flush=True)
         continue
     data = tod.data["atmosphere"]
     obs = sim.obs_list[0]
@@ -70,7 +93,7 @@ for trial in range(trials):
         bound = path.coarse_krj_bound()
         print(f"   coarse-form bound {bound:.2e} (limit {path.COARSE_KRJ_LIMIT:.0e}: {'coarse grid' if bound <= path.COARSE_KRJ_LIMIT else 'per sample'}); "
               f"elevation step per knot {np.abs(np.diff(atm.boresight.el)).max():.2e} rad, scan el range {np.ptp(atm.boresight.el):.3f} rad", flush=True)
-    print(f"trial {trial}: n={dets.n} bands={n_bands} T={T} Ta={len(atm.boresight.t)} {model} layers={len(layers)} {method} {units} {spectrum}: {err:.2e} "
+    print(f"trial {trial}: n={dets.n} bands={n_bands} T={T} Ta={len(atm.boresight.t)} {model} layers={len(layers)} {method} {units} {spectrum} {pattern} az {az0:.1f} el {el0:.1f}: {err:.2e} "
           f"gain {gain.min():.3f}..{gain.max():.3f} {'ok' if ok else 'BAD'}", flush=True)
     # a detector shard of the same simulation, with the noise on: every field the same rows bit for bit, and the
     # round trip through the other unit within float32
@@ -87,9 +110,12 @@ for trial in range(trials):
             same = [f for f in ("atmosphere", "noise") if not np.array_equal(part.data[f], full.data[f][lo:hi])] or True
             other = "pW" if units == "K_RJ" else "K_RJ"
             back = part.to(other).to(units)
-            rt = max(rel(back.data[f], part.data[f]) for f in ("atmosphere", "noise"))
+            rt = max(rel(back.data[f], part.data[f]) for f in ("atmosphere", "noise")) if hi > lo else 0.0  # (a rank of no rows)
             ok2 = same is True and rt < 2e-6 and np.isfinite(full.data["noise"]).all()
         except Exception as exc:  # noqa: BLE001
+            import traceback
+
+            traceback.print_exc()
             ok2, same, rt = False, f"{type(exc).__name__}: {exc}", float("nan")
         bad += not ok2
         print(f"   shard {rank}/{world} with noise: rows identical {same}, unit round trip {rt:.1e} {'ok' if ok2 else 'BAD'}", flush=True)
