@@ -2,7 +2,7 @@
 """Development aid: randomised instruments, scans and atmospheres through Simulation.run() against the oracle chain on the
 downloaded screens (pW and K_RJ, gains, detector shards with the noise on, both turbulence spectra, 1-6 layers or the 3-D model, both
 interpolation methods).
-Usage: python scripts/fuzz_frontend.py [seed] [trials]"""
+Usage: python scripts/fuzz_frontend.py [seed] [trials] [big]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -13,6 +13,7 @@ from oracle import hotpath
 
 seed = int(sys.argv[1]) if len(sys.argv) > 1 else 0
 trials = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+big = len(sys.argv) > 3 and sys.argv[3] == "big"  # thousands of rows: the pipelined step (2 and 4 detector blocks on two streams)
 rng = np.random.default_rng(seed)
 bad = 0
 
@@ -25,9 +26,9 @@ for trial in range(trials):
     n_bands = int(rng.integers(1, 3))
     centers = [93e9, 150e9, 220e9]
     bands = [Band(center=centers[b], width=0.25 * centers[b], shape="top_hat", name=f"b{b}", gain_error=float(rng.choice([0.0, 0.05]))) for b in range(n_bands)]
-    n = int(rng.integers(7, 400))
+    n = int(rng.integers(7, 400)) if not big else int(rng.integers(2100 // n_bands, 5200 // n_bands))
     inst = Instrument(Detectors.hexagon(n, float(rng.uniform(0.05, 1.0)), bands, primary_size=float(rng.uniform(3.0, 30.0))))
-    duration, fs = float(rng.uniform(8.0, 60.0)), float(rng.choice([20.0, 50.0, 100.0]))
+    duration, fs = float(rng.uniform(8.0, 60.0)), float(rng.choice([20.0, 50.0, 100.0]) if not big else rng.choice([50.0, 100.0, 400.0]))
     az0 = float(rng.choice([0.0, 359.95, 180.0])) if rng.random() < 0.25 else float(rng.uniform(0, 360))  # (the wrap of the azimuth)
     el0 = float(rng.uniform(25.0, 84.0))
     pattern = str(rng.choice(["daisy", "daisy", "triangle", "lissajous", "stare"]))
