@@ -498,8 +498,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kT == 1 
 // (sum_l rms_l y_l ~ 3 % of pwv0) and added to the float64 pwv0 once per step.
 constexpr int kMaxAnchors = 2048;  // (step, layer) pairs of one work item: 32 KiB of LDS at most
 
+#ifndef MRX_PX_STAGES
+#define MRX_PX_STAGES 3
+#endif
+#ifndef MRX_PX_WAVES
+#define MRX_PX_WAVES 6
+#endif
+constexpr int kPxStages = MRX_PX_STAGES;  // layers in the software pipeline of the resident (kPipe) instance
+constexpr int kPxWaves = MRX_PX_WAVES;    // its register budget: 512 / kPxWaves
+
 template <bool kLdsTables, int kT, bool kPipe>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kT == 1 ? 8 : 5, kT == 1 ? 8 : 5))) void atm_sample_px_kernel(
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kT == 1 ? (kPipe ? kPxWaves : 8) : 5, kT == 1 ? (kPipe ? kPxWaves : 8) : 5))) void atm_sample_px_kernel(
     const mrx_layer_fast* __restrict__ fast, const mrx_layer_px* __restrict__ lpx, int n_layers,
     const double2* __restrict__ offpx, const mrx_table_dev* __restrict__ tables, int n_tables,
     const float* __restrict__ table_data, int table_floats, const float* __restrict__ az,
@@ -622,21 +631,22 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kT == 1 
           fl[tt] = __builtin_fmaf(g.rms, __builtin_fmaf(g.we[tt], y1 - y0, y0), fl[tt]);
         }
       };
-      // two stages in turn, no copies: a stage's loads land while the other one is blended.  (The pass
-      // after the last layer fetches layer n - 1 once more -- same lines, its weights already counted --
-      // instead of branching around the issue.)
-      Stage ga, gb;
+      Stage ga;
       if (kPipe) {
-        if (n_layers > 0) issue(0, ga);
-        for (int l = 0; l < n_layers; l += 2) {
-          issue(min(l + 1, n_layers - 1), gb);
-          __builtin_amdgcn_sched_barrier(0);
-          blend(ga);
-          __builtin_amdgcn_sched_barrier(0);
-          issue(min(l + 2, n_layers - 1), ga);
-          __builtin_amdgcn_sched_barrier(0);
-          if (l + 1 < n_layers) blend(gb);
-          __builtin_amdgcn_sched_barrier(0);
+        // kPxStages stages in a ring: kPxStages - 1 layers' gathers stay in flight while one is blended (blends in
+        // layer order, so the float32 sum is the plain loop's bit for bit); fully unrolled, the ring lives in registers
+        Stage g[kPxStages];
+#pragma unroll
+        for (int k = 0; k < kPxStages - 1; ++k)
+          if (k < n_layers) issue(k, g[k]);
+        for (int l = 0; l < n_layers; l += kPxStages) {
+#pragma unroll
+          for (int k = 0; k < kPxStages; ++k) {
+            if (l + k + kPxStages - 1 < n_layers) issue(l + k + kPxStages - 1, g[(k + kPxStages - 1) % kPxStages]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (l + k < n_layers) blend(g[k]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
       } else {  // alone on the chip at 8 waves per SIMD the occupancy hides the latency: the plain loop is 12 % faster there
         for (int l = 0; l < n_layers; ++l) {

@@ -13,6 +13,7 @@ for a contiguous block of detector rows.  The stages are the reference's
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -621,6 +622,7 @@ class DevicePath:
         per-stage breakdown of exactly the launches the pipelined step makes."""
         if self.plan is None:
             raise RuntimeError("no screens bound: call set_screens() or generate_screens() first")
+        resident_wgs_per_cu = int(os.environ.get("MRX_AB_RESIDENT_WGS", resident_wgs_per_cu))  # (A/B runs)
         main = torch.cuda.current_stream(self.device)
         st = self._pipeline_state(blocks, main)
         side, ctx2 = st["side"], st["ctx2"]
