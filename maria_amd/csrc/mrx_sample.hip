@@ -588,8 +588,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kT == 1 
         whi[tt] = 1.0f;
       }
       // ---- layer stack (atmosphere/atmosphere.py:317-373) ---------------------
-      // Software-pipelined by hand: the gathers of layer l + 1 are issued before layer l is blended, so
-      // that a wave has 4 kT loads in flight while it computes (the compiler, left alone, issues a
+      // Software-pipelined by hand: the gathers of the next layers are issued before layer l is blended, so
+      // that a wave has 2 (kPxStages - 1) kT loads in flight while it computes (the compiler, left alone, issues a
       // layer's two loads and waits for them: at the 3 waves per SIMD this kernel gets beside the TOD
       // writer that exposed the whole L2 latency 8 times per step).  sched_barrier pins the order.
       const float4* an = anchor + it * n_layers;
