@@ -632,9 +632,6 @@ class DevicePath:
         serial = serial_events is not None
         if serial:
             side, ctx2 = main, self.ctx
-        else:
-            st["start"].record(main)  # screens (and the previous run's writers) come first
-            side.wait_event(st["start"])
         if not serial:
             # the sampler runs through the side context: what the caller set on this path's context (the cell rule, the
             # pointing chain: MRX_OPT_AXIS_LITERAL, MRX_OPT_POINTING_CHAIN) applies there too
@@ -649,12 +646,17 @@ class DevicePath:
             # software-pipelined (round 3, atlast_10k: 2.12 ms at 3 per CU, 2.15 at 4, 2.27 at 5, 2.44 at 2;
             # two steps per thread at 96 registers: 2.18)
             alone = i == 0 or serial
-            ctx2.set_option(_lib.OPT_SAMPLE_WGS_PER_CU, saved[0] if alone else resident_wgs_per_cu)
-            ctx2.set_option(_lib.OPT_SAMPLE_TIMES, saved[1] if alone else resident_times)
+            # block 0 has nothing to run beside: its sampler goes on the caller's stream, straight behind the screens and
+            # straight before its writer (a kernel follows a kernel of its own stream after ~6 us, an event of another
+            # stream after ~20: the kernel trace of the step showed five such waits on its critical path, two of them here)
+            c, s_ = (self.ctx, main) if i == 0 else (ctx2, side)
+            if c is ctx2:
+                ctx2.set_option(_lib.OPT_SAMPLE_WGS_PER_CU, saved[0] if alone else resident_wgs_per_cu)
+                ctx2.set_option(_lib.OPT_SAMPLE_TIMES, saved[1] if alone else resident_times)
             if serial:
                 tev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
                 tev[0].record(main)
-            ctx2.call(
+            c.call(
                 "mrx_atm_sample", self.plan, ptr(self.d_az), ptr(self.d_el), self.Ta,
                 sl(self.d_dx, lo, hi), sl(self.d_dy, lo, hi), sl(self.d_band, lo, hi), sl(self.d_m00, lo, hi), n,
                 self.pwv0, None, ptr(st["loading"][i]), ptr(self.d_flags),
@@ -663,11 +665,14 @@ class DevicePath:
                 if self._krj_split() < self.T:  # (the samples past the last knot: per sample, from the loading in pW,
                     if "tail" not in st:        #  in one pass over all rows after the last block)
                         st["tail"] = torch.empty((self._krj_tail_knots(), self.D), dtype=torch.float32, device=self.device)
-                    with torch.cuda.stream(side):
+                    with torch.cuda.stream(s_):
                         st["tail"][:, lo:hi].copy_(st["loading"][i][self.Ta - self._krj_tail_knots() :])
-                self.coarse_to_krj(st["loading"][i], n, slice(lo, hi), ctx2)
+                self.coarse_to_krj(st["loading"][i], n, slice(lo, hi), c)
             if serial:
                 tev[1].record(main)
+            elif i == 0:
+                st["start"].record(main)  # the side stream starts block 1 behind the screens, the previous run's writers
+                side.wait_event(st["start"])  # (they read the coarse buffers it is about to fill) and block 0's sampler
             else:
                 st["ready"][i].record(side)
                 main.wait_event(st["ready"][i])
