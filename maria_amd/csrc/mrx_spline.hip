@@ -1079,12 +1079,23 @@ __global__ __launch_bounds__(kBlock) void coarse_krj_kernel(
   const CalDet c = make_cal_det(dxs[d], dys[d], min(max(band[d], 0), n_bands - 1), 1.0f);
   const float4* C = cal_cells + c.band * (n_el - 1);
   const float el_first = cal_cells[0].x, el_last = cal_axis[n_el - 1], el_inv = cal_cells[0].z;
-  for (int j = j0; j < j1; ++j) {
-    // coords/transforms.py:20-28 in float32: im = sin(el_det), el_det = asin(im)
-    const float2 cs = trig[j - j0];
-    const float im = __fadd_rn(__fmul_rn(c.a_re, cs.y), __fmul_rn(c.a_im, cs.x));
-    const float den = den_lookup(asinf(im), C, n_el, el_first, el_last, el_inv);
-    out[(size_t)j * D + d] = loading[(size_t)j * D + d] * __builtin_amdgcn_rcpf(den);
+  // eight steps' loads in flight per thread (one at a time, the loop was a chain of 32 memory latencies: 65 us for a block
+  // of 2 500 rows beside the TOD writer, on the sampler's stream of the pipelined step)
+  constexpr int kAhead = 8;
+  for (int jb = j0; jb < j1; jb += kAhead) {
+    float v[kAhead];
+#pragma unroll
+    for (int k = 0; k < kAhead; ++k) v[k] = loading[(size_t)min(jb + k, j1 - 1) * D + d];
+#pragma unroll
+    for (int k = 0; k < kAhead; ++k) {
+      const int j = jb + k;
+      if (j >= j1) break;
+      // coords/transforms.py:20-28 in float32: im = sin(el_det), el_det = asin(im)
+      const float2 cs = trig[j - j0];
+      const float im = __fadd_rn(__fmul_rn(c.a_re, cs.y), __fmul_rn(c.a_im, cs.x));
+      const float den = den_lookup(asinf(im), C, n_el, el_first, el_last, el_inv);
+      out[(size_t)j * D + d] = v[k] * __builtin_amdgcn_rcpf(den);
+    }
   }
 }
 

@@ -107,11 +107,11 @@ class Detectors:
 
     @property
     def band_name(self):
-        return np.array([self.bands[b].name for b in self.band_index])
+        return np.array([b.name for b in self.bands])[self.band_index]
 
     @property
     def band_center(self):
-        return np.array([self.bands[b].center for b in self.band_index])
+        return np.array([b.center for b in self.bands], float)[self.band_index]
 
     @property
     def field_of_view(self):
