@@ -605,7 +605,7 @@ class DevicePath:
         ctx2 = Context(self.ctx.device)
         ctx2.set_stream(side)
         st = dict(blocks=blocks, bounds=bounds, side=side, ctx2=ctx2, main=main.cuda_stream,
-                  ready=[torch.cuda.Event() for _ in bounds], start=torch.cuda.Event(),
+                  ready=[torch.cuda.Event() for _ in bounds], start=torch.cuda.Event(), tail_done=torch.cuda.Event(),
                   loading=[torch.empty((self.Ta, hi - lo), dtype=torch.float32, device=self.device) for lo, hi in bounds])
         self._pipe = st
         return st
@@ -697,8 +697,15 @@ class DevicePath:
         ctx2.set_option(_lib.OPT_SAMPLE_WGS_PER_CU, saved[0])
         ctx2.set_option(_lib.OPT_SAMPLE_TIMES, saved[1])
         if krj and krj != "sample" and self._krj_split() < self.T:
-            # (the copies into st["tail"] precede each block's ready event on the side stream, and main has waited for every one)
-            self._krj_tail(st["tail"], self.D, slice(0, self.D), out, ptr(self.d_rows), self.ctx)
+            if serial:
+                self._krj_tail(st["tail"], self.D, slice(0, self.D), out, ptr(self.d_rows), self.ctx)
+            else:
+                # on the side stream, beside the last block's writer (other samples of the same rows): the copies into
+                # st["tail"] precede it there, block 0's precedes the start event; its scratch belongs to that stream
+                with torch.cuda.stream(side):
+                    self._krj_tail(st["tail"], self.D, slice(0, self.D), out, ptr(self.d_rows), ctx2)
+                st["tail_done"].record(side)
+                main.wait_event(st["tail_done"])
         self._pipelined = True
         self._pwv_stale = True
         return out
