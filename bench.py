@@ -39,6 +39,7 @@ Prints ONE JSON line on rank 0, including
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
 import sys
@@ -421,11 +422,14 @@ def run(args):
     barrier()
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    gc.collect()
+    gc.disable()  # (a collection inside a 25-ms timed region would be a tenth of it)
     t_start = time.perf_counter()
     for k in range(args.steps):
         step(ev[k])
     barrier()
     elapsed = time.perf_counter() - t_start
+    gc.enable()
     flags = path.check_flags()
 
     if world > 1:
@@ -482,6 +486,9 @@ def run(args):
             "screens": "sharded by layer + broadcast by the owners" if own_layers is not None else "regenerated on every rank from the Philox key",
             "parallelism": f"detector-sharded x{world}, no data-path collective",
         },
+        # the same K steps on the GPU's own clock (events around every step, on the stream the step runs on): the
+        # wall-clock figure above should sit within a few per cent of it; a host hiccup inside the timed region shows here
+        "gpu_ms_per_step": float(ev[0][0].elapsed_time(ev[-1][2])) / args.steps,
         "stage_ms": {
             "screens": float(step_ms[0]),
             "tod_synthesis_pipelined": float(step_ms[1]),
