@@ -31,9 +31,10 @@
 extern "C" {
 #endif
 
-#define MRX_VERSION 130 /* 0.2.0 (120): mrx_spline_upsample_fused, mrx_allgather_tod_p2p, mrx_exchange_screens,
+#define MRX_VERSION 131 /* 0.2.0 (120): mrx_spline_upsample_fused, mrx_allgather_tod_p2p, mrx_exchange_screens,
                            mrx_resample_columns; MRX_OPT_SAMPLE_TILES retired.  130: mrx_screen_amplitudes,
-                           mrx_screen_desc.d_amp, mrx_screen_generate_3d(..., d_amp) */
+                           mrx_screen_desc.d_amp, mrx_screen_generate_3d(..., d_amp), mrx_streams_concurrent.
+                           131: mrx_coarse_to_krj_keep_tail */
 
 typedef enum mrx_status {
   MRX_OK = 0,
@@ -298,6 +299,17 @@ int mrx_coarse_to_krj(mrx_ctx* ctx, const float* d_loading, int D, int Ta, const
                       const float* d_dx, const float* d_dy, const int32_t* d_band,
                       const float* d_cal_axis_el, const float* d_cal_values, int n_el, int n_bands,
                       float* d_out);
+
+/* The same, and the loading in pW of the last `tail_knots` coarse steps kept aside as it is read:
+ * d_tail_pw[k * ld_tail + d] = d_loading[(Ta - tail_knots + k) * D + d].  The samples past the last
+ * coarse knot are not written in the coarse form (an extrapolated spline of y / g is not the
+ * reference's extrapolated spline of y, divided; maria/sim/atmosphere.py:72-82 extrapolates): the caller
+ * converts them one by one from these knots (mrx_spline_prepare + mrx_spline_upsample_krj on the window),
+ * and d_out may be d_loading.  d_tail_pw = NULL or tail_knots = 0: mrx_coarse_to_krj. */
+int mrx_coarse_to_krj_keep_tail(mrx_ctx* ctx, const float* d_loading, int D, int Ta, const float* d_bore_el_coarse,
+                                const float* d_dx, const float* d_dy, const int32_t* d_band,
+                                const float* d_cal_axis_el, const float* d_cal_values, int n_el, int n_bands,
+                                float* d_out, float* d_tail_pw, int tail_knots, size_t ld_tail);
 
 /* TOD.to("K_RJ") of a field that is already at the full rate -- the noise (and later map /
  * cmb) fields, tod/tod.py:106-142 -- in place: d_data[row(d) * ld + s] *= d_scale[d] /

@@ -169,6 +169,7 @@ SIGNATURES = {
     "mrx_spline_upsample_fused": (_i, [_vp, _vp, _i, _i, _d, _d, _vp, _i, _vp, _vp, _vp, _sz]),
     "mrx_spline_upsample_krj": (_i, [_vp, _vp, _i, _i, _d, _d, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _sz]),
     "mrx_coarse_to_krj": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "mrx_coarse_to_krj_keep_tail": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _sz]),
     "mrx_tod_to_krj": (_i, [_vp, _vp, _sz, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i]),
     "mrx_tod_from_krj": (_i, [_vp, _vp, _sz, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i]),
     "mrx_pointing_broadcast": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _vp, _sz]),

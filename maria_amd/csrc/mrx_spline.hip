@@ -1064,7 +1064,7 @@ __global__ __launch_bounds__(kBlock) void coarse_krj_kernel(
     const float* __restrict__ loading, int D, int Ta, const float* __restrict__ bore_el,
     const float* __restrict__ dxs, const float* __restrict__ dys, const int32_t* __restrict__ band,
     const float* __restrict__ cal_axis, const float* __restrict__ cal_values, int n_el, int n_bands,
-    float* __restrict__ out) {
+    float* __restrict__ out, float* __restrict__ tail, int tail_first, size_t ld_tail) {
   extern __shared__ __align__(16) float4 cal_cells[];  // [n_bands][n_el - 1], see stage_cal_cells
   __shared__ float2 trig[kCoarseKrjSteps];  // (cos, sin) of (boresight elevation - pi/2) of the block's steps
   stage_cal_cells(cal_cells, cal_axis, cal_values, n_el, n_bands);
@@ -1095,6 +1095,7 @@ __global__ __launch_bounds__(kBlock) void coarse_krj_kernel(
       const float im = __fadd_rn(__fmul_rn(c.a_re, cs.y), __fmul_rn(c.a_im, cs.x));
       const float den = den_lookup(asinf(im), C, n_el, el_first, el_last, el_inv);
       out[(size_t)j * D + d] = v[k] * __builtin_amdgcn_rcpf(den);
+      if (tail && j >= tail_first) tail[(size_t)(j - tail_first) * ld_tail + d] = v[k];  // (uniform: j is the block's)
     }
   }
 }
@@ -1406,9 +1407,20 @@ int mrx_coarse_to_krj(mrx_ctx* ctx, const float* d_loading, int D, int Ta, const
                       const float* d_dx, const float* d_dy, const int32_t* d_band,
                       const float* d_cal_axis_el, const float* d_cal_values, int n_el, int n_bands,
                       float* d_out) {
+  return mrx_coarse_to_krj_keep_tail(ctx, d_loading, D, Ta, d_bore_el_coarse, d_dx, d_dy, d_band, d_cal_axis_el, d_cal_values,
+                                     n_el, n_bands, d_out, nullptr, 0, 0);
+}
+
+int mrx_coarse_to_krj_keep_tail(mrx_ctx* ctx, const float* d_loading, int D, int Ta, const float* d_bore_el_coarse,
+                                const float* d_dx, const float* d_dy, const int32_t* d_band,
+                                const float* d_cal_axis_el, const float* d_cal_values, int n_el, int n_bands,
+                                float* d_out, float* d_tail_pw, int tail_knots, size_t ld_tail) {
   MRX_ENTER(ctx);
   if (!ctx) return MRX_ERR_INVALID;
   MRX_REQUIRE(ctx, D >= 0 && Ta >= 0, "negative size");
+  MRX_REQUIRE(ctx, tail_knots >= 0 && tail_knots <= Ta, "tail_knots must lie in [0, Ta]");
+  if (!d_tail_pw || tail_knots == 0) { d_tail_pw = nullptr; tail_knots = 0; }
+  MRX_REQUIRE(ctx, !d_tail_pw || ld_tail >= (size_t)D, "ld_tail is shorter than a row of D detectors");
   if (D == 0 || Ta == 0) return MRX_OK;
   MRX_REQUIRE(ctx, d_loading && d_out && d_bore_el_coarse && d_dx && d_dy && d_band && d_cal_axis_el && d_cal_values,
               "null pointer");
@@ -1420,7 +1432,7 @@ int mrx_coarse_to_krj(mrx_ctx* ctx, const float* d_loading, int D, int Ta, const
   const size_t lds = sizeof(float4) * (size_t)(n_el - 1) * n_bands;
   MRX_LDS_CAP(ctx, coarse_krj_kernel, lds);
   hipLaunchKernelGGL(coarse_krj_kernel, grid, dim3(kBlock), lds, ctx->stream, d_loading, D, Ta, d_bore_el_coarse,
-                     d_dx, d_dy, d_band, d_cal_axis_el, d_cal_values, n_el, n_bands, d_out);
+                     d_dx, d_dy, d_band, d_cal_axis_el, d_cal_values, n_el, n_bands, d_out, d_tail_pw, Ta - tail_knots, ld_tail);
   MRX_CHECK_LAUNCH(ctx);
   return MRX_OK;
 }

@@ -649,7 +649,7 @@ class DevicePath:
             # block 0 has nothing to run beside: its sampler goes on the caller's stream, straight behind the screens and
             # straight before its writer (a kernel follows a kernel of its own stream after ~6 us, an event of another
             # stream after ~20: the kernel trace of the step showed five such waits on its critical path, two of them here)
-            c, s_ = (self.ctx, main) if i == 0 else (ctx2, side)
+            c = self.ctx if i == 0 else ctx2
             if c is ctx2:
                 ctx2.set_option(_lib.OPT_SAMPLE_WGS_PER_CU, saved[0] if alone else resident_wgs_per_cu)
                 ctx2.set_option(_lib.OPT_SAMPLE_TIMES, saved[1] if alone else resident_times)
@@ -662,12 +662,12 @@ class DevicePath:
                 self.pwv0, None, ptr(st["loading"][i]), ptr(self.d_flags),
             )
             if krj and krj != "sample":  # TOD.to("K_RJ") on the coarse grid: the writer below then writes K_RJ at the pW writer's cost
+                tail = None
                 if self._krj_split() < self.T:  # (the samples past the last knot: per sample, from the loading in pW,
-                    if "tail" not in st:        #  in one pass over all rows after the last block)
+                    if "tail" not in st:        #  in one pass over all rows beside the last block's writer)
                         st["tail"] = torch.empty((self._krj_tail_knots(), self.D), dtype=torch.float32, device=self.device)
-                    with torch.cuda.stream(s_):
-                        st["tail"][:, lo:hi].copy_(st["loading"][i][self.Ta - self._krj_tail_knots() :])
-                self.coarse_to_krj(st["loading"][i], n, slice(lo, hi), c)
+                    tail = st["tail"][:, lo:hi]  # filled by the conversion kernel as it reads those knots
+                self.coarse_to_krj(st["loading"][i], n, slice(lo, hi), c, tail=tail)
             if serial:
                 tev[1].record(main)
             elif i == 0:
@@ -812,9 +812,10 @@ class DevicePath:
         # the reciprocal over 4 samples)
         return float(1.1 * (kink * rel_jump * step + smooth * rel_slope * d4) + 4e-7)
 
-    def coarse_to_krj(self, loading=None, n=None, rows=slice(None), ctx=None):
+    def coarse_to_krj(self, loading=None, n=None, rows=slice(None), ctx=None, tail=None):
         """mrx_coarse_to_krj on the coarse loading (``loading``: a block's [Ta, n] buffer, in
-        place; default: the whole shard's into a buffer of its own, which prepare(krj=True) reads)."""
+        place; default: the whole shard's into a buffer of its own, which prepare(krj=True) reads).
+        ``tail``: a [k, n] view that receives the last k knots in pW as they are read (_krj_tail's input)."""
         c = self._cal
         if loading is None:
             if getattr(self, "d_loading_krj", None) is None:
@@ -823,8 +824,9 @@ class DevicePath:
         else:
             src = dst = loading
         (ctx or self.ctx).call(
-            "mrx_coarse_to_krj", ptr(src), n, self.Ta, ptr(self.d_el), ptr(c["dx"][rows]), ptr(c["dy"][rows]), ptr(self.d_band[rows]),
+            "mrx_coarse_to_krj_keep_tail", ptr(src), n, self.Ta, ptr(self.d_el), ptr(c["dx"][rows]), ptr(c["dy"][rows]), ptr(self.d_band[rows]),
             ptr(c["axis"]), ptr(c["values"]), c["n_el"], c["n_bands"], ptr(dst),
+            ptr(tail), 0 if tail is None else tail.shape[0], 0 if tail is None else tail.stride(0),
         )
 
     def upsample_krj(self, out):

@@ -170,6 +170,45 @@ def test_coarse_krj_form_stays_within_its_bound(gpu_ctx):
         assert not q.coarse_krj_bound() <= q.COARSE_KRJ_LIMIT
 
 
+def test_coarse_to_krj_keeps_the_last_knots_aside(gpu_ctx):
+    """mrx_coarse_to_krj_keep_tail: the same output as mrx_coarse_to_krj (also in place), and the last k steps of the
+    INPUT -- the loading in pW, which the per-sample conversion past the last knot starts from -- in the caller's
+    [k][ld] buffer, columns of a wider array included; bad arguments refused."""
+    import torch
+
+    from maria_amd._lib import ptr
+
+    rng = np.random.default_rng(12)
+    D, Ta, k, n_el, nb = 333, 77, 9, 21, 2
+    dev = "cuda:0"
+    f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)  # noqa: E731
+    loading = f32(rng.uniform(1.0, 2.0, (Ta, D)))
+    el = f32(np.radians(55.0) + 0.02 * np.sin(np.arange(Ta) / 9.0))
+    dx, dy = f32(rng.normal(0, 3e-3, D)), f32(rng.normal(0, 3e-3, D))
+    band = torch.as_tensor(rng.integers(0, nb, D).astype(np.int32)).to(dev)
+    axis = f32(np.radians(np.linspace(20.0, 90.1, n_el)))
+    values = f32(rng.uniform(0.5, 1.5, (nb, n_el)))
+    args = (ptr(el), ptr(dx), ptr(dy), ptr(band), ptr(axis), ptr(values), n_el, nb)
+    ref = torch.empty_like(loading)
+    gpu_ctx.call("mrx_coarse_to_krj", ptr(loading), D, Ta, *args, ptr(ref))
+    assert torch.isfinite(ref).all() and not torch.equal(ref, loading)
+    wide = torch.full((k, D + 40), -1.0, dtype=torch.float32, device=dev)  # the block's columns of a wider array
+    out = torch.empty_like(loading)
+    gpu_ctx.call("mrx_coarse_to_krj_keep_tail", ptr(loading), D, Ta, *args, ptr(out), ptr(wide[:, 25:]), k, wide.stride(0))
+    assert torch.equal(out, ref)
+    assert torch.equal(wide[:, 25 : 25 + D], loading[Ta - k :])
+    assert (wide[:, :25] == -1).all() and (wide[:, 25 + D :] == -1).all()
+    inplace = loading.clone()
+    tail = torch.empty((Ta, D), dtype=torch.float32, device=dev)  # every step kept: k = Ta
+    gpu_ctx.call("mrx_coarse_to_krj_keep_tail", ptr(inplace), D, Ta, *args, ptr(inplace), ptr(tail), Ta, D)
+    assert torch.equal(inplace, ref) and torch.equal(tail, loading)
+    gpu_ctx.call("mrx_coarse_to_krj_keep_tail", ptr(loading), D, Ta, *args, ptr(out), None, 0, 0)  # no tail asked for
+    assert torch.equal(out, ref)
+    for bad in ((ptr(tail), Ta + 1, D), (ptr(tail), -1, D), (ptr(tail), k, D - 1)):
+        with pytest.raises(RuntimeError):
+            gpu_ctx.call("mrx_coarse_to_krj_keep_tail", ptr(loading), D, Ta, *args, ptr(out), *bad)
+
+
 @pytest.mark.parametrize("el_range_deg", [(25.0, 80.0), (50.0, 52.2), (50.0, 51.5), (84.0, 89.5)])
 def test_krj_conversion_under_an_elevation_slew(gpu_ctx, el_range_deg):
     """The K_RJ kernels model a detector's elevation per 1024-sample tile as linear in the
