@@ -100,7 +100,8 @@ enum {
                                   writer (tuning; 0 = automatic) */
   MRX_OPT_NOISE_GENERIC = 5, /* bit 0: the LDS second pass even where the register one applies;
                                 bit 1: the Stockham first pass even where the radix-16 register
-                                one applies (tests, A/B runs) */
+                                one applies; bit 2: the lanes' first batches of equal length
+                                (tests, A/B runs) */
   MRX_OPT_SAMPLE_WGS_PER_CU = 6, /* mrx_atm_sample runs as a resident grid of this many workgroups
                                     per CU that walk the work items (tuning; 0 = default, 8) */
   MRX_OPT_RESERVED_7 = 7, /* (was MRX_OPT_SAMPLE_TILES: screen windows staged in LDS measured slower than

@@ -979,11 +979,22 @@ int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T
     MRX_HIP(ctx, hipEventRecord(ctx->side_ev[0], ctx->stream));  // after the tables and whatever precedes the call
     for (int l = 1; l < lanes; ++l) MRX_HIP(ctx, hipStreamWaitEvent(ctx->side_streams[l - 1], ctx->side_ev[0], 0));
   }
-  int batch = 0;
-  for (int d0 = 0; d0 < D; d0 += 2 * pairs_lane, ++batch) {
+  // The lanes' first batches are of different lengths -- (l + 1) / lanes of a batch on lane l -- so that the lanes run a
+  // fraction of a cycle apart: started together they stay in step (the kernel trace showed three of four lanes in their
+  // first pass at the same time, 520 us each instead of 350-430, then in their second pass together), which is the
+  // one arrangement in which an arithmetic-bound pass never runs beside an HBM-bound one.  (Option bit 4 of
+  // MRX_OPT_NOISE_GENERIC: equal batches, for A/B runs; the result does not depend on the batching.)
+  const bool stagger = lanes > 1 && !(ctx->options[MRX_OPT_NOISE_GENERIC] & 4);
+  int d0 = 0;
+  for (int batch = 0; d0 < D; ++batch) {
     const int lane = batch % lanes;
     hipStream_t stream = lane ? ctx->side_streams[lane - 1] : ctx->stream;
-    const int count = D - d0 < 2 * pairs_lane ? D - d0 : 2 * pairs_lane;
+    int want = 2 * pairs_lane;
+    if (stagger && batch < lanes) {
+      const int p = (int)((long long)pairs_lane * (lane + 1) / lanes);
+      want = 2 * (p > 1 ? p : 1);
+    }
+    const int count = D - d0 < want ? D - d0 : want;
     const int pairs = (count + 1) / 2;
     CombineArgs h = g;
     h.row0 = d0;
@@ -1028,6 +1039,7 @@ int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T
                          stream, Al, n1, n2, l1, lj, h, key0, key1);
     }
     MRX_CHECK_LAUNCH(ctx);
+    d0 += count;
   }
   for (int l = 1; l < lanes; ++l) {  // join: the context's stream continues after every lane
     MRX_HIP(ctx, hipEventRecord(ctx->side_ev[l], ctx->side_streams[l - 1]));
