@@ -92,3 +92,5 @@ def test_recorded_bench_lines_carry_the_contract_fields():
             assert cpu["parity_max_rel_err_vs_gpu"] <= 1e-5 and cpu["parity_fluct_rel_err"] <= 5e-4
             # the kernel's measured HBM traffic stays near its algorithmic bytes (re-reads would show here first)
             assert 1.0 <= roof["traffic"] / roof["bytes_per_launch"] < 1.15
+            # the wall-clock figure against the same steps on the GPU's own clock: no host stall inside the timed region
+            assert 0.97 < line["gpu_ms_per_step"] / line["ms_per_step"] <= 1.0
