@@ -113,6 +113,19 @@ for trial in range(trials):
     bad += not ok
     print(f"{label} T={got.shape[1]}: |diff| {err:.2e} bound {bound:.2e} max {np.abs(ref).max():.2e} {'ok' if ok else 'BAD'}", flush=True)
 
+    # the default units: the same per-sample factor on the map field as on the atmosphere field (tod/tod.py:130-136)
+    if with_atm:
+        try:
+            (tod_k,) = Simulation(inst, plan, site, **common).run()
+            f_atm = tod_k.data["atmosphere"].astype(np.float64) / tod.data["atmosphere"]
+            e3 = float(np.abs(tod_k.data["map"] - got * f_atm).max() / max(np.abs(got * f_atm).max(), 1e-300))
+            ok3 = tod_k.units == "K_RJ" and e3 <= 5e-6 and np.isfinite(tod_k.data["map"]).all()
+            msg3 = f"{e3:.1e}"
+        except Exception as exc:  # noqa: BLE001
+            ok3, msg3 = False, f"{type(exc).__name__}: {exc}"
+        bad += not ok3
+        print(f"   K_RJ: map field against pW x the atmosphere's factor {msg3} {'ok' if ok3 else 'BAD'}", flush=True)
+
     # the mapper on that TOD against the oracle's binning of the same samples
     bilinear = bool(rng.random() < 0.4)
     mres = float(rng.uniform(0.5, 3.0)) * res
