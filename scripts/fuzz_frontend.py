@@ -25,7 +25,8 @@ def rel(a, b):
 for trial in range(trials):
     n_bands = int(rng.integers(1, 3))
     centers = [93e9, 150e9, 220e9]
-    bands = [Band(center=centers[b], width=0.25 * centers[b], shape="top_hat", name=f"b{b}", gain_error=float(rng.choice([0.0, 0.05]))) for b in range(n_bands)]
+    bands = [Band(center=centers[b], width=0.25 * centers[b], shape="top_hat", name=f"b{b}", gain_error=float(rng.choice([0.0, 0.05])),
+                  NEP_per_loading=float(rng.choice([0.0, 0.0, 0.1])), knee=float(rng.choice([0.3, 1.0]))) for b in range(n_bands)]  # (the NEP that grows with the loading: the sharded leg below)
     n = int(rng.integers(7, 400)) if not big else int(rng.integers(2100 // n_bands, 5200 // n_bands))
     inst = Instrument(Detectors.hexagon(n, float(rng.uniform(0.05, 1.0)), bands, primary_size=float(rng.uniform(3.0, 30.0))))
     duration, fs = float(rng.uniform(8.0, 60.0)), float(rng.choice([20.0, 50.0, 100.0]) if not big else rng.choice([50.0, 100.0, 400.0]))
