@@ -146,9 +146,11 @@ typedef struct mrx_layer {
   /* Optional uniform-axis hint: the float64 grids behind the two axes are
    * extrusion[i] = e0 + i*de (np.arange, atmosphere.py:241-245) and
    * cross_section[i] = c0 + i*dc (np.linspace, :208-219).  When
-   * float32(e0 + i*de) reproduces d_axis_e bit for bit (checked on the device
-   * at plan creation) the kernel works in pixel coordinates, (x - e0)/de in float64,
-   * instead of searching the axis (see MRX_OPT_AXIS_LITERAL).  Set de / dc to 0 when unknown. */
+   * float32(e0 + i*de) reproduces every node of d_axis_e to one float32 ulp (checked on
+   * the device at plan creation; the float64 grid is itself rounded, so a node in ~1e5 parts
+   * from the model by an ulp) the kernel works in pixel coordinates, (x - e0)/de in float64,
+   * instead of searching the axis (see MRX_OPT_AXIS_LITERAL).  Set de / dc to 0 when unknown.
+   * Screens of 2^22 nodes a side or 4 GiB and more take the general kernel. */
   double e0, de, c0, dc;
   float pwv_rms;         /* float32(layer.pwv_rms), extrusion.py:100-105       */
   int32_t reserved;

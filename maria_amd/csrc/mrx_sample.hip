@@ -70,15 +70,19 @@ struct alignas(64) mrx_layer_fast {
 };
 static_assert(sizeof(mrx_layer_fast) == 64, "one cache line per layer");
 
-// The float32 record of the pixel-coordinate kernel (atm_sample_px_kernel): one s_load_dwordx16.
+// The float32 record of the pixel-coordinate kernel (atm_sample_px_kernel): one scalar load per layer and wave.
 struct alignas(64) mrx_layer_px {
-  const float* values;
+  const float* values;   // the screen: the lower corners of a cell
+  const float* values1;  // the screen from its second row on: the upper corners, at the same byte offset
   float pe_x, pe_y, pc_x, pc_y;
-  int n_e, n_c;
+  int nc4;               // 4 n_c: a row in bytes
+  uint32_t bytes;        // 4 n_e n_c (< 4 GiB, plan_finish_layers): the range the hardware checks the gathers against
+  uint32_t bytes1;       // bytes - nc4
   float pwv_rms;
-  int pad_[7];
+  float half_e, half_c;  // (n_e - 1) / 2, (n_c - 1) / 2: a position is on the grid while |position - middle| <= half
+  int pad_[2];
 };
-static_assert(sizeof(mrx_layer_px) == 64, "one s_load_dwordx16 per layer");
+static_assert(sizeof(mrx_layer_px) == 64, "one cache line per layer");
 
 // Device-side band table descriptor: offsets (in floats) into the packed table
 // buffer, which is [values 2*np*ne][axis_pwv np][axis_el ne] per band.
@@ -155,6 +159,12 @@ __device__ __forceinline__ int cvt_flr_i32(float x) {
 __device__ __forceinline__ int med3_i32(int x, int lo, int hi) {
   int r;
   asm("v_med3_i32 %0, %1, %2, %3" : "=v"(r) : "v"(x), "v"(lo), "s"(hi));
+  return r;
+}
+// v_mad_i32_i24: a * b + c with a, b signed 24-bit (a cell offset of a few pixels times a row pitch below 2^24)
+__device__ __forceinline__ int mad_i32_i24(int a, int b, int c) {
+  int r;
+  asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(b), "v"(c));
   return r;
 }
 typedef float pair4 __attribute__((ext_vector_type(2), aligned(4)));
@@ -496,7 +506,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kT == 1 
 // lerps along c and one along e (6 operations; jax's four weighted corners sum to the same value
 // to rounding), the layer's term is accumulated in float32 on the FLUCTUATION only
 // (sum_l rms_l y_l ~ 3 % of pwv0) and added to the float64 pwv0 once per step.
-constexpr int kMaxAnchors = 2048;  // (step, layer) pairs of one work item: 32 KiB of LDS at most
+constexpr int kMaxAnchors = 1024;  // (step, layer) pairs of one work item: 32 KiB of LDS at most
 
 #ifndef MRX_PX_STAGES
 #define MRX_PX_STAGES 3
@@ -507,6 +517,64 @@ constexpr int kMaxAnchors = 2048;  // (step, layer) pairs of one work item: 32 K
 constexpr int kPxStages = MRX_PX_STAGES;  // layers in the software pipeline of the resident (kPipe) instance
 constexpr int kPxWaves = MRX_PX_WAVES;    // its register budget: 512 / kPxWaves
 
+// a / b to within an ulp (correctly rounded but for rare ties) in four instructions instead of the ten of the
+// IEEE sequence: v_rcp_f32, the quotient, its residual, one correction.  b is a table step or sin(elevation):
+// normal numbers; b = 0, infinite or NaN gives NaN or infinity, which the callers flag.
+__device__ __forceinline__ float div_near(float a, float b) {
+  const float r = __builtin_amdgcn_rcpf(b);
+  const float q = a * r;
+  return __builtin_fmaf(__builtin_fmaf(-b, q, a), r, q);
+}
+
+// jax's _find_indices on one axis of a band table whose first step predicts the cell (the `am` axes are uniform
+// but for the last elevation node, which the clamp absorbs): the guess, its two nodes, and -- only when some lane
+// of the wave sits within rounding of a node or the axis is not uniform -- the search of find_cell.
+template <typename NodeFn>
+__device__ __forceinline__ Cell guess_cell(NodeFn node, int n, float x, float first, float inv, float last) {
+  const float f = fminf(fmaxf((x - first) * inv, -1.0f), 2.0e9f);
+  Cell c;
+  c.i = min(max((int)f, 0), n - 2);
+  float lo = node(c.i), hi = node(c.i + 1);
+  const bool miss = (c.i < n - 2 && hi < x) || (c.i > 0 && lo >= x);
+  if (__builtin_amdgcn_ballot_w64(miss) != 0) {
+    while (c.i < n - 2 && hi < x) { ++c.i; lo = hi; hi = node(c.i + 1); }
+    while (c.i > 0 && lo >= x) { --c.i; hi = lo; lo = node(c.i); }
+  }
+  c.w = div_near(x - lo, hi - lo);
+  c.oob = !(x >= first && x <= last);  // also true for NaN
+  return c;
+}
+
+// band_loading's linear branch for the pixel kernel: the same 8-term float32 sum in the reference's order
+// (band/band.py:283-286), cells from guess_cell, weights from div_near.
+__device__ __forceinline__ float band_loading_px(const mrx_table_dev& tb, const float* __restrict__ tdata, float xp,
+                                                 float theta, float m00, bool& table_oob) {
+  const float* __restrict__ ax_p = tdata + tb.off_pwv;
+  const float* __restrict__ ax_e = tdata + tb.off_el;
+  const float* __restrict__ tv = tdata + tb.off_values;
+  const int slab = tb.n_pwv * tb.n_el;
+  const float xel = fminf(theta, kHalfPiF);  // .clip(max=pi/2), sim/atmosphere.py:60
+  const Cell cp_ = guess_cell([=](int i) { return ax_p[i]; }, tb.n_pwv, xp, tb.p_first, tb.p_inv, ax_p[tb.n_pwv - 1]);
+  const Cell cl = guess_cell([=](int i) { return ax_e[i]; }, tb.n_el, xel, tb.e_first, tb.e_inv, ax_e[tb.n_el - 1]);
+  const float* q = tv + cp_.i * tb.n_el + cl.i;
+  float val = 0.0f;
+#pragma unroll
+  for (int ia = 0; ia < 2; ++ia) {
+    const float w1 = 1.0f * (ia ? tb.w_t : 1.0f - tb.w_t);
+#pragma unroll
+    for (int ib = 0; ib < 2; ++ib) {
+      const float w2 = w1 * (ib ? cp_.w : 1.0f - cp_.w);
+#pragma unroll
+      for (int ic = 0; ic < 2; ++ic) {
+        const float w3 = w2 * (ic ? cl.w : 1.0f - cl.w);
+        val = val + q[ia * slab + ib * tb.n_el + ic] * w3;
+      }
+    }
+  }
+  table_oob = cp_.oob || cl.oob || tb.t_oob;
+  return table_oob ? __builtin_nanf("") : m00 * val;
+}
+
 template <bool kLdsTables, int kT, bool kPipe>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kT == 1 ? (kPipe ? kPxWaves : 8) : 5, kT == 1 ? (kPipe ? kPxWaves : 8) : 5))) void atm_sample_px_kernel(
     const mrx_layer_fast* __restrict__ fast, const mrx_layer_px* __restrict__ lpx, int n_layers,
@@ -515,19 +583,31 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kT == 1 
     const float* __restrict__ el, int Ta, const float* __restrict__ dxs, const float* __restrict__ dys,
     const int32_t* __restrict__ band, const float* __restrict__ mueller00, int D, double pwv0,
     double* __restrict__ pwv_out, float* __restrict__ loading, uint32_t* __restrict__ flags, int chunk,
-    int nbx, int n_items) {
-  extern __shared__ __align__(16) float4 lds_px[];  // [chunk * n_layers anchors][band tables]
+    int nbx, int nby) {
+  // [chunk * n_layers anchors of 32 bytes: (fraction e, fraction c, middle e, middle c), byte offset of the anchor's
+  //  cell, padding][band tables]
+  extern __shared__ __align__(16) float4 lds_px[];
   __shared__ float4 bore[kMaxChunk];   // per step: cos/sin of (el - pi/2), cos/sin of az
   __shared__ float2 borec[kMaxChunk];  // per step: unit-height projection of the boresight itself
   float4* anchor = lds_px;
-  float* lds_tables = reinterpret_cast<float*>(lds_px + chunk * n_layers);
+  float* lds_tables = reinterpret_cast<float*>(lds_px + 2 * chunk * n_layers);
   if (kLdsTables)
     for (int i = threadIdx.x; i < table_floats; i += kBlock) lds_tables[i] = table_data[i];
   const float* __restrict__ tdata = kLdsTables ? lds_tables : table_data;
   uint32_t myflags = 0u;
 
-  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
-    const int t_first = (item / nbx) * chunk;
+  // Work items = (time chunk, block of 256 detectors), dealt so that the workgroups of one XCD (blockIdx mod 8 under
+  // the round-robin placement: a matter of speed only) share their time chunks: XCD x walks the chunks x, x + 8, ...,
+  // its workgroups taking the detector blocks of a chunk side by side.  The lines of sight of one chunk meet a few
+  // hundred KB of the layer stack; with the items dealt round-robin every XCD's 4 MB L2 saw the footprints of all
+  // ~80 chunks in flight at once -- 16 MB for 16 layers of 4096^2, 40 % of its L2 reads missing (profiles/r04_50k_*).
+  const int n_xcd = (gridDim.x & 7) == 0 ? 8 : 1;  // (a grid that is no multiple of 8: one group, the plain order)
+  const int xcd = blockIdx.x % n_xcd, per_xcd = gridDim.x / n_xcd;
+  for (int pair = blockIdx.x / n_xcd;; pair += per_xcd) {
+    const int by = (pair / nbx) * n_xcd + xcd;
+    if (by >= nby) break;
+    const int bx = pair % nbx;
+    const int t_first = by * chunk;
     uint32_t iflags = 0u;
     __syncthreads();  // the previous item's readers of bore[] and anchor[] are done
     if ((int)threadIdx.x < chunk) {
@@ -548,13 +628,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kT == 1 
       const float2 pc = borec[it];
       const double Fe = fma((double)pc.x, lf.pe_x, fma((double)pc.y, lf.pe_y, o.x));
       const double Fc = fma((double)pc.x, lf.pc_x, fma((double)pc.y, lf.pc_y, o.y));
-      // (a NaN position gives a finite cell and a NaN fraction: every lane then reads inside the
-      // screen and reports the line of sight as off it)
+      // (a NaN position gives a finite cell and a NaN fraction, which every lane then reports as off the screen;
+      // an anchor far outside wraps its byte offset: any offset is safe, the gathers are range-checked)
       const double ce = floor(fmin(fmax(Fe, -1.0e9), 1.0e9)), cc = floor(fmin(fmax(Fc, -1.0e9), 1.0e9));
-      anchor[k] = make_float4(__int_as_float((int)ce), __int_as_float((int)cc), (float)(Fe - ce), (float)(Fc - cc));
+      anchor[2 * k] = make_float4((float)(Fe - ce), (float)(Fc - cc), (float)(0.5 * (double)(lf.n_e - 1) - ce),
+                                  (float)(0.5 * (double)(lf.n_c - 1) - cc));
+      reinterpret_cast<int*>(anchor + 2 * k + 1)[0] = (int)(uint32_t)(((long long)ce * lf.n_c + (long long)cc) * 4ll);
     }
 
-    const int d = (item % nbx) * kBlock + threadIdx.x;
+    const int d = bx * kBlock + threadIdx.x;
     const bool live = d < D;
     const int dd = live ? d : D - 1;  // keep addresses valid; stores are masked
     // ---- per-detector constants (coords/transforms.py:14-23), float32 ------
@@ -571,7 +653,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kT == 1 
     __syncthreads();  // anchors are in place
 
     for (int it = 0; it < chunk && t_first + it < Ta; it += kT) {
-      float theta[kT], dpx[kT], dpy[kT], fl[kT], wlo[kT], whi[kT];
+      float theta[kT], dpx[kT], dpy[kT], fl[kT];
+      bool outside[kT];  // some layer's position left its grid (the compiler keeps it as a lane mask in scalar registers)
 #pragma unroll
       for (int tt = 0; tt < kT; ++tt) {
         // transforms.py:20-28 and the unit-height ground projection (see atm_sample_kernel)
@@ -580,19 +663,27 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kT == 1 
         const float re = A * bt.x - cr * bt.y;
         const float im = A * bt.y + cr * bt.x;
         theta[tt] = asinf(im);
-        const float inv_im = 1.0f / im;
+        const float inv_im = div_near(1.0f, im);
         dpx[tt] = (re * bt.z - Y * bt.w) * inv_im - pc.x;
         dpy[tt] = (Y * bt.z + re * bt.w) * inv_im - pc.y;
         fl[tt] = 0.0f;
-        wlo[tt] = 0.0f;  // smallest / largest interpolation weight met on the way through the layers
-        whi[tt] = 1.0f;
+        outside[tt] = false;
       }
       // ---- layer stack (atmosphere/atmosphere.py:317-373) ---------------------
-      // Software-pipelined by hand: the gathers of the next layers are issued before layer l is blended, so
-      // that a wave has 2 (kPxStages - 1) kT loads in flight while it computes (the compiler, left alone, issues a
-      // layer's two loads and waits for them: at the 3 waves per SIMD this kernel gets beside the TOD
-      // writer that exposed the whole L2 latency 8 times per step).  sched_barrier pins the order.
-      const float4* an = anchor + it * n_layers;
+      // Per layer and sample: the position relative to the anchor's cell, f = fraction + delta (two fused
+      // multiply-adds per axis); cell = floor(f) and weight = fract(f) (one instruction each); on the grid while
+      // |f - middle| <= half the grid (a subtraction and a comparison per axis; exact but for the float32 rounding
+      // of that difference, 1e-4 pixel at the rim of a 4096-node axis -- the reference's own float32 coordinate is
+      // coarser); the byte offset of the cell from the anchor's (two integer multiply-adds); the two rows' corner
+      // pairs as two 8-byte BUFFER loads, which the hardware checks against the screen's size -- no clamp, and
+      // whatever a degenerate pointing produces reads zeros instead of faulting; two lerps along c and one along e.
+      // 21 vector instructions against the 29 of round 3 (which clamped the cell per axis, rebuilt the weight from
+      // the clamped cell and tracked the smallest / largest weight).
+      // Software-pipelined by hand in the resident (kPipe) instance: the gathers of the next layers are issued
+      // before layer l is blended, so that a wave has 2 (kPxStages - 1) kT loads in flight while it computes
+      // (at the 3 waves per SIMD this kernel gets beside the TOD writer the compiler's own order -- issue a layer's
+      // two loads, wait -- exposed the whole L2 latency once per layer).  sched_barrier pins the order.
+      const float4* an = anchor + 2 * it * n_layers;
       struct Stage {  // one layer's gathers in flight, for the thread's kT steps
         pair4 r0[kT], r1[kT];
         float we[kT], wc[kT];
@@ -600,27 +691,24 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kT == 1 
       };
       auto issue = [&](int l, Stage& g) {
         const mrx_layer_px lp = lpx[l];  // wave-uniform: one scalar load
-        const char_g* row0 = (const char_g*)lp.values;
-        const char_g* row1 = (const char_g*)(lp.values + lp.n_c);
-        const int ne2 = lp.n_e - 2, nc2 = lp.n_c - 2, nc4 = lp.n_c * 4;
+        const int nc4 = lp.nc4;
+        // two raw buffers: the screen, and the screen from its second row on -- the upper corners of a cell take the
+        // same offset in the second, and each load is checked against its own range
+        const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)lp.values, 0, (int)lp.bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)lp.values1, 0, (int)lp.bytes1, 0x00020000);
         g.rms = lp.pwv_rms;
 #pragma unroll
         for (int tt = 0; tt < kT; ++tt) {
-          const float4 a4 = an[tt * n_layers + l];
-          const int ae = __float_as_int(a4.x), ac = __float_as_int(a4.y);
-          const float fe = a4.z + __builtin_fmaf(dpx[tt], lp.pe_x, dpy[tt] * lp.pe_y);
-          const float fc = a4.w + __builtin_fmaf(dpx[tt], lp.pc_x, dpy[tt] * lp.pc_y);
-          // cell = anchor cell + floor(f), clamped into the grid; weight relative to the clamped cell, so
-          // that a position outside shows as a weight outside [0, 1] (the last node belongs to the last cell)
-          const int ie = med3_i32(ae + cvt_flr_i32(fe), 0, ne2);
-          const int ic = med3_i32(ac + cvt_flr_i32(fc), 0, nc2);
-          g.we[tt] = fe - (float)(ie - ae);
-          g.wc[tt] = fc - (float)(ic - ac);
-          wlo[tt] = fminf(fminf(wlo[tt], g.we[tt]), g.wc[tt]);
-          whi[tt] = fmaxf(fmaxf(whi[tt], g.we[tt]), g.wc[tt]);
-          const uint32_t boff = __umul24(ie, nc4) + ((uint32_t)ic << 2);  // < 4 GiB: sides below 2^23 and the screen fits memory
-          g.r0[tt] = *(const gpair*)(row0 + boff);
-          g.r1[tt] = *(const gpair*)(row1 + boff);
+          const float4 a4 = an[2 * (tt * n_layers + l)];
+          const int a0 = reinterpret_cast<const int*>(an + 2 * (tt * n_layers + l) + 1)[0];
+          const float fe = __builtin_fmaf(dpx[tt], lp.pe_x, __builtin_fmaf(dpy[tt], lp.pe_y, a4.x));
+          const float fc = __builtin_fmaf(dpx[tt], lp.pc_x, __builtin_fmaf(dpy[tt], lp.pc_y, a4.y));
+          g.we[tt] = __builtin_amdgcn_fractf(fe);
+          g.wc[tt] = __builtin_amdgcn_fractf(fc);
+          outside[tt] |= !(__builtin_fabsf(fe - a4.z) <= lp.half_e) || !(__builtin_fabsf(fc - a4.w) <= lp.half_c);
+          const int boff = mad_i32_i24(cvt_flr_i32(fe), nc4, a0) + (cvt_flr_i32(fc) << 2);
+          g.r0[tt] = __builtin_bit_cast(pair4, __builtin_amdgcn_raw_buffer_load_b64(rs0, boff, 0, 0));
+          g.r1[tt] = __builtin_bit_cast(pair4, __builtin_amdgcn_raw_buffer_load_b64(rs1, boff, 0, 0));
         }
       };
       auto blend = [&](const Stage& g) {
@@ -658,12 +746,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kT == 1 
 #pragma unroll
       for (int tt = 0; tt < kT; ++tt) {
         const int t = t_first + it + tt;
-        // a line of sight off a screen is jax's NaN fill (atmosphere.py:359-369): some weight left
-        // [0, 1], or a NaN position made the sum NaN (min / max skip NaN operands)
-        const bool off = !(wlo[tt] >= 0.0f && whi[tt] <= 1.0f) || fl[tt] != fl[tt];
+        // a line of sight off a screen is jax's NaN fill (atmosphere.py:359-369); a NaN position makes the sum NaN
+        const bool off = outside[tt] || fl[tt] != fl[tt];
         const double pwv = off ? (double)__builtin_nanf("") : pwv0 + (double)fl[tt];
-        if (off && t < Ta) iflags |= MRX_FLAG_SCREEN_OOB;
-        const float out = band_loading<false>(tb, tdata, pwv, theta[tt], m00, t < Ta, iflags);
+        bool table_oob;
+        const float out = band_loading_px(tb, tdata, (float)pwv, theta[tt], m00, table_oob);
+        if (t < Ta) iflags |= (off ? MRX_FLAG_SCREEN_OOB : 0u) | (table_oob ? MRX_FLAG_TABLE_OOB : 0u) | (out != out ? MRX_FLAG_NAN : 0u);
         if (live && t < Ta) {
           const size_t o = (size_t)t * D + d;
           loading[o] = out;
@@ -689,11 +777,18 @@ __global__ void plan_finish_layers(mrx_layer_dev* layers, mrx_layer_fast* fast, 
     ok_c = ly.dc != 0.0;
   }
   __syncthreads();
+  // A node may sit one float32 ulp off float32(g0 + i*dg): the caller's float64 grid is itself rounded (np.arange /
+  // np.linspace: start + i*step), and where that value falls within ~1e-11 of the midpoint of two float32 numbers the
+  // two roundings part -- one node in ~1e5 at 4096 nodes 70 km from the origin (BASELINE config 5: two of its 32 axes,
+  // which sent the whole plan to the general kernel).  An ulp of a node is ~1e-3 pixel there, the rounding the
+  // reference's own float32 coordinate carries (MRX_OPT_AXIS_LITERAL), so such an axis is uniform for this purpose.
+  auto off_grid = [](double g0, double dg, int i, float node) {
+    const float a = (float)((double)i * dg + g0);
+    return !(fabsf(a - node) <= fmaxf(fmaxf(fabsf(a), fabsf(node)), (float)fabs(dg)) * 1.1920929e-7f);  // 2^-23; NaN is off
+  };
   int bad_e = 0, bad_c = 0;
-  for (int i = threadIdx.x; i < ly.n_e; i += blockDim.x)
-    bad_e |= (float)((double)i * ly.de + ly.e0) != ly.axis_e[i];
-  for (int i = threadIdx.x; i < ly.n_c; i += blockDim.x)
-    bad_c |= (float)((double)i * ly.dc + ly.c0) != ly.axis_c[i];
+  for (int i = threadIdx.x; i < ly.n_e; i += blockDim.x) bad_e |= off_grid(ly.e0, ly.de, i, ly.axis_e[i]);
+  for (int i = threadIdx.x; i < ly.n_c; i += blockDim.x) bad_c |= off_grid(ly.c0, ly.dc, i, ly.axis_c[i]);
   if (bad_e) atomicAnd(&ok_e, 0);
   if (bad_c) atomicAnd(&ok_c, 0);
   __syncthreads();
@@ -718,13 +813,19 @@ __global__ void plan_finish_layers(mrx_layer_dev* layers, mrx_layer_fast* fast, 
     f.pe_x = ly.pe_x; f.pe_y = ly.pe_y; f.pc_x = ly.pc_x; f.pc_y = ly.pc_y;
     f.n_e = ly.n_e; f.n_c = ly.n_c;
     f.pwv_rms = ly.pwv_rms;
-    // (sides below 2^23: the pixel kernel forms cell indices with 24-bit multiplies)
-    f.pixel = ok_e && ok_c && ly.de > 0.0 && ly.dc > 0.0 && ly.n_e < (1 << 23) && ly.n_c < (1 << 23);
+    // the pixel kernel addresses a screen with a 32-bit byte offset formed by a 24-bit multiply, ie * (4 n_c):
+    // sides below 2^22 and screens below 4 GiB (larger ones -- a caller's own 32768^2 -- take the general kernel)
+    f.pixel = ok_e && ok_c && ly.de > 0.0 && ly.dc > 0.0 && ly.n_e < (1 << 22) && ly.n_c < (1 << 22) &&
+              (unsigned long long)ly.n_e * (unsigned long long)ly.n_c * 4ull < (1ull << 32);
     mrx_layer_px& q = px[l];
     q.values = ly.values;
+    q.values1 = ly.values + ly.n_c;
     q.pe_x = (float)ly.pe_x; q.pe_y = (float)ly.pe_y; q.pc_x = (float)ly.pc_x; q.pc_y = (float)ly.pc_y;
-    q.n_e = ly.n_e; q.n_c = ly.n_c;
+    q.nc4 = 4 * ly.n_c;
     q.pwv_rms = ly.pwv_rms;
+    q.half_e = 0.5f * (float)(ly.n_e - 1); q.half_c = 0.5f * (float)(ly.n_c - 1);
+    q.bytes = f.pixel ? (uint32_t)((unsigned long long)ly.n_e * (unsigned long long)ly.n_c * 4ull) : 0u;
+    q.bytes1 = f.pixel ? q.bytes - (uint32_t)q.nc4 : 0u;
   }
 }
 
@@ -972,8 +1073,10 @@ int mrx_atm_sample(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d_az,
     const int nby = mrx_ceil_div(Ta, chunk);
     const long long n_items = (long long)nbx * nby;
     MRX_REQUIRE(ctx, n_items <= 0x7fffffffLL, "too many work items for one launch");
-    const dim3 gridp((unsigned)std::min(n_items, (long long)per_cu * (ctx->n_cu > 0 ? ctx->n_cu : 256)));
-    const size_t lds_p = sizeof(float4) * (size_t)chunk * plan->n_layers + lds_bytes;
+    long long wgs_p = std::min(n_items, (long long)per_cu * (ctx->n_cu > 0 ? ctx->n_cu : 256));
+    if (wgs_p >= 8) wgs_p &= ~7LL;  // whole groups of 8: one workgroup per XCD and turn (the kernel's item order)
+    const dim3 gridp((unsigned)wgs_p);
+    const size_t lds_p = 2 * sizeof(float4) * (size_t)chunk * plan->n_layers + lds_bytes;
     // a small resident grid (beside the TOD writer) takes the software-pipelined layer loop
     const bool pipe = ctx->options[MRX_OPT_SAMPLE_WGS_PER_CU] > 0 && ctx->options[MRX_OPT_SAMPLE_WGS_PER_CU] < 8;
     if (kt == 4) kt = 2;  // (no instance: four interleaved steps spill at 96 registers)
@@ -984,7 +1087,7 @@ int mrx_atm_sample(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d_az,
                        plan->d_fast, plan->d_px, plan->n_layers, plan->d_offpx, plan->d_tables,      \
                        plan->n_tables, plan->d_table_data, plan->table_floats, d_az, d_el, Ta, d_dx, \
                        d_dy, d_band, d_mueller00, D, pwv0, d_pwv, d_loading, d_flags, chunk, nbx,    \
-                       (int)n_items);                                                                \
+                       nby);                                                                         \
   } while (0)
 #define MRX_LAUNCH_PX_T(L, P) do { if (kt == 1) MRX_LAUNCH_PX(L, 1, P); else MRX_LAUNCH_PX(L, 2, P); } while (0)
     if (lds) {

@@ -263,8 +263,9 @@ class DevicePath:
             ly.pwv_rms = float(np.float32(layer["pwv_rms"]))
             # uniform-axis hint (include/mrx.h): the f64 grids behind the f32 axes
             ex, cs = np.asarray(layer["extrusion"], float), np.asarray(layer["cross_section"], float)
-            ly.e0, ly.de = float(ex[0]), float(ex[1] - ex[0])
-            ly.c0, ly.dc = float(cs[0]), float(cs[1] - cs[0])
+            # (the step from the whole span: the difference of two neighbouring nodes carries their rounding)
+            ly.e0, ly.de = float(ex[0]), float((ex[-1] - ex[0]) / (len(ex) - 1))
+            ly.c0, ly.dc = float(cs[0]), float((cs[-1] - cs[0]) / (len(cs) - 1))
         if self.plan is not None:
             self.ctx.call("mrx_atm_plan_destroy", self.plan)
         plan = C.c_void_p()
@@ -557,19 +558,25 @@ class DevicePath:
         return out
 
     def default_blocks(self):
-        """Detector blocks of the pipelined run: 4 from 4096 rows up (round 3, atlast_10k: 2.12 ms with 4
-        blocks, 2.17 with 8, 2.24-2.34 with 12, 2.69 serial), 2 from 2048 (the shard of a 4-GPU run, 2 512 rows:
+        """Detector blocks of the pipelined run: about 0.65e9 samples each from 4096 rows up -- 4 for atlast_10k
+        (2.12 ms with 4 blocks, 2.17 with 8, 2.24-2.34 with 12, 2.69 serial), 12 for the per-GPU share of
+        atlast_50k (6 250 x 1 440 000 samples, 16 layers: 9.1-9.4 ms with 12 or 16 blocks, 9.8 with 8, 10.4 with 4,
+        12.6 serial; round 4, scripts/exp_50k_sweep.py) --, 2 from 2048 rows (the shard of a 4-GPU run, 2 512 rows:
         0.63 ms against 0.66 serial and 0.69 with 4), 1 below (1 264 rows: 0.35 against 0.37;
         scripts/exp_small_blocks.py)."""
         if self.keep_pwv or self.D < 2048:
             return 1
-        # screens that do not fit the Infinity Cache (atlast_50k: 16 x 4096^2 = 1.07 GB) make the
-        # sampler memory-bound, and beside the writer it then loses more than the overlap gains
-        # (measured: 13.9 ms serial against 16.6-17.8 pipelined for 6250 x 1 440 000 samples)
-        screens_bytes = 4 * sum(len(l["extrusion"]) * len(l["cross_section"]) for l in self.problem["layers"])
-        if screens_bytes > 256 << 20:
-            return 1
-        return 4 if self.D >= 4096 else 2
+        if self.D < 4096:
+            return 2
+        return int(min(max(round(self.D * self.T / 0.65e9), 4), 16, self.D // 256))
+
+    def default_resident_wgs(self):
+        """Workgroups per CU of the sampler that runs beside a writer.  The register file is what the two share: 3
+        where the writer is the longer of the two (atlast_10k: 8 layers, sampler 0.7 ms against the writer's 1.8),
+        4 where the sampler has as much to do (atlast_50k: 16 layers, 5.5 against 6.8 ms: 9.1 ms with 4, 9.9 with 3
+        or 5, 10.8 with 6).  The measure is layer-samples per TOD sample."""
+        work = len(self.problem["layers"]) * self.Ta / max(self.T, 1)
+        return 4 if work >= 0.3 else 3
 
     def _side_stream(self, main):
         """A stream that really runs beside ``main``: HIP spreads streams round-robin over four hardware queues,
@@ -610,7 +617,7 @@ class DevicePath:
         self._pipe = st
         return st
 
-    def _run_pipelined(self, out, blocks, resident_wgs_per_cu=3, writer_events=None, serial_events=None, krj=False,
+    def _run_pipelined(self, out, blocks, resident_wgs_per_cu=None, writer_events=None, serial_events=None, krj=False,
                        resident_times=1):
         """The sampler of block b on the side stream, the writer of block b (spline solve fused
         in: mrx_spline_upsample_fused) on the caller's stream behind an event; block 0's sampler
@@ -622,6 +629,8 @@ class DevicePath:
         per-stage breakdown of exactly the launches the pipelined step makes."""
         if self.plan is None:
             raise RuntimeError("no screens bound: call set_screens() or generate_screens() first")
+        if resident_wgs_per_cu is None:
+            resident_wgs_per_cu = self.default_resident_wgs()
         resident_wgs_per_cu = int(os.environ.get("MRX_AB_RESIDENT_WGS", resident_wgs_per_cu))  # (A/B runs)
         main = torch.cuda.current_stream(self.device)
         st = self._pipeline_state(blocks, main)
@@ -642,9 +651,9 @@ class DevicePath:
         sl = lambda t, lo, hi: None if t is None else ptr(t[lo:hi])  # noqa: E731
         for i, (lo, hi) in enumerate(st["bounds"]):
             n = hi - lo
-            # beside a writer: a resident grid of 3 workgroups per CU at 64 registers, the layer loop
-            # software-pipelined (round 3, atlast_10k: 2.12 ms at 3 per CU, 2.15 at 4, 2.27 at 5, 2.44 at 2;
-            # two steps per thread at 96 registers: 2.18)
+            # beside a writer: a resident grid of default_resident_wgs() workgroups per CU, the layer loop
+            # software-pipelined (atlast_10k: 2.12 ms at 3 per CU, 2.15 at 4, 2.27 at 5, 2.44 at 2; two steps
+            # per thread at 96 registers: 2.18)
             alone = i == 0 or serial
             # block 0 has nothing to run beside: its sampler goes on the caller's stream, straight behind the screens and
             # straight before its writer (a kernel follows a kernel of its own stream after ~6 us, an event of another

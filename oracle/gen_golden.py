@@ -10,7 +10,10 @@ exist on the GPU box):
 astropy, h5py ... are not installed).  Registering bare parent
 packages lets the leaf modules that only need numpy/scipy load unmodified:
 ``maria.constants``, ``maria.functions``, ``maria.beam``, ``maria.utils.linalg``,
-``maria.utils.rotations``, ``maria.utils.signal``, ``maria.plan.patterns``.  No third-party library is stubbed.  The outputs below
+``maria.utils.rotations``, ``maria.utils.signal``, ``maria.plan.patterns``.  No third-party library is stubbed.
+Where jax IS installed (not in the build container) the run also writes tests/golden/jax_steps.json: the
+reference's float32 pointing chain and jax's RegularGridInterpolator on fixed inputs (``jax_steps`` below) --
+the three steps whose parity is otherwise unpinned.  The outputs below
 are data (inputs and the reference's answers); no reference source is copied.
 """
 
@@ -164,6 +167,77 @@ def main():
     with open(OUT, "w") as f:
         json.dump(g, f, indent=1)
     print("wrote", OUT, os.path.getsize(OUT), "bytes")
+    jax_steps()
+
+
+JAX_OUT = os.path.join(os.path.dirname(OUT), "jax_steps.json")
+
+
+def jax_step_inputs():
+    """The inputs of the jax leg (seeded; tests/test_oracle_golden.py rebuilds the oracle's answers from the
+    copies stored in the file, so this function is only called here)."""
+    rng = np.random.default_rng(20260612)
+    offsets = np.radians(rng.uniform(-1.0, 1.0, (24, 2)))
+    offsets[0] = 0.0                                    # the boresight itself
+    offsets[1] = np.radians([0.0, 0.75])                # on an axis: atan2(-0, -dy)
+    az = np.radians(np.r_[rng.uniform(0, 360, 12), 359.999, 0.0, 45.0, 180.0])
+    el = np.radians(np.r_[rng.uniform(20, 85, 12), 60.0, 89.2, 30.0, 45.0])
+    # a screen-shaped lookup (atmosphere.py:359-366): float64 axes of a ribbon far from its origin, points inside,
+    # on nodes, on the last node and outside
+    ext = -3000.0 + 5.0 * np.arange(48)
+    cross = np.linspace(1234.5 - 7.0, 1234.5 + 120.0 + 7.0, 19)
+    values = rng.standard_normal((48, 19))
+    pe = np.r_[rng.uniform(ext[0], ext[-1], 40), ext[[0, 7, 47]], ext[0] - 1.0, ext[-1] + 1e-3, 0.5 * (ext[3] + ext[4])]
+    pc = np.r_[rng.uniform(cross[0], cross[-1], 40), cross[[0, 9, 18]], cross[5], cross[5], cross[-1] + 2.0]
+    # a table-shaped lookup (band.py:283-286): (scalar T0, pwv, elevation) on a (T, pwv, el) grid whose last elevation
+    # node is 90.1 deg (spectrum/atmosphere.py:48-50)
+    T = np.array([250.0, 270.0, 290.0])
+    pwv = np.linspace(0.0, 10.0, 21)
+    elg = np.radians(np.r_[np.linspace(10.0, 87.5, 15), 90.1])
+    tab = 30.0 * (T[:, None, None] / 270.0) * (1 - np.exp(-(0.04 + 0.025 * pwv[None, :, None]) / np.sin(np.minimum(elg, np.pi / 2))[None, None, :]))
+    qp = np.r_[rng.uniform(0.2, 3.0, 30), 0.0, 10.0, 10.5, 1.0]
+    qe = np.radians(np.r_[rng.uniform(25, 85, 30), 10.0, 90.0, 60.0, 9.0])
+    return dict(offsets=offsets, az=az, el=el, ext=ext, cross=cross, values=values, pe=pe, pc=pc, T=T, pwv=pwv, elg=elg, tab=tab,
+                T0=273.15, qp=qp, qe=qe)
+
+
+def jax_steps():
+    """Optional leg: where jax is installed, pin the three steps SURVEY 8(c) lists as unpinned -- the float32 pointing
+    chain (coords/transforms.py:10-29, the reference's own function, loaded unmodified through the bare-parent loader)
+    and jax.scipy.interpolate.RegularGridInterpolator as called at atmosphere/atmosphere.py:359-366 and
+    band/band.py:283-286 -- into tests/golden/jax_steps.json.  jax is never stubbed: without it this leg does nothing
+    and tests/test_oracle_golden.py::test_jax_* skip."""
+    try:
+        import jax  # noqa: F401
+        import jax.scipy as jsp
+    except ImportError:
+        print("jax is not installed: tests/golden/jax_steps.json not written (the jax steps stay unpinned)")
+        return
+    m = types.ModuleType("maria.coords")
+    m.__path__ = [os.path.join(REF, "maria", "coords")]
+    sys.modules["maria.coords"] = m
+    import maria.coords.transforms as transforms
+
+    x = jax_step_inputs()
+    lst = lambda a: np.asarray(a).tolist()  # noqa: E731
+    g = {"_generator": "oracle/gen_golden.py (jax leg)", "_jax_version": jax.__version__,
+         "_x64": bool(jax.config.read("jax_enable_x64"))}
+    # Coordinates.broadcast (coordinates.py:378-386): offsets[..., None, :] against the boresight arrays
+    pt = np.asarray(transforms.unjitted_offsets_to_phi_theta(x["offsets"][:, None, :], x["az"], x["el"]))
+    g["offsets_to_phi_theta"] = {"offsets": lst(x["offsets"]), "az": lst(x["az"]), "el": lst(x["el"]), "dtype": str(pt.dtype),
+                                 "phi": lst(pt[..., 0].astype(np.float64)), "theta": lst(pt[..., 1].astype(np.float64))}
+    y = np.asarray(jsp.interpolate.RegularGridInterpolator((x["ext"], x["cross"]), x["values"], method="linear")(
+        np.stack([x["pe"], x["pc"]], axis=-1)))
+    g["rgi_screen"] = {"extrusion": lst(x["ext"]), "cross_section": lst(x["cross"]), "values": lst(x["values"]),
+                       "points_e": lst(x["pe"]), "points_c": lst(x["pc"]), "dtype": str(y.dtype),
+                       "y": [None if v != v else float(v) for v in y.astype(np.float64)]}
+    p = np.asarray(jsp.interpolate.RegularGridInterpolator((x["T"], x["pwv"], x["elg"]), x["tab"])((x["T0"], x["qp"], x["qe"])))
+    g["rgi_table"] = {"T": lst(x["T"]), "pwv": lst(x["pwv"]), "el": lst(x["elg"]), "values": lst(x["tab"]), "T0": x["T0"],
+                      "points_pwv": lst(x["qp"]), "points_el": lst(x["qe"]), "dtype": str(p.dtype),
+                      "p": [None if v != v else float(v) for v in p.astype(np.float64)]}
+    with open(JAX_OUT, "w") as f:
+        json.dump(g, f, indent=1)
+    print("wrote", JAX_OUT, os.path.getsize(JAX_OUT), "bytes")
 
 
 if __name__ == "__main__":

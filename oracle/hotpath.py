@@ -34,6 +34,18 @@ f32 = np.float32
 HALF_PI_F32 = f32(np.pi / 2)  # jnp.pi / 2 is weakly typed -> float32 next to a float32 array
 
 
+class Transcendentals:
+    """The float32 elementary functions of the pointing chain.  XLA's float32 sin / cos / atan2 / asin / tan / sqrt are
+    not numpy's to the last ulp and cannot be restated without jax; the functions below go through this table so that
+    tests/test_oracle_golden.py::test_one_ulp_envelope_of_the_float32_transcendentals can replace every one of them
+    by a version that is off by +-1 ulp and measure what that does to the loading."""
+
+    sqrt, arctan2, sin, cos, arcsin, tan = np.sqrt, np.arctan2, np.sin, np.cos, np.arcsin, np.tan
+
+
+TR = Transcendentals
+
+
 # ---------------------------------------------------------------------------
 # pointing
 # ---------------------------------------------------------------------------
@@ -48,16 +60,16 @@ def offsets_to_phi_theta(dx, dy, cphi, ctheta):
     """
     dx, dy = np.asarray(dx, f32), np.asarray(dy, f32)
     cphi, ctheta = np.asarray(cphi, f32), np.asarray(ctheta, f32)
-    r = np.sqrt(dx * dx + dy * dy)
-    p = np.arctan2(-dx, -dy)
-    a_re = np.sin(r) * np.cos(p)
-    a_im = np.cos(r)
+    r = TR.sqrt(dx * dx + dy * dy)
+    p = TR.arctan2(-dx, -dy)
+    a_re = TR.sin(r) * TR.cos(p)
+    a_im = TR.cos(r)
     ang = ctheta - HALF_PI_F32
-    b_re, b_im = np.cos(ang), np.sin(ang)
+    b_re, b_im = TR.cos(ang), TR.sin(ang)
     re = a_re * b_re - a_im * b_im
     im = a_re * b_im + a_im * b_re
-    phi = np.arctan2(np.sin(r) * np.sin(p), re) + cphi
-    theta = np.arcsin(im)
+    phi = TR.arctan2(TR.sin(r) * TR.sin(p), re) + cphi
+    theta = TR.arcsin(im)
     return phi.astype(f32), theta.astype(f32)
 
 
@@ -97,9 +109,9 @@ def project_unit(phi, theta):
     ``(z - self.z)`` promotes the result to float64.
     """
     phi, theta = np.asarray(phi, f32), np.asarray(theta, f32)
-    tan_theta = np.tan(theta)
-    px = (np.cos(phi) / tan_theta).astype(np.float64)
-    py = (np.sin(phi) / tan_theta).astype(np.float64)
+    tan_theta = TR.tan(theta)
+    px = (TR.cos(phi) / tan_theta).astype(np.float64)
+    py = (TR.sin(phi) / tan_theta).astype(np.float64)
     return np.stack([px, py, np.ones_like(px)], axis=-1)
 
 

@@ -200,3 +200,110 @@ def test_spatial_basis_matches_reference():
     ref = np.array(g["B"])
     np.testing.assert_allclose(onoise.generate_spatial_basis(off, k=g["k"], n_side=g["n_side"], scale=g["scale"]), ref, rtol=0, atol=1e-11)
     np.testing.assert_allclose(mnoise.spatial_basis(off, k=g["k"], n_side=g["n_side"], scale=g["scale"]), ref, rtol=0, atol=1e-11)
+
+
+# ---- the jax steps: pinned where a jax run has been recorded, bounded where it has not -------------------------
+
+JAX_GOLD_PATH = os.path.join(os.path.dirname(__file__), "golden", "jax_steps.json")
+needs_jax_golden = pytest.mark.skipif(
+    not os.path.exists(JAX_GOLD_PATH),
+    reason="tests/golden/jax_steps.json is written by oracle/gen_golden.py where jax is installed (not in the build "
+    "container): the float32 pointing chain and the two RegularGridInterpolator lookups stay unpinned until then")
+
+
+def _jax_gold():
+    return json.load(open(JAX_GOLD_PATH))
+
+
+@needs_jax_golden
+def test_jax_pointing_chain_bit_for_bit():
+    """oracle.hotpath.offsets_to_phi_theta against the reference's own unjitted_offsets_to_phi_theta (coords/transforms.py:10-29)
+    run under jax: every float32 bit."""
+    g = _jax_gold()["offsets_to_phi_theta"]
+    assert g["dtype"] == "float32"
+    off = np.array(g["offsets"])
+    phi, theta = hotpath.broadcast(off, np.array(g["az"]), np.array(g["el"]))
+    np.testing.assert_array_equal(phi, np.array(g["phi"], np.float32))
+    np.testing.assert_array_equal(theta, np.array(g["theta"], np.float32))
+
+
+@needs_jax_golden
+def test_jax_regular_grid_interpolator_bit_for_bit():
+    """oracle.hotpath.rgi_linear_f32 against jax.scipy.interpolate.RegularGridInterpolator as called at
+    atmosphere/atmosphere.py:359-366 (screen) and band/band.py:283-286 (table), out-of-grid points included."""
+    g = _jax_gold()
+    s = g["rgi_screen"]
+    assert s["dtype"] == "float32"
+    got = hotpath.rgi_linear_f32((s["extrusion"], s["cross_section"]), s["values"], (np.array(s["points_e"]), np.array(s["points_c"])))
+    want = np.array([np.nan if v is None else v for v in s["y"]], np.float32)
+    np.testing.assert_array_equal(got, want)
+    t = g["rgi_table"]
+    got = hotpath.rgi_linear_f32((t["T"], t["pwv"], t["el"]), t["values"], (np.asarray(t["T0"]), np.array(t["points_pwv"]), np.array(t["points_el"])))
+    want = np.array([np.nan if v is None else v for v in t["p"]], np.float32)
+    np.testing.assert_array_equal(got, want)
+
+
+def _one_ulp_off(fn, rng):
+    """``fn`` with every float32 result moved one ulp up or down at random (exact zeros and non-finite values stay)."""
+
+    def off(*args):
+        y = np.asarray(fn(*args))
+        assert y.dtype == np.float32
+        away = np.where(rng.random(y.shape) < 0.5, np.float32(-np.inf), np.float32(np.inf))
+        return np.where(np.isfinite(y) & (y != 0), np.nextafter(y, away), y).astype(np.float32)
+
+    return off
+
+
+def _ulp_envelope(problem, draws, seed):
+    """(largest move of the TOD relative to its largest value, largest move of the fluctuation -- per-detector mean
+    removed -- relative to the largest fluctuation, same for the coarse loading) over ``draws`` runs of the oracle in
+    which EVERY float32 transcendental of the pointing chain and of the ground projection is one ulp off at random."""
+    base, mid = hotpath.run_path(problem, return_intermediates=True)
+    rng = np.random.default_rng(seed)
+    plain = hotpath.TR
+    names = ("sqrt", "arctan2", "sin", "cos", "arcsin", "tan")
+    fl = lambda a: a - a.mean(axis=-1, keepdims=True)  # noqa: E731
+    worst = np.zeros(4)
+    try:
+        for _ in range(draws):
+            hotpath.TR = type("OneUlpOff", (), {n: staticmethod(_one_ulp_off(getattr(plain, n), rng)) for n in names})
+            tod, m = hotpath.run_path(problem, return_intermediates=True)
+            worst = np.maximum(worst, [
+                np.abs(tod - base).max() / np.abs(base).max(),
+                np.abs(fl(tod.astype(float)) - fl(base.astype(float))).max() / np.abs(fl(base.astype(float))).max(),
+                np.abs(m["loading_a"] - mid["loading_a"]).max() / np.abs(mid["loading_a"]).max(),
+                np.abs(fl(m["pwv"]) - fl(mid["pwv"])).max() / np.abs(fl(mid["pwv"])).max()])
+    finally:
+        hotpath.TR = plain
+    return worst
+
+
+def test_one_ulp_envelope_of_the_float32_transcendentals():
+    """What cannot be restated without jax: XLA's float32 sin / cos / atan2 / asin (and numpy's own tan / cos / sin of the
+    ground projection, coordinates.py:339-347) are not these to the last ulp.  With EVERY such call one ulp off at random
+    (20 draws) the loading stays far inside north_star's 1e-5; the move of the fluctuation alone is reported and bounded
+    at 2x what was measured."""
+    from helpers import small_problem
+
+    tod, fluct, coarse, pwv = _ulp_envelope(small_problem(), draws=20, seed=7)
+    print(f"small_problem: TOD moves {tod:.2e} of its maximum, its fluctuation {fluct:.2e}; coarse loading {coarse:.2e}, pwv fluctuation {pwv:.2e}")
+    assert tod <= 1e-5 and coarse <= 1e-5  # measured 3.6e-6 and 5.4e-7
+    assert fluct <= 1.5e-3 and pwv <= 3e-5  # measured 7.2e-4 (fluctuations of 0.5 % of the loading) and 1.4e-5
+
+
+def test_one_ulp_envelope_on_atlast_10k_rows():
+    """The same on 12 rows of BASELINE config 4 (full duration, 8 layers of 2048^2): rows at the centre, mid-radius and
+    rim of the 2-degree focal plane."""
+    from helpers import attach_numpy_screens
+    from maria_amd import synthetic
+
+    p = synthetic.config_problem("atlast_10k")
+    rows = np.r_[0:2, 2500:2502, 5000:5002, 7500:7502, 9996:10000]
+    for key in ("offsets", "band_index", "m00"):
+        p[key] = p[key][rows]
+    attach_numpy_screens(p, seed=3)
+    tod, fluct, coarse, pwv = _ulp_envelope(p, draws=20, seed=11)
+    print(f"atlast_10k rows: TOD moves {tod:.2e} of its maximum, its fluctuation {fluct:.2e}; coarse loading {coarse:.2e}, pwv fluctuation {pwv:.2e}")
+    assert tod <= 1e-5 and coarse <= 1e-5  # measured 4.0e-6 and 5.7e-7
+    assert fluct <= 6e-4 and pwv <= 1e-5  # measured 2.9e-4 and 4.8e-6
