@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define MRX_VERSION 131 /* 0.2.0 (120): mrx_spline_upsample_fused, mrx_allgather_tod_p2p, mrx_exchange_screens,
+#define MRX_VERSION 140 /* 0.2.0 (120): mrx_spline_upsample_fused, mrx_allgather_tod_p2p, mrx_exchange_screens,
                            mrx_resample_columns; MRX_OPT_SAMPLE_TILES retired.  130: mrx_screen_amplitudes,
                            mrx_screen_desc.d_amp, mrx_screen_generate_3d(..., d_amp), mrx_streams_concurrent.
                            131: mrx_coarse_to_krj_keep_tail */
@@ -394,14 +394,20 @@ int mrx_map_smooth(mrx_ctx* ctx, const float* d_data, const float* d_weight,
  * atmosphere/atmosphere.py:341-344 (scipy.ndimage.gaussian_filter: reflect, truncate 4)
  * folded in: along y on the half spectra between the two FFT passes, along x on the
  * finished row; float32 accumulation (equal to mrx_gauss_smooth2d of the unsmoothed
- * screen to ~1e-6 of its rms).  Only the top-left out_ny x out_nx block of the
+ * screen to ~1e-6 of its rms) -- or, per screen (periodic_beam), as a factor of the spectrum.  Only the top-left out_ny x out_nx block of the
  * periodic domain is smoothed and written (reflection at ITS edges): a layer may use a
  * larger FFT domain than its grid so that opposite edges decorrelate. */
 typedef struct mrx_screen_desc {
   float* d_out;            /* [out_ny][ld_out] f32                                  */
   uint32_t stream;         /* Philox stream of this screen (the layer index)        */
   int32_t out_ny, out_nx;  /* written block; 0 = the whole domain                   */
-  int32_t reserved;
+  int32_t periodic_beam;   /* 0: the beam as scipy applies it to the written block (reflection at its
+                              edges).  1: the same truncated, normalised taps as a convolution on the
+                              PERIODIC FFT domain, folded into the spectrum (the two stencils, a quarter
+                              of the generator's arithmetic, disappear): pixels at least the stencil
+                              radius int(4 sigma + 0.5) from every edge of the written block are the
+                              same to rounding, nearer ones see the field beyond the edge instead of its
+                              mirror image.  For callers whose lines of sight keep that distance.      */
   size_t ld_out;           /* row pitch in floats; 0 = out_nx                        */
   double dy, dx;           /* grid steps (m)                                         */
   double r0, nu;           /* outer scale (m), Matern smoothness                     */

@@ -93,7 +93,7 @@ class MrxScreenDesc(C.Structure):
         ("stream", C.c_uint32),
         ("out_ny", C.c_int32),
         ("out_nx", C.c_int32),
-        ("reserved", C.c_int32),
+        ("periodic_beam", C.c_int32),
         ("ld_out", C.c_size_t),
         ("dy", C.c_double),
         ("dx", C.c_double),

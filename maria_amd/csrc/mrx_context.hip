@@ -125,6 +125,8 @@ int mrx_destroy(mrx_ctx* ctx) {
     if (slot.d_taps) (void)hipFree(slot.d_taps);
   for (auto& slot : ctx->ftaps)
     if (slot.d_taps) (void)hipFree(slot.d_taps);
+  for (auto& slot : ctx->fresp)
+    if (slot.d_resp) (void)hipFree(slot.d_resp);
   if (ctx->d_reduce) (void)hipFree(ctx->d_reduce);
   for (hipStream_t st : ctx->side_streams)
     if (st) (void)hipStreamDestroy(st);

@@ -42,6 +42,16 @@ struct mrx_ctx {
   } ftaps[kFTapSlots];
   int ftaps_next = 0;
   unsigned long long ftaps_batch = 0;
+  // transfer functions of those taps on a periodic axis of n nodes (the beam folded into the spectrum,
+  // mrx_screen_desc.periodic_beam): n/2 + 1 floats per (sigma, n); pinned per batch like the taps
+  static constexpr int kFRespSlots = 64;
+  struct FRespSlot {
+    double sigma = -1.0;
+    int n = 0, radius = 0;
+    float* d_resp = nullptr;
+    unsigned long long pinned = 0;
+  } fresp[kFRespSlots];
+  int fresp_next = 0;
   int options[MRX_OPT_COUNT] = {0};
   // screen normalisations (sum of the PSD over the FFT grid), one device double
   // per distinct (grid, spectrum)

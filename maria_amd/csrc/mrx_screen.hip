@@ -59,6 +59,8 @@ struct ScreenLayerArgs {
   const float* taps_y;    // [kMaxFusedRadius + 1] normalised Gaussian taps, zero beyond the radius
   const float* taps_x;
   const float* amp;       // [nx/2 + 1][ny/2 + 1] amplitudes of mrx_screen_amplitudes (even in ky), or null: the power law
+  const float* resp_y;    // [ny/2 + 1] transfer function of the beam's taps along y on the periodic domain, or null
+  const float* resp_x;    // [nx/2 + 1] (periodic_beam: the beam as a factor of the spectrum; ry = rx = 0 then)
   int from_work;          // 1: the half spectrum of this plane already sits in `work` (3-D generator,
                           // written by screen3d_fft_h); pass 1 transforms it in place instead of drawing
   double dy, dx, k0sq;
@@ -193,8 +195,13 @@ __device__ __forceinline__ void half_spectrum_column_stockham(const ScreenLayerA
     // keeps the (real) covariance along h and makes S'[-ky] = conj S'[ky]; the self-conjugate
     // cells become sqrt 2 Re S.
     const float2* src = L.work + (size_t)ix * (ny + kPitchPad);
+    const float hx = L.resp_x ? L.resp_x[ix] : 1.0f;
     for (int iy = threadIdx.x; iy < half; iy += kBlock) {
-      const float2 a = src[iy], b = src[iy + half];
+      float2 a = src[iy], b = src[iy + half];
+      if (L.resp_y) {  // the beam as a factor of the spectrum (even in ky: cell iy + ny/2 mirrors ny/2 - iy)
+        const float h0 = hx * L.resp_y[iy], h1 = hx * L.resp_y[half - iy];
+        a.x *= h0; a.y *= h0; b.x *= h1; b.y *= h1;
+      }
       if (!edge) {
         data[iy] = a;
         data[iy + half] = b;
@@ -202,7 +209,8 @@ __device__ __forceinline__ void half_spectrum_column_stockham(const ScreenLayerA
         data[0] = make_float2(1.41421356f * a.x, 0.0f);
         data[half] = make_float2(1.41421356f * b.x, 0.0f);
       } else {
-        const float2 m = src[ny - iy];
+        float2 m = src[ny - iy];
+        if (L.resp_y) { m.x *= hx * L.resp_y[iy]; m.y *= hx * L.resp_y[iy]; }
         const float2 h = make_float2(kRoot * (a.x + m.x), kRoot * (a.y - m.y));
         data[iy] = h;
         data[ny - iy] = make_float2(h.x, -h.y);
@@ -220,6 +228,11 @@ __device__ __forceinline__ void half_spectrum_column_stockham(const ScreenLayerA
       const double ky0 = wavenumber(iy, ny, L.dy), ky1 = wavenumber(iy + half, ny, L.dy);
       amp0 = spectrum_amp(L.k0sq + kx * kx + ky0 * ky0, L.expo);
       amp1 = spectrum_amp(L.k0sq + kx * kx + ky1 * ky1, L.expo);
+    }
+    if (L.resp_y) {
+      const float hx = L.resp_x[ix];
+      amp0 *= hx * L.resp_y[iy];
+      amp1 *= hx * L.resp_y[half - iy];
     }
     const float2 g0 = box_muller(rnd.x, rnd.y), g1 = box_muller(rnd.z, rnd.w);
     if (!edge) {
@@ -278,9 +291,18 @@ __global__ __launch_bounds__(kBlock) void screen_half_spectrum_regs(const Screen
       const float2* src = L.work + (size_t)ix * (ny + kPitchPad);
 #pragma unroll
       for (int b = 0; b < 16; ++b) v[b] = src[t + T * b];
+      if (L.resp_y) {  // the beam as a factor of the spectrum: |ky| = iy for b < 8, ny/2 - iy for the mirrored half
+        const float hx = L.resp_x[ix];
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+          const float h0 = hx * L.resp_y[t + T * b], h1 = hx * L.resp_y[half - (t + T * b)];
+          v[b].x *= h0; v[b].y *= h0; v[b + 8].x *= h1; v[b + 8].y *= h1;
+        }
+      }
     } else {
       constexpr float kRoot = 0.70710678118654752f;
       const double kx = wavenumber(ix, nx, L.dx);
+      const float hx = L.resp_x ? L.resp_x[ix] : 1.0f;
       auto draw = [&](auto tabulated) {
         float a0[8], a1[8];
         if constexpr (decltype(tabulated)::value) {  // all 16 loads in flight before the first draw
@@ -303,6 +325,10 @@ __global__ __launch_bounds__(kBlock) void screen_half_spectrum_regs(const Screen
             const double ky0 = wavenumber(iy, ny, L.dy), ky1 = wavenumber(iy + half, ny, L.dy);
             amp0 = spectrum_amp(L.k0sq + kx * kx + ky0 * ky0, L.expo);
             amp1 = spectrum_amp(L.k0sq + kx * kx + ky1 * ky1, L.expo);
+          }
+          if (L.resp_y) {  // (uniform)
+            amp0 *= hx * L.resp_y[iy];
+            amp1 *= hx * L.resp_y[half - iy];
           }
           const float2 g0 = box_muller(rnd.x, rnd.y), g1 = box_muller(rnd.z, rnd.w);
           v[b] = make_float2(kRoot * amp0 * g0.x, kRoot * amp0 * g0.y);
@@ -741,6 +767,49 @@ int get_ftaps(mrx_ctx* ctx, double sigma, int radius, const float** d_out) {
   return MRX_OK;
 }
 
+// Transfer function of the same taps on a periodic axis of n nodes: H[k] = w_0 + 2 sum_j w_j cos(2 pi j k / n),
+// k = 0 .. n/2 (real and even: the taps are symmetric), float64 on the host; cached per (sigma, n).
+int get_fresp(mrx_ctx* ctx, double sigma, int radius, int n, const float** d_out) {
+  for (auto& slot : ctx->fresp)
+    if (slot.d_resp && slot.sigma == sigma && slot.n == n && slot.radius == radius) {
+      slot.pinned = ctx->ftaps_batch;
+      *d_out = slot.d_resp;
+      return MRX_OK;
+    }
+  std::vector<double> w((size_t)radius + 1);
+  double sum = 0.0;
+  for (int k = 0; k <= radius; ++k) {
+    w[(size_t)k] = std::exp(-0.5 / (sigma * sigma) * (double)k * (double)k);
+    sum += k ? 2.0 * w[(size_t)k] : w[(size_t)k];
+  }
+  std::vector<float> h((size_t)n / 2 + 1);
+  for (int k = 0; k <= n / 2; ++k) {
+    double acc = w[0];
+    for (int j = 1; j <= radius; ++j)
+      acc += 2.0 * w[(size_t)j] * std::cos(6.283185307179586476925 * (double)(((long long)j * k) % n) / (double)n);
+    h[(size_t)k] = (float)(acc / sum);
+  }
+  int pick = ctx->fresp_next;
+  for (int m = 0; m < mrx_ctx::kFRespSlots && ctx->fresp[pick].d_resp && ctx->fresp[pick].pinned == ctx->ftaps_batch; ++m)
+    pick = (pick + 1) % mrx_ctx::kFRespSlots;
+  auto& slot = ctx->fresp[pick];
+  ctx->fresp_next = (pick + 1) % mrx_ctx::kFRespSlots;
+  slot.pinned = ctx->ftaps_batch;
+  if (slot.d_resp) {  // a kernel in flight may still read the evicted table
+    MRX_HIP(ctx, hipDeviceSynchronize());
+    (void)hipFree(slot.d_resp);
+    slot.d_resp = nullptr;
+  }
+  MRX_HIP(ctx, hipMalloc(&slot.d_resp, h.size() * sizeof(float)));
+  MRX_HIP(ctx, hipMemcpyAsync(slot.d_resp, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+  MRX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // h goes out of scope
+  slot.sigma = sigma;
+  slot.n = n;
+  slot.radius = radius;
+  *d_out = slot.d_resp;
+  return MRX_OK;
+}
+
 int ilog2_exact(int n) {
   int l = 0;
   while ((1 << l) < n) ++l;
@@ -875,13 +944,21 @@ static int run_screen_passes(mrx_ctx* ctx, uint64_t seed, int ny, int nx, const 
       // scipy: radius = int(truncate * sigma + 0.5), truncate = 4; a sigma <= 1e-15 skips the axis
       const int ry = d.sigma_y > 1e-15 ? (int)(4.0 * d.sigma_y + 0.5) : 0;
       const int rx = d.sigma_x > 1e-15 ? (int)(4.0 * d.sigma_x + 0.5) : 0;
+      L.taps_y = L.taps_x = L.resp_y = L.resp_x = nullptr;
+      if (d.periodic_beam && (ry > 0 || rx > 0)) {
+        // the beam as a factor of the spectrum (a skipped axis: sigma = 0 has the response 1: one tap)
+        MRX_REQUIRE(ctx, ry < ny / 2 && rx < nx / 2, "periodic_beam: the stencil radius must stay below half the domain");
+        if ((rc = get_fresp(ctx, ry > 0 ? d.sigma_y : 1.0, ry, ny, &L.resp_y)) != MRX_OK) return rc;
+        if ((rc = get_fresp(ctx, rx > 0 ? d.sigma_x : 1.0, rx, nx, &L.resp_x)) != MRX_OK) return rc;
+        L.ry = L.rx = 0;
+      } else {
       // radii beyond the LDS tap table (beams of > 32 pixels) take the separate stencil kernels
       late_smooth[i] = ry > kMaxFusedRadius || rx > kMaxFusedRadius;
       L.ry = late_smooth[i] ? 0 : ry;
       L.rx = late_smooth[i] ? 0 : rx;
-      L.taps_y = L.taps_x = nullptr;
       if (L.ry > 0 && (rc = get_ftaps(ctx, d.sigma_y, L.ry, &L.taps_y)) != MRX_OK) return rc;
       if (L.rx > 0 && (rc = get_ftaps(ctx, d.sigma_x, L.rx, &L.taps_x)) != MRX_OK) return rc;
+      }
       L.out_ny = out_ny;
       L.out_nx = out_nx;
       L.stream = d.stream;

@@ -303,6 +303,40 @@ class DevicePath:
             self._amp[key] = table
         return self._amp[key]
 
+    def sampled_margins_px(self):
+        """Per layer, the smallest distance in pixels between any line of sight of this shard and an edge of the
+        layer's grid, over the whole observation: (margin along the extrusion axis, margin across).  Host-side and
+        conservative: the boresight track with a ring of 24 directions around the focal plane's outermost detector,
+        pushed out to circumscribe the circle, through the float64 form of the pointing
+        (coords/transforms.py:10-29) and the layer's projection (atmosphere/atmosphere.py:346-347)."""
+        if getattr(self, "_margins", None) is None:
+            p = self.problem
+            off = np.asarray(p["offsets"], float)[self.det_slice]
+            rad = float(np.hypot(off[:, 0], off[:, 1]).max()) if len(off) else 0.0
+            ang = np.linspace(0.0, 2.0 * np.pi, 24, endpoint=False)
+            ring = np.r_[np.zeros((1, 2)), (rad / np.cos(np.pi / 24) * 1.001 + 1e-9) * np.c_[np.cos(ang), np.sin(ang)]]
+            az, el = np.asarray(p["az_a"], float), np.asarray(p["el_a"], float)
+            dx, dy = ring[:, 0][:, None], ring[:, 1][:, None]
+            r, q = np.hypot(dx, dy), np.arctan2(-dx, -dy)
+            z = (np.sin(r) * np.cos(q) + 1j * np.cos(r)) * np.exp(1j * (el[None, :] - np.pi / 2))
+            phi, theta = np.arctan2(np.sin(r) * np.sin(q), z.real) + az[None, :], np.arcsin(z.imag)
+            with np.errstate(divide="ignore", invalid="ignore"):
+                px, py = np.cos(phi) / np.tan(theta), np.sin(phi) / np.tan(theta)
+            out = []
+            for layer in p["layers"]:
+                oe, oc = self.layer_offsets(layer)
+                R = np.asarray(layer["transform"], float)
+                e = layer["h"] * (px * R[0, 0] + py * R[1, 0]) + oe[None, :]
+                c = layer["h"] * (px * R[0, 1] + py * R[1, 1]) + oc[None, :]
+                ex, cs = np.asarray(layer["extrusion"], float), np.asarray(layer["cross_section"], float)
+                de, dc = (ex[-1] - ex[0]) / (len(ex) - 1), (cs[-1] - cs[0]) / (len(cs) - 1)
+                if not (np.isfinite(e).all() and np.isfinite(c).all()):
+                    out.append((-np.inf, -np.inf))
+                    continue
+                out.append((float(min(e.min() - ex[0], ex[-1] - e.max()) / de), float(min(c.min() - cs[0], cs[-1] - c.max()) / dc)))
+            self._margins = out
+        return self._margins
+
     def generate_screens(self, smooth=True, only=None):
         """Philox + k-space filter + complex-to-real iFFT on the device with the beam
         smoothing (atmosphere/atmosphere.py:328-344) folded into the two FFT passes
@@ -366,6 +400,27 @@ class DevicePath:
                 nc = max(shapes[l][1] for l in self._gen_fine)
                 self._gen_tmp = torch.empty((2, ne * nc), dtype=torch.float32, device=dev)
             self.set_screens(self._gen_screens)
+        # The beam as a factor of the spectrum (mrx_screen_desc.periodic_beam: no stencils, a third of the generator's
+        # arithmetic less) where every line of sight of the observation keeps at least the stencil's radius + 2 pixels
+        # from the edges of the layer's grid: what those pixels hold is then scipy's reflect-mode result to rounding,
+        # and the pixels that differ (the rim) are never sampled.  The reference's own ribbons leave a margin of one or
+        # two pixels (atmosphere.py:208-245): they keep the stencils, and scipy's edges.
+        if getattr(self, "_beam_in_spectrum", None) is None or getattr(self, "_beam_smooth", None) != smooth:
+            self._beam_smooth = smooth
+            self._beam_in_spectrum = [False] * len(layers)
+            if smooth and self.problem.get("beam_in_spectrum", True):
+                margins = None
+                for l, layer in enumerate(layers):
+                    sigma = float(layer.get("beam_sigma", 0) or 0)
+                    if sigma <= 0 or layer.get("volume") is not None or l in self._gen_fine:
+                        continue
+                    if margins is None:
+                        margins = self.sampled_margins_px()
+                    de = float(layer["extrusion"][1] - layer["extrusion"][0])
+                    dc = float(layer["cross_section"][1] - layer["cross_section"][0])
+                    ry, rx = int(4.0 * sigma / de + 0.5), int(4.0 * sigma / float(layer.get("res") or dc) + 0.5)
+                    fe, fc = fft_shapes[l]
+                    self._beam_in_spectrum[l] = bool(margins[l][0] >= ry + 2 and margins[l][1] >= rx + 2 and ry < fe // 2 and rx < fc // 2)
 
         def pixel_sigmas(layer):
             """(sigma_e, sigma_c) of the beam in pixels as the reference forms them (atmosphere.py:338-339):
@@ -386,6 +441,7 @@ class DevicePath:
                     out = self._gen_screens[l]
                     dc = float(layer["cross_section"][1] - layer["cross_section"][0])
                     d.sigma_y, d.sigma_x = pixel_sigmas(layer)
+                    d.periodic_beam = int(self._beam_in_spectrum[l])
                 else:  # unsmoothed, on the generation grid
                     out = fine["plane"]
                     dc = float(layer["gen"]["cross"][1] - layer["gen"]["cross"][0])

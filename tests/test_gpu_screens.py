@@ -155,6 +155,7 @@ def _generate_batch(ctx, seed, ny, nx, specs):
         d.dy, d.dx, d.r0, d.nu = sp["dy"], sp["dx"], sp["r0"], sp["nu"]
         d.sigma_y, d.sigma_x = sp.get("sigma_y", 0.0), sp.get("sigma_x", 0.0)
         d.d_amp = sp["amp"].data_ptr() if sp.get("amp") is not None else None
+        d.periodic_beam = int(sp.get("periodic_beam", 0))
     n = C.c_size_t()
     _lib.load().mrx_screen_work_floats(ny, nx, len(specs), C.byref(n))
     work = torch.empty(n.value, dtype=torch.float32, device="cuda:0")
@@ -186,6 +187,50 @@ def test_screen_batch_with_fused_smoothing(gpu_ctx, ny, nx):
         ref = scipy.ndimage.gaussian_filter(block, sigma=(sp.get("sigma_y", 0.0), sp.get("sigma_x", 0.0)))
         assert g.shape == ref.shape and not np.isnan(g).any()
         assert np.abs(g - ref).max() <= 1e-5 * np.abs(ref).max(), sp
+
+
+@pytest.mark.parametrize("ny,nx", [(256, 512), (2048, 2048), (1024, 4096), (64, 128)])
+def test_beam_folded_into_the_spectrum_equals_the_stencil_inside(gpu_ctx, ny, nx):
+    """mrx_screen_desc.periodic_beam: scipy's truncated, normalised Gaussian taps as a factor of the spectrum (their
+    transfer function on the periodic domain) instead of two stencils on the written block.  Pixels at least the
+    stencil radius from every edge of the block equal scipy.ndimage.gaussian_filter of the unsmoothed screen
+    (atmosphere/atmosphere.py:341-344) to 1e-5 of its peak -- whole-domain and cropped blocks, per-axis sigmas, a
+    skipped axis, a radius beyond the fused tap table --; on the whole domain every pixel equals the filter with
+    mode="wrap"; the Stockham and the register column transforms agree."""
+    from maria_amd import _lib
+
+    base = dict(dy=5.0, dx=6.0, r0=800.0, nu=5.0 / 6.0, periodic_beam=1)
+    specs = [
+        dict(base, stream=0, sigma_y=4.25, sigma_x=3.5),
+        dict(base, stream=1, sigma_y=0.0, sigma_x=2.0, r0=500.0),
+        dict(base, stream=2, sigma_y=1.7, sigma_x=0.0, nu=1.0 / 3.0),
+        dict(base, stream=3, sigma_y=2.0, sigma_x=3.0, out_ny=ny - 27, out_nx=nx - 21),
+        dict(base, stream=5),
+    ]
+    if ny >= 1024:
+        specs.append(dict(base, stream=6, sigma_y=40.0, sigma_x=1.0))  # radius 160: no tap-table limit in this form
+    got = _generate_batch(gpu_ctx, 11, ny, nx, specs)
+    for sp, g in zip(specs, got):
+        plain = _generate(gpu_ctx, 11, sp["stream"], ny, nx, sp["dy"], sp["dx"], sp["r0"], sp["nu"])
+        sig = (sp.get("sigma_y", 0.0), sp.get("sigma_x", 0.0))
+        wrap = scipy.ndimage.gaussian_filter(plain, sigma=sig, mode="wrap")
+        oy, ox = sp.get("out_ny") or ny, sp.get("out_nx") or nx
+        assert g.shape == (oy, ox) and not np.isnan(g).any()
+        assert np.abs(g - wrap[:oy, :ox]).max() <= 1e-5 * np.abs(wrap).max(), sp
+        ry, rx = (int(4.0 * s_ + 0.5) if s_ > 1e-15 else 0 for s_ in sig)
+        ref = scipy.ndimage.gaussian_filter(plain[:oy, :ox], sigma=sig)  # reflect at the block's edges
+        inner = (slice(ry, oy - ry), slice(rx, ox - rx))
+        assert np.abs(g[inner] - ref[inner]).max() <= 1e-5 * np.abs(ref).max(), sp
+        if ry or rx:  # ... and the edges do differ (the two semantics are not the same thing)
+            assert np.abs(g - ref).max() > 1e-4 * np.abs(ref).max()
+    if ny in (1024, 2048):
+        gpu_ctx.set_option(_lib.OPT_SCREEN_STOCKHAM, 1)
+        try:
+            other = _generate_batch(gpu_ctx, 11, ny, nx, specs[:2])
+        finally:
+            gpu_ctx.set_option(_lib.OPT_SCREEN_STOCKHAM, 0)
+        for a, b in zip(got, other):
+            assert np.abs(a - b).max() <= 2e-5 * np.abs(b).max()
 
 
 def test_tap_cache_eviction_spares_the_batch_under_assembly():
