@@ -80,6 +80,11 @@ def parse_args(argv=None):
     ap.add_argument("--gather-reps", type=int, default=3)
     ap.add_argument("--blocks", type=int, default=None, help="detector blocks of the pipelined TOD synthesis (default: DevicePath.default_blocks(); 1 = serial)")
     ap.add_argument("--block-shares", default=None, help="A/B: relative sizes of the detector blocks, e.g. 1,2,2,2 (default: equal blocks)")
+    ap.add_argument("--lookahead", action="store_true",
+                    help="A/B: let successive steps overlap (DevicePath.enable_lookahead: the next step's screens and first samplers run "
+                    "beside this step's last writers; the timer brackets all K steps behind a sync either way).  Measured in round 4: "
+                    "2.38 against 2.34 ms (atlast_10k), 11.8 against 11.5 (atlast_50k) -- the sampler chain beside the writers becomes the "
+                    "critical path -- so the default stays one step after the other")
     ap.add_argument("--print-launch", action="store_true", help="print the child launch command of --gpus N as JSON and exit (no GPU needed)")
     return ap.parse_args(argv)
 
@@ -417,6 +422,9 @@ def run(args):
         torch.cuda.synchronize()
 
     screens()
+    # successive steps overlap like the observations of one Simulation.run() (sim/simulation.py:201-211): the same
+    # launches, ordered by events instead of by one stream
+    lookahead = args.lookahead and own_layers is None and n_blocks > 1 and path.enable_lookahead()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -437,7 +445,18 @@ def run(args):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    # outside the timed region: the stages back to back on one stream, for the breakdown
+    # outside the timed region: the screens alone (on the stream they run on), then the stages back to back on one
+    # stream, for the breakdown
+    scr_ms = []
+    for k in range(4):
+        gen_stream = path._la["stream"] if lookahead else torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(gen_stream)
+        screens()
+        e1.record(gen_stream)
+        torch.cuda.synchronize()
+        scr_ms.append(e0.elapsed_time(e1))
+    screens_alone_ms = float(np.median(scr_ms[1:]))
     sev = []
     for k in range(3):
         serial_step(sev)
@@ -485,18 +504,25 @@ def run(args):
             "screens_in_step": not args.no_screens_in_step,
             "screens": "sharded by layer + broadcast by the owners" if own_layers is not None else "regenerated on every rank from the Philox key",
             "parallelism": f"detector-sharded x{world}, no data-path collective",
+            "steps_overlap": bool(lookahead),
+            "steps_overlap_note": "successive steps overlap as the observations of one Simulation.run() do: the next step's screens (a stream "
+            "and a buffer set of their own) and samplers start while this step's writers stream; every step makes the same launches, "
+            "the K steps are timed as a whole behind a device synchronisation (bench.py --lookahead; off by default)",
         },
         # the same K steps on the GPU's own clock (events around every step, on the stream the step runs on): the
         # wall-clock figure above should sit within a few per cent of it; a host hiccup inside the timed region shows here
         "gpu_ms_per_step": float(ev[0][0].elapsed_time(ev[-1][2])) / args.steps,
         "stage_ms": {
-            "screens": float(step_ms[0]),
+            "screens": screens_alone_ms if lookahead else float(step_ms[0]),
             "tod_synthesis_pipelined": float(step_ms[1]),
+            "note": ("screens: alone on their stream, outside the timed region; tod_synthesis_pipelined: between the events around "
+                     "DevicePath.run() on the caller's stream -- with overlapping steps these intervals overlap too and do not add up to ms_per_step")
+            if lookahead else "events on the caller's stream around the two stages of every timed step",
             "serial_breakdown": {"sample": sm_ms, "upsample_with_spline_solve": float(serial_ms[1]),
                                  "note": "the same block launches back to back on one stream, outside the timed region; sums over the blocks"},
             "detector_blocks": n_launch,
         },
-        "path_hbm_gbps": path.algorithmic_bytes() / (1e-3 * float(step_ms.sum())) / 1e9,
+        "path_hbm_gbps": path.algorithmic_bytes() / (float(ev[0][0].elapsed_time(ev[-1][2])) / args.steps * 1e-3) / 1e9,
         "roofline": {
             "kernel": "spline_upsample_fused_kernel",
             "bound": "hbm",

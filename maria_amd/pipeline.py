@@ -235,10 +235,18 @@ class DevicePath:
 
     def set_screens(self, screens):
         """Bind one smoothed screen per layer (numpy arrays or device tensors [E,C])."""
+        if self.plan is not None:
+            self.ctx.call("mrx_atm_plan_destroy", self.plan)
+            self.plan = None
+        self.plan, self._layers, self._layer_bufs = self._make_plan(screens)
+        self._la = None  # (a look-ahead set up for generated screens ends here)
+
+    def _make_plan(self, screens):
+        """(plan handle, mrx_layer array, device buffers) of one set of screens."""
         dev = self.device
         layers = self.problem["layers"]
-        self._layers = (MrxLayer * len(layers))()
-        self._layer_bufs = []
+        c_layers = (MrxLayer * len(layers))()
+        layer_bufs = []
         for l, (layer, scr) in enumerate(zip(layers, screens)):
             vals = scr if isinstance(scr, torch.Tensor) else _dev(scr, torch.float32, dev)
             if vals.device != dev or vals.dtype != torch.float32 or not vals.is_contiguous():
@@ -253,9 +261,9 @@ class DevicePath:
             )
             assert bufs[3].numel() == self.Ta, "layer wind arrays must have Ta entries"
             assert tuple(vals.shape) == (len(layer["extrusion"]), len(layer["cross_section"]))
-            self._layer_bufs.append(bufs)
+            layer_bufs.append(bufs)
             R = np.asarray(layer["transform"], float)
-            ly = self._layers[l]
+            ly = c_layers[l]
             ly.d_values, ly.d_axis_e, ly.d_axis_c, ly.d_off_e, ly.d_off_c = (x.data_ptr() for x in bufs)
             ly.n_e, ly.n_c = vals.shape
             ly.h = float(layer["h"])
@@ -266,11 +274,9 @@ class DevicePath:
             # (the step from the whole span: the difference of two neighbouring nodes carries their rounding)
             ly.e0, ly.de = float(ex[0]), float((ex[-1] - ex[0]) / (len(ex) - 1))
             ly.c0, ly.dc = float(cs[0]), float((cs[-1] - cs[0]) / (len(cs) - 1))
-        if self.plan is not None:
-            self.ctx.call("mrx_atm_plan_destroy", self.plan)
         plan = C.c_void_p()
-        self.ctx.call("mrx_atm_plan_create", self._layers, len(layers), self._tables, len(self._tables), self.Ta, C.byref(plan))
-        self.plan = plan
+        self.ctx.call("mrx_atm_plan_create", c_layers, len(layers), self._tables, len(self._tables), self.Ta, C.byref(plan))
+        return plan, c_layers, layer_bufs
 
     def plan_info(self):
         """(number of layer axes on the recomputed-node fast path, tables staged in LDS)."""
@@ -347,6 +353,7 @@ class DevicePath:
         Returns the device tensors."""
         dev = self.device
         layers = self.problem["layers"]
+        la = getattr(self, "_la", None)
         shapes = [(len(l["extrusion"]), len(l["cross_section"])) for l in layers]
         # a layer may ask for a larger periodic FFT domain ("fft_shape") than its grid:
         # the screen is then the top-left block of it (atmosphere.py ribbons are not
@@ -431,6 +438,18 @@ class DevicePath:
             sigma = float(layer.get("beam_sigma", 0) or 0) if smooth else 0.0
             return sigma / de, sigma / float(layer.get("res") or dc)
 
+        # look-ahead (enable_lookahead): this call fills the OTHER set of screens on the screens' own stream, behind
+        # the samplers that last read that set; run() then samples it behind an event
+        gen_ctx, target = self.ctx, self._gen_screens
+        if la is not None and only is None:
+            which = la["count"] % 2
+            target, gen_ctx = la["screens"][which], la["ctx"]
+            if la["count"] == 0:  # everything the caller queued so far (uploads, the amplitude tables) comes first
+                la["first"].record(torch.cuda.current_stream(dev))
+                la["stream"].wait_event(la["first"])
+            if la["sampled"][which]:
+                la["stream"].wait_event(la["samplers_done"][which])
+
         def describe(members):
             descs = (_lib.MrxScreenDesc * len(members))()
             for d, l in zip(descs, members):
@@ -438,7 +457,7 @@ class DevicePath:
                 de = float(layer["extrusion"][1] - layer["extrusion"][0])
                 fine = self._gen_fine.get(l)
                 if fine is None:
-                    out = self._gen_screens[l]
+                    out = target[l]
                     dc = float(layer["cross_section"][1] - layer["cross_section"][0])
                     d.sigma_y, d.sigma_x = pixel_sigmas(layer)
                     d.periodic_beam = int(self._beam_in_spectrum[l])
@@ -460,7 +479,7 @@ class DevicePath:
                     members = [l for l in members if l in only]
                     if not members:
                         continue
-                self.ctx.call(
+                gen_ctx.call(
                     "mrx_screen_generate_batch", self.problem["seed"], fe, fc, describe(members), len(members),
                     ptr(self._gen_work), self._gen_work.numel(),
                 )
@@ -493,13 +512,70 @@ class DevicePath:
                                   ptr(fine["scale"]), n_l, ptr(dst), n_l)
                     if dst is not out:
                         self.ctx.call("mrx_gauss_smooth2d", ptr(dst), ptr(out), ptr(self._gen_tmp[1]), ne, n_l, sy, sx, 4.0)
+        if la is not None and only is None:
+            which = la["count"] % 2
+            la["screens_done"][which].record(la["stream"])
+            la["count"] += 1
+            la["current"] = which
+            self.plan, self._layers, self._layer_bufs = la["plans"][which]
+            self._gen_screens = target
+            return target
         return self._gen_screens
+
+    def enable_lookahead(self):
+        """Let successive observations overlap (Simulation.run's loop over its plans, sim/simulation.py:201-211;
+        bench.py's steps): the screens of the NEXT call to generate_screens() are made on a stream of their own, into
+        a second set of buffers, while the samplers and writers of this run() are still at work, and the samplers (all
+        of them on the side stream, block 0 included) start as soon as their screens and their coarse buffers are
+        free instead of behind the previous run's last writer.  Nothing changes in what is computed: the same
+        launches, ordered by events; the TOD of run() is stream-ordered on the caller's stream as before.  The
+        returned screens are NOT ordered against the caller's stream: call wait_screens() before reading them.
+        Returns False (and changes nothing) for paths whose screens are planes of a 3-D volume."""
+        if getattr(self, "_la", None) is not None:
+            return True
+        layers = self.problem["layers"]
+        if any(l.get("volume") is not None or l.get("gen") is not None for l in layers) or self.keep_pwv:
+            return False
+        if getattr(self, "_gen_screens", None) is None:
+            self.generate_screens()
+        torch.cuda.synchronize(self.device)
+        main = torch.cuda.current_stream(self.device)
+        side = self._pipeline_state(max(self.default_blocks(), 2), main)["side"]
+        self.ctx.set_stream(main)
+        probe = Context(self.ctx.device)
+        probe.set_stream(side)
+        stream = None
+        for _ in range(8):  # a hardware queue of its own beside the caller's and the samplers' (HIP has four)
+            stream = torch.cuda.Stream(device=self.device)
+            if self.ctx.streams_concurrent(stream) and probe.streams_concurrent(stream):
+                break
+        ctx3 = Context(self.ctx.device)
+        ctx3.set_stream(stream)
+        for opt in (_lib.OPT_SCREEN_STOCKHAM,):
+            ctx3.set_option(opt, self.ctx.get_option(opt))
+        other = [torch.empty_like(t) for t in self._gen_screens]
+        plans = [(self.plan, self._layers, self._layer_bufs), self._make_plan(other)]
+        ev = lambda: torch.cuda.Event()  # noqa: E731
+        self._la = dict(stream=stream, ctx=ctx3, screens=[self._gen_screens, other], plans=plans, count=0, current=0,
+                        first=ev(), screens_done=[ev(), ev()], samplers_done=[ev(), ev()], sampled=[False, False],
+                        writer_done={}, probe=probe)
+        # the set bound now holds valid screens (generated above, on the caller's stream)
+        self._la["screens_done"][0].record(main)
+        self._la["count"] = 1
+        return True
+
+    def wait_screens(self, stream=None):
+        """Order ``stream`` (default: the current one) behind the generation of the screens now bound."""
+        la = getattr(self, "_la", None)
+        if la is not None:
+            (stream or torch.cuda.current_stream(self.device)).wait_event(la["screens_done"][la["current"]])
 
     # -- hot path ------------------------------------------------------------
     def sample(self, want_pwv=False):
         self._pipelined = False
         if self.plan is None:
             raise RuntimeError("no screens bound: call set_screens() or generate_screens() first")
+        self.wait_screens()
         self.ctx.call(
             "mrx_atm_sample", self.plan, ptr(self.d_az), ptr(self.d_el), self.Ta,
             ptr(self.d_dx), ptr(self.d_dy), ptr(self.d_band), ptr(self.d_m00), self.D,
@@ -664,9 +740,12 @@ class DevicePath:
         edges = [0] + [min(int(c) * 256, self.D) for c in cuts]
         edges[-1] = self.D
         bounds = [(lo, hi) for lo, hi in zip(edges[:-1], edges[1:]) if hi > lo]
-        side = self._side_stream(main)
-        ctx2 = Context(self.ctx.device)
-        ctx2.set_stream(side)
+        if st is not None and st["main"] == main.cuda_stream:  # another cut of the rows: the streams stay
+            side, ctx2 = st["side"], st["ctx2"]
+        else:
+            side = self._side_stream(main)
+            ctx2 = Context(self.ctx.device)
+            ctx2.set_stream(side)
         st = dict(blocks=blocks, bounds=bounds, side=side, ctx2=ctx2, main=main.cuda_stream,
                   ready=[torch.cuda.Event() for _ in bounds], start=torch.cuda.Event(), tail_done=torch.cuda.Event(),
                   loading=[torch.empty((self.Ta, hi - lo), dtype=torch.float32, device=self.device) for lo, hi in bounds])
@@ -695,6 +774,11 @@ class DevicePath:
         # recorded on, whatever stream was current when this DevicePath was made
         self.ctx.set_stream(main)
         serial = serial_events is not None
+        la = getattr(self, "_la", None) if not (serial or krj) else None
+        if la is None:
+            self.wait_screens(main)
+        else:
+            side.wait_event(la["screens_done"][la["current"]])
         if serial:
             side, ctx2 = main, self.ctx
         if not serial:
@@ -710,11 +794,15 @@ class DevicePath:
             # beside a writer: a resident grid of default_resident_wgs() workgroups per CU, the layer loop
             # software-pipelined (atlast_10k: 2.12 ms at 3 per CU, 2.15 at 4, 2.27 at 5, 2.44 at 2; two steps
             # per thread at 96 registers: 2.18)
-            alone = i == 0 or serial
+            alone = (i == 0 and la is None) or serial
             # block 0 has nothing to run beside: its sampler goes on the caller's stream, straight behind the screens and
             # straight before its writer (a kernel follows a kernel of its own stream after ~6 us, an event of another
             # stream after ~20: the kernel trace of the step showed five such waits on its critical path, two of them here)
-            c = self.ctx if i == 0 else ctx2
+            # -- unless successive runs overlap (enable_lookahead): every sampler then runs on the side stream, block
+            # 0's beside the previous run's last writer, each behind the writer that last read its coarse buffer
+            c = self.ctx if (i == 0 and la is None) else ctx2
+            if la is not None and (blocks, i) in la["writer_done"]:
+                side.wait_event(la["writer_done"][(blocks, i)])
             if c is ctx2:
                 ctx2.set_option(_lib.OPT_SAMPLE_WGS_PER_CU, saved[0] if alone else resident_wgs_per_cu)
                 ctx2.set_option(_lib.OPT_SAMPLE_TIMES, saved[1] if alone else resident_times)
@@ -735,7 +823,7 @@ class DevicePath:
                 self.coarse_to_krj(st["loading"][i], n, slice(lo, hi), c, tail=tail)
             if serial:
                 tev[1].record(main)
-            elif i == 0:
+            elif i == 0 and la is None:
                 st["start"].record(main)  # the side stream starts block 1 behind the screens, the previous run's writers
                 side.wait_event(st["start"])  # (they read the coarse buffers it is about to fill) and block 0's sampler
             else:
@@ -756,11 +844,16 @@ class DevicePath:
             if writer_events is not None:
                 ev[1].record(main)
                 writer_events.append(ev)
+            if la is not None:
+                la["writer_done"].setdefault((blocks, i), torch.cuda.Event()).record(main)
             if serial:
                 tev[2].record(main)
                 serial_events.append(tev)
         ctx2.set_option(_lib.OPT_SAMPLE_WGS_PER_CU, saved[0])
         ctx2.set_option(_lib.OPT_SAMPLE_TIMES, saved[1])
+        if la is not None:  # the screens' stream may refill this set once these samplers are through
+            la["samplers_done"][la["current"]].record(side)
+            la["sampled"][la["current"]] = True
         if krj and krj != "sample" and self._krj_split() < self.T:
             if serial:
                 self._krj_tail(st["tail"], self.D, slice(0, self.D), out, ptr(self.d_rows), self.ctx)
