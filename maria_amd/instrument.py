@@ -13,23 +13,22 @@ C_LIGHT = 299792458.0  # maria/constants.py
 K_B = 1.380649e-23
 
 
+# The passband shapes of band/band.py:62-86, all of one family: tau = 2^-(|2 (nu - center) / width|^p) has half its
+# peak at center +- width / 2 for every p -- a Gaussian of that FWHM (p = 2), a flat-topped curve (p = 8), and in the limit
+# p -> infinity the boxcar of that width.  Per shape: (half of the sampled range in units of the width, p).
+PASSBAND_SHAPES = {"gaussian": (1.5, 2.0), "top_hat": (1.0, 8.0), "flat": (0.6, np.inf)}
+
+
 def generate_passband(center, width, shape, samples=256):
-    """band/band.py:62-86."""
-    if shape == "flat":
-        nu_min, nu_max = center - 0.6 * width, center + 0.6 * width
-    elif shape == "top_hat":
-        nu_min, nu_max = center - width, center + width
-    else:
-        nu_min, nu_max = center - 1.5 * width, center + 1.5 * width
-    nu = np.linspace(nu_min, nu_max, samples)
-    if shape == "flat":
-        tau = np.where((nu > center - 0.5 * width) & (nu < center + 0.5 * width), 1, 0)
-    elif shape == "gaussian":
-        tau = np.exp(np.log(0.5) * (2 * (nu - center) / width) ** 2)
-    elif shape == "top_hat":
-        tau = np.exp(np.log(0.5) * (2 * (nu - center) / width) ** 8)
-    else:
+    """``samples`` frequencies across the band and its transmission there (band/band.py:62-86)."""
+    if shape not in PASSBAND_SHAPES:
         raise ValueError(f"Invalid shape '{shape}'")
+    half_range, power = PASSBAND_SHAPES[shape]
+    nu = np.linspace(center - half_range * width, center + half_range * width, samples)
+    x = np.abs(2.0 * (nu - center) / width)
+    tau = np.where(x < 1.0, 1, 0) if np.isinf(power) else np.exp(np.log(0.5) * x**power)
+    if np.trapezoid(tau, x=nu) < 1e-2 * 2.0 * half_range * width:  # (the reference's sanity check, :83-84)
+        raise ValueError("Error generating band")
     return nu, tau
 
 

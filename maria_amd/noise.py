@@ -67,12 +67,15 @@ def simulate_noise(ctx, dets, T, sample_rate, seed, noise_kwargs=None, device="c
         idx = np.nonzero(dets.band_index == b)[0]
         if len(idx) == 0:
             continue
-        if not (np.diff(idx) == 1).all():
-            raise NotImplementedError("detectors of a band must be contiguous rows")
-        first, last = max(lo, int(idx[0])), min(hi, int(idx[-1]) + 1)  # this shard's rows of the band
-        if last <= first:
+        # the reference masks rows by band name (sim/noise.py:32): a band's rows need not be neighbours.  The draws
+        # are keyed by a detector's index WITHIN its band; this shard holds the band's members k0 .. k1 - 1
+        k0, k1 = int(np.searchsorted(idx, lo, side="left")), int(np.searchsorted(idx, hi, side="left"))
+        if k1 <= k0:
             continue
-        offset = first - int(idx[0])  # index within the band: what the draws are keyed by
+        mine = idx[k0:k1]
+        contiguous = bool((np.diff(mine) == 1).all())
+        first, last = int(mine[0]), int(mine[0]) + (k1 - k0)  # (row range of the contiguous case)
+        offset = k0  # index within the band: what the draws are keyed by
         per_loading = float(getattr(band, "NEP_per_loading", 0.0))
         if per_loading and loading is None:
             raise ValueError(f"band {band.name} has NEP_per_loading != 0: pass the summed loading (sim/noise.py:35-37)")
@@ -106,8 +109,13 @@ def simulate_noise(ctx, dets, T, sample_rate, seed, noise_kwargs=None, device="c
                 1e12 * per_loading, ptr(dst), dst.stride(0), 0, ptr(work), need.value,
             )
 
-        view = out[first - lo : last - lo]
-        lview = loading[first - lo : last - lo] if per_loading else None
+        if contiguous:
+            view = out[first - lo : last - lo]
+            lview = loading[first - lo : last - lo] if per_loading else None
+        else:  # scattered rows: drawn into a buffer of their own and copied to their rows below
+            d_rows = torch.as_tensor(mine - lo, device=dev)
+            view = torch.empty((k1 - k0, T), dtype=torch.float32, device=dev)
+            lview = loading.index_select(0, d_rows) if per_loading else None
         start = 0
         if offset % 2:
             # the shard begins on the second detector of a pair: that pair is drawn whole into two scratch rows (its first
@@ -130,5 +138,7 @@ def simulate_noise(ctx, dets, T, sample_rate, seed, noise_kwargs=None, device="c
             stop = count - 1
         if stop > start:
             generate(offset + start, stop - start, view[start:stop], None if lview is None else lview[start:stop])
+        if not contiguous:
+            out.index_copy_(0, d_rows, view)
         del work
     return out

@@ -330,10 +330,12 @@ class Simulation:
         """Host part of ``TOD.to("K_RJ")`` (tod/tod.py:90-97): collapse the bands' transmission
         tables at the scalars the TOD metadata carries, rounded as run_obs stores them."""
         atm, dets = obs.atmosphere, obs.instrument.dets
-        key = (id(atm._device_path()), metadata["base_temperature"], metadata["pwv"])
-        if getattr(obs, "_cal_key", None) == key:  # same path, same scalars: the tables are on the device already
+        path = atm._device_path()
+        key = (metadata["base_temperature"], metadata["pwv"])
+        # (the key lives on the path itself: a path rebuilt for another shard has none, whatever address it got)
+        if getattr(path, "_cal_key", None) == key and hasattr(path, "_cal"):  # same path, same scalars: the tables are on the device already
             return
-        obs._cal_key = key
+        path._cal_key = key
         sp = atm.spectrum
         tables = [{"T": sp.side_base_temperature, "pwv": sp.side_zenith_pwv, "el": sp.side_elevation,
                    "values": band.transmission_table(sp)} for band in dets.bands]
@@ -401,8 +403,9 @@ class Simulation:
             idx = np.nonzero(dets.band_index == b)[0]
             if len(idx) == 0:
                 continue
-            if not (np.diff(idx) == 1).all():
-                raise NotImplementedError("detectors of a band must be contiguous rows")
+            # the reference masks rows by band name (sim/map.py:90-95): a band's rows need not be neighbours.  Contiguous
+            # rows are written in place; scattered ones into a buffer of their own, copied to their rows below
+            contiguous = bool((np.diff(idx) == 1).all())
             # ideally one beam per channel; the reference smooths once per band (map.py:101-104)
             fwhm = float(compute_angular_fwhm(fwhm_0=dets.primary_size.mean(), z=np.inf, nu=band.center))
             smoothed = self.map.smooth(fwhm, ctx=ctx, device=device)  # [S, C, eta, xi]
@@ -427,14 +430,17 @@ class Simulation:
             kw = {}
             if atm is not None:
                 sp = atm.spectrum
-                pwv = path.coarse_pwv()[int(idx[0]) : int(idx[-1]) + 1].T.contiguous()  # [Ta, D_band]
+                pwv = path.coarse_pwv()[torch.as_tensor(idx, device=device)].T.contiguous()  # [Ta, D_band]
                 kw = dict(cal_tables=np.stack(tables), cal_axis_pwv=sp.side_zenith_pwv, cal_axis_el=sp.side_elevation,
                           coarse_pwv=pwv, ta0=path.ta0, dta=path.dta, t=obs.coords.t)
             else:
                 kw = dict(cal_scalars=scalars)
+            dst = out[int(idx[0]) : int(idx[-1]) + 1] if contiguous else torch.zeros((len(idx), T), dtype=torch.float32, device=device)
             mmap.sample_map(ctx, values, self.map.eta, self.map.xi, self.map.center, obs.boresight._baz, obs.boresight._bel,
-                            offsets[idx], stokes_rows[idx], out=out[int(idx[0]) : int(idx[-1]) + 1],
+                            offsets[idx], stokes_rows[idx], out=dst,
                             transform=transform, bilinear=bool(self.map_kwargs["bilinear_sampling"]), device=device, **kw)
+            if not contiguous:
+                out.index_copy_(0, torch.as_tensor(idx, device=device), dst)
         return out
 
     def _simulate_noise(self, obs, loading=None, rows=None):

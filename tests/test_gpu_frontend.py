@@ -358,3 +358,27 @@ def test_3d_layers_on_their_own_grids(gpu_ctx):
         timestep=float(atm.timestep), gain=None,
     )
     assert rel_err(tod.data["atmosphere"], hotpath.run_path(prob)) <= 1e-5
+
+
+def test_bands_whose_rows_are_not_neighbours(gpu_ctx):
+    """The reference selects a band's detectors by name (sim/noise.py:32, sim/atmosphere.py:54, sim/map.py:90-95), so an
+    array may interleave its bands.  Every field of such an instrument -- atmosphere, noise (drawn per index within
+    the band, correlated modes included), in K_RJ -- equals the same detectors' rows of the band-major instrument."""
+    from maria_amd.instrument import Band, Detectors, Instrument, Site
+    from maria_amd.sim import Plan, Simulation
+
+    bands = [Band(center=93e9, width=27e9, shape="top_hat", name="f093", NEP=2e-17, knee=0.8),
+             Band(center=150e9, width=41e9, shape="gaussian", name="f150", NEP=3e-17, knee=1.5)]
+    dets = Detectors.hexagon(19, 0.3, bands, primary_size=6.0)
+    perm = np.arange(dets.n).reshape(2, -1).T.ravel()  # f093, f150, f093, f150, ...
+    plan = Plan.daisy(start_time=1.7e9, duration=30.0, sample_rate=50.0, scan_center=(45.0, 55.0), radius=0.4, speed=0.4)
+    runs = []
+    for d in (dets, dets.subset(perm)):
+        sim = Simulation(Instrument(d), plan, Site(altitude=1000.0), atmosphere="2d", atmosphere_kwargs={"n_layers": 2, "seed": 3},
+                         noise=True, noise_seed=11)
+        runs.append(sim.run()[0])
+    major, mixed = runs
+    assert not (np.diff(np.nonzero(mixed.dets.band_index == 0)[0]) == 1).all()
+    for name in ("atmosphere", "noise"):
+        a, b = major.data[name][perm], mixed.data[name]
+        assert np.isfinite(b).all() and np.abs(a - b).max() <= 2e-6 * np.abs(a).max(), name

@@ -70,6 +70,32 @@ def test_every_shard_draws_whole_pairs_and_covers_its_rows(sizes):
                 assert row0 >= b_lo - b_lo % 2 and row0 + n_rows <= min(b_hi + b_hi % 2, sizes[band])
 
 
+@pytest.mark.parametrize("sizes", [(4, 4), (5, 3, 6), (9, 2)])
+def test_bands_whose_rows_are_interleaved(sizes):
+    """The reference masks rows by band name (sim/noise.py:32): a band's rows need not be neighbours.  Rows shuffled
+    across bands, every shard: each row still carries (its band, its index within the band), drawn in whole pairs."""
+    from maria_amd.instrument import Band, Detectors
+    from maria_amd.noise import simulate_noise
+
+    rng = np.random.default_rng(3)
+    band_index = rng.permutation(np.repeat(np.arange(len(sizes)), sizes))
+    bands = [Band(center=90e9 + 30e9 * b, width=20e9, name=f"b{b}", NEP=1e-17, knee=1.0) for b in range(len(sizes))]
+    dets = Detectors(rng.normal(0, 1e-3, (sum(sizes), 2)), bands, band_index, primary_size=10.0)
+    within = np.zeros(dets.n, int)
+    for b in range(len(sizes)):
+        within[band_index == b] = np.arange(sizes[b])
+    want = 1000.0 * band_index + within
+    n, T = dets.n, 3
+    for lo in range(n):
+        for hi in range(lo + 1, n + 1):
+            ctx = _RecordingContext(sizes)
+            out = simulate_noise(ctx, dets, T, 50.0, 100, device="cpu", det_slice=slice(lo, hi))
+            np.testing.assert_array_equal(out.numpy(), np.repeat(want[lo:hi, None], T, axis=1), err_msg=f"{sizes} [{lo}, {hi})")
+            for band, row0, n_rows in ctx.calls:
+                assert row0 % 2 == 0 and row0 + n_rows <= sizes[band]
+                assert (row0 + n_rows) % 2 == 0 or row0 + n_rows == sizes[band]
+
+
 def test_the_unsharded_call_is_one_draw_per_band():
     from maria_amd.noise import simulate_noise
 
