@@ -347,6 +347,59 @@ __global__ __launch_bounds__(kBlock) void screen_half_spectrum_regs(const Screen
   if (live) smooth_column_store(L, ex1, L.work + (size_t)ix * (ny + kPitchPad), t, T);
 }
 
+// Epilogue of pass 2 for one real row held in LDS (`row`, natural order): Gaussian along x (scipy.ndimage semantics on
+// the written block) or nothing (periodic_beam / no beam), the unit-variance scale, 16-byte stores; `nt` threads
+// (t = 0 .. nt - 1) work on the row.
+__device__ __forceinline__ void finish_row(const ScreenLayerArgs& L, const float* row, int y, int t, int nt) {
+  const float norm = (float)(1.0 / sqrt(*L.psd_sum));
+  const int r = L.rx, nxo = L.out_nx;
+  const float* __restrict__ taps = L.taps_x;
+  const bool vec_ok = (L.ld_out & 3) == 0 && (reinterpret_cast<uintptr_t>(L.out) & 15) == 0;
+  float* dst = L.out + (size_t)y * L.ld_out;
+  if (r > kFastRadius) {
+    for (int x = t; x < nxo; x += nt) dst[x] = norm * smooth_real_at(row, x, nxo, r, taps);
+    return;
+  }
+  float tp[kFastRadius + 1] = {0.0f};
+  if (r > 0) uniform_taps(taps, tp);
+  for (int x0 = 4 * t; x0 < nxo; x0 += 4 * nt) {
+    float o[4];
+    constexpr int R = kFastRadius;
+    if (r == 0) {
+      const float4 q = *reinterpret_cast<const float4*>(row + x0);
+      o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w;
+    } else {
+      float win[4 + 2 * R];
+      if (x0 >= R && x0 + 4 + R <= nxo) {
+        const float4* wp = reinterpret_cast<const float4*>(row + (x0 - R));
+#pragma unroll
+        for (int j = 0; j < 1 + R / 2; ++j) {
+          const float4 q = wp[j];
+          win[4 * j] = q.x; win[4 * j + 1] = q.y; win[4 * j + 2] = q.z; win[4 * j + 3] = q.w;
+        }
+      } else {  // the window crosses an end of the row: gather it through the reflection
+#pragma unroll
+        for (int j = 0; j < 4 + 2 * R; ++j) win[j] = row[reflect_index(x0 - R + j, nxo)];
+      }
+#pragma unroll
+      for (int v = 0; v < 4; ++v) o[v] = tp[0] * win[R + v];
+#pragma unroll
+      for (int k = 1; k <= R; ++k) {
+        const float w = tp[k];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) o[v] = fmaf(w, win[R + v - k] + win[R + v + k], o[v]);
+      }
+    }
+    if (vec_ok && x0 + 4 <= nxo) {
+      *reinterpret_cast<float4*>(dst + x0) = make_float4(o[0] * norm, o[1] * norm, o[2] * norm, o[3] * norm);
+    } else {
+#pragma unroll
+      for (int v = 0; v < 4; ++v)
+        if (x0 + v < nxo) dst[x0 + v] = o[v] * norm;
+    }
+  }
+}
+
 // pass 2: 2^LJ rows of one layer: fold the half spectra, batched inverse FFT of length
 // nx/2, Gaussian along x, unit-variance scale
 template <int LJ>
@@ -405,58 +458,75 @@ __global__ __launch_bounds__(kBlock) void screen_c2r_x(const ScreenBatchArgs arg
     *reinterpret_cast<float2*>(rows + (size_t)b * nx + 2 * n) = res[idx];
   }
   __syncthreads();
-  const float norm = (float)(1.0 / sqrt(*L.psd_sum));
-  const int r = L.rx, nxo = L.out_nx;
-  const float* __restrict__ taps = L.taps_x;
-  const bool vec_ok = (L.ld_out & 3) == 0 && (reinterpret_cast<uintptr_t>(L.out) & 15) == 0;
-  float tp[kFastRadius + 1] = {0.0f};
-  if (r > 0 && r <= kFastRadius) uniform_taps(taps, tp);
   for (int b = 0; b < B; ++b) {
     const int y = y0 + b;
     if (y >= L.out_ny) break;
-    const float* row = rows + (size_t)b * nx;
-    float* dst = L.out + (size_t)y * L.ld_out;
-    if (r > kFastRadius) {
-      for (int x = threadIdx.x; x < nxo; x += kBlock) dst[x] = norm * smooth_real_at(row, x, nxo, r, taps);
-      continue;
-    }
-    for (int x0 = 4 * threadIdx.x; x0 < nxo; x0 += 4 * kBlock) {
-      float o[4];
-      constexpr int R = kFastRadius;
-      if (r == 0) {
-        const float4 q = *reinterpret_cast<const float4*>(row + x0);
-        o[0] = q.x; o[1] = q.y; o[2] = q.z; o[3] = q.w;
-      } else {
-        float win[4 + 2 * R];
-        if (x0 >= R && x0 + 4 + R <= nxo) {
-          const float4* wp = reinterpret_cast<const float4*>(row + (x0 - R));
-#pragma unroll
-          for (int j = 0; j < 1 + R / 2; ++j) {
-            const float4 q = wp[j];
-            win[4 * j] = q.x; win[4 * j + 1] = q.y; win[4 * j + 2] = q.z; win[4 * j + 3] = q.w;
-          }
-        } else {  // the window crosses an end of the row: gather it through the reflection
-#pragma unroll
-          for (int j = 0; j < 4 + 2 * R; ++j) win[j] = row[reflect_index(x0 - R + j, nxo)];
-        }
-#pragma unroll
-        for (int v = 0; v < 4; ++v) o[v] = tp[0] * win[R + v];
-#pragma unroll
-        for (int k = 1; k <= R; ++k) {
-          const float w = tp[k];
-#pragma unroll
-          for (int v = 0; v < 4; ++v) o[v] = fmaf(w, win[R + v - k] + win[R + v + k], o[v]);
-        }
-      }
-      if (vec_ok && x0 + 4 <= nxo) {
-        *reinterpret_cast<float4*>(dst + x0) = make_float4(o[0] * norm, o[1] * norm, o[2] * norm, o[3] * norm);
-      } else {
-#pragma unroll
-        for (int v = 0; v < 4; ++v)
-          if (x0 + v < nxo) dst[x0 + v] = o[v] * norm;
-      }
-    }
+    finish_row(L, rows + (size_t)b * nx, y, threadIdx.x, kBlock);
   }
+}
+
+// pass 2 with the row transforms in registers (fft_regs: nx = 512 RB, 16 RB threads a row, 16 / RB rows a workgroup):
+// a thread gathers its 16 cells X[k], k = t + T b, of the row's half spectrum, one LDS exchange brings it the mirrored
+// cells X[n2 - k], the fold Z[k] = (X[k] + conj X[n2 - k]) + i w^k (X[k] - conj X[n2 - k]) happens in registers (w^k
+// from one v_sin / v_cos pair per thread times the sixteen constant 32nd roots), and the n2-point transform runs
+// through the two conflict-free exchanges of fft_regs instead of four or five Stockham passes through LDS, whose
+// accesses conflicted on a third of their cycles (profiles/r03_kernel_pmc.txt): 15 LDS accesses per cell -> 8.
+// Same values as screen_c2r_x to rounding (tests/test_gpu_screens.py::test_register_transforms_match_the_stockham_ones).
+template <int RB>
+__global__ __launch_bounds__(kBlock) void screen_c2r_regs(const ScreenBatchArgs args, int ny) {
+  extern __shared__ __align__(16) float2 lds2[];
+  constexpr int T = 16 * RB, n2 = 256 * RB, nx = 2 * n2, G = kBlock / T;
+  const ScreenLayerArgs& L = args.l[blockIdx.y];
+  const int which = threadIdx.x / T, t = threadIdx.x % T;
+  float2* ex1 = lds2 + (size_t)which * 2 * kFft4096Pitch * T;
+  float2* ex2 = ex1 + kFft4096Pitch * T;
+  // row blocks that share the 128-byte lines of G (16 consecutive y) run on one XCD (see screen_c2r_x)
+  const int nblocks = gridDim.x;
+  int yb = blockIdx.x;
+  if ((nblocks & 7) == 0) yb = (blockIdx.x & 7) * (nblocks >> 3) + (blockIdx.x >> 3);
+  const int y = yb * G + which;
+  const bool live = y < L.out_ny;  // uniform over the row's waves
+  const size_t pitch = (size_t)ny + kPitchPad;
+  float2 x[16];
+#pragma unroll
+  for (int b = 0; b < 16; ++b) x[b] = live ? L.work[(size_t)(t + T * b) * pitch + y] : make_float2(0.f, 0.f);
+  const float nyq = live ? L.work[(size_t)n2 * pitch + y].x : 0.0f;  // G[nx/2][y] is real up to rounding
+#pragma unroll
+  for (int b = 0; b < 16; ++b) ex1[t + T * b] = x[b];
+  __syncthreads();
+  // w^k = exp(2 pi i k / nx), k = t + T b: exp(2 pi i t / nx) exp(2 pi i b / 32)
+  const float2 wt = make_float2(__builtin_amdgcn_cosf((float)t * (1.0f / (float)nx)), __builtin_amdgcn_sinf((float)t * (1.0f / (float)nx)));
+  constexpr float kC32[16] = {1.0f, 0.98078528040323044f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f,
+                              0.55557023301960222f, 0.38268343236508977f, 0.19509032201612827f, 0.0f, -0.19509032201612827f,
+                              -0.38268343236508977f, -0.55557023301960222f, -0.70710678118654752f, -0.83146961230254524f,
+                              -0.92387953251128674f, -0.98078528040323044f};
+  constexpr float kS32[16] = {0.0f, 0.19509032201612827f, 0.38268343236508977f, 0.55557023301960222f, 0.70710678118654752f,
+                              0.83146961230254524f, 0.92387953251128674f, 0.98078528040323044f, 1.0f, 0.98078528040323044f,
+                              0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f, 0.55557023301960222f,
+                              0.38268343236508977f, 0.19509032201612827f};
+  float2 v[16];
+#pragma unroll
+  for (int b = 0; b < 16; ++b) {
+    const int k = t + T * b;
+    float2 xk = x[b], xm;
+    if (k == 0) {
+      xk.y = 0.0f;
+      xm = make_float2(nyq, 0.0f);
+    } else {
+      xm = ex1[n2 - k];
+    }
+    const float2 w = cmul(wt, make_float2(kC32[b], kS32[b]));
+    const float2 e = make_float2(xk.x + xm.x, xk.y - xm.y);
+    const float2 o = cmul(make_float2(xk.x - xm.x, xk.y + xm.y), w);
+    v[b] = make_float2(e.x - o.y, e.y + o.x);
+  }
+  __syncthreads();  // the mirrored cells are read: fft_regs may write ex1
+  fft_regs<RB>(v, ex1, ex2, t);
+  // x[2n] + i x[2n+1] = y[n]: the row in natural order (ex1 is free again behind the transform's second barrier)
+#pragma unroll
+  for (int f = 0; f < 16; ++f) ex1[t + T * f] = v[dft16_pos(f)];
+  __syncthreads();
+  if (live) finish_row(L, reinterpret_cast<const float*>(ex1), y, t, T);
 }
 
 // ---- 3-D generator (model="3d": one process of many layers, vertically correlated) ----
@@ -987,6 +1057,22 @@ static int run_screen_passes(mrx_ctx* ctx, uint64_t seed, int ny, int nx, const 
                          args, ny, nx, ly, key0, key1);
     }
     MRX_CHECK_LAUNCH(ctx);
+    // the row transforms: in registers for nx = 2048, 4096, 8192 (MRX_OPT_SCREEN_STOCKHAM keeps the LDS form)
+    const int rb2 = ctx->options[MRX_OPT_SCREEN_STOCKHAM] ? 0 : nx == 2048 ? 4 : nx == 4096 ? 8 : nx == 8192 ? 16 : 0;
+    if (rb2) {
+      const size_t lds_r2 = 2 * (size_t)kFft4096Pitch * kBlock * sizeof(float2);
+      const dim3 grid_r2(mrx_ceil_div(max_out_ny, 16 / rb2), nb);
+      if (rb2 == 4) {
+        MRX_LDS_CAP(ctx, screen_c2r_regs<4>, lds_r2);
+        hipLaunchKernelGGL(screen_c2r_regs<4>, grid_r2, dim3(kBlock), lds_r2, ctx->stream, args, ny);
+      } else if (rb2 == 8) {
+        MRX_LDS_CAP(ctx, screen_c2r_regs<8>, lds_r2);
+        hipLaunchKernelGGL(screen_c2r_regs<8>, grid_r2, dim3(kBlock), lds_r2, ctx->stream, args, ny);
+      } else {
+        MRX_LDS_CAP(ctx, screen_c2r_regs<16>, lds_r2);
+        hipLaunchKernelGGL(screen_c2r_regs<16>, grid_r2, dim3(kBlock), lds_r2, ctx->stream, args, ny);
+      }
+    } else {
     const dim3 grid2(mrx_ceil_div(max_out_ny, 1 << lj), nb);
     if (lj == 2)
       hipLaunchKernelGGL(screen_c2r_x<2>, grid2, dim3(kBlock), lds2, ctx->stream, args, ny, nx, lx - 1);
@@ -994,6 +1080,7 @@ static int run_screen_passes(mrx_ctx* ctx, uint64_t seed, int ny, int nx, const 
       hipLaunchKernelGGL(screen_c2r_x<1>, grid2, dim3(kBlock), lds2, ctx->stream, args, ny, nx, lx - 1);
     else
       hipLaunchKernelGGL(screen_c2r_x<0>, grid2, dim3(kBlock), lds2, ctx->stream, args, ny, nx, lx - 1);
+    }
     MRX_CHECK_LAUNCH(ctx);
     for (int i = 0; i < nb; ++i) {
       if (!late_smooth[i]) continue;

@@ -258,7 +258,7 @@ def test_tap_cache_eviction_spares_the_batch_under_assembly():
         assert np.array_equal(g, alone), sp
 
 
-@pytest.mark.parametrize("ny,nx", [(1024, 512), (2048, 2048), (4096, 256), (2048, 1024)])
+@pytest.mark.parametrize("ny,nx", [(1024, 512), (2048, 2048), (4096, 256), (2048, 1024), (256, 4096), (128, 8192), (1024, 4096)])
 def test_register_transforms_match_the_stockham_ones(gpu_ctx, ny, nx):
     """Sides of 1024, 2048 and 4096 take the transforms in registers (fft_regs: 16 x RB x 16, the
     spectrum cells drawn straight into the first pass's registers); MRX_OPT_SCREEN_STOCKHAM keeps
