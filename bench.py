@@ -22,7 +22,10 @@ over ranks.  N = 1 is the named configuration on one GPU (atlast_50k: its per-GP
     regenerates the (small) screens from the same Philox key, so the data path has no
     collective.  The one RCCL all-gather of the final TOD the north star names runs
     through the C ABI (mrx_allgather_tod, in place in the full [n_det, T] buffer) and is
-    timed on its OWN clock, reported beside `value`, never folded into it.
+    timed on its OWN clock (median of the repetitions, max over ranks).  `value` is the
+    configuration AS STATED -- synthesis + gather, the two times added --, `value_synthesis_only`
+    the synthesis alone; when the gather could not be timed `value` is the synthesis alone
+    and `config.parallelism` says so.
   * atlast_50k (config 5) is WEAK scaling (the configuration per GPU; its 288 GB TOD
     cannot be gathered onto one GPU).  --scaling overrides either default.
 
@@ -378,14 +381,16 @@ def run(args):
     if own_layers is not None and args.backend == "nccl" and gatherer is None:
         own_layers = None  # no communicator: fall back to regenerating every layer on every rank
 
+    def exchange(scr):
+        """the owners broadcast their layers: on the stream the screens were generated on (the current one)"""
+        if gatherer is not None:  # RCCL through the C ABI
+            gatherer.ctx.set_stream(torch.cuda.current_stream())
+            gatherer.exchange_screens(scr)
+        else:  # gloo rehearsal
+            exchange_layer_screens(scr)
+
     def screens():
-        path.generate_screens(only=own_layers)
-        if own_layers is not None:
-            if gatherer is not None:  # RCCL through the C ABI, on the communicator's stream = the current one
-                gatherer.ctx.set_stream(torch.cuda.current_stream())
-                gatherer.exchange_screens(path._gen_screens)
-            else:  # gloo rehearsal
-                exchange_layer_screens(path._gen_screens)
+        path.generate_screens(only=own_layers, exchange=exchange if own_layers is not None else None)
 
     writer_events = []
     n_blocks = args.blocks if args.blocks is not None else path.default_blocks()
@@ -424,7 +429,7 @@ def run(args):
     screens()
     # successive steps overlap like the observations of one Simulation.run() (sim/simulation.py:201-211): the same
     # launches, ordered by events instead of by one stream
-    lookahead = args.lookahead and own_layers is None and n_blocks > 1 and path.enable_lookahead()
+    lookahead = args.lookahead and n_blocks > 1 and path.enable_lookahead()
     for _ in range(args.warmup):
         step()
     barrier()
@@ -503,7 +508,8 @@ def run(args):
             "n_samples": T,
             "screens_in_step": not args.no_screens_in_step,
             "screens": "sharded by layer + broadcast by the owners" if own_layers is not None else "regenerated on every rank from the Philox key",
-            "parallelism": f"detector-sharded x{world}, no data-path collective",
+            "parallelism": (f"detector-sharded x{world}, no data-path collective" if world == 1 or scaling == "weak" else
+                            f"detector-sharded x{world}; value is the SYNTHESIS ONLY (the all-gather of the TOD was not timed: see allgather)"),
             "steps_overlap": bool(lookahead),
             "steps_overlap_note": "successive steps overlap as the observations of one Simulation.run() do: the next step's screens (a stream "
             "and a buffer set of their own) and samplers start while this step's writers stream; every step makes the same launches, "
@@ -656,7 +662,7 @@ def run(args):
                     dt = float(tmax.item())
                     entry = {
                         "ms": 1e3 * dt, "received_GB_per_rank": nbytes / 1e9, "GBps_per_rank": nbytes / dt / 1e9,
-                        "in_timed_region": False, "in_place": True, "reps": len(times),
+                        "in_timed_region": False, "in_value": algo == algos[0], "in_place": True, "reps": len(times),
                         "transport": {"allgather": "RCCL ncclAllGather via libmrx mrx_allgather_tod",
                                       "p2p": "RCCL grouped ncclSend/ncclRecv to every peer via libmrx mrx_allgather_tod_p2p"}[algo],
                         "NCCL_ALGO": os.environ.get("NCCL_ALGO"),
@@ -665,6 +671,17 @@ def run(args):
                         "value_with_gather": n_step * T / (elapsed / args.steps + dt),
                     }
                     result["allgather" if algo == algos[0] else f"allgather_{algo}"] = entry
+                    if algo == algos[0] and same:
+                        # BASELINE config 4 as stated ends with every GPU holding the whole TOD: `value` is the
+                        # synthesis AND the gather (each on its own clock, added); the synthesis alone stays beside it
+                        result["value_synthesis_only"] = result["value"]
+                        result["ms_per_step_synthesis_only"] = result["ms_per_step"]
+                        result["value"] = entry["value_with_gather"]
+                        result["ms_per_step"] = entry["step_plus_gather_ms"]
+                        result["config"]["parallelism"] = (
+                            f"detector-sharded x{world}; synthesis has no collective; ONE all-gather of the TOD per step over xGMI "
+                            f"({entry['transport']}; in place, {nbytes / 1e9:.2f} GB received per rank), timed on its own clock "
+                            "(median of the repetitions, max over ranks) and ADDED to the step: value = detector-samples / (synthesis + gather)")
                     if algo != algos[-1]:  # the next variant must move the rows again
                         full.zero_()
                         path.run(tod, blocks=n_blocks)

@@ -297,7 +297,8 @@ int mrx_spline_upsample_krj(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
  * kinks where a detector's elevation crosses a node of the table's axis, where the error is at
  * most 0.25 x (jump of the relative slope of den at the node) x (elevation step per coarse
  * sample).  The caller bounds that on the host and takes mrx_spline_upsample_krj when it is
- * not far below the tolerance (maria_amd/pipeline.py: DevicePath.coarse_krj_bound). */
+ * not far below the tolerance (maria_amd/pipeline.py: DevicePath.coarse_krj_bound).
+ * d_out may be d_loading (conversion in place). */
 int mrx_coarse_to_krj(mrx_ctx* ctx, const float* d_loading, int D, int Ta, const float* d_bore_el_coarse,
                       const float* d_dx, const float* d_dy, const int32_t* d_band,
                       const float* d_cal_axis_el, const float* d_cal_values, int n_el, int n_bands,

@@ -235,13 +235,13 @@ int smooth_axis0(mrx_ctx* ctx, const float* in, float* out, int ny, int nx,
 
 // Linear resampling of every row onto new column positions (model="3d": a layer's own cross-section
 // grid, atmosphere/atmosphere.py:208-219, from the grid its process's volume was generated on).
-__global__ __launch_bounds__(256) void resample_columns_kernel(const float* __restrict__ in, int n_e, size_t ld_in,
+__global__ __launch_bounds__(256) void resample_columns_kernel(const float* __restrict__ in, int n_e, int n_in, size_t ld_in,
                                                                const int32_t* __restrict__ idx, const float* __restrict__ w,
                                                                const float* __restrict__ scale, int n_out,
                                                                float* __restrict__ out, size_t ld_out) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= n_out) return;
-  const int i = idx[j];
+  const int i = min(max(idx[j], 0), n_in - 2);  // a caller's index outside 0 .. n_in - 2 must not read outside the row
   const float wj = w[j], sj = scale[j];
   for (int e = blockIdx.y; e < n_e; e += gridDim.y) {
     const float* row = in + (size_t)e * ld_in + i;
@@ -262,7 +262,7 @@ int mrx_resample_columns(mrx_ctx* ctx, const float* d_in, int n_e, int n_in, siz
   MRX_REQUIRE(ctx, d_in && d_idx && d_w && d_scale && d_out, "null pointer");
   MRX_REQUIRE(ctx, n_in >= 2 && ld_in >= (size_t)n_in && ld_out >= (size_t)n_out, "need n_in >= 2 and leading dimensions >= the rows");
   const dim3 grid(mrx_ceil_div(n_out, 256), n_e < 1024 ? n_e : 1024);
-  hipLaunchKernelGGL(resample_columns_kernel, grid, dim3(256), 0, ctx->stream, d_in, n_e, ld_in, d_idx, d_w, d_scale, n_out,
+  hipLaunchKernelGGL(resample_columns_kernel, grid, dim3(256), 0, ctx->stream, d_in, n_e, n_in, ld_in, d_idx, d_w, d_scale, n_out,
                      d_out, ld_out);
   MRX_CHECK_LAUNCH(ctx);
   return MRX_OK;

@@ -1060,11 +1060,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
 // by the plain pW writer.  Time-major like the sampler's output: lanes are detectors.
 constexpr int kCoarseKrjSteps = 32;
 
+// (`loading` and `out` may be the same buffer -- the pipelined run converts a block's coarse loading in place --: no
+// __restrict__ on either; every element is read once, by the thread that then writes it)
 __global__ __launch_bounds__(kBlock) void coarse_krj_kernel(
-    const float* __restrict__ loading, int D, int Ta, const float* __restrict__ bore_el,
+    const float* loading, int D, int Ta, const float* __restrict__ bore_el,
     const float* __restrict__ dxs, const float* __restrict__ dys, const int32_t* __restrict__ band,
     const float* __restrict__ cal_axis, const float* __restrict__ cal_values, int n_el, int n_bands,
-    float* __restrict__ out, float* __restrict__ tail, int tail_first, size_t ld_tail) {
+    float* out, float* __restrict__ tail, int tail_first, size_t ld_tail) {
   extern __shared__ __align__(16) float4 cal_cells[];  // [n_bands][n_el - 1], see stage_cal_cells
   __shared__ float2 trig[kCoarseKrjSteps];  // (cos, sin) of (boresight elevation - pi/2) of the block's steps
   stage_cal_cells(cal_cells, cal_axis, cal_values, n_el, n_bands);

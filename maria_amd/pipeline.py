@@ -343,14 +343,16 @@ class DevicePath:
             self._margins = out
         return self._margins
 
-    def generate_screens(self, smooth=True, only=None):
+    def generate_screens(self, smooth=True, only=None, exchange=None):
         """Philox + k-space filter + complex-to-real iFFT on the device with the beam
         smoothing (atmosphere/atmosphere.py:328-344) folded into the two FFT passes
         (mrx_screen_generate_batch), into persistent screen buffers.  The first call
         allocates the buffers and binds them; later calls only launch kernels: two per
         group of layers that share an FFT domain.  ``only``: generate just these layer indices
-        (sharded generation, maria_amd.dist.exchange_layer_screens fills in the rest).
-        Returns the device tensors."""
+        (sharded generation); ``exchange``: a callable that takes the list of screens and fills in the
+        other ranks' layers (maria_amd.dist), run on the stream the screens are generated on -- with
+        enable_lookahead() the exchange of the next observation's screens then rides beside this one's
+        synthesis.  Returns the device tensors."""
         dev = self.device
         layers = self.problem["layers"]
         la = getattr(self, "_la", None)
@@ -441,7 +443,7 @@ class DevicePath:
         # look-ahead (enable_lookahead): this call fills the OTHER set of screens on the screens' own stream, behind
         # the samplers that last read that set; run() then samples it behind an event
         gen_ctx, target = self.ctx, self._gen_screens
-        if la is not None and only is None:
+        if la is not None:
             which = la["count"] % 2
             target, gen_ctx = la["screens"][which], la["ctx"]
             if la["count"] == 0:  # everything the caller queued so far (uploads, the amplitude tables) comes first
@@ -512,14 +514,19 @@ class DevicePath:
                                   ptr(fine["scale"]), n_l, ptr(dst), n_l)
                     if dst is not out:
                         self.ctx.call("mrx_gauss_smooth2d", ptr(dst), ptr(out), ptr(self._gen_tmp[1]), ne, n_l, sy, sx, 4.0)
-        if la is not None and only is None:
+        if la is not None:
             which = la["count"] % 2
+            if exchange is not None:
+                with torch.cuda.stream(la["stream"]):
+                    exchange(target)
             la["screens_done"][which].record(la["stream"])
             la["count"] += 1
             la["current"] = which
             self.plan, self._layers, self._layer_bufs = la["plans"][which]
             self._gen_screens = target
             return target
+        if exchange is not None:
+            exchange(self._gen_screens)
         return self._gen_screens
 
     def enable_lookahead(self):
@@ -644,6 +651,8 @@ class DevicePath:
     def coarse_loading(self):
         """[D, Ta] float32 coarse loading in the caller's detector order (device tensor)."""
         if getattr(self, "_pipelined", False):  # the last run kept it in per-block buffers
+            if getattr(self, "_pipelined_krj", False):
+                raise RuntimeError("the last run() converted its coarse buffers to K_RJ in place: call sample() (pW) before coarse_loading()")
             return torch.cat(self._pipe["loading"], dim=1).T.index_select(0, self._d_inverse)
         return self.d_loading.T.index_select(0, self._d_inverse)
 
@@ -865,6 +874,7 @@ class DevicePath:
                 st["tail_done"].record(side)
                 main.wait_event(st["tail_done"])
         self._pipelined = True
+        self._pipelined_krj = bool(krj and krj != "sample")  # (the coarse buffers then hold K_RJ, not pW)
         self._pwv_stale = True
         return out
 
