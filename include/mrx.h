@@ -34,7 +34,8 @@ extern "C" {
 #define MRX_VERSION 140 /* 0.2.0 (120): mrx_spline_upsample_fused, mrx_allgather_tod_p2p, mrx_exchange_screens,
                            mrx_resample_columns; MRX_OPT_SAMPLE_TILES retired.  130: mrx_screen_amplitudes,
                            mrx_screen_desc.d_amp, mrx_screen_generate_3d(..., d_amp), mrx_streams_concurrent.
-                           131: mrx_coarse_to_krj_keep_tail */
+                           131: mrx_coarse_to_krj_keep_tail.  140: mrx_screen_desc.periodic_beam,
+                           mrx_noise_generate_krj, the noise generator's two-rate form */
 
 typedef enum mrx_status {
   MRX_OK = 0,
@@ -682,6 +683,28 @@ int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T
                        const float* d_loading, size_t ld_loading, double per_loading,
                        float* d_out, size_t ld_out, int accumulate,
                        float* d_work, size_t work_floats);
+/* Two-rate form (chosen by the library: fs, knee and T decide).  Where the pink part at a quarter (half) of the
+ * Nyquist frequency has fallen below 2 % of the white level -- 2 rate knee / fs <= 0.02: rate 4 at 400 Hz and a knee
+ * of 1 Hz -- and T >= 32768, the pink and correlated-pink parts are synthesised at fs / rate (a period, a scratch
+ * round trip and an arithmetic rate times smaller), interpolated with the four-point Catmull-Rom cubic, and the white
+ * parts -- the detectors' own and the modes', which reach the Nyquist frequency -- are drawn per sample as the field is
+ * written.  What changes against the one-rate form: no pink power between fs / (2 rate) and fs / 2 (< 2 % of the
+ * spectrum there) and the interpolation's roll-off of the pink part in the octave below (smaller still); white level,
+ * modes' covariance, zero pink mean over the TOD, shard / batch independence as before.  MRX_OPT_NOISE_GENERIC bit 8
+ * keeps the one-rate form.
+ *
+ * mrx_noise_generate_krj: the field in K_RJ (tod/tod.py:106-142): every sample divided by den_band(d)(el(d, t)) as
+ * mrx_tod_to_krj does (same elevation model, same lookup), with d_bore_el [T] and d_dx, d_dy, d_band [D] indexed like
+ * the rows of d_out.  In the two-rate form the division rides on the writer's store (the field is written once);
+ * otherwise the call is mrx_noise_generate followed by mrx_tod_to_krj. */
+int mrx_noise_generate_krj(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T,
+                           double sample_rate, double knee, double corr_prop,
+                           const float* d_basis, int n_modes, const float* d_scale,
+                           const float* d_loading, size_t ld_loading, double per_loading,
+                           float* d_out, size_t ld_out,
+                           float* d_work, size_t work_floats,
+                           const float* d_bore_el, const float* d_dx, const float* d_dy, const int32_t* d_band,
+                           const float* d_cal_axis_el, const float* d_cal_values, int n_el, int n_bands);
 
 /* Philox-4x32-10 standard normals, the generator behind the screens, exposed
  * so tests can check the stream against the published known-answer vectors.

@@ -205,6 +205,8 @@ SIGNATURES = {
     "mrx_noise_period": (_i, [_i, C.POINTER(_i), C.POINTER(_i)]),
     "mrx_noise_work_floats": (_i, [_i, _i, _i, C.POINTER(_sz)]),
     "mrx_noise_generate": (_i, [_vp, C.c_uint64, _i, _i, _i, _d, _d, _d, _vp, _i, _vp, _vp, _sz, _d, _vp, _sz, _i, _vp, _sz]),
+    "mrx_noise_generate_krj": (_i, [_vp, C.c_uint64, _i, _i, _i, _d, _d, _d, _vp, _i, _vp, _vp, _sz, _d, _vp, _sz, _vp, _sz,
+                                    _vp, _vp, _vp, _vp, _vp, _vp, _i, _i]),
     "mrx_philox_normal": (_i, [_vp, C.c_uint64, C.c_uint32, _sz, _vp]),
     "mrx_philox_raw": (_i, [_vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
 }

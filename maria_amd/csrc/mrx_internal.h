@@ -159,6 +159,43 @@ inline int mrx_lds_cap(mrx_ctx* ctx, const void* fn, size_t bytes) {
     if (rc__ != MRX_OK) return rc__;                                                       \
   } while (0)
 
+// The last stage of the two-rate noise generator (mrx_noise.hip builds the slow part, mrx_spline.hip holds the writer
+// next to the K_RJ machinery it shares with mrx_tod_to_krj): see noise_two_rate_kernel.
+struct mrx_two_rate_args {
+  const float* lo;          // [rows of this launch][ld_lo]: pink + correlated pink parts at fs / rate; sample t' at lo[t' + 1]
+  size_t ld_lo;
+  int rate;                 // 2 or 4
+  const float* mode_white;  // [n_modes][ld_mw] unit white series of the modes, or null
+  size_t ld_mw;
+  int n_modes;
+  const float* basis;       // [rows of the call][n_modes] (indexed by absolute row, like scale)
+  float w_corr;             // sqrt(correlated proportion)
+  float sqrt_fs;
+  const float* scale;       // [rows of the call] or null
+  const float* loading;     // [rows of the call][ld_loading] or null
+  size_t ld_loading;
+  float per_loading;
+  float* out;               // [rows of the call][ld]
+  size_t ld;
+  int row0, rows;           // this launch: rows row0 .. row0 + rows - 1
+  uint32_t id0;             // white-noise id of row 0 of the call
+  int T;
+  int accumulate;
+  // TOD.to("K_RJ") in the same pass (arrays indexed by the call's rows), or bore_el = null
+  const float* bore_el;
+  const float* dx;
+  const float* dy;
+  const int32_t* band;
+  const float* cal_axis;
+  const float* cal_values;
+  int n_el, n_bands;
+  uint32_t key0, key1;
+};
+int mrx_noise_two_rate_write(mrx_ctx* ctx, hipStream_t stream, const mrx_two_rate_args& a);
+// four white normals for samples 4 q .. 4 q + 3 of row `id`: the counter every white draw of the noise generator uses
+constexpr uint32_t kMrxTagWhite = 0x57484954u;      // 'WHIT'
+constexpr uint32_t kMrxTagModeWhite = 0x4d57484du;  // 'MWHM': the modes' white series (two-rate form)
+
 static inline int mrx_ceil_div(long long a, long long b) {
   return (int)((a + b - 1) / b);
 }

@@ -755,6 +755,15 @@ __global__ __launch_bounds__(kBlock) void noise_combine_rows(const float2* __res
   }
 }
 
+// the modes' white parts as time series (two-rate form): unit normals, 4 samples per thread, mode = blockIdx.y
+__global__ __launch_bounds__(kBlock) void noise_mode_white_kernel(float* __restrict__ mw, size_t ld, int T, uint32_t key0, uint32_t key1) {
+  const size_t t0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * 4;
+  if (t0 >= (size_t)T) return;
+  const U4 rnd = philox4x32_10(U4{(uint32_t)(t0 >> 2), blockIdx.y, 0u, kMrxTagModeWhite}, key0, key1);
+  const float2 a = box_muller(rnd.x, rnd.y), b = box_muller(rnd.z, rnd.w);
+  *reinterpret_cast<vfloat4*>(mw + (size_t)blockIdx.y * ld + t0) = vfloat4{a.x, a.y, b.x, b.y};  // (ld: whole groups of 4)
+}
+
 // knee = 0: white noise only (generation.py:25), 4 samples per thread
 __global__ __launch_bounds__(kBlock) void noise_white_kernel(CombineArgs g, uint32_t key0, uint32_t key1) {
   const size_t t0 = ((size_t)blockIdx.x * kBlock + threadIdx.x) * 4;
@@ -859,6 +868,35 @@ int mrx_noise_work_floats(int T, int n_modes, int batch, size_t* floats) {
   return MRX_OK;
 }
 
+// TOD.to("K_RJ") of the field as it is written (mrx_noise_generate_krj), arrays indexed by the call's rows
+struct NoiseKrj {
+  const float* bore_el;
+  const float* dx;
+  const float* dy;
+  const int32_t* band;
+  const float* cal_axis;
+  const float* cal_values;
+  int n_el, n_bands;
+};
+
+// The slow part's sample rate: fs / rate, rate the largest of 4, 2 for which the pink part at the slow Nyquist
+// frequency, knee / (fs / (2 rate)), stays below 2 % of the white level (what the form leaves out above it; the
+// interpolation's roll-off just below is smaller still) -- 4 at 400 Hz with a knee of 1 Hz, 1 (the one-rate form)
+// at 50 Hz.  Short series and option bit 8 of MRX_OPT_NOISE_GENERIC keep the one-rate form.
+static int two_rate_factor(const mrx_ctx* ctx, int T, double sample_rate, double knee) {
+  if ((ctx->options[MRX_OPT_NOISE_GENERIC] & 8) || !(knee > 0.0) || T < 32768) return 1;
+  for (int rate = 4; rate >= 2; rate >>= 1)
+    if (2.0 * rate * knee / sample_rate <= 0.02 + 1e-12) return rate;
+  return 1;
+}
+
+static int noise_generate_impl(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T,
+                               double sample_rate, double knee, double corr_prop,
+                               const float* d_basis, int n_modes, const float* d_scale,
+                               const float* d_loading, size_t ld_loading, double per_loading,
+                               float* d_out, size_t ld_out, int accumulate,
+                               float* d_work, size_t work_floats, const NoiseKrj* krj);
+
 int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T,
                        double sample_rate, double knee, double corr_prop,
                        const float* d_basis, int n_modes, const float* d_scale,
@@ -866,7 +904,41 @@ int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T
                        float* d_out, size_t ld_out, int accumulate,
                        float* d_work, size_t work_floats) {
   MRX_ENTER(ctx);
+  return noise_generate_impl(ctx, seed, D, det_offset, T, sample_rate, knee, corr_prop, d_basis, n_modes, d_scale, d_loading,
+                             ld_loading, per_loading, d_out, ld_out, accumulate, d_work, work_floats, nullptr);
+}
+
+int mrx_noise_generate_krj(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T,
+                           double sample_rate, double knee, double corr_prop,
+                           const float* d_basis, int n_modes, const float* d_scale,
+                           const float* d_loading, size_t ld_loading, double per_loading,
+                           float* d_out, size_t ld_out,
+                           float* d_work, size_t work_floats,
+                           const float* d_bore_el, const float* d_dx, const float* d_dy, const int32_t* d_band,
+                           const float* d_cal_axis_el, const float* d_cal_values, int n_el, int n_bands) {
+  MRX_ENTER(ctx);
   if (!ctx) return MRX_ERR_INVALID;
+  MRX_REQUIRE(ctx, d_bore_el && d_dx && d_dy && d_band && d_cal_axis_el && d_cal_values, "null calibration pointer");
+  const NoiseKrj k{d_bore_el, d_dx, d_dy, d_band, d_cal_axis_el, d_cal_values, n_el, n_bands};
+  if (D > 0 && T > 0 && two_rate_factor(ctx, T, sample_rate, knee) > 1)  // the conversion rides on the two-rate form's writer
+    return noise_generate_impl(ctx, seed, D, det_offset, T, sample_rate, knee, corr_prop, d_basis, n_modes, d_scale, d_loading,
+                               ld_loading, per_loading, d_out, ld_out, 0, d_work, work_floats, &k);
+  // otherwise: the field in pW, then mrx_tod_to_krj's pass over it
+  int rc = noise_generate_impl(ctx, seed, D, det_offset, T, sample_rate, knee, corr_prop, d_basis, n_modes, d_scale, d_loading,
+                               ld_loading, per_loading, d_out, ld_out, 0, d_work, work_floats, nullptr);
+  if (rc != MRX_OK) return rc;
+  return mrx_tod_to_krj(ctx, d_out, ld_out, D, T, nullptr, nullptr, d_bore_el, d_dx, d_dy, d_band, d_cal_axis_el, d_cal_values, n_el,
+                        n_bands);
+}
+
+static int noise_generate_impl(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T_full,
+                               double sample_rate, double knee, double corr_prop,
+                               const float* d_basis, int n_modes, const float* d_scale,
+                               const float* d_loading, size_t ld_loading, double per_loading,
+                               float* d_out, size_t ld_out, int accumulate,
+                               float* d_work, size_t work_floats, const NoiseKrj* krj) {
+  if (!ctx) return MRX_ERR_INVALID;
+  int T = T_full;  // samples the spectral part is made for: the TOD's, or the slow series' of the two-rate form
   MRX_REQUIRE(ctx, D >= 0 && T >= 0, "negative size");
   if (D == 0 || T == 0) return MRX_OK;
   MRX_REQUIRE(ctx, d_out, "null pointer");
@@ -882,6 +954,9 @@ int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T
               "0 <= n_modes <= 8 and a basis when n_modes > 0");
   const uint32_t key0 = (uint32_t)seed, key1 = (uint32_t)(seed >> 32);
   const bool pink = knee > 0.0;
+  const int rate = (D > 0 && T > 0) ? two_rate_factor(ctx, T_full, sample_rate, knee) : 1;
+  const bool two_rate = rate > 1;
+  MRX_REQUIRE(ctx, !krj || two_rate, "internal: the fused K_RJ conversion belongs to the two-rate form");
 
   CombineArgs g{};
   g.scale = d_scale;
@@ -912,13 +987,24 @@ int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T
 
   MRX_REQUIRE(ctx, d_work && (reinterpret_cast<uintptr_t>(d_work) & 15u) == 0,
               "work buffer must be 16-byte aligned");
+  // Two-rate form: the spectral machinery below makes the SLOW series -- pink parts only, T_full / rate + 4 samples
+  // (one before and up to three after the TOD's span, for the interpolation) at fs / rate -- into a buffer of their
+  // own; noise_two_rate_kernel then writes the TOD.  Its scratch comes out of the same work buffer: the slow
+  // series' spectra take a quarter (half) of the one-rate form's room.
+  size_t ld_lo = 0, ld_mw = 0;
+  if (two_rate) {
+    T = (T_full + rate - 1) / rate + 4;
+    ld_lo = ((size_t)T + 3) & ~(size_t)3;
+    ld_mw = ((size_t)T_full + 3) & ~(size_t)3;
+  }
   int n1, n2;
   if (mrx_noise_period(T, &n1, &n2) != MRX_OK)
     return mrx_fail(ctx, MRX_ERR_UNSUPPORTED, "T = %d exceeds the 2^23-sample noise period", T);
   const size_t n = (size_t)n1 * n2;
-  MRX_REQUIRE(ctx, work_floats >= 16 + 2 * n * (size_t)n_modes + (2 * n + 4) + 16,
-              "work buffer too small: see mrx_noise_work_floats");
-  const size_t fit = (work_floats - 32 - 2 * n * (size_t)n_modes) / (2 * n + 4);
+  const size_t fixed = 32 + 2 * n * (size_t)n_modes + (two_rate ? (size_t)n_modes * ld_mw + 16 : 0);
+  const size_t per_pair = 2 * n + 4 + (two_rate ? 2 * ld_lo : 0);
+  MRX_REQUIRE(ctx, work_floats >= fixed + per_pair, "work buffer too small: see mrx_noise_work_floats");
+  const size_t fit = (work_floats - fixed) / per_pair;
   const int pairs_max = (int)(fit < 16384 ? fit : 16384);
   const int l1 = ilog2(n1), l2 = ilog2(n2);
   const int lj = ilog2(kTileCells) - l1;  // J = 4096 / n1 >= 4
@@ -927,6 +1013,8 @@ int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T
   double2* mean = reinterpret_cast<double2*>(d_work + 16);         // [pairs_max] pairs' pink window means
   float2* F = reinterpret_cast<float2*>(d_work + 16 + 4 * (size_t)pairs_max);  // [n_modes][n]
   float2* A = F + (size_t)n_modes * n;                             // [pairs][n]
+  float* Lo = reinterpret_cast<float*>(A + (size_t)pairs_max * n);  // two-rate: [2 pairs_max][ld_lo]
+  float* MW = Lo + 2 * (size_t)pairs_max * ld_lo;                   // two-rate: [n_modes][ld_mw] (16-byte aligned: all sizes are multiples of 4)
   const size_t lds1 = (size_t)(2 * n2 + n2 / 4) * sizeof(float2);
   const size_t lds2 = (size_t)(2 * kTileCells + n1 / 4) * sizeof(float2);
   int threads1 = kBlock;
@@ -944,7 +1032,7 @@ int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T
   SpectrumArgs sp{};
   sp.knee = (float)knee;
   sp.w_ind = 1.0f;
-  sp.white_var = (float)(sample_rate / (double)n);
+  sp.white_var = two_rate ? 0.0f : (float)(sample_rate / (double)n);  // (two-rate: the white parts are drawn per sample by the writer)
   sp.win.T = T;
   sp.win.k_min = (int)((n + (size_t)T - 1) / (size_t)T);  // ceil(N / T): nothing slower than the TOD
   sp.win.k_cut = (int)(64LL * sp.win.k_min < (long long)(n / 2) ? 64 * sp.win.k_min : n / 2);
@@ -954,7 +1042,10 @@ int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T
     hipLaunchKernelGGL(noise_mode_means, dim3(n_modes), dim3(kBlock), 0, ctx->stream, (int)n, (float)knee,
                        sp.win, key0, key1);
     hipLaunchKernelGGL(noise_mode_table, dim3(mrx_ceil_div((long long)n, kBlock), n_modes), dim3(kBlock),
-                       0, ctx->stream, F, n1, n2, (float)(sample_rate / (double)n), (float)knee, sp.win, key0, key1);
+                       0, ctx->stream, F, n1, n2, sp.white_var, (float)knee, sp.win, key0, key1);
+    if (two_rate)
+      hipLaunchKernelGGL(noise_mode_white_kernel, dim3(mrx_ceil_div(mrx_ceil_div(T_full, 4), kBlock), n_modes), dim3(kBlock), 0,
+                         ctx->stream, MW, ld_mw, T_full, key0, key1);
     MRX_CHECK_LAUNCH(ctx);
     sp.F = F;
     sp.basis = d_basis;
@@ -999,6 +1090,16 @@ int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T
     CombineArgs h = g;
     h.row0 = d0;
     h.rows = count;
+    float* lo_lane = Lo + 2 * (size_t)lane * pairs_lane * ld_lo;
+    if (two_rate) {  // pass 2 writes the slow series of the batch's rows, unscaled, into the lane's buffer
+      h.out = lo_lane - (size_t)d0 * ld_lo;  // (row d0 + i -> lo_lane[i])
+      h.ld = ld_lo;
+      h.T = T;
+      h.scale = nullptr;
+      h.loading = nullptr;
+      h.accumulate = 0;
+      h.vec_ok = 1;
+    }
     sp.row0 = d0;
     sp.rows = count;
     sp.series0 = 16u + (uint32_t)((det_offset + d0) / 2);  // detector pair (2q, 2q+1) is series 16 + q
@@ -1039,6 +1140,37 @@ int mrx_noise_generate(mrx_ctx* ctx, uint64_t seed, int D, int det_offset, int T
                          stream, Al, n1, n2, l1, lj, h, key0, key1);
     }
     MRX_CHECK_LAUNCH(ctx);
+    if (two_rate) {
+      mrx_two_rate_args a{};
+      a.lo = lo_lane;
+      a.ld_lo = ld_lo;
+      a.rate = rate;
+      a.mode_white = n_modes > 0 ? MW : nullptr;
+      a.ld_mw = ld_mw;
+      a.n_modes = n_modes;
+      a.basis = d_basis;
+      a.w_corr = n_modes > 0 ? (float)sqrt(corr_prop) : 0.0f;
+      a.sqrt_fs = (float)sqrt(sample_rate);
+      a.scale = d_scale;
+      a.loading = d_loading;
+      a.ld_loading = ld_loading;
+      a.per_loading = (float)per_loading;
+      a.out = d_out;
+      a.ld = ld_out;
+      a.row0 = d0;
+      a.rows = count;
+      a.id0 = (uint32_t)det_offset;
+      a.T = T_full;
+      a.accumulate = accumulate;
+      if (krj) {
+        a.bore_el = krj->bore_el; a.dx = krj->dx; a.dy = krj->dy; a.band = krj->band;
+        a.cal_axis = krj->cal_axis; a.cal_values = krj->cal_values; a.n_el = krj->n_el; a.n_bands = krj->n_bands;
+      }
+      a.key0 = key0;
+      a.key1 = key1;
+      const int rc = mrx_noise_two_rate_write(ctx, stream, a);
+      if (rc != MRX_OK) return rc;
+    }
     d0 += count;
   }
   for (int l = 1; l < lanes; ++l) {  // join: the context's stream continues after every lane

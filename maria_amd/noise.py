@@ -48,14 +48,15 @@ def diameter(offsets):
 
 
 def simulate_noise(ctx, dets, T, sample_rate, seed, noise_kwargs=None, device="cuda:0", batch=1024, out=None, loading=None,
-                   det_slice=None):
+                   det_slice=None, krj=None):
     """sim/noise.py:18-63: one band at a time, [ndet, T] float32 in pW on the device.
     ``dets`` is a ``maria_amd.instrument.Detectors``; bands carry ``NEP`` (W sqrt(s)), ``knee``
     (Hz) and ``NEP_per_loading``; ``loading`` is the [ndet, T] float32 device tensor of the summed
     loadings in pW, needed only by bands whose NEP grows with it (noise.py:35-37).
     ``det_slice``: generate only these rows of every band-major table (a detector shard; it may
     begin or end inside a detector pair): a shard's rows equal the same rows of the unsharded call,
-    modes included."""
+    modes included.  ``krj``: ``DevicePath.krj_row_tables()`` -- the field is then written in K_RJ
+    (mrx_noise_generate_krj: TOD.to("K_RJ"), tod/tod.py:106-142, on the generator's own store where its two-rate form applies)."""
     kw = dict(DEFAULT_NOISE_SIM_KWARGS)
     kw.update(noise_kwargs or {})
     dev = torch.device(device)
@@ -98,22 +99,27 @@ def simulate_noise(ctx, dets, T, sample_rate, seed, noise_kwargs=None, device="c
         ctx.lib.mrx_noise_work_floats(int(T), int(n_modes), int(min(batch, count)), C.byref(need))
         work = torch.empty(need.value, dtype=torch.float32, device=dev)
 
-        def generate(row0, n_rows, dst, dst_loading):
-            """rows row0 .. row0 + n_rows - 1 of the band (row0 even: the pink series come in pairs) into ``dst``"""
+        def generate(row0, n_rows, dst, dst_loading, rows_of_out):
+            """rows row0 .. row0 + n_rows - 1 of the band (row0 even: the pink series come in pairs) into ``dst``;
+            ``rows_of_out``: the rows of ``out`` they are (an index tensor), for the K_RJ tables"""
             d_basis = torch.as_tensor(np.ascontiguousarray(basis[row0 : row0 + n_rows], np.float32)).to(dev)
             d_scale = torch.full((n_rows,), float(1e12 * band.NEP), dtype=torch.float32, device=dev)  # noise.py:62
-            ctx.call(
-                "mrx_noise_generate", int(seed) + 7919 * b, n_rows, row0, int(T), float(sample_rate), float(band.knee),
-                float(kw.get("correlated_noise_proportion", 0)), ptr(d_basis), int(n_modes), ptr(d_scale),
-                ptr(dst_loading) if per_loading else None, dst_loading.stride(0) if per_loading else 0,
-                1e12 * per_loading, ptr(dst), dst.stride(0), 0, ptr(work), need.value,
-            )
+            args = (int(seed) + 7919 * b, n_rows, row0, int(T), float(sample_rate), float(band.knee),
+                    float(kw.get("correlated_noise_proportion", 0)), ptr(d_basis), int(n_modes), ptr(d_scale),
+                    ptr(dst_loading) if per_loading else None, dst_loading.stride(0) if per_loading else 0,
+                    1e12 * per_loading, ptr(dst), dst.stride(0))
+            if krj is None:
+                ctx.call("mrx_noise_generate", *args, 0, ptr(work), need.value)
+            else:
+                dx, dy, bd = (krj[k].index_select(0, rows_of_out) for k in ("dx", "dy", "band"))
+                ctx.call("mrx_noise_generate_krj", *args, ptr(work), need.value, ptr(krj["bore_el"]), ptr(dx), ptr(dy), ptr(bd),
+                         ptr(krj["axis"]), ptr(krj["values"]), krj["n_el"], krj["n_bands"])
 
+        d_rows = torch.as_tensor(mine - lo, device=dev)  # the band's rows of ``out``
         if contiguous:
             view = out[first - lo : last - lo]
             lview = loading[first - lo : last - lo] if per_loading else None
         else:  # scattered rows: drawn into a buffer of their own and copied to their rows below
-            d_rows = torch.as_tensor(mine - lo, device=dev)
             view = torch.empty((k1 - k0, T), dtype=torch.float32, device=dev)
             lview = loading.index_select(0, d_rows) if per_loading else None
         start = 0
@@ -124,7 +130,7 @@ def simulate_noise(ctx, dets, T, sample_rate, seed, noise_kwargs=None, device="c
             pl = None
             if per_loading:  # the first row's loading is not ours: any finite values do for a row that is dropped
                 pl = torch.stack([lview[0], lview[0]])
-            generate(offset - 1, 2, pair, pl)
+            generate(offset - 1, 2, pair, pl, d_rows[[0, 0]])
             view[0].copy_(pair[1])
             start = 1
         # ... and likewise when it ends on the FIRST detector of a pair whose second one exists (in the next shard): drawn
@@ -133,11 +139,11 @@ def simulate_noise(ctx, dets, T, sample_rate, seed, noise_kwargs=None, device="c
         if (offset + count) % 2 and offset + count < len(idx) and count > start:
             pair = torch.empty((2, T), dtype=torch.float32, device=dev)
             pl = torch.stack([lview[count - 1], lview[count - 1]]) if per_loading else None
-            generate(offset + count - 1, 2, pair, pl)
+            generate(offset + count - 1, 2, pair, pl, d_rows[[count - 1, count - 1]])
             view[count - 1].copy_(pair[0])
             stop = count - 1
         if stop > start:
-            generate(offset + start, stop - start, view[start:stop], None if lview is None else lview[start:stop])
+            generate(offset + start, stop - start, view[start:stop], None if lview is None else lview[start:stop], d_rows[start:stop])
         if not contiguous:
             out.index_copy_(0, d_rows, view)
         del work

@@ -1006,6 +1006,15 @@ class DevicePath:
             ptr(c["axis"]), ptr(c["values"]), c["n_el"], c["n_bands"], ptr(out), out.stride(0),
         )
 
+    def krj_row_tables(self):
+        """What mrx_noise_generate_krj takes besides the field: the calibration of set_calibration() with the per-detector
+        arrays in the CALLER's row order (the rows of the field it writes)."""
+        c = self._cal
+        if "rows" not in c:
+            c["rows"] = dict(dx=c["dx"].index_select(0, self._d_inverse), dy=c["dy"].index_select(0, self._d_inverse),
+                             band=self.d_band.index_select(0, self._d_inverse))
+        return dict(c["rows"], bore_el=c["bore_el"], axis=c["axis"], values=c["values"], n_el=c["n_el"], n_bands=c["n_bands"])
+
     def to_krj(self, data):
         """mrx_tod_to_krj: convert a full-rate [D, T] pW field (caller's row order) to K_RJ in
         place with the calibration of ``set_calibration`` (tod/tod.py:106-142)."""

@@ -443,10 +443,10 @@ class Simulation:
                 out.index_copy_(0, torch.as_tensor(idx, device=device), dst)
         return out
 
-    def _simulate_noise(self, obs, loading=None, rows=None):
+    def _simulate_noise(self, obs, loading=None, rows=None, krj=None):
         """sim/noise.py:18-63 on the device, in pW; ``loading`` (pW, [D, T] on the device) only
         for bands whose NEP grows with the loading.  The gain error does not apply to the
-        noise field (simulation.py:243-245)."""
+        noise field (simulation.py:243-245).  ``krj``: DevicePath.krj_row_tables() -- the field in K_RJ."""
         import torch
 
         from . import noise as mnoise
@@ -466,7 +466,7 @@ class Simulation:
         self._noise_runs += 1
         return mnoise.simulate_noise(ctx, dets, len(t), fs, self._noise_seed + 104729 * self._noise_runs,
                                      self.noise_kwargs, device=device, loading=loading,
-                                     det_slice=None if rows is None else slice(*rows))
+                                     det_slice=None if rows is None else slice(*rows), krj=krj)
 
     def run_obs(self, obs, units: str = "pW") -> TOD:
         """sim/simulation.py:213-272 (followed by ``.to(units)`` of :206), for this process's
@@ -527,7 +527,12 @@ class Simulation:
                     total = fields[0] if len(fields) == 1 else fields[0] + fields[1]
                 else:
                     total = torch.zeros((dets.n, len(obs.coords.t)), dtype=torch.float32, device=device)
-            noise = self._simulate_noise(obs, loading=total, rows=rows)
+            # in the default units the noise leaves its generator in K_RJ (mrx_noise_generate_krj)
+            noise_krj = None
+            if units == "K_RJ" and has_atm:
+                self._set_calibration(obs, metadata)
+                noise_krj = obs.atmosphere._device_path().krj_row_tables()
+            noise = self._simulate_noise(obs, loading=total, rows=rows, krj=noise_krj)
         if has_gain:  # the gain error applies to every field but the noise (simulation.py:243-245)
             d_gain = torch.as_tensor(gain.astype(np.float32), device=device)[:, None]
             if map_loading is not None:
@@ -540,9 +545,8 @@ class Simulation:
             if loading_nep:
                 self._set_calibration(obs, metadata)
                 path.to_krj(loading)
-            for field in (map_loading, noise):
-                if field is not None:
-                    path.to_krj(field)
+            if map_loading is not None:  # (the noise was written in K_RJ)
+                path.to_krj(map_loading)
         elif units == "K_RJ":
             den = torch.as_tensor(self._band_denominators(all_dets)[lo:hi].astype(np.float32), device=device)[:, None]
             for field in (map_loading, noise):

@@ -363,3 +363,42 @@ def test_tod_to_round_trip_like_the_reference_noise_test(gpu_ctx):
     for f in again.fields:
         np.testing.assert_allclose(again.data[f], k.data[f], rtol=3e-6, atol=1e-6 * np.abs(k.data[f]).max())
     assert k.to("K_RJ") is k
+
+
+@pytest.mark.parametrize("T,fs,knee", [(70001, 400.0, 1.0), (40000, 400.0, 2.0), (20000, 100.0, 1.0), (9000, 100.0, 0.0)])
+def test_noise_written_in_krj(gpu_ctx, T, fs, knee):
+    """mrx_noise_generate_krj: the field of mrx_noise_generate divided by den_band(d)(el(d, t)) as mrx_tod_to_krj divides
+    it -- on the two-rate writer's own store (rates 4 and 2: the same arithmetic, bit for bit) or, where the one-rate
+    form or the white-only path applies, by that pass itself."""
+    import ctypes as C
+
+    import torch
+
+    from maria_amd import _lib
+    from maria_amd._lib import ptr
+    from maria_amd.pipeline import DevicePath
+
+    p = small_problem(n_det=46, n_bands=2, n_layers=1)
+    rng = np.random.default_rng(5)
+    coords_offsets = np.radians(rng.uniform(-0.4, 0.4, (46, 2)))
+    tt = np.arange(T) / fs
+    bore_el = np.radians(55.0) + np.radians(0.4) * np.sin(2 * np.pi * tt / 7.3)
+    path = DevicePath(dict(p, t=tt), device="cuda:0", ctx=gpu_ctx)
+    path.set_calibration(_cal_tables(2), 273.15, 1.0, bore_el, coords_offsets, [False, True])
+    k = path.krj_row_tables()
+    D, n_modes = path.D, 3
+    basis = torch.as_tensor(rng.normal(size=(D, n_modes)).astype(np.float32)).to("cuda:0")
+    scale = torch.as_tensor(rng.uniform(1.0, 2.0, D).astype(np.float32)).to("cuda:0")
+    need = C.c_size_t()
+    _lib.load().mrx_noise_work_floats(T, n_modes, D, C.byref(need))
+    work = torch.empty(need.value, dtype=torch.float32, device="cuda:0")
+    head = (77, D, 0, T, fs, knee, 0.5, ptr(basis), n_modes, ptr(scale), None, 0, 0.0)
+    plain = torch.empty((D, T), dtype=torch.float32, device="cuda:0")
+    gpu_ctx.call("mrx_noise_generate", *head, ptr(plain), plain.stride(0), 0, ptr(work), need.value)
+    fused = torch.empty((D, T), dtype=torch.float32, device="cuda:0")
+    gpu_ctx.call("mrx_noise_generate_krj", *head, ptr(fused), fused.stride(0), ptr(work), need.value, ptr(k["bore_el"]), ptr(k["dx"]),
+                 ptr(k["dy"]), ptr(k["band"]), ptr(k["axis"]), ptr(k["values"]), k["n_el"], k["n_bands"])
+    ref = path.to_krj(plain.clone())
+    torch.cuda.synchronize()
+    assert torch.isfinite(fused).all() and not torch.equal(fused, plain)
+    assert torch.equal(fused, ref)

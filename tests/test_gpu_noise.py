@@ -321,3 +321,76 @@ def test_tiny_and_odd_sizes(gpu_ctx, D, T):
         assert x.shape == (D, T) and np.isfinite(x).all() and bool((buf[:, T:] == 9.0).all())
         if T > 1000:
             assert 0.5 < x.std() / np.sqrt(50.0 * (1 + 2 * 2.0 / 50.0 * np.log(T / 2))) < 2.0
+
+
+@pytest.mark.parametrize("fs,knee,rate", [(400.0, 1.0, 4), (400.0, 2.0, 2)])
+def test_two_rate_form(gpu_ctx, fs, knee, rate):
+    """Where the pink part at fs / (2 rate) is below 2 % of the white level (and T >= 32768) the generator makes the
+    pink and correlated-pink parts at fs / rate, interpolates them, and draws the white parts per sample
+    (noise_two_rate_kernel).  Against the one-rate form (MRX_OPT_NOISE_GENERIC bit 8) on the same parameters: the
+    same spectrum band by band (the missing pink power above fs / (2 rate) is < 2 %), the same covariance between
+    detectors below and above the knee, unit white level; and as before: shards bit-identical to their rows,
+    batch-size independent, accumulating, loading-dependent amplitude."""
+    import torch
+
+    from maria_amd import _lib
+    from maria_amd import noise as mnoise
+    from maria_amd import synthetic
+
+    D, T, c = 96, 100003, 0.5
+    off = synthetic.hex_pack(D, np.radians(0.5))
+    B = mnoise.spatial_basis(off, k=5, n_side=16, scale=mnoise.diameter(off))
+    scale = np.linspace(1.0, 2.0, D)
+    two = _generate(gpu_ctx, D, T, fs, knee, corr=c, basis=B, scale=scale, seed=31, batch=64)
+    gpu_ctx.set_option(_lib.OPT_NOISE_GENERIC, 8)
+    try:
+        one = _generate(gpu_ctx, D, T, fs, knee, corr=c, basis=B, scale=scale, seed=31, batch=64)
+    finally:
+        gpu_ctx.set_option(_lib.OPT_NOISE_GENERIC, 0)
+    assert not torch.equal(one, two)  # (another realisation: the white parts are drawn per sample)
+    x2, x1 = (t.cpu().numpy().astype(np.float64) / scale[:, None] for t in (two, one))
+    f = np.fft.rfftfreq(T, 1 / fs)
+    p2, p1 = ((np.abs(np.fft.rfft(x, axis=1)) ** 2).mean(axis=0) for x in (x2, x1))
+    cut = fs / (2 * rate)
+    for lo, hi in [(0.02, 0.2), (0.2, 2.0), (2.0, 0.25 * cut), (0.25 * cut, 0.5 * cut), (0.5 * cut, cut), (cut, 2 * cut), (2 * cut, fs / 2)]:
+        m = (f >= lo) & (f < hi)
+        if not m.any():
+            continue
+        assert abs(p2[m].sum() / p1[m].sum() - 1) < 0.04, (lo, hi, p2[m].sum() / p1[m].sum())
+    # the white level alone -- the top of the band, where the pink part is below a per cent -- is that of the model:
+    # a detector's own white part plus the modes' through its row of the basis
+    m = f > 0.4 * fs
+    assert abs(p2[m].mean() / (T * fs * (1 + c * (B**2).sum(axis=1).mean())) - 1) < 0.03
+    # covariance between detectors: c B B^T (1 + knee / f) + ((1 - c) knee / f + 1) I, below and above the knee
+    off_diag = ~np.eye(D, dtype=bool)
+    for lo, hi in [(0.05, knee), (20.0, 0.45 * fs)]:
+        got = []
+        for x in (x2, x1):  # (the low band holds a few hundred bins of a 250 s series: the one-rate form sets the scale)
+            cov, fb = _band_covariance(x, fs, lo, hi, lambda f: 1 + knee / f)
+            ind = np.mean(((1 - c) * knee / fb + 1) / (1 + knee / fb))
+            model = c * (B @ B.T) + ind * np.eye(D)
+            s = np.trace(cov) / np.trace(model)
+            got.append((np.corrcoef(cov[off_diag], model[off_diag])[0, 1], np.sum(cov[off_diag] * model[off_diag]) / np.sum(model[off_diag] ** 2) / s))
+        (r2, slope2), (r1, slope1) = got
+        print(f"band {lo}-{hi} Hz: correlation with the model {r2:.3f} (one-rate {r1:.3f}), slope {slope2:.3f} ({slope1:.3f})")
+        assert r2 > r1 - 0.08 and abs(slope2 - slope1) < 0.15, (lo, hi, got)
+        if lo > knee:
+            assert r2 > 0.9 and abs(slope2 - 1) < 0.1, (lo, hi, got)
+    # zero mean of the pink part over the TOD: the mean of a row is that of its white part, sqrt(fs / T) sigma
+    means = x2.mean(axis=1)
+    assert abs(means.std() / np.sqrt(fs / T * (1 + c * (B**2).sum(axis=1).mean())) - 1) < 0.3
+    # shards, batches, accumulation, loading
+    for lo, hi in [(0, 16), (16, 96), (34, 35)]:
+        part = _generate(gpu_ctx, hi - lo, T, fs, knee, corr=c, basis=B[lo:hi], scale=scale[lo:hi], seed=31, det_offset=lo)
+        if (hi - lo) % 2 == 0 or hi == D:
+            assert torch.equal(part, two[lo:hi])
+        else:
+            assert torch.allclose(part, two[lo:hi], rtol=0, atol=2e-4 * float(two.abs().max()))
+    assert torch.equal(_generate(gpu_ctx, D, T, fs, knee, corr=c, basis=B, scale=scale, seed=31, batch=10), two)
+    base = torch.full((D, T + 5), 3.0, dtype=torch.float32, device="cuda:0")
+    acc = _generate(gpu_ctx, D, T, fs, knee, corr=c, basis=B, scale=scale, seed=31, accumulate=1, out=base)
+    assert torch.allclose(acc[:, :T], two + 3.0, atol=1e-4) and bool((acc[:, T:] == 3.0).all())
+    loading = torch.rand((D, T), device="cuda:0") + 0.5
+    lnep = _generate(gpu_ctx, D, T, fs, knee, corr=c, basis=B, scale=scale, seed=31, loading=loading, per_loading=0.7)
+    want = two * ((torch.as_tensor(scale, dtype=torch.float32, device="cuda:0")[:, None] + 0.7 * loading) / torch.as_tensor(scale, dtype=torch.float32, device="cuda:0")[:, None])
+    assert torch.allclose(lnep, want, rtol=2e-6, atol=1e-5 * float(two.abs().max()))
