@@ -886,7 +886,7 @@ struct NoiseKrj {
 static int two_rate_factor(const mrx_ctx* ctx, int T, double sample_rate, double knee) {
   if ((ctx->options[MRX_OPT_NOISE_GENERIC] & 8) || !(knee > 0.0) || T < 32768) return 1;
   for (int rate = 4; rate >= 2; rate >>= 1)
-    if (2.0 * rate * knee / sample_rate <= 0.02 + 1e-12) return rate;
+    if (2.0 * rate * knee / sample_rate <= 0.0205) return rate;  // (2 %, with room for a rate of 399.99 Hz read off a time axis)
   return 1;
 }
 

@@ -1172,7 +1172,7 @@ __global__ __launch_bounds__(kBlock) void tod_krj_kernel(
 // consecutive samples -- one interval of the slow series at rate 4, two at rate 2.
 typedef float nvfloat4 __attribute__((ext_vector_type(4)));
 
-template <bool kKrj>
+template <bool kKrj, int kModes>  // kModes: 0, 5 (up to five modes: the reference's spatial basis) or 8
 __global__ __launch_bounds__(kBlock) void noise_two_rate_kernel(const mrx_two_rate_args a) {
   extern __shared__ __align__(16) float4 cal_cells[];  // K_RJ: [n_bands][n_el - 1]
   __shared__ CalDet cdet[kTileDet];
@@ -1194,9 +1194,9 @@ __global__ __launch_bounds__(kBlock) void noise_two_rate_kernel(const mrx_two_ra
   __syncthreads();
   if (sb >= a.T) return;
   // the modes' white parts of this thread's four samples
-  float mw[8][kSamplesPerThread];
+  float mw[kModes > 0 ? kModes : 1][kSamplesPerThread];
 #pragma unroll
-  for (int m = 0; m < 8; ++m) {
+  for (int m = 0; m < kModes; ++m) {
 #pragma unroll
     for (int q = 0; q < kSamplesPerThread; ++q) mw[m][q] = 0.0f;
     if (m < a.n_modes) {  // (uniform)
@@ -1212,6 +1212,7 @@ __global__ __launch_bounds__(kBlock) void noise_two_rate_kernel(const mrx_two_ra
   constexpr float kW12[4] = {-0.0625f, 0.5625f, 0.5625f, -0.0625f};
   constexpr float kW34[4] = {-0.0234375f, 0.2265625f, 0.8671875f, -0.0703125f};
   auto rows_loop = [&](auto curved) {
+#pragma unroll 2
     for (int dl = 0; dl < nd; ++dl) {
       const int row = a.row0 + r0 + dl;  // row of the call
       // the slow part: samples t' - 1 .. t' + 2 (.. t' + 3 at rate 2) around the thread's interval(s), stored one to the right
@@ -1237,7 +1238,7 @@ __global__ __launch_bounds__(kBlock) void noise_two_rate_kernel(const mrx_two_ra
       const float2 g0 = mrx_dev::box_muller(rnd.x, rnd.y), g1 = mrx_dev::box_muller(rnd.z, rnd.w);
       float v[kSamplesPerThread] = {a.sqrt_fs * g0.x + p[0], a.sqrt_fs * g0.y + p[1], a.sqrt_fs * g1.x + p[2], a.sqrt_fs * g1.y + p[3]};
 #pragma unroll
-      for (int m = 0; m < 8; ++m) {
+      for (int m = 0; m < kModes; ++m) {
         const float cm = coef[dl][m];
 #pragma unroll
         for (int q = 0; q < kSamplesPerThread; ++q) v[q] = fmaf(cm, mw[m][q], v[q]);
@@ -1368,10 +1369,16 @@ int mrx_noise_two_rate_write(mrx_ctx* ctx, hipStream_t stream, const mrx_two_rat
     MRX_REQUIRE(ctx, a.n_el >= 2 && a.n_bands >= 1 && (size_t)(a.n_el - 1) * a.n_bands <= 6144,
                 "calibration tables need 2 <= n_el and (n_el-1)*n_bands <= 6144");
     const size_t lds = sizeof(float4) * (size_t)(a.n_el - 1) * a.n_bands;
-    MRX_LDS_CAP(ctx, noise_two_rate_kernel<true>, lds);
-    hipLaunchKernelGGL(noise_two_rate_kernel<true>, grid, dim3(kBlock), lds, stream, a);
+#define MRX_TWO_RATE(K, M)                                                                     \
+  do {                                                                                         \
+    MRX_LDS_CAP(ctx, (noise_two_rate_kernel<K, M>), lds);                                      \
+    hipLaunchKernelGGL((noise_two_rate_kernel<K, M>), grid, dim3(kBlock), lds, stream, a);     \
+  } while (0)
+    if (a.n_modes == 0) MRX_TWO_RATE(true, 0); else if (a.n_modes <= 5) MRX_TWO_RATE(true, 5); else MRX_TWO_RATE(true, 8);
   } else {
-    hipLaunchKernelGGL(noise_two_rate_kernel<false>, grid, dim3(kBlock), 0, stream, a);
+    const size_t lds = 0;
+    if (a.n_modes == 0) MRX_TWO_RATE(false, 0); else if (a.n_modes <= 5) MRX_TWO_RATE(false, 5); else MRX_TWO_RATE(false, 8);
+#undef MRX_TWO_RATE
   }
   MRX_CHECK_LAUNCH(ctx);
   return MRX_OK;
