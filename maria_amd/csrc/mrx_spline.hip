@@ -1171,6 +1171,7 @@ __global__ __launch_bounds__(kBlock) void tod_krj_kernel(
 // mrx_tod_to_krj (same per-tile elevation model, same lookup).  Tile: 16 rows x 1024 samples; a thread owns 4
 // consecutive samples -- one interval of the slow series at rate 4, two at rate 2.
 typedef float nvfloat4 __attribute__((ext_vector_type(4)));
+typedef float nvfloat4u __attribute__((ext_vector_type(4), aligned(4)));  // 16 bytes at any 4-byte address: one global_load_dwordx4
 
 template <bool kKrj, int kModes>  // kModes: 0, 5 (up to five modes: the reference's spatial basis) or 8
 __global__ __launch_bounds__(kBlock) void noise_two_rate_kernel(const mrx_two_rate_args a) {
@@ -1219,15 +1220,15 @@ __global__ __launch_bounds__(kBlock) void noise_two_rate_kernel(const mrx_two_ra
       const float* lo = a.lo + (size_t)(r0 + dl) * a.ld_lo;
       float p[kSamplesPerThread];
       if (a.rate == 4) {
-        const float* q = lo + (sb >> 2);
+        const nvfloat4u q = *reinterpret_cast<const nvfloat4u*>(lo + (sb >> 2));
         const float p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3];
         p[0] = p1;
         p[1] = kW14[0] * p0 + kW14[1] * p1 + kW14[2] * p2 + kW14[3] * p3;
         p[2] = kW12[0] * p0 + kW12[1] * p1 + kW12[2] * p2 + kW12[3] * p3;
         p[3] = kW34[0] * p0 + kW34[1] * p1 + kW34[2] * p2 + kW34[3] * p3;
       } else {
-        const float* q = lo + (sb >> 1);
-        const float p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3], p4 = q[4];
+        const nvfloat4u q = *reinterpret_cast<const nvfloat4u*>(lo + (sb >> 1));
+        const float p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3], p4 = lo[(sb >> 1) + 4];
         p[0] = p1;
         p[1] = kW12[0] * p0 + kW12[1] * p1 + kW12[2] * p2 + kW12[3] * p3;
         p[2] = p2;
