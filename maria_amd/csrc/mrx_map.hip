@@ -211,10 +211,42 @@ struct CalLds {
   const float* tab;  // [C][n_pwv][n_el] (LDS)
 };
 
+// the cell of the calibration tables a (zenith pwv, elevation) pair falls in, with jax's index rule and weights
+struct CalCell {
+  int ip, ie;
+  float wp, we;
+  bool oob;
+};
+
+__device__ __forceinline__ CalCell cal_cell(const CalLds& cl, float pw, float el_d) {
+  CalCell k;
+  bool o1, o2;
+  rgi_axis(cl.pwv, pw, k.ip, k.wp, o1);
+  rgi_axis(cl.el, el_d, k.ie, k.we, o2);
+  k.oob = o1 || o2;
+  return k;
+}
+
+// pW per K_RJ of channel c there (band/band.py:250-255): float32 corner sum in product order, weights built as
+// (1 * w_pwv) * w_el; 1e12 k_B as a weak scalar on a float32 array
+__device__ __forceinline__ float cal_factor(const MapArgs& g, const CalLds& cl, const CalCell& k, int c) {
+  const float* tab = cl.tab + c * g.n_pwv * g.n_el + k.ip * g.n_el + k.ie;
+  const float wp0 = __fsub_rn(1.0f, k.wp), we0 = __fsub_rn(1.0f, k.we);
+  float v = __fmul_rn(tab[0], __fmul_rn(wp0, we0));
+  v = __fadd_rn(v, __fmul_rn(tab[1], __fmul_rn(wp0, k.we)));
+  v = __fadd_rn(v, __fmul_rn(tab[g.n_el], __fmul_rn(k.wp, we0)));
+  v = __fadd_rn(v, __fmul_rn(tab[g.n_el + 1], __fmul_rn(k.wp, k.we)));
+  if (k.oob) v = __builtin_nanf("");
+  return __fmul_rn(1.380649e-11f, v);
+}
+
+constexpr int kCalFastChannels = 4;  // channels whose factors a thread keeps in registers (the stretch form below)
+
+// kCal with fixed_cal != nullptr: the per-channel factors of this sample are given (interpolated by the caller)
 template <bool kCal, int kS>
 __device__ __forceinline__ float sample_value(const MapArgs& g, const CalLds& cl, const Axis& ax_eta, const Axis& ax_xi,
                                               const DetConst& dc, int d, const SampleConst& sc, float ox,
-                                              float oy, float el_d, double y0, double y1) {
+                                              float oy, float el_d, double y0, double y1, const float* fixed_cal = nullptr) {
   int e0, e1, x0, x1;
   float pe, px;
   axis_weights(ax_eta, oy, g.bilinear, e0, e1, pe);
@@ -222,16 +254,8 @@ __device__ __forceinline__ float sample_value(const MapArgs& g, const CalLds& cl
   // float32 weights and sums (round 3): the reference's float64 sparse product P @ map is rounded to
   // float32 per channel anyway (map.py:155); a float32 evaluation is within 2e-7 of it
   const float qe = 1.0f - pe;
-  float cal_w_p = 0.f, cal_w_e = 0.f;
-  int ip = 0, ie = 0;
-  bool oob = false;
-  if (kCal) {
-    const float pw = (float)fma(sc.u, y1 - y0, y0);  // demoted to float32 by the jax interpolator
-    bool o1, o2;
-    rgi_axis(cl.pwv, pw, ip, cal_w_p, o1);
-    rgi_axis(cl.el, el_d, ie, cal_w_e, o2);
-    oob = o1 || o2;
-  }
+  CalCell cell{};
+  if (kCal && !fixed_cal) cell = cal_cell(cl, (float)fma(sc.u, y1 - y0, y0), el_d);  // (pwv demoted to float32 by the jax interpolator)
   const int plane = g.n_eta * g.n_xi;  // < 2^29: checked by the host (byte offsets in 32 bits)
   // The two corners of a row as ONE 8-byte load (x, x + 1): x is moved to n_xi - 2 when the sample sits in the
   // last column or beyond (both indices n_xi - 1), where the upper weight 1 selects that column.  Byte offsets
@@ -257,15 +281,7 @@ __device__ __forceinline__ float sample_value(const MapArgs& g, const CalLds& cl
     }
     float pw_per_k;
     if (kCal) {
-      const float* tab = cl.tab + c * g.n_pwv * g.n_el + ip * g.n_el + ie;
-      // float32 corner sum in product order, weights built as (1 * w_pwv) * w_el
-      const float wp0 = __fsub_rn(1.0f, cal_w_p), we0 = __fsub_rn(1.0f, cal_w_e);
-      float v = __fmul_rn(tab[0], __fmul_rn(wp0, we0));
-      v = __fadd_rn(v, __fmul_rn(tab[1], __fmul_rn(wp0, cal_w_e)));
-      v = __fadd_rn(v, __fmul_rn(tab[g.n_el], __fmul_rn(cal_w_p, we0)));
-      v = __fadd_rn(v, __fmul_rn(tab[g.n_el + 1], __fmul_rn(cal_w_p, cal_w_e)));
-      if (oob) v = __builtin_nanf("");
-      pw_per_k = __fmul_rn(1.380649e-11f, v);  // 1e12 k_B as a weak scalar on a float32 array
+      pw_per_k = fixed_cal ? fixed_cal[c] : cal_factor(g, cl, cell, c);
     } else {
       pw_per_k = (float)(1.380649e-11 * g.scalar[c]);
     }
@@ -349,6 +365,15 @@ __device__ __forceinline__ void sample_offsets(const MapArgs& g, const DetConst&
     oy = -dz_im * f;
     if (kNeedEl) el_d = asin_poly(im);
   }
+}
+
+// the same with the sample's per-channel calibration factors given: no detector elevation, no pwv
+template <bool kChain, int kS>
+__device__ __forceinline__ float raw_sample_fixed(const MapArgs& g, const CalLds& cl, const Axis& ax_eta, const Axis& ax_xi,
+                                                  const DetConst& dc, int d, const SampleConst& sc, const float* cal) {
+  float ox, oy, el_d;
+  sample_offsets<kChain, false>(g, dc, sc, ox, oy, el_d);
+  return sample_value<true, kS>(g, cl, ax_eta, ax_xi, dc, d, sc, ox, oy, el_d, 0.0, 0.0, cal);
 }
 
 // (jj0, y0, y1): the coarse pwv pair the caller already holds for this detector (the samples
@@ -827,8 +852,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kChain ?
   // (slot 0 / 1025: the halo samples of the 3-tap kernel) and the row loop fetches it with three 8-byte
   // reads, instead of five records held in 65 registers per thread (168 -> 63 registers).
   constexpr bool kLdsSc = !kChain;
-  constexpr int kRec = kCal ? 10 : 6;  // + cos / sin of the boresight elevation, coarse interval and weight
+  // With the calibration a sample also needs cos / sin of the boresight elevation, its coarse interval and weight there:
+  // kept for every thread's FIRST sample only (the stretch form below looks the factor up there), 4 KB instead of 16 --
+  // 41 KB of records held the kernel to three workgroups per CU; the per-sample fallback recomputes them.
+  constexpr int kRec = 6;
   __shared__ __align__(16) float sc_lds[kLdsSc ? kRec * (kTileSamples + 2) : 8];
+  __shared__ float4 sc_cal[kLdsSc && kCal ? kBlock : 1];
   SampleConst sc[kSamplesPerThread], sc_halo;
   const bool first = threadIdx.x == 0, last = threadIdx.x == kBlock - 1;
   if (kLdsSc) {
@@ -837,12 +866,8 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kChain ?
       sample_const(g, s_tile - 1 + i, false, one);
 #pragma unroll
       for (int k = 0; k < 6; ++k) sc_lds[kRec * i + k] = one.G[k];
-      if (kCal) {
-        sc_lds[kRec * i + 6] = one.ca;
-        sc_lds[kRec * i + 7] = one.sa;
-        sc_lds[kRec * i + 8] = __int_as_float(one.jj);
-        sc_lds[kRec * i + 9] = (float)one.u;  // (the interpolated pwv is rounded to float32 anyway)
-      }
+      if (kCal && i >= 1 && ((i - 1) & (kSamplesPerThread - 1)) == 0 && (i - 1) / kSamplesPerThread < kBlock)
+        sc_cal[(i - 1) / kSamplesPerThread] = make_float4(one.ca, one.sa, __int_as_float(one.jj), (float)one.u);  // (the interpolated pwv is rounded to float32 anyway)
     }
   } else {
 #pragma unroll
@@ -868,12 +893,19 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kChain ?
     const float2* rec = reinterpret_cast<const float2*>(sc_lds + kRec * slot);
     const float2 a = rec[0], b = rec[1], c = rec[2];
     one.G[0] = a.x; one.G[1] = a.y; one.G[2] = b.x; one.G[3] = b.y; one.G[4] = c.x; one.G[5] = c.y;
-    if (kCal) {
-      const float2 d = rec[3], e = rec[4];
-      one.ca = d.x; one.sa = d.y;
-      one.jj = __float_as_int(e.x);
-      one.u = (double)e.y;
-    }
+    return one;
+  };
+  // the calibration's part of a record, recomputed (the per-sample fallback; sample_const's arithmetic)
+  auto with_cal = [&](SampleConst one, int slot) {
+    const int sidx = min(max(s_tile - 1 + slot, 0), g.T - 1);
+    const float a = __fsub_rn(g.el[sidx], kHalfPiF);
+    one.ca = cosf(a);
+    one.sa = sinf(a);
+    const double tt = g.t[sidx];
+    int jj = (int)floor(fmin(fmax((tt - g.ta0) * g.inv_dta, -1.0), 2.0e9));
+    jj = min(max(jj, 0), g.Ta - 2);
+    one.jj = jj;
+    one.u = (double)(float)((tt - (g.ta0 + (double)jj * g.dta)) * g.inv_dta);
     return one;
   };
   const bool full = (sb + kSamplesPerThread <= g.T) && g.vec_ok;
@@ -888,18 +920,62 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kChain ?
     const DetConst dc = dets[dl];
     const int d = d0 + dl;
     float r[kSamplesPerThread];
-    const int jj0 = kCal ? (kLdsSc ? __float_as_int(sc_lds[kRec * (1 + threadIdx.x * kSamplesPerThread) + 8]) : sc[0].jj) : 0;
+    const int jj0 = kCal ? (kLdsSc ? __float_as_int(sc_cal[threadIdx.x].z) : sc[0].jj) : 0;
     double y0 = 0.0, y1 = 0.0;
     if (kCal) {
       y0 = g.pwv[(size_t)jj0 * g.D + d];
       y1 = g.pwv[(size_t)(jj0 + 1) * g.D + d];
     }
+    float halo = 0.0f;
+    // The calibration factor -- pW per K_RJ at the sample's zenith pwv and the detector's elevation, per channel --
+    // moves by parts in 1e7 over a thread's four samples (10 ms at 400 Hz): ONE lookup per thread, at its first
+    // sample; the next thread's value comes over by a lane shuffle (the wave's last lane extrapolates its neighbour's
+    // step) and the thread's samples take the chord.  A kink of the tables inside those 10 ms is missed by less
+    // than 1e-8 of the factor.  Any lane off the tables (NaN: jax's fill) sends the row through the per-sample form,
+    // which marks exactly the samples that are off.  (Up to kCalFastChannels channels; not with the literal chain.)
+    bool stretch = false;
+    if constexpr (kCal && kLdsSc) {
+      float f0[kCalFastChannels], df[kCalFastChannels];
+      if (g.C <= kCalFastChannels) {  // (uniform)
+        const float4 s0 = sc_cal[threadIdx.x];  // (cos, sin, coarse interval = jj0, weight) at the thread's first sample
+        const float im = __fadd_rn(__fmul_rn(dc.c_re, s0.y), __fmul_rn(dc.c_cr, s0.x));
+        const CalCell cell = cal_cell(cl, (float)fma((double)s0.w, y1 - y0, y0), asin_poly(im));
+        const int lane = threadIdx.x & 63;
+        bool bad = false;
+#pragma unroll
+        for (int c = 0; c < kCalFastChannels; ++c) {
+          f0[c] = c < g.C ? cal_factor(g, cl, cell, c) : 0.0f;
+          const float nxt = __shfl_down(f0[c], 1, 64), prv = __shfl_up(f0[c], 1, 64);
+          df[c] = 0.25f * (lane < 63 ? nxt - f0[c] : f0[c] - prv);
+          bad |= !(f0[c] == f0[c]) || !(df[c] == df[c]);
+        }
+        stretch = __builtin_amdgcn_ballot_w64(bad) == 0 && (sb + kSamplesPerThread <= g.T);
+        stretch = __syncthreads_and(stretch);  // (the row's waves take the same form: one barrier pattern below)
+        if (stretch) {
+#pragma unroll
+          for (int q = 0; q < kSamplesPerThread; ++q) {
+            float cf[kCalFastChannels];
+#pragma unroll
+            for (int c = 0; c < kCalFastChannels; ++c) cf[c] = fmaf(df[c], (float)q, f0[c]);
+            r[q] = raw_sample_fixed<kChain, kS>(g, cl, ax_eta, ax_xi, dc, d, record(1 + threadIdx.x * kSamplesPerThread + q), cf);
+          }
+          if (first || last) {
+            float cf[kCalFastChannels];
+#pragma unroll
+            for (int c = 0; c < kCalFastChannels; ++c) cf[c] = fmaf(df[c], first ? -1.0f : 4.0f, f0[c]);
+            halo = raw_sample_fixed<kChain, kS>(g, cl, ax_eta, ax_xi, dc, d, record(first ? 0 : kTileSamples + 1), cf);
+          }
+        }
+      }
+    }
+    if (!stretch) {
+      auto rec_of = [&](int slot) { return (kCal && kLdsSc) ? with_cal(record(slot), slot) : record(slot); };
 #pragma unroll
     for (int q = 0; q < kSamplesPerThread; ++q)
-      r[q] = raw_sample<kChain, kCal, kS>(g, cl, ax_eta, ax_xi, dc, d, kLdsSc ? record(1 + threadIdx.x * kSamplesPerThread + q) : sc[q], jj0, y0, y1);
-    float halo = 0.0f;
+      r[q] = raw_sample<kChain, kCal, kS>(g, cl, ax_eta, ax_xi, dc, d, kLdsSc ? rec_of(1 + threadIdx.x * kSamplesPerThread + q) : sc[q], jj0, y0, y1);
     if (first || last)
-      halo = raw_sample<kChain, kCal, kS>(g, cl, ax_eta, ax_xi, dc, d, kLdsSc ? record(first ? 0 : kTileSamples + 1) : sc_halo, jj0, y0, y1);
+      halo = raw_sample<kChain, kCal, kS>(g, cl, ax_eta, ax_xi, dc, d, kLdsSc ? rec_of(first ? 0 : kTileSamples + 1) : sc_halo, jj0, y0, y1);
+    }
     edge[dl & 1][threadIdx.x] = make_float2(r[0], r[kSamplesPerThread - 1]);
     __syncthreads();
     const float left = first ? halo : edge[dl & 1][threadIdx.x - 1].y;
