@@ -31,11 +31,12 @@
 extern "C" {
 #endif
 
-#define MRX_VERSION 140 /* 0.2.0 (120): mrx_spline_upsample_fused, mrx_allgather_tod_p2p, mrx_exchange_screens,
+#define MRX_VERSION 141 /* 0.2.0 (120): mrx_spline_upsample_fused, mrx_allgather_tod_p2p, mrx_exchange_screens,
                            mrx_resample_columns; MRX_OPT_SAMPLE_TILES retired.  130: mrx_screen_amplitudes,
                            mrx_screen_desc.d_amp, mrx_screen_generate_3d(..., d_amp), mrx_streams_concurrent.
                            131: mrx_coarse_to_krj_keep_tail.  140: mrx_screen_desc.periodic_beam,
-                           mrx_noise_generate_krj, the noise generator's two-rate form */
+                           mrx_noise_generate_krj, the noise generator's two-rate form.  141: mrx_atm_synthesize,
+                           MRX_FLAG_HANDOVER */
 
 typedef enum mrx_status {
   MRX_OK = 0,
@@ -53,6 +54,8 @@ typedef enum mrx_status {
 #define MRX_FLAG_TABLE_OOB 2u  /* (pwv, el) left the emission table: jax fill
                                   value NaN (band/band.py:283-286)              */
 #define MRX_FLAG_NAN 4u        /* a NaN reached the output                      */
+#define MRX_FLAG_HANDOVER 8u   /* mrx_atm_synthesize: a writer gave up waiting for the sampler (its bound of
+                                  ~seconds; the call's TOD is then invalid)     */
 
 typedef struct mrx_ctx mrx_ctx;
 typedef struct mrx_atm_plan mrx_atm_plan;
@@ -264,6 +267,37 @@ int mrx_spline_upsample_fused(mrx_ctx* ctx, const float* d_y, int D, int Ta,
                               double ta0, double dta, const double* d_t, int T,
                               const float* d_scale, const int32_t* d_rows,
                               float* d_out, size_t ld_out);
+
+/* Atmosphere -> TOD for one observation in ONE launch: mrx_atm_sample followed by
+ * mrx_spline_upsample_fused, block of detectors by block of detectors -- the reference's
+ * _simulate_atmosphere from the layer loop to the interpolation at the sample rate
+ * (atmosphere/atmosphere.py:317-373, sim/atmosphere.py:43-82) --, with the hand-over from the
+ * sampler to the writer on the device: the first workgroups of the grid sample the blocks in
+ * order and count their finished work items per block, the others write TOD tiles and wait
+ * (poll, acquire) for the block a tile belongs to.  The writer of the first block starts
+ * after block_rows rows have been sampled instead of after a whole launch, and no launch
+ * boundary or stream event separates the blocks.  Bit-identical to the two calls.
+ *  block_rows        detectors per block, rounded up to a multiple of 256 (<= 0: one block); at
+ *                    most 1024 blocks, 4 * Ta * block_rows < 2^31
+ *  head_rows         detectors (rounded up to whole blocks) that ALL sampler workgroups -- a grid that
+ *                    fills the chip -- sample before the writers enter; the rest is sampled by
+ *                    MRX_OPT_SAMPLE_WGS_PER_CU workgroups per CU (unset: 2) beside the writers.  The
+ *                    sampler beside a writer runs at half its speed alone: a head start of about a
+ *                    third of the rows keeps the writers from catching up (0 = none)
+ *  d_coarse          f32, out (scratch the caller may read), 128-byte aligned, Ta * round_up(D, 32)
+ *                    floats: the coarse loading in pW, block b (rows b*block_rows ...) as its own
+ *                    time-major array at d_coarse + Ta * b * block_rows, [Ta][pitch] with
+ *                    pitch = its rows rounded up to 32 (the columns past the last row: padding)
+ *  other arguments   as mrx_atm_sample (d_az ... pwv0, d_flags) and mrx_spline_upsample
+ *                    (ta0 ... ld_out)
+ * MRX_ERR_UNSUPPORTED (nothing launched) for plans or options the pixel-coordinate sampler
+ * does not take -- a layer on a non-uniform axis, MRX_OPT_AXIS_LITERAL, MRX_OPT_POINTING_CHAIN,
+ * bicubic band tables --: use the two calls there.  MRX_FLAG_HANDOVER in d_flags: see above. */
+int mrx_atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d_az, const float* d_el,
+                       int Ta, const float* d_dx, const float* d_dy, const int32_t* d_band,
+                       const float* d_mueller00, int D, double pwv0, float* d_coarse, int block_rows,
+                       int head_rows, uint32_t* d_flags, double ta0, double dta, const double* d_t, int T,
+                       const float* d_scale, const int32_t* d_rows, float* d_out, size_t ld_out);
 
 /* mrx_spline_upsample fused with TOD.to("K_RJ") (tod/tod.py:106-142): each sample
  * is divided by den_b(el) = (0.5 if polarized else 1) * k_B * 1e12 *

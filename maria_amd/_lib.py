@@ -19,6 +19,7 @@ MRX_OK = 0
 FLAG_SCREEN_OOB = 1
 FLAG_TABLE_OOB = 2
 FLAG_NAN = 4
+FLAG_HANDOVER = 8
 OPT_POINTING_CHAIN = 0
 OPT_AXIS_LITERAL = 1
 OPT_SAMPLE_TIMES = 2
@@ -167,6 +168,7 @@ SIGNATURES = {
     "mrx_spline_prepare": (_i, [_vp, _vp, _i, _i, _vp]),
     "mrx_spline_upsample": (_i, [_vp, _vp, _i, _i, _d, _d, _vp, _i, _vp, _vp, _vp, _sz]),
     "mrx_spline_upsample_fused": (_i, [_vp, _vp, _i, _i, _d, _d, _vp, _i, _vp, _vp, _vp, _sz]),
+    "mrx_atm_synthesize": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _d, _vp, _i, _i, _vp, _d, _d, _vp, _i, _vp, _vp, _vp, _sz]),
     "mrx_spline_upsample_krj": (_i, [_vp, _vp, _i, _i, _d, _d, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _sz]),
     "mrx_coarse_to_krj": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "mrx_coarse_to_krj_keep_tail": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _sz]),

@@ -53,6 +53,10 @@ struct mrx_ctx {
   } fresp[kFRespSlots];
   int fresp_next = 0;
   int options[MRX_OPT_COUNT] = {0};
+  // tile queues + per-block counters of the launches that take their work from a queue (mrx_spline.hip: mrx_synth_ctl)
+  static constexpr int kSynthCtlSlots = 8;
+  int* d_synth_ctl = nullptr;
+  int synth_ctl_next = 0;
   // screen normalisations (sum of the PSD over the FFT grid), one device double
   // per distinct (grid, spectrum)
   static constexpr int kPsdSlots = 64;

@@ -27,6 +27,8 @@
 
 #include "mrx_internal.h"
 #include "mrx_spectral.h"  // Philox, Box-Muller (the two-rate noise writer)
+#define MRX_PX_CONTRACT_FAST_AFTER  // (the sampler's code keeps its two roundings; this TU contracts as before)
+#include "mrx_sample_px.h"  // the sampler role of atm_tod_kernel
 
 namespace {
 
@@ -406,30 +408,26 @@ struct FusedLds {
                                    sizeof(float) * kRows * ((kMaxKnots + 2 * kFHalo + 6) | 1) + sizeof(int) * kRows;
 };
 
-template <bool kHasScale, int kMaxKnots, int kG>
-// 5 waves per SIMD = up to 96 registers (the kernel takes 94, nothing spilled).  Beside the resident sampler
-// (3 workgroups per CU x 64 registers) 3 writer waves per SIMD still fit (192 + 288 <= 512); with 2 the writer
-// loses a fifth of its rate (DESIGN 3.2).  The first fused version was capped at 72 registers (the round-2
-// sampler took 3 x 96) and spilled 10 values: 44 bytes of scratch per lane = 11 KB per workgroup against the
-// 128 KB it writes -- the 8 % of extra WRITE_SIZE in profiles/r03_traffic.json, and 3 % of the step.
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_WRITER_WAVES))) void spline_upsample_fused_kernel(
-    const float* __restrict__ y, int D, int n, double ta0, double inv_dta,
+// One tile of the fused writer: time tile `sx` (kTileSamples samples), row group `by` (batches x kRows rows of the
+// D rows `y` holds).  The body of spline_upsample_fused_kernel (one tile per workgroup) and of the writer role of
+// atm_tod_kernel (a workgroup takes tiles from a queue); `fused_lds` is the dynamic LDS, FusedLds<...>::kBytes;
+// `ldy` the pitch of y's rows in floats (D in the stand-alone kernel).
+template <bool kHasScale, int kMaxKnots, int kG, bool kHandedOver = false>
+__device__ __forceinline__ void fused_writer_tile(
+    const float* __restrict__ y, int ldy, int D, int n, double ta0, double inv_dta,
     const double* __restrict__ t, int T, const float* __restrict__ scale,
     const int32_t* __restrict__ rows, float* __restrict__ out, size_t ld,
-    int vec_ok, int batches) {
+    int vec_ok, int batches, int sx, int by, unsigned char* fused_lds) {
   constexpr int kRows = kTileDet * kG;
   constexpr int kPitch = kMaxKnots + 1;
   constexpr int kWin = kMaxKnots + 2 * kFHalo + 6;  // raw knots: the image's + (halo + 3) either side
   constexpr int kWPitch = kWin | 1;                 // odd: rows fall on distinct banks
   constexpr int kSegKnots = kMaxKnots - 2;          // knots of one segment before the widening at the ends
-  // dynamic LDS (FusedLds<...>::kBytes): with a static size the compiler derives the occupancy
-  // from it and ignores the register bound above
-  extern __shared__ __align__(16) unsigned char fused_lds[];
   float2* tile = reinterpret_cast<float2*>(fused_lds);                 // [kRows][kPitch]
   float* yraw = reinterpret_cast<float*>(tile + kRows * kPitch);       // [kRows][kWPitch]
   int* row_lds = reinterpret_cast<int*>(yraw + kRows * kWPitch);       // [kRows]
   auto row_of = [&](int dl, int d) -> size_t { return rows ? (size_t)row_lds[dl] : (size_t)d; };
-  const int s_tile = blockIdx.x * kTileSamples;
+  const int s_tile = sx * kTileSamples;
   const int sb = s_tile + threadIdx.x * kSamplesPerThread;
 
   // the thread's sample times: loaded now (in flight during the staging below), turned into interval
@@ -449,7 +447,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_WRIT
   const bool full = (sb + kSamplesPerThread <= T) && vec_ok && single;
 
   for (int g = 0; g < batches; ++g) {
-    const int d0 = (blockIdx.y * batches + g) * kRows;
+    const int d0 = (by * batches + g) * kRows;
     if (d0 >= D) break;
     const int nd = min(kRows, D - d0);
     for (int ja = j_first; ja < j_end; ja += kSegKnots - 1) {
@@ -468,11 +466,16 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_WRIT
         const int dl = threadIdx.x & (kRows - 1);
         const int d = d0 + dl;
         constexpr int kStep = kBlock / kRows, kFly = 8;
-        const float* src = y + (size_t)w0 * D + min(d, D - 1);
+        const float* src = y + (size_t)w0 * ldy + min(d, D - 1);
         for (int kk0 = threadIdx.x / kRows; kk0 < Wn; kk0 += kStep * kFly) {
           float v[kFly];
 #pragma unroll
-          for (int u = 0; u < kFly; ++u) v[u] = src[(size_t)min(kk0 + u * kStep, Wn - 1) * D];
+          for (int u = 0; u < kFly; ++u) {
+            const float* q = src + (size_t)min(kk0 + u * kStep, Wn - 1) * ldy;
+            // kHandedOver: y was written in THIS launch by other CUs (write-through stores): global_load_dword sc1,
+            // past this CU's L1, which no other CU's store refreshes (atm_tod_kernel)
+            v[u] = kHandedOver ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+          }
 #pragma unroll
           for (int u = 0; u < kFly; ++u)
             if (kk0 + u * kStep < Wn) yraw[dl * kWPitch + kk0 + u * kStep] = d < D ? v[u] : 0.0f;
@@ -646,8 +649,320 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_WRIT
             for (int q = 0; q < kSamplesPerThread; ++q) o[q] *= gsc;
           }
           const vfloat4 v = {o[0], o[1], o[2], o[3]};
+          // (nt: beside the sampler it is the policy that costs least -- 2.17 ms against 2.43 plain, 2.47 sc1, 2.28 sc1 nt)
           __builtin_nontemporal_store(
               v, reinterpret_cast<vfloat4*>(out + row_of(dl, d0 + dl) * ld + sb));
+        }
+      } else {
+        for (int dl = 0; dl < nd; ++dl) {
+          const float2* row = tile + dl * kPitch;
+          const float gsc = kHasScale ? scale[d0 + dl] : 1.0f;
+          float* dst = out + row_of(dl, d0 + dl) * ld + sb;
+#pragma unroll
+          for (int q = 0; q < kSamplesPerThread; ++q)
+            if (sb + q < T) dst[q] = gsc * spline_eval(w, q, row[r[q]], row[r[q] + 1]);
+        }
+      }
+    } else {
+      // low upsampling ratio: knots straight from global memory
+      for (int dl = 0; dl < nd; ++dl) {
+        const int d = d0 + dl;
+        const float gsc = kHasScale ? scale[d] : 1.0f;
+        float* dst = out + (rows ? (size_t)rows[d] : (size_t)d) * ld + sb;
+#pragma unroll
+        for (int q = 0; q < kSamplesPerThread; ++q)
+          if (sb + q < T)
+            dst[q] = gsc * spline_eval(w, q, ym[(size_t)w.j[q] * D + d],
+                                       ym[(size_t)(w.j[q] + 1) * D + d]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Solve + evaluation in ONE kernel: the writer reads the raw coarse samples y
+// (time-major, what the sampler wrote) and computes the second derivatives of its
+// own tile in the prologue, so no (y, m) buffer and no separate solve launch exist.
+//
+// A tile of 1024 samples needs the knots jmin..jmax (~28 at 400 Hz over 0.1 s
+// knots).  The tile stages y of those knots plus kFHalo + 3 either side, then
+//   1. sweeps: one thread per (row, direction) runs the first-order recurrences
+//      of the twisted factorisation over the window -- from a zero state kFHalo
+//      knots outside (0.268^16 = 7e-10 of a second difference, see the header of
+//      this file) or from the true boundary when the window reaches it, with the
+//      true pivots q(k) either way -- leaving dL_{i-1} and dR_{i+1} in knot i's
+//      LDS slot;
+//   2. combine: one thread per (row, knot) forms m_i and overwrites the slot with
+//      (y_i, m_i); the not-a-knot ends m_0, m_{n-1} follow from their neighbours;
+//   3. the evaluation loop of spline_upsample_kernel, unchanged.
+// kG groups of 16 rows are solved together (32 rows x 2 directions = one wave).
+// The sweeps cost latency in one wave (~50 dependent float64 steps), not
+// throughput: the other workgroups of the CU keep the store pipeline busy.
+constexpr int kFHalo = 16;
+#ifndef MRX_WRITER_WAVES
+#define MRX_WRITER_WAVES 5  // occupancy target of the fused writer (see the kernel): 6 -> 80 registers, 2 spilled
+#endif
+
+template <int kMaxKnots, int kG>
+struct FusedLds {
+  static constexpr int kRows = kTileDet * kG;
+  static constexpr size_t kBytes = sizeof(float2) * kRows * (kMaxKnots + 1) +
+                                   sizeof(float) * kRows * ((kMaxKnots + 2 * kFHalo + 6) | 1) + sizeof(int) * kRows;
+};
+
+// One tile of the fused writer: time tile `sx` (kTileSamples samples), row group `by` (batches x kRows rows of the
+// D rows `y` holds).  The body of spline_upsample_fused_kernel (one tile per workgroup) and of the writer role of
+// atm_tod_kernel (a workgroup takes tiles from a queue); `fused_lds` is the dynamic LDS, FusedLds<...>::kBytes;
+// `ldy` the pitch of y's rows in floats (D in the stand-alone kernel).
+template <bool kHasScale, int kMaxKnots, int kG, bool kHandedOver = false>
+__device__ __forceinline__ void fused_writer_tile(
+    const float* __restrict__ y, int ldy, int D, int n, double ta0, double inv_dta,
+    const double* __restrict__ t, int T, const float* __restrict__ scale,
+    const int32_t* __restrict__ rows, float* __restrict__ out, size_t ld,
+    int vec_ok, int batches, int sx, int by, unsigned char* fused_lds) {
+  constexpr int kRows = kTileDet * kG;
+  constexpr int kPitch = kMaxKnots + 1;
+  constexpr int kWin = kMaxKnots + 2 * kFHalo + 6;  // raw knots: the image's + (halo + 3) either side
+  constexpr int kWPitch = kWin | 1;                 // odd: rows fall on distinct banks
+  constexpr int kSegKnots = kMaxKnots - 2;          // knots of one segment before the widening at the ends
+  float2* tile = reinterpret_cast<float2*>(fused_lds);                 // [kRows][kPitch]
+  float* yraw = reinterpret_cast<float*>(tile + kRows * kPitch);       // [kRows][kWPitch]
+  int* row_lds = reinterpret_cast<int*>(yraw + kRows * kWPitch);       // [kRows]
+  auto row_of = [&](int dl, int d) -> size_t { return rows ? (size_t)row_lds[dl] : (size_t)d; };
+  const int s_tile = sx * kTileSamples;
+  const int sb = s_tile + threadIdx.x * kSamplesPerThread;
+
+  // the thread's sample times: loaded now (in flight during the staging below), turned into interval
+  // and weights after the solve -- 8 registers live through the prologue instead of 24
+  double tq[kSamplesPerThread];
+#pragma unroll
+  for (int q = 0; q < kSamplesPerThread; ++q) tq[q] = t[min(sb + q, T - 1)];
+
+  // knot range of the tile (workgroup-uniform; t ascending).  It normally fits the image: one
+  // segment.  A tile that spans more knots (upsampling ratio below ~1024 / kMaxKnots) is
+  // walked in segments of kSegKnots knots, each solved and evaluated on its own.
+  const int s_last = min(s_tile + kTileSamples, T) - 1;
+  const int j_first = interval_of((t[s_tile] - ta0) * inv_dta, n);
+  const int j_end = interval_of((t[s_last] - ta0) * inv_dta, n) + 1;  // last knot needed
+  const bool single = j_end - j_first + 1 <= kSegKnots;
+  const int lo = 2, hi = n - 3;  // interior unknowns (empty if n < 5)
+  const bool full = (sb + kSamplesPerThread <= T) && vec_ok && single;
+
+  for (int g = 0; g < batches; ++g) {
+    const int d0 = (by * batches + g) * kRows;
+    if (d0 >= D) break;
+    const int nd = min(kRows, D - d0);
+    for (int ja = j_first; ja < j_end; ja += kSegKnots - 1) {
+      // intervals ja .. jb - 1 are evaluated from knots ja .. jb; widened so that the knots the
+      // not-a-knot ends are derived from (1, 2 and n-2, n-3) are solved in the same image
+      const int jb = min(ja + kSegKnots - 1, j_end);
+      int jmin = ja, jmax = jb;
+      if (jmin == 0) jmax = max(jmax, 2);
+      if (jmax == n - 1) jmin = min(jmin, n - 3);
+      const int K = jmax - jmin + 1;  // <= kMaxKnots
+      const int w0 = max(jmin - 3 - kFHalo, 0), w1 = min(jmax + 3 + kFHalo, n - 1);
+      const int Wn = w1 - w0 + 1;
+      if (g > 0 || ja > j_first) __syncthreads();  // the previous pass is done with the images
+      if (rows && (int)threadIdx.x < nd) row_lds[threadIdx.x] = rows[d0 + threadIdx.x];
+      {  // kRows lanes cover the rows of one knot: 64 or 128 contiguous bytes; 8 loads in flight per thread
+        const int dl = threadIdx.x & (kRows - 1);
+        const int d = d0 + dl;
+        constexpr int kStep = kBlock / kRows, kFly = 8;
+        const float* src = y + (size_t)w0 * ldy + min(d, D - 1);
+        for (int kk0 = threadIdx.x / kRows; kk0 < Wn; kk0 += kStep * kFly) {
+          float v[kFly];
+#pragma unroll
+          for (int u = 0; u < kFly; ++u) {
+            const float* q = src + (size_t)min(kk0 + u * kStep, Wn - 1) * ldy;
+            // kHandedOver: y was written in THIS launch by other CUs (write-through stores): global_load_dword sc1,
+            // past this CU's L1, which no other CU's store refreshes (atm_tod_kernel)
+            v[u] = kHandedOver ? __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *q;
+          }
+#pragma unroll
+          for (int u = 0; u < kFly; ++u)
+            if (kk0 + u * kStep < Wn) yraw[dl * kWPitch + kk0 + u * kStep] = d < D ? v[u] : 0.0f;
+        }
+      }
+      __syncthreads();
+      // Far from both ends of the knot axis (all but the first and last tile or two) every pivot the
+      // sweeps and the combine touch equals alpha to float32 rounding (q_k - alpha ~ 0.02 x 0.072^k)
+      // and no not-a-knot term applies: float32 recurrences with a constant multiplier, every thread
+      // busy.  Second differences are formed as (y_{i-1} - y_i) + (y_{i+1} - y_i): both differences
+      // are exact in float32 for a smooth series, so nothing is lost against the float64 form.
+      const bool interior = jmin - 1 - kFHalo - lo >= 8 && hi - (jmax + 1 + kFHalo) >= 8;  // workgroup-uniform
+      if (interior) {
+        // ---- 1. sweeps: (row, direction, segment of the knot range), run-in of kFHalo knots each ----
+        constexpr int kSeg = kBlock / (2 * kRows);
+        constexpr float kAlphaF = (float)kAlpha;
+        {
+          const int dl = threadIdx.x & (kRows - 1);
+          const int rest = threadIdx.x / kRows;
+          const int seg = rest % kSeg, dir = rest / kSeg;  // dir is wave-uniform
+          const int sgn = dir ? -1 : 1;
+          const int Ls = (K + kSeg - 1) / kSeg;
+          if (seg * Ls < K) {
+            // targets in the order of travel: dL_i for i = jmin-1 .. jmax-1 (stored with knot i+1),
+            // dR_i for i = jmax+1 .. jmin+1 (stored with knot i-1)
+            const int f = dir ? jmax + 1 - seg * Ls : jmin - 1 + seg * Ls;
+            const int cnt = min(Ls, K - seg * Ls);
+            const float* yr = yraw + dl * kWPitch - w0;
+            float* dst = reinterpret_cast<float*>(tile + dl * kPitch - jmin) + dir;  // dst[2 * knot]
+            // the recurrence d <- alpha (delta_i - d) as one fused multiply-add per step on the critical
+            // path; knots are fetched eight at a time (reads past the segment's end stay inside the LDS
+            // allocation and feed steps whose result is not stored)
+            constexpr int kFly = 8;
+            static_assert(kFHalo % kFly == 0, "the run-in is a whole number of batches");
+            int i = f - sgn * kFHalo;
+            float prev = yr[i - sgn], cur = yr[i], d = 0.0f;
+            for (int k0 = 0; k0 < kFHalo + cnt; k0 += kFly) {
+              float nx[kFly];
+#pragma unroll
+              for (int u = 0; u < kFly; ++u) nx[u] = yr[i + sgn * (u + 1)];
+#pragma unroll
+              for (int u = 0; u < kFly; ++u) {
+                const float rr = ((prev - cur) + (nx[u] - cur)) * kAlphaF;
+                d = fmaf(-kAlphaF, d, rr);
+                if (k0 + u >= kFHalo && k0 + u < kFHalo + cnt) dst[2 * (i + sgn * (u + 1))] = d;
+                prev = cur;
+                cur = nx[u];
+              }
+              i += sgn * kFly;
+            }
+          }
+        }
+        __syncthreads();
+        // ---- 2. combine -------------------------------------------------------------------
+        {
+          const int dl = threadIdx.x & (kRows - 1);
+          const float* yr = yraw + dl * kWPitch - w0 + jmin;
+          constexpr float kInvDenF = (float)(1.0 / (4.0 - 2.0 * kAlpha));
+          for (int kk = threadIdx.x / kRows; kk < K; kk += kBlock / kRows) {
+            float2* slot = tile + dl * kPitch + kk;
+            const float2 sv = *slot;
+            const float yc_ = yr[kk];
+            const float delta = (yr[kk - 1] - yc_) + (yr[kk + 1] - yc_);
+            *slot = make_float2(yc_, ((delta - sv.x) - sv.y) * kInvDenF);
+          }
+        }
+        __syncthreads();
+      } else {
+      // ---- 1. sweeps (near an end): one thread per (row, direction), float64, the true pivots ----
+      if ((int)threadIdx.x < 2 * kRows) {
+        const int dl = threadIdx.x & (kRows - 1);
+        const float* yr = yraw + dl * kWPitch - w0;  // yr[i] = y_i of this row
+        float2* slot = tile + dl * kPitch - jmin;    // slot[i] = knot i
+        // m_1, m_{n-2}: only a sweep that touches lo / hi uses them, and then the window holds
+        // the three knots (w0 = 0 whenever a sweep starts at or reaches lo; likewise for hi)
+        const double m1 = w0 == 0 ? (((double)yr[0] - 2.0 * (double)yr[1]) + (double)yr[2]) * (1.0 / 6.0) : 0.0;
+        const double mn2 = w1 == n - 1 ? (((double)yr[n - 3] - 2.0 * (double)yr[n - 2]) + (double)yr[n - 1]) * (1.0 / 6.0) : 0.0;
+        if ((int)threadIdx.x < kRows) {  // left to right: dL_i goes to knot i + 1
+          const int s0 = max(lo, jmin - 1 - kFHalo), s1 = min(hi, jmax - 1);
+          if (s0 <= s1) {
+            double ym_ = (double)yr[s0 - 1], yc_ = (double)yr[s0], dl_ = 0.0;
+            for (int i = s0; i <= s1; ++i) {
+              const double yp_ = (double)yr[i + 1];
+              double rr = (ym_ - 2.0 * yc_) + yp_;
+              if (i == lo) rr -= m1;
+              if (i == hi) rr -= mn2;
+              dl_ = (rr - dl_) * qf(i - lo);
+              if (i + 1 >= jmin) slot[i + 1].x = (float)dl_;
+              ym_ = yc_;
+              yc_ = yp_;
+            }
+          }
+        } else {  // right to left: dR_i goes to knot i - 1
+          const int e0 = min(hi, jmax + 1 + kFHalo), e1 = max(lo, jmin + 1);
+          if (e0 >= e1) {
+            double yp_ = (double)yr[e0 + 1], yc_ = (double)yr[e0], dr_ = 0.0;
+            for (int i = e0; i >= e1; --i) {
+              const double ym_ = (double)yr[i - 1];
+              double rr = (ym_ - 2.0 * yc_) + yp_;
+              if (i == lo) rr -= m1;
+              if (i == hi) rr -= mn2;
+              dr_ = (rr - dr_) * qf(hi - i);
+              if (i - 1 <= jmax) slot[i - 1].y = (float)dr_;
+              yp_ = yc_;
+              yc_ = ym_;
+            }
+          }
+        }
+      }
+      __syncthreads();
+      // ---- 2. combine: (dL_{i-1}, dR_{i+1}) -> (y_i, m_i) for knots 1 .. n-2 --------------
+      {
+        const int dl = threadIdx.x & (kRows - 1);
+        const float* yr = yraw + dl * kWPitch - w0;
+        for (int kk = threadIdx.x / kRows; kk < K; kk += kBlock / kRows) {
+          const int i = jmin + kk;
+          float2* slot = tile + dl * kPitch + kk;
+          const double yc_ = (double)yr[i];
+          double m = 0.0;
+          if (i >= 1 && i <= n - 2) {
+            const double delta = ((double)yr[i - 1] - 2.0 * yc_) + (double)yr[i + 1];
+            if (i == 1 || i == n - 2) {
+              m = delta * (1.0 / 6.0);
+            } else {
+              const float2 s = *slot;
+              double num = delta, den = 4.0;
+              if (i == lo) num -= (((double)yr[0] - 2.0 * (double)yr[1]) + (double)yr[2]) * (1.0 / 6.0);
+              if (i == hi) num -= (((double)yr[n - 3] - 2.0 * (double)yr[n - 2]) + (double)yr[n - 1]) * (1.0 / 6.0);
+              if (i > lo) {
+                num -= (double)s.x;
+                den -= qf(i - 1 - lo);
+              }
+              if (i < hi) {
+                num -= (double)s.y;
+                den -= qf(hi - i - 1);
+              }
+              m = num / den;
+            }
+          }
+          *slot = make_float2((float)yc_, (float)m);
+        }
+      }
+      __syncthreads();
+      if (jmin == 0 || jmax == n - 1) {  // workgroup-uniform: m_0 = 2 m_1 - m_2, m_{n-1} = 2 m_{n-2} - m_{n-3}
+        if ((int)threadIdx.x < kRows) {
+          float2* row = tile + threadIdx.x * kPitch - jmin;
+          if (jmin == 0) row[0].y = (float)(2.0 * (double)row[1].y - (double)row[2].y);
+          if (jmax == n - 1) row[n - 1].y = (float)(2.0 * (double)row[n - 2].y - (double)row[n - 3].y);
+        }
+        __syncthreads();
+      }
+      }
+      // ---- 3. evaluation -------------------------------------------------------------
+      SampleWeights w;
+      sample_weights_at(tq, n, ta0, inv_dta, w);
+      int r[kSamplesPerThread];
+#pragma unroll
+      for (int q = 0; q < kSamplesPerThread; ++q)
+        r[q] = min(max(w.j[q] - jmin, 0), K - 2);  // in range even if t is unsorted
+      if (full) {
+#pragma unroll 4
+        for (int dl = 0; dl < nd; ++dl) {
+          const float2* row = tile + dl * kPitch;
+          float o[kSamplesPerThread];
+#pragma unroll
+          for (int q = 0; q < kSamplesPerThread; ++q)
+            o[q] = spline_eval(w, q, row[r[q]], row[r[q] + 1]);
+          if (kHasScale) {
+            const float gsc = scale[d0 + dl];
+#pragma unroll
+            for (int q = 0; q < kSamplesPerThread; ++q) o[q] *= gsc;
+          }
+          const vfloat4 v = {o[0], o[1], o[2], o[3]};
+#if defined(MRX_TOD_STORE) && MRX_TOD_STORE == 1
+          asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(out + row_of(dl, d0 + dl) * ld + sb), "v"(v) : "memory");
+#elif defined(MRX_TOD_STORE) && MRX_TOD_STORE == 2
+          asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(out + row_of(dl, d0 + dl) * ld + sb), "v"(v) : "memory");
+#elif defined(MRX_TOD_STORE) && MRX_TOD_STORE == 3
+          *reinterpret_cast<vfloat4*>(out + row_of(dl, d0 + dl) * ld + sb) = v;
+#elif defined(MRX_TOD_STORE) && MRX_TOD_STORE == 4
+          asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(out + row_of(dl, d0 + dl) * ld + sb), "v"(v) : "memory");
+#else
+          __builtin_nontemporal_store(
+              v, reinterpret_cast<vfloat4*>(out + row_of(dl, d0 + dl) * ld + sb));
+#endif
         }
       } else {
         // a sample belongs to the segment that holds its interval (every sample of a
@@ -667,6 +982,162 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_WRIT
       }
     }
   }
+}
+
+
+constexpr int kSynthMaxBlocks = 1024;
+// the control block of a launch: [0] tile queue, [16] workgroups that have left, [32 + b] finished work items of
+// block b (each on a line of its own kind: the queue is hammered by every writer, the counters by the samplers).
+// All zero between launches: the last workgroup to leave clears what the launch used, so a launch needs no memset.
+constexpr int kSynthCtlInts = 32 + kSynthMaxBlocks;
+
+// Leaves the control block as it was found: the workgroup whose exit is the grid's last (atomicInc wraps the exit
+// count to 0 by itself) zeroes the queue and the block counters -- nobody reads them any more, and the next launch
+// on the stream starts after this one has ended.
+__device__ __forceinline__ void synth_leave(int* ctl, int n_blocks) {
+  __syncthreads();
+  __shared__ int s_last;
+  if (threadIdx.x == 0) s_last = atomicInc(reinterpret_cast<unsigned*>(ctl + 16), gridDim.x - 1) == gridDim.x - 1;
+  __syncthreads();
+  if (s_last) {
+    if (threadIdx.x == 0) __hip_atomic_store(ctl, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int b = threadIdx.x; b < n_blocks; b += kBlock)
+      __hip_atomic_store(ctl + 32 + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+// A RESIDENT grid takes tiles from a queue (one agent-scope atomic per tile; tiles numbered row group by row group,
+// time tile fastest -- the order a two-dimensional grid is dispatched in): against one workgroup per tile, 1.59 vs
+// 1.69 ms for 10 000 x 240 000 alone (0.76 of 8 TB/s): no dispatch per tile, no tail of half-empty CUs.  The queue
+// and not a fixed stride, because beside a resident sampler only some of the grid is on the chip at first.
+template <bool kHasScale, int kMaxKnots, int kG>
+// 5 waves per SIMD = up to 96 registers (the kernel takes 94, nothing spilled).  Beside the resident sampler
+// (3 workgroups per CU x 64 registers) 3 writer waves per SIMD still fit (192 + 288 <= 512); with 2 the writer
+// loses a fifth of its rate (DESIGN 3.2).  The first fused version was capped at 72 registers (the round-2
+// sampler took 3 x 96) and spilled 10 values: 44 bytes of scratch per lane = 11 KB per workgroup against the
+// 128 KB it writes -- the 8 % of extra WRITE_SIZE in profiles/r03_traffic.json, and 3 % of the step.
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_WRITER_WAVES))) void spline_upsample_fused_kernel(
+    const float* __restrict__ y, int D, int n, double ta0, double inv_dta,
+    const double* __restrict__ t, int T, const float* __restrict__ scale,
+    const int32_t* __restrict__ rows, float* __restrict__ out, size_t ld,
+    int vec_ok, int batches, int nsx, int total, int* ctl) {
+  // dynamic LDS (FusedLds<...>::kBytes): with a static size the compiler derives the occupancy
+  // from it and ignores the register bound above
+  extern __shared__ __align__(16) unsigned char fused_lds[];
+  __shared__ int s_next;
+  for (;;) {
+    if (threadIdx.x == 0) s_next = __hip_atomic_fetch_add(ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();  // (also: the previous tile's readers of the LDS images are done)
+    const int tile = s_next;
+    if (tile >= total) break;
+    const int by = tile / nsx;
+    fused_writer_tile<kHasScale, kMaxKnots, kG>(y, D, D, n, ta0, inv_dta, t, T, scale, rows, out, ld, vec_ok, batches,
+                                                 tile - by * nsx, by, fused_lds);
+  }
+  synth_leave(ctl, 0);
+}
+
+// ---------------------------------------------------------------------------
+// Atmosphere -> TOD in ONE launch (mrx_atm_synthesize): the sampler and the writer as two ROLES of one grid, the
+// hand-over on the device.  Replaces, for one observation, screens -> [sampler of block b on a side stream |
+// writer of block b behind an event] x blocks: there the writer of block 0 cannot start before the whole first
+// block is sampled (0.2 ms of the 2.3-ms step of atlast_10k with HBM idle) and every launch boundary drains and
+// refills the chip (4-14 per step).
+//
+//   * the first `n_sampler_wgs` workgroups (lowest block indices: the dispatcher hands them out first, so they are
+//     resident before any writer -- and they never wait for anything, so the grid always drains) run
+//     px_sample_items over the detector blocks in order: block b's coarse loading is its own [Ta][rows] array;
+//   * the loading leaves the sampler's CUs as write-through (sc1) 16-byte stores, every 128-byte line written whole
+//     by one store instruction (px_sample_items<..., kWriteThrough>); after each finished work item every wave
+//     drains its stores (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, and ONE lane adds 1 to done[b]
+//     (agent scope, relaxed);
+//   * every other workgroup is a writer: it takes tile numbers from a queue (one agent-scope atomic per tile; tiles
+//     are numbered block by block, time tile fastest -- the order the two-dimensional grid of
+//     spline_upsample_fused_kernel is dispatched in), and before its FIRST tile of a block one lane polls done[b]
+//     (global_load_dword sc1, s_sleep between) until all of the block's items are in, then the workgroup meets at a
+//     barrier; the tile stages its knots with sc1 loads (past the CU's L1), then fused_writer_tile as in the
+//     stand-alone kernel.
+// The per-XCD L2s are not coherent and a CU's L1 is not refreshed by other CUs' stores.  Write-through stores +
+// drained waves + one agent-scope add per workgroup on the producer's side, an sc1 poll + a workgroup barrier + sc1
+// loads on the consumer's, is one of the forms MI355X_MICROARCH.md lists as measured valid on gfx950 (its table of
+// hand-offs without fences, third row).  The first version used the fenced form (release fence per work item, acquire
+// per writer and block): correct too, but a release writes back the XCD's whole L2 under a streaming writer --
+// 0.18 ms of a 1.9-ms step in fences, 0.15-0.3 more in waits.
+// A poll gives up after `poll_limit` tries and raises MRX_FLAG_HANDOVER (the host then fails the call): a bound,
+// not a path -- it cannot trigger while the sampler role is resident.
+// Results: the same bits as mrx_atm_sample + mrx_spline_upsample_fused per block (same bodies, same order of
+// operations; tests/test_gpu_synthesize.py).
+template <bool kLdsTables, bool kHasScale, int kMaxKnots, int kG>
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_WRITER_WAVES, MRX_WRITER_WAVES))) void atm_tod_kernel(
+    const mrx_layer_fast* __restrict__ fast, const mrx_layer_px* __restrict__ lpx, int n_layers,
+    const double2* __restrict__ offpx, const mrx_table_dev* __restrict__ tables, int n_tables,
+    const float* __restrict__ table_data, int table_floats, const float* __restrict__ az,
+    const float* __restrict__ el, int Ta, const float* __restrict__ dxs, const float* __restrict__ dys,
+    const int32_t* __restrict__ band, const float* __restrict__ mueller00, int D, double pwv0,
+    float* loading,  // written by the sampler role, read by the writer role: no __restrict__, no const
+    uint32_t* __restrict__ flags, int chunk, int nby, int block_rows, int n_blocks, int n_sampler_wgs,
+    int n_long_wgs, int head_blocks, double ta0, double inv_dta, const double* __restrict__ t, int T,
+    const float* __restrict__ scale, const int32_t* __restrict__ rows, float* __restrict__ out, size_t ld, int vec_ok,
+    int batches, int* ctl, int poll_limit) {
+  extern __shared__ __align__(16) unsigned char synth_lds[];
+  if ((int)blockIdx.x < n_sampler_wgs) {
+    // two phases: the first `head_blocks` blocks by ALL sampler workgroups (nothing else is resident yet: the chip is
+    // theirs), the rest by the first `n_long_wgs` of them -- the others leave and writers take their places
+    for (int ph = 0; ph < 2; ++ph) {
+      const int nw = ph ? n_long_wgs : n_sampler_wgs;
+      if ((int)blockIdx.x >= nw) break;
+      const int b0 = ph ? head_blocks : 0, b1 = ph ? n_blocks : head_blocks;
+      if (b1 <= b0) continue;
+      mrx_px::px_sample_items<kLdsTables, 1, true, true>(
+          fast, lpx, n_layers, offpx, tables, n_tables, table_data, table_floats, az, el, Ta, dxs, dys, band, mueller00,
+          D, pwv0, nullptr, loading, flags, chunk, nby, block_rows, n_blocks, b0, b1, (int)blockIdx.x, nw,
+          reinterpret_cast<float4*>(synth_lds), [&](int blk) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's (write-through) stores of the item are out
+            __syncthreads();
+            if (threadIdx.x == 0) __hip_atomic_fetch_add(ctl + 32 + blk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          });
+    }
+    synth_leave(ctl, n_blocks);
+    return;
+  }
+  constexpr int kRows = kTileDet * kG;
+  __shared__ int s_next;
+  const int nsx = (T + kTileSamples - 1) / kTileSamples;
+  const int rows_per_tile = kRows * batches;
+  const int last_rows = D - (n_blocks - 1) * block_rows;
+  const int tiles_full = nsx * ((block_rows + rows_per_tile - 1) / rows_per_tile);
+  const int total = tiles_full * (n_blocks - 1) + nsx * ((last_rows + rows_per_tile - 1) / rows_per_tile);
+  int have = -1;  // blocks up to this one are known to be sampled
+  for (;;) {
+    if (threadIdx.x == 0) s_next = __hip_atomic_fetch_add(ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();  // (also: the previous tile's readers of the LDS images are done)
+    const int tile = s_next;
+    if (tile >= total) break;
+    const int blk = min(tile / tiles_full, n_blocks - 1);
+    const int rem = tile - blk * tiles_full;
+    const int by = rem / nsx, sx = rem - by * nsx;
+    const int Db = blk == n_blocks - 1 ? last_rows : block_rows;
+    if (blk > have) {  // workgroup-uniform
+      if (threadIdx.x == 0) {
+        const int want = nby * ((Db + mrx_px::kPxBlock - 1) / mrx_px::kPxBlock);
+        int tries = 0;
+        while (__hip_atomic_load(ctl + 32 + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+          if (++tries > poll_limit) {
+            atomicOr(flags, MRX_FLAG_HANDOVER);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(32);
+        }
+      }
+      __syncthreads();  // between the poll and EVERY load of the block's bytes, the polling wave's own too
+      have = blk;
+    }
+    const size_t row0 = (size_t)blk * block_rows;
+    fused_writer_tile<kHasScale, kMaxKnots, kG, true>(loading + (size_t)Ta * row0, (Db + 31) & ~31, Db, Ta, ta0, inv_dta, t, T,
+                                                       kHasScale ? scale + row0 : nullptr, rows ? rows + row0 : nullptr,
+                                                       rows ? out : out + row0 * ld, ld, vec_ok, batches, sx, by, synth_lds);
+  }
+  synth_leave(ctl, n_blocks);
 }
 
 // ---------------------------------------------------------------------------
@@ -1452,6 +1923,19 @@ int mrx_spline_upsample(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
   return MRX_OK;
 }
 
+// The control block of the next launch that takes tiles from a queue: a ring of kSynthCtlSlots blocks per context,
+// zeroed once (every launch leaves its block zero: synth_leave), so that launches of one context that overlap on
+// different streams do not share a queue.
+static int mrx_synth_ctl(mrx_ctx* ctx, int** out) {
+  if (!ctx->d_synth_ctl) {
+    MRX_HIP(ctx, hipMalloc(&ctx->d_synth_ctl, sizeof(int) * kSynthCtlInts * mrx_ctx::kSynthCtlSlots));
+    MRX_HIP(ctx, hipMemset(ctx->d_synth_ctl, 0, sizeof(int) * kSynthCtlInts * mrx_ctx::kSynthCtlSlots));
+  }
+  *out = ctx->d_synth_ctl + (size_t)kSynthCtlInts * ctx->synth_ctl_next;
+  ctx->synth_ctl_next = (ctx->synth_ctl_next + 1) % mrx_ctx::kSynthCtlSlots;
+  return MRX_OK;
+}
+
 int mrx_spline_upsample_fused(mrx_ctx* ctx, const float* d_y, int D, int Ta,
                               double ta0, double dta, const double* d_t, int T,
                               const float* d_scale, const int32_t* d_rows,
@@ -1485,18 +1969,133 @@ int mrx_spline_upsample_fused(mrx_ctx* ctx, const float* d_y, int D, int Ta,
   while (batches > 1 && (long long)mrx_ceil_div(T, kTileSamples) *
                                 mrx_ceil_div(D, rows_per_batch * batches) < 4LL * 256 * 4)
     batches /= 2;  // keep the chip full on small problems
-  dim3 grid(mrx_ceil_div(T, kTileSamples), mrx_ceil_div(D, rows_per_batch * batches));
-  MRX_REQUIRE(ctx, grid.y <= 65535u, "D too large for one launch");
+  const long long nsx = mrx_ceil_div(T, kTileSamples);
+  const long long n_tiles = nsx * mrx_ceil_div(D, rows_per_batch * batches);
+  MRX_REQUIRE(ctx, n_tiles <= 0x7fffffffLL - 65536, "too many tiles for one launch");
+  const size_t lds = small ? FusedLds<64, 2>::kBytes : FusedLds<256, 1>::kBytes;
+  const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
+  const long long per_cu = std::max<long long>(1, std::min<long long>(MRX_WRITER_WAVES, (long long)(ctx->lds_per_cu > 0 ? ctx->lds_per_cu : 160 * 1024) / (long long)(lds + 64)));
+  const dim3 grid((unsigned)std::min(n_tiles, per_cu * n_cu));
+  int* ctl = nullptr;
+  {
+    const int rc = mrx_synth_ctl(ctx, &ctl);
+    if (rc != MRX_OK) return rc;
+  }
 #define MRX_LAUNCH_UPF(S, K, G)                                                      \
   hipLaunchKernelGGL((spline_upsample_fused_kernel<S, K, G>), grid, dim3(kBlock), (FusedLds<K, G>::kBytes), \
                      ctx->stream, d_y, D, Ta, ta0, 1.0 / dta, d_t, T, d_scale,       \
-                     d_rows, d_out, ld_out, vec_ok, batches)
+                     d_rows, d_out, ld_out, vec_ok, batches, (int)nsx, (int)n_tiles, ctl)
   if (d_scale) {
     if (small) MRX_LAUNCH_UPF(true, 64, 2); else MRX_LAUNCH_UPF(true, 256, 1);
   } else {
     if (small) MRX_LAUNCH_UPF(false, 64, 2); else MRX_LAUNCH_UPF(false, 256, 1);
   }
 #undef MRX_LAUNCH_UPF
+  MRX_CHECK_LAUNCH(ctx);
+  return MRX_OK;
+}
+
+int mrx_atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d_az, const float* d_el, int Ta,
+                       const float* d_dx, const float* d_dy, const int32_t* d_band, const float* d_mueller00, int D,
+                       double pwv0, float* d_coarse, int block_rows, int head_rows, uint32_t* d_flags, double ta0,
+                       double dta, const double* d_t, int T, const float* d_scale, const int32_t* d_rows, float* d_out,
+                       size_t ld_out) {
+  MRX_ENTER(ctx);
+  if (!ctx) return MRX_ERR_INVALID;
+  MRX_REQUIRE(ctx, D >= 0 && Ta >= 0 && T >= 0, "negative size");
+  if (D == 0 || T == 0) return MRX_OK;
+  MRX_REQUIRE(ctx, plan != nullptr, "plan is null");
+  MRX_REQUIRE(ctx, d_az && d_el && d_dx && d_dy && d_band && d_mueller00, "null input pointer");
+  MRX_REQUIRE(ctx, d_coarse && d_flags && d_t && d_out, "null pointer");
+  MRX_REQUIRE(ctx, plan->n_layers == 0 || Ta == plan->n_t, "Ta differs from the plan's n_t (length of the wind offsets)");
+  MRX_REQUIRE(ctx, dta > 0.0, "coarse step must be positive");
+  MRX_REQUIRE(ctx, ld_out >= (size_t)T, "ld_out smaller than T");
+  if (Ta < 4)
+    return mrx_fail(ctx, MRX_ERR_UNSUPPORTED, "cubic interpolation needs at least 4 coarse samples (got %d), as scipy "
+                    "interp1d(kind='cubic') does", Ta);
+  // the one-launch form exists for what the default step runs: every layer on a verified-uniform axis, the
+  // reference's default cell rule and pointing, linear band tables (otherwise: mrx_atm_sample + mrx_spline_upsample_fused)
+  const bool literal = ctx->options[MRX_OPT_AXIS_LITERAL] != 0 || ctx->options[MRX_OPT_POINTING_CHAIN] != 0;
+  if (!plan->all_pixel || literal || plan->any_cubic || plan->n_layers > mrx_px::kMaxAnchors)
+    return mrx_fail(ctx, MRX_ERR_UNSUPPORTED, "mrx_atm_synthesize: this plan or option set takes the two-call form");
+  const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
+  if (block_rows <= 0) block_rows = D;
+  block_rows = std::min(mrx_ceil_div(block_rows, kBlock) * kBlock, mrx_ceil_div(D, 32) * 32);  // whole groups of 256 lanes; rows of whole lines
+  const int n_blocks = mrx_ceil_div(D, block_rows);
+  MRX_REQUIRE(ctx, n_blocks <= kSynthMaxBlocks, "too many detector blocks");
+  MRX_REQUIRE(ctx, (long long)Ta * block_rows * 4 < (1LL << 31), "a block's coarse array must stay below 2 GiB");
+  MRX_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(d_coarse) & 127u) == 0, "d_coarse must be 128-byte aligned");
+  // ---- writer role: mrx_spline_upsample_fused's choices ----
+  const int vec_ok = (ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15u) == 0);
+  const double knots_per_tile = (double)kTileSamples * (double)Ta / (double)T;
+  const bool small = knots_per_tile + 6.0 <= 64.0;
+  const int rows_per_batch = small ? 2 * kTileDet : kTileDet;
+  int batches = ctx->options[MRX_OPT_UPSAMPLE_GROUPS];
+  if (batches <= 0) batches = 1;
+  while (batches > 1 && (long long)mrx_ceil_div(T, kTileSamples) * mrx_ceil_div(D, rows_per_batch * batches) < 4LL * 256 * 4)
+    batches /= 2;
+  const long long rows_per_tile = (long long)rows_per_batch * batches;
+  const long long nsx = mrx_ceil_div(T, kTileSamples);
+  const long long n_tiles = nsx * ((long long)(n_blocks - 1) * ((block_rows + rows_per_tile - 1) / rows_per_tile) +
+                                   ((D - (long long)(n_blocks - 1) * block_rows) + rows_per_tile - 1) / rows_per_tile);
+  MRX_REQUIRE(ctx, n_tiles <= 0x7fffffffLL - 65536, "too many tiles for one launch");
+  const size_t lds_w = small ? FusedLds<64, 2>::kBytes : FusedLds<256, 1>::kBytes;
+  // ---- sampler role: mrx_atm_sample's choices for a resident grid ----
+  int chunk = ctx->options[MRX_OPT_SAMPLE_CHUNK];
+  if (chunk <= 0) {
+    chunk = mrx_px::kMaxChunk;
+    const long long want = 24LL * n_cu;
+    while (chunk > 1 && (long long)mrx_ceil_div(D, kBlock) * mrx_ceil_div(Ta, chunk) < want) chunk /= 2;
+  }
+  chunk = chunk < 1 ? 1 : chunk > mrx_px::kMaxChunk ? mrx_px::kMaxChunk : chunk;
+  while (chunk > 1 && chunk * plan->n_layers > mrx_px::kMaxAnchors) chunk /= 2;
+  // the launch has ONE dynamic LDS size and a CU's LDS is what bounds its writers: the sampler's anchors stay under
+  // the writer's images (16 layers at 64 steps a work item took 37 KB -- and a writer's place on every CU)
+  const size_t lds_turn = sizeof(float) * 4 * kBlock;  // four steps of every lane (px_sample_items<..., kWriteThrough>)
+  while (chunk > 8 && 2 * sizeof(float4) * (size_t)chunk * plan->n_layers + lds_turn > lds_w) chunk /= 2;
+  const int nby = mrx_ceil_div(Ta, chunk);
+  const long long n_items = (long long)nby * ((long long)(n_blocks - 1) * mrx_ceil_div(block_rows, kBlock) +
+                                              mrx_ceil_div(D - (n_blocks - 1) * block_rows, kBlock));
+  MRX_REQUIRE(ctx, n_items <= 0x7fffffffLL, "too many work items for one launch");
+  int per_cu = ctx->options[MRX_OPT_SAMPLE_WGS_PER_CU];
+  if (per_cu <= 0 || per_cu >= 8) per_cu = 2;
+  long long wgs_s = std::min(n_items, (long long)per_cu * n_cu);
+  if (wgs_s >= 8) wgs_s &= ~7LL;
+  // the head start: the first blocks by a grid that fills the chip (MRX_WRITER_WAVES workgroups per CU)
+  const int head_blocks = std::max(0, std::min(mrx_ceil_div(std::max(head_rows, 0), block_rows), n_blocks));
+  long long wgs_head = head_blocks > 0 ? std::max(wgs_s, std::min(n_items, (long long)MRX_WRITER_WAVES * n_cu) & ~7LL) : wgs_s;
+  const size_t lds_anchor = 2 * sizeof(float4) * (size_t)chunk * plan->n_layers;
+  const size_t lds_tables = sizeof(float) * (size_t)((plan->table_floats + 3) / 4 * 4);
+  // band tables in LDS only where they fit under the writer's images too
+  const bool lds_tab = plan->table_floats <= mrx_px::kMaxLdsTableFloats && lds_anchor + lds_tables + lds_turn <= lds_w;
+  const size_t lds = std::max(lds_w, lds_anchor + (lds_tab ? lds_tables : 0) + lds_turn);
+  // writers: as many as fit a CU once the samplers have left (the surplus is dispatched as those exit)
+  const long long per_cu_w = std::max<long long>(1, std::min<long long>(MRX_WRITER_WAVES, (long long)(ctx->lds_per_cu > 0 ? ctx->lds_per_cu : 160 * 1024) / (long long)(lds + 1552)));
+  const long long wgs_w = std::min(n_tiles, per_cu_w * n_cu);
+  int* ctl = nullptr;
+  {
+    const int rc = mrx_synth_ctl(ctx, &ctl);
+    if (rc != MRX_OK) return rc;
+  }
+  const dim3 grid((unsigned)(wgs_head + wgs_w));
+  const int poll_limit = 1 << 22;  // x >= 0.5 us a try: seconds
+#define MRX_LAUNCH_SYNTH(L, S, K, G)                                                                              \
+  do {                                                                                                            \
+    MRX_LDS_CAP(ctx, (atm_tod_kernel<L, S, K, G>), lds);                                                          \
+    hipLaunchKernelGGL((atm_tod_kernel<L, S, K, G>), grid, dim3(kBlock), lds, ctx->stream, plan->d_fast,          \
+                       plan->d_px, plan->n_layers, plan->d_offpx, plan->d_tables, plan->n_tables,                 \
+                       plan->d_table_data, plan->table_floats, d_az, d_el, Ta, d_dx, d_dy, d_band, d_mueller00,   \
+                       D, pwv0, d_coarse, d_flags, chunk, nby, block_rows, n_blocks, (int)wgs_head, (int)wgs_s, head_blocks, ta0, 1.0 / dta,  \
+                       d_t, T, d_scale, d_rows, d_out, ld_out, vec_ok, batches, ctl, poll_limit);                \
+  } while (0)
+#define MRX_LAUNCH_SYNTH_S(L, S) do { if (small) MRX_LAUNCH_SYNTH(L, S, 64, 2); else MRX_LAUNCH_SYNTH(L, S, 256, 1); } while (0)
+  if (lds_tab) {
+    if (d_scale) MRX_LAUNCH_SYNTH_S(true, true); else MRX_LAUNCH_SYNTH_S(true, false);
+  } else {
+    if (d_scale) MRX_LAUNCH_SYNTH_S(false, true); else MRX_LAUNCH_SYNTH_S(false, false);
+  }
+#undef MRX_LAUNCH_SYNTH_S
+#undef MRX_LAUNCH_SYNTH
   MRX_CHECK_LAUNCH(ctx);
   return MRX_OK;
 }

@@ -19,7 +19,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import Context, MrxBandTable, MrxLayer, ptr
+from ._lib import Context, MrxBandTable, MrxError, MrxLayer, ptr
 
 
 class _range:
@@ -580,6 +580,7 @@ class DevicePath:
     # -- hot path ------------------------------------------------------------
     def sample(self, want_pwv=False):
         self._pipelined = False
+        self._synthesized = False
         if self.plan is None:
             raise RuntimeError("no screens bound: call set_screens() or generate_screens() first")
         self.wait_screens()
@@ -650,6 +651,13 @@ class DevicePath:
 
     def coarse_loading(self):
         """[D, Ta] float32 coarse loading in the caller's detector order (device tensor)."""
+        if getattr(self, "_synthesized", False):  # the last run was one launch: blocks of [Ta][pitch] (mrx_atm_synthesize)
+            br, parts = self._synth_block_rows, []
+            for lo in range(0, self.D, br):
+                n = min(br, self.D - lo)
+                pitch = (n + 31) // 32 * 32
+                parts.append(self._coarse_blocks[self.Ta * lo : self.Ta * lo + self.Ta * pitch].view(self.Ta, pitch)[:, :n])
+            return torch.cat(parts, dim=1).T.index_select(0, self._d_inverse)
         if getattr(self, "_pipelined", False):  # the last run kept it in per-block buffers
             if getattr(self, "_pipelined_krj", False):
                 raise RuntimeError("the last run() converted its coarse buffers to K_RJ in place: call sample() (pW) before coarse_loading()")
@@ -680,6 +688,13 @@ class DevicePath:
         (the pW writer then writes K_RJ), per sample by mrx_spline_upsample_krj otherwise."""
         if out is None:
             out = torch.empty((self.D, self.T), dtype=torch.float32, device=self.device)
+        if blocks is None and not krj and self.synthesize_applies():
+            try:
+                return self.synthesize(out, writer_events=writer_events)
+            except MrxError as e:
+                if e.code != -4:  # MRX_ERR_UNSUPPORTED
+                    raise
+                self._synth_unsupported = True  # (a layer off a uniform axis, a literal option, cubic tables: the two-call forms)
         if blocks is None:
             blocks = self.default_blocks()
         if krj and not self.coarse_krj_bound() <= self.COARSE_KRJ_LIMIT:
@@ -696,6 +711,65 @@ class DevicePath:
             if krj:
                 self.coarse_to_krj()
             self.upsample_fused(out, krj=krj)
+        return out
+
+    def synthesize_applies(self):
+        """Does run() take the one-launch form by default?  From 2048 rows (below, the stages back to back are as
+        fast: 0.36 ms for 1 250 rows either way) and where the writer has more to do than the sampler (atlast_10k:
+        2.0 against 2.2 ms pipelined on two streams; with the 16 layers of atlast_50k the two-stream form stays ahead,
+        9.5 against 10.5 ms: there the sampler wants four workgroups per CU at 80 registers beside a writer at 94, and one
+        kernel has one register budget)."""
+        work = len(self.problem["layers"]) * self.Ta / max(self.T, 1)
+        return (not self.keep_pwv and self.D >= 2048 and work < 0.3 and not getattr(self, "_synth_unsupported", False)
+                and getattr(self, "_la", None) is None)
+
+    def synthesize(self, out=None, block_rows=None, resident_wgs_per_cu=None, head_rows=None, writer_events=None):
+        """Atmosphere -> TOD in ONE launch (mrx_atm_synthesize): the sampler and the writer as two roles of one grid,
+        the hand-over between them on the device.  Same bits as the two-call forms.  ``block_rows``: detectors per
+        block, the unit of the hand-over; ``head_rows``: rows sampled by a grid that fills the chip before the writers
+        enter; ``resident_wgs_per_cu``: sampler workgroups per CU beside the writers.  Defaults from sweeps on 2 512,
+        5 000 and 10 000 rows of atlast_10k (scripts/exp_synth.py): a third of the rows as head start, 1024-row blocks
+        and 2 workgroups from 8192 rows, 512-row blocks and 3 workgroups below."""
+        if self.plan is None:
+            raise RuntimeError("no screens bound: call set_screens() or generate_screens() first")
+        if out is None:
+            out = torch.empty((self.D, self.T), dtype=torch.float32, device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        self.ctx.set_stream(main)
+        self.wait_screens(main)
+        big = self.D >= 8192
+        if block_rows is None:
+            block_rows = 1024 if big else 512
+        if resident_wgs_per_cu is None:
+            resident_wgs_per_cu = 2 if big else 3
+        if head_rows is None:
+            head_rows = int(0.35 * self.D)
+        if writer_events is not None:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record(main)
+        if getattr(self, "_coarse_blocks", None) is None:
+            self._coarse_blocks = torch.empty(self.Ta * ((self.D + 31) // 32 * 32), dtype=torch.float32, device=self.device)
+        saved = self.ctx.get_option(_lib.OPT_SAMPLE_WGS_PER_CU)
+        self.ctx.set_option(_lib.OPT_SAMPLE_WGS_PER_CU, int(resident_wgs_per_cu))
+        try:
+            with _range("Sampling turbulence + Computing atmospheric emission + Upsampling atmospheric loading"):
+                self.ctx.call(
+                    "mrx_atm_synthesize", self.plan, ptr(self.d_az), ptr(self.d_el), self.Ta, ptr(self.d_dx), ptr(self.d_dy),
+                    ptr(self.d_band), ptr(self.d_m00), self.D, self.pwv0, ptr(self._coarse_blocks), int(block_rows), int(head_rows),
+                    ptr(self.d_flags), self.ta0, self.dta, ptr(self.d_t), self.T,
+                    None if self.d_gain is None else ptr(self.d_gain), None if self.d_rows is None else ptr(self.d_rows),
+                    ptr(out), out.stride(0),
+                )
+        finally:
+            self.ctx.set_option(_lib.OPT_SAMPLE_WGS_PER_CU, saved)
+        if writer_events is not None:
+            ev[1].record(main)
+            writer_events.append(ev)
+        br = int(block_rows) if int(block_rows) > 0 else self.D
+        self._synth_block_rows = min((br + 255) // 256 * 256, (self.D + 31) // 32 * 32)  # as the library rounds it
+        self._synthesized = True
+        self._pipelined = False
+        self._pwv_stale = True
         return out
 
     def default_blocks(self):
@@ -874,6 +948,7 @@ class DevicePath:
                 st["tail_done"].record(side)
                 main.wait_event(st["tail_done"])
         self._pipelined = True
+        self._synthesized = False
         self._pipelined_krj = bool(krj and krj != "sample")  # (the coarse buffers then hold K_RJ, not pW)
         self._pwv_stale = True
         return out
@@ -1040,6 +1115,8 @@ class DevicePath:
         """Raise the reference's errors if a sample left a screen or a table."""
         word = C.c_uint32()
         self.ctx.call("mrx_read_flags", ptr(self.d_flags), C.byref(word))
+        if word.value & _lib.FLAG_HANDOVER:
+            raise RuntimeError("mrx_atm_synthesize: a writer gave up waiting for the sampler (MRX_FLAG_HANDOVER): the TOD of that run is invalid")
         if word.value & _lib.FLAG_SCREEN_OOB:
             # atmosphere/atmosphere.py:368-369
             raise RuntimeError("A layer introduced nans into PWV simulation (line of sight left its screen).")
