@@ -30,8 +30,9 @@ over ranks.  N = 1 is the named configuration on one GPU (atlast_50k: its per-GP
     cannot be gathered onto one GPU).  --scaling overrides either default.
 
 Prints ONE JSON line on rank 0, including
-  roofline      : the dominant kernel (spline solve + cubic upsample, HBM-bound streaming write),
-                  timed live with events on the launch stream
+  roofline      : the dominant kernel -- the one-launch synthesis (atm_tod_kernel: sampler and writer roles, the HBM-bound
+                  streaming write sets its time) where DevicePath.run() takes that form, else the writer (spline solve + cubic
+                  upsample) --, timed live with events on the launch stream
   second_kernel : the same for the sampler (VALU / vector-memory-latency bound)
   cpu_baseline  : the numpy/scipy oracle on a detector subset, on one host core and on
                   min(64, physical cores) processes; parity of the GPU rows against it, on the
@@ -53,7 +54,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak (spec); ~6300 achievable
-TRAFFIC_FILES = ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json")  # newest first
+TRAFFIC_FILES = ("r04_traffic.json", "r04_traffic_writer.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")  # newest first
 
 
 def parse_args(argv=None):
@@ -393,19 +394,25 @@ def run(args):
         path.generate_screens(only=own_layers, exchange=exchange if own_layers is not None else None)
 
     writer_events = []
-    n_blocks = args.blocks if args.blocks is not None else path.default_blocks()
+    # the form DevicePath.run() takes by itself: ONE launch (mrx_atm_synthesize: sampler and writer as two roles of one
+    # grid) where it applies, else detector blocks pipelined on two streams, else the stages back to back
+    one_launch = args.blocks is None and not args.block_shares and not args.lookahead and path.synthesize_applies()
+    n_blocks = 1 if one_launch else args.blocks if args.blocks is not None else path.default_blocks()
     if args.block_shares:
         path.block_shares = [int(x) for x in args.block_shares.split(",")]
         n_blocks = len(path.block_shares)
 
     def step(ev=None):
-        """One pass: screens, then the TOD synthesis -- detector blocks pipelined on two streams
-        (DevicePath.run: the sampler of block b+1 beside the writer of block b)."""
+        """One pass: screens, then the TOD synthesis (DevicePath.run: one launch, or the sampler of block b+1 beside the
+        writer of block b on two streams)."""
         if ev: ev[0].record()
         if not args.no_screens_in_step:
             screens()
         if ev: ev[1].record()
-        path.run(tod, blocks=n_blocks, writer_events=writer_events if (ev and n_blocks > 1) else None)
+        if one_launch:
+            path.run(tod, writer_events=writer_events if ev else None)
+        else:
+            path.run(tod, blocks=n_blocks, writer_events=writer_events if (ev and n_blocks > 1) else None)
         if ev: ev[2].record()
 
     def serial_step(sev):
@@ -478,9 +485,12 @@ def run(args):
         rows_per_launch = D / n_launch
     else:
         up_ms, rows_per_launch = serial_up_launch_ms, D / n_launch
-    up_bytes = 4.0 * rows_per_launch * T + 4.0 * rows_per_launch * Ta + 8.0 * T  # TOD write + coarse loading read + sample times read
+    writer_bytes = 4.0 * rows_per_launch * T + 4.0 * rows_per_launch * Ta + 8.0 * T  # TOD write + coarse loading read + sample times read
+    # one launch: the kernel IS the atmosphere -> TOD path (SURVEY 8(d)'s B_alg: TOD + coarse loading written and read +
+    # every screen once + inputs); otherwise the writer's launch
+    up_bytes = float(path.algorithmic_bytes()) if one_launch else writer_bytes
     achieved = up_bytes / (up_ms * 1e-3) / 1e9
-    alone = up_bytes / (serial_up_launch_ms * 1e-3) / 1e9
+    alone = writer_bytes / (serial_up_launch_ms * 1e-3) / 1e9
     # the sampler: 4 B/det-step written + each screen read once + inputs (it is not HBM-bound)
     sm_ms = float(serial_ms[0])
     sm_bytes = 4.0 * D * Ta + 4.0 * sum(len(l["extrusion"]) * len(l["cross_section"]) for l in problem["layers"]) + 8.0 * Ta + 8.0 * D
@@ -527,10 +537,12 @@ def run(args):
             "serial_breakdown": {"sample": sm_ms, "upsample_with_spline_solve": float(serial_ms[1]),
                                  "note": "the same block launches back to back on one stream, outside the timed region; sums over the blocks"},
             "detector_blocks": n_launch,
+            "form": ("one launch (mrx_atm_synthesize): sampler and writer as two roles of one grid, hand-over on the device"
+                     if one_launch else "detector blocks pipelined on two streams" if n_blocks > 1 else "stages back to back on one stream"),
         },
         "path_hbm_gbps": path.algorithmic_bytes() / (float(ev[0][0].elapsed_time(ev[-1][2])) / args.steps * 1e-3) / 1e9,
         "roofline": {
-            "kernel": "spline_upsample_fused_kernel",
+            "kernel": "atm_tod_kernel" if one_launch else "spline_upsample_fused_kernel",
             "bound": "hbm",
             "achieved": achieved,
             "peak": HBM_PEAK_GBPS,
@@ -540,13 +552,16 @@ def run(args):
             "bytes_per_launch": up_bytes,
             "ms_per_launch": up_ms,
             "launches_per_step": n_launch,
-            "note": "timed in the timed region, where each launch shares the chip with the next block's sampler; "
+            "note": ("the whole atmosphere -> TOD synthesis in one launch, timed in the timed region: its algorithmic bytes are the "
+                     "path's (TOD + coarse loading + screens + inputs); the stand-alone writer (spline_upsample_fused_kernel, "
+                     "serial breakdown) reaches frac_alone on its own bytes") if one_launch else
+                    "timed in the timed region, where each launch shares the chip with the next block's sampler; "
                     "the same launches back to back on one stream (serial breakdown) reach frac_alone",
             "frac_alone": alone / HBM_PEAK_GBPS,
         },
         "second_kernel": {
             "kernel": "atm_sample_px_kernel",
-            "bound": "valu + vector-memory latency (not hbm): see DESIGN 3.2 and profiles/r03_kernel_pmc.txt",
+            "bound": "valu + vector-memory latency (not hbm): see DESIGN 3.2 and profiles/r04_50k_kernel_pmc.txt",
             "ms_per_step": sm_ms,
             "launches_per_step": n_launch,
             "note": "sum over the step's block launches run back to back on one stream (serial breakdown)",
@@ -684,7 +699,7 @@ def run(args):
                             "(median of the repetitions, max over ranks) and ADDED to the step: value = detector-samples / (synthesis + gather)")
                     if algo != algos[-1]:  # the next variant must move the rows again
                         full.zero_()
-                        path.run(tod, blocks=n_blocks)
+                        path.run(tod, blocks=None if one_launch else n_blocks)
             elif args.backend != "nccl":
                 # rehearsal on one device: the torch.distributed fallback on a small CPU slice
                 from maria_amd.dist import all_gather_tod

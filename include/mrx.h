@@ -108,8 +108,10 @@ enum {
                                 (tests, A/B runs) */
   MRX_OPT_SAMPLE_WGS_PER_CU = 6, /* mrx_atm_sample runs as a resident grid of this many workgroups
                                     per CU that walk the work items (tuning; 0 = default, 8) */
-  MRX_OPT_RESERVED_7 = 7, /* (was MRX_OPT_SAMPLE_TILES: screen windows staged in LDS measured slower than
-                             the global gathers in round 2 and the kernel was removed; ignored) */
+  MRX_OPT_WRITER_PER_TILE = 7, /* 1: mrx_spline_upsample_fused launches one workgroup per tile instead of a resident
+                                  grid over a tile queue (the default, 6 % faster alone): for a launch that shares the
+                                  chip with kernels launched after it on another stream -- a resident grid never makes
+                                  room for them.  (Slot of the retired MRX_OPT_SAMPLE_TILES.) */
   MRX_OPT_NOISE_LANES = 8, /* streams mrx_noise_generate spreads its batches over (1..4; 0 = automatic:
                               up to 4, each with at least 128 detectors of the work buffer) */
   MRX_OPT_SCREEN_STOCKHAM = 9, /* 1: the screen generator's transforms as LDS Stockham passes even

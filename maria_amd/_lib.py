@@ -25,6 +25,7 @@ OPT_AXIS_LITERAL = 1
 OPT_SAMPLE_TIMES = 2
 OPT_SAMPLE_WGS_PER_CU = 6
 OPT_NOISE_GENERIC = 5
+OPT_WRITER_PER_TILE = 7
 OPT_NOISE_LANES = 8
 OPT_SCREEN_STOCKHAM = 9
 

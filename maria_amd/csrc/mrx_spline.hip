@@ -698,8 +698,11 @@ __device__ __forceinline__ void synth_leave(int* ctl, int n_blocks) {
 // A RESIDENT grid takes tiles from a queue (one agent-scope atomic per tile; tiles numbered row group by row group,
 // time tile fastest -- the order a two-dimensional grid is dispatched in): against one workgroup per tile, 1.59 vs
 // 1.69 ms for 10 000 x 240 000 alone (0.76 of 8 TB/s): no dispatch per tile, no tail of half-empty CUs.  The queue
-// and not a fixed stride, because beside a resident sampler only some of the grid is on the chip at first.
-template <bool kHasScale, int kMaxKnots, int kG>
+// and not a fixed stride, because only some of the grid may be on the chip at first.  A launch that SHARES the chip
+// with another kernel's launches to come (the two-stream pipeline: the next block's sampler must find room while
+// this writer runs) takes one workgroup per tile instead, MRX_OPT_WRITER_PER_TILE: a resident grid never makes room
+// (pipelined atlast_10k 2.61 against 2.3 ms).
+template <bool kHasScale, int kMaxKnots, int kG, bool kQueue>
 // 5 waves per SIMD = up to 96 registers (the kernel takes 94, nothing spilled).  Beside the resident sampler
 // (3 workgroups per CU x 64 registers) 3 writer waves per SIMD still fit (192 + 288 <= 512); with 2 the writer
 // loses a fifth of its rate.  The first fused version was capped at 72 registers (the round-2
@@ -713,6 +716,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_WRIT
   // dynamic LDS (FusedLds<...>::kBytes): with a static size the compiler derives the occupancy
   // from it and ignores the register bound above
   extern __shared__ __align__(16) unsigned char fused_lds[];
+  if (!kQueue) {  // one workgroup per tile, a two-dimensional grid (time tiles x row groups): MRX_OPT_WRITER_PER_TILE
+    fused_writer_tile<kHasScale, kMaxKnots, kG>(y, D, D, n, ta0, inv_dta, t, T, scale, rows, out, ld, vec_ok, batches,
+                                                 (int)blockIdx.x, (int)blockIdx.y, fused_lds);
+    return;
+  }
   __shared__ int s_next;
   for (;;) {
     if (threadIdx.x == 0) s_next = __hip_atomic_fetch_add(ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1664,21 +1672,26 @@ int mrx_spline_upsample_fused(mrx_ctx* ctx, const float* d_y, int D, int Ta,
   const size_t lds = small ? FusedLds<64, 2>::kBytes : FusedLds<256, 1>::kBytes;
   const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
   const long long per_cu = std::max<long long>(1, std::min<long long>(MRX_WRITER_WAVES, (long long)(ctx->lds_per_cu > 0 ? ctx->lds_per_cu : 160 * 1024) / (long long)(lds + 64)));
-  const dim3 grid((unsigned)std::min(n_tiles, per_cu * n_cu));
+  const bool per_tile = ctx->options[MRX_OPT_WRITER_PER_TILE] != 0;
+  const dim3 grid_q((unsigned)std::min(n_tiles, per_cu * n_cu));
+  const dim3 grid_t((unsigned)nsx, (unsigned)mrx_ceil_div(D, rows_per_batch * batches));
+  MRX_REQUIRE(ctx, !per_tile || grid_t.y <= 65535u, "D too large for one launch");
   int* ctl = nullptr;
-  {
+  if (!per_tile) {
     const int rc = mrx_synth_ctl(ctx, &ctl);
     if (rc != MRX_OK) return rc;
   }
-#define MRX_LAUNCH_UPF(S, K, G)                                                      \
-  hipLaunchKernelGGL((spline_upsample_fused_kernel<S, K, G>), grid, dim3(kBlock), (FusedLds<K, G>::kBytes), \
+#define MRX_LAUNCH_UPF_Q(S, K, G, Q)                                                 \
+  hipLaunchKernelGGL((spline_upsample_fused_kernel<S, K, G, Q>), Q ? grid_q : grid_t, dim3(kBlock), (FusedLds<K, G>::kBytes), \
                      ctx->stream, d_y, D, Ta, ta0, 1.0 / dta, d_t, T, d_scale,       \
                      d_rows, d_out, ld_out, vec_ok, batches, (int)nsx, (int)n_tiles, ctl)
+#define MRX_LAUNCH_UPF(S, K, G) do { if (per_tile) MRX_LAUNCH_UPF_Q(S, K, G, false); else MRX_LAUNCH_UPF_Q(S, K, G, true); } while (0)
   if (d_scale) {
     if (small) MRX_LAUNCH_UPF(true, 64, 2); else MRX_LAUNCH_UPF(true, 256, 1);
   } else {
     if (small) MRX_LAUNCH_UPF(false, 64, 2); else MRX_LAUNCH_UPF(false, 256, 1);
   }
+#undef MRX_LAUNCH_UPF_Q
 #undef MRX_LAUNCH_UPF
   MRX_CHECK_LAUNCH(ctx);
   return MRX_OK;

@@ -919,6 +919,10 @@ class DevicePath:
             if writer_events is not None:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record(main)
+            # a writer the next block's sampler has to find room beside: one workgroup per tile (a resident grid over
+            # the tile queue -- the stand-alone default -- holds every slot of the chip until its last tile); the last
+            # block's writer has the chip to itself
+            self.ctx.set_option(_lib.OPT_WRITER_PER_TILE, 0 if (serial or (i == len(st["bounds"]) - 1 and la is None)) else 1)
             self.ctx.call(
                 "mrx_spline_upsample_fused", ptr(st["loading"][i]), n, self.Ta, self.ta0, self.dta,
                 ptr(self.d_t), self._krj_split() if krj else self.T, sl(self.d_gain, lo, hi), rows, ptr(dst), out.stride(0),
@@ -934,6 +938,7 @@ class DevicePath:
                 serial_events.append(tev)
         ctx2.set_option(_lib.OPT_SAMPLE_WGS_PER_CU, saved[0])
         ctx2.set_option(_lib.OPT_SAMPLE_TIMES, saved[1])
+        self.ctx.set_option(_lib.OPT_WRITER_PER_TILE, 0)
         if la is not None:  # the screens' stream may refill this set once these samplers are through
             la["samplers_done"][la["current"]].record(side)
             la["sampled"][la["current"]] = True
