@@ -764,6 +764,13 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_WRIT
 // not a path -- it cannot trigger while the sampler role is resident.
 // Results: the same bits as mrx_atm_sample + mrx_spline_upsample_fused per block (same bodies, same order of
 // operations; tests/test_gpu_synthesize.py).
+// who samples what: blocks [end[p-1], end[p]) by the first wgs[p] sampler workgroups (wgs descending)
+struct SynthPhases {
+  int n;
+  int end[4];
+  int wgs[4];
+};
+
 template <bool kLdsTables, bool kHasScale, int kMaxKnots, int kG>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_WRITER_WAVES, MRX_WRITER_WAVES))) void atm_tod_kernel(
     const mrx_layer_fast* __restrict__ fast, const mrx_layer_px* __restrict__ lpx, int n_layers,
@@ -773,26 +780,28 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_WRIT
     const int32_t* __restrict__ band, const float* __restrict__ mueller00, int D, double pwv0,
     float* loading,  // written by the sampler role, read by the writer role: no __restrict__, no const
     uint32_t* __restrict__ flags, int chunk, int nby, int block_rows, int n_blocks, int n_sampler_wgs,
-    int n_long_wgs, int head_blocks, double ta0, double inv_dta, const double* __restrict__ t, int T,
+    SynthPhases phases, double ta0, double inv_dta, const double* __restrict__ t, int T,
     const float* __restrict__ scale, const int32_t* __restrict__ rows, float* __restrict__ out, size_t ld, int vec_ok,
     int batches, int* ctl, int poll_limit) {
   extern __shared__ __align__(16) unsigned char synth_lds[];
   if ((int)blockIdx.x < n_sampler_wgs) {
-    // two phases: the first `head_blocks` blocks by ALL sampler workgroups (nothing else is resident yet: the chip is
-    // theirs), the rest by the first `n_long_wgs` of them -- the others leave and writers take their places
-    for (int ph = 0; ph < 2; ++ph) {
-      const int nw = ph ? n_long_wgs : n_sampler_wgs;
+    // phases: the first blocks by ALL sampler workgroups (nothing else is resident yet: the chip is theirs), the next
+    // ones by fewer and fewer of them -- those that leave make room for writers --, the rest by the first few
+    int b0 = 0;
+    for (int ph = 0; ph < phases.n; ++ph) {
+      const int nw = phases.wgs[ph];
       if ((int)blockIdx.x >= nw) break;
-      const int b0 = ph ? head_blocks : 0, b1 = ph ? n_blocks : head_blocks;
-      if (b1 <= b0) continue;
-      mrx_px::px_sample_items<kLdsTables, 1, true, true>(
-          fast, lpx, n_layers, offpx, tables, n_tables, table_data, table_floats, az, el, Ta, dxs, dys, band, mueller00,
-          D, pwv0, nullptr, loading, flags, chunk, nby, block_rows, n_blocks, b0, b1, (int)blockIdx.x, nw,
-          reinterpret_cast<float4*>(synth_lds), [&](int blk) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's (write-through) stores of the item are out
-            __syncthreads();
-            if (threadIdx.x == 0) __hip_atomic_fetch_add(ctl + 32 + blk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          });
+      const int b1 = phases.end[ph];
+      if (b1 > b0)
+        mrx_px::px_sample_items<kLdsTables, 1, true, true>(
+            fast, lpx, n_layers, offpx, tables, n_tables, table_data, table_floats, az, el, Ta, dxs, dys, band, mueller00,
+            D, pwv0, nullptr, loading, flags, chunk, nby, block_rows, n_blocks, b0, b1, (int)blockIdx.x, nw,
+            reinterpret_cast<float4*>(synth_lds), [&](int blk) {
+              asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's (write-through) stores of the item are out
+              __syncthreads();
+              if (threadIdx.x == 0) __hip_atomic_fetch_add(ctl + 32 + blk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            });
+      b0 = max(b0, b1);
     }
     synth_leave(ctl, n_blocks);
     return;
@@ -1765,7 +1774,19 @@ int mrx_atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d_az
   if (wgs_s >= 8) wgs_s &= ~7LL;
   // the head start: the first blocks by a grid that fills the chip (MRX_WRITER_WAVES workgroups per CU)
   const int head_blocks = std::max(0, std::min(mrx_ceil_div(std::max(head_rows, 0), block_rows), n_blocks));
-  long long wgs_head = head_blocks > 0 ? std::max(wgs_s, std::min(n_items, (long long)MRX_WRITER_WAVES * n_cu) & ~7LL) : wgs_s;
+  const long long wgs_full = std::max(wgs_s, std::min(n_items, (long long)MRX_WRITER_WAVES * n_cu) & ~7LL);
+  SynthPhases phases = {};
+  // (a staircase -- the head's blocks in shares to 5, 4, 3 workgroups per CU, writers entering as each step leaves --
+  //  measured no better than one step: 1.98-2.05 against 1.93-1.98 ms)
+  if (head_blocks > 0) {
+    phases.n = 2;
+    phases.end[0] = head_blocks; phases.wgs[0] = (int)wgs_full;
+    phases.end[1] = n_blocks;    phases.wgs[1] = (int)wgs_s;
+  } else {
+    phases.n = 1;
+    phases.end[0] = n_blocks; phases.wgs[0] = (int)wgs_s;
+  }
+  const long long wgs_head = phases.wgs[0];
   const size_t lds_anchor = 2 * sizeof(float4) * (size_t)chunk * plan->n_layers;
   const size_t lds_tables = sizeof(float) * (size_t)((plan->table_floats + 3) / 4 * 4);
   // band tables in LDS only where they fit under the writer's images too
@@ -1787,7 +1808,7 @@ int mrx_atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d_az
     hipLaunchKernelGGL((atm_tod_kernel<L, S, K, G>), grid, dim3(kBlock), lds, ctx->stream, plan->d_fast,          \
                        plan->d_px, plan->n_layers, plan->d_offpx, plan->d_tables, plan->n_tables,                 \
                        plan->d_table_data, plan->table_floats, d_az, d_el, Ta, d_dx, d_dy, d_band, d_mueller00,   \
-                       D, pwv0, d_coarse, d_flags, chunk, nby, block_rows, n_blocks, (int)wgs_head, (int)wgs_s, head_blocks, ta0, 1.0 / dta,  \
+                       D, pwv0, d_coarse, d_flags, chunk, nby, block_rows, n_blocks, (int)wgs_head, phases, ta0, 1.0 / dta,           \
                        d_t, T, d_scale, d_rows, d_out, ld_out, vec_ok, batches, ctl, poll_limit);                \
   } while (0)
 #define MRX_LAUNCH_SYNTH_S(L, S) do { if (small) MRX_LAUNCH_SYNTH(L, S, 64, 2); else MRX_LAUNCH_SYNTH(L, S, 256, 1); } while (0)

@@ -728,8 +728,8 @@ class DevicePath:
         the hand-over between them on the device.  Same bits as the two-call forms.  ``block_rows``: detectors per
         block, the unit of the hand-over; ``head_rows``: rows sampled by a grid that fills the chip before the writers
         enter; ``resident_wgs_per_cu``: sampler workgroups per CU beside the writers.  Defaults from sweeps on 2 512,
-        5 000 and 10 000 rows of atlast_10k (scripts/exp_synth.py): a third of the rows as head start, 1024-row blocks
-        and 2 workgroups from 8192 rows, 512-row blocks and 3 workgroups below."""
+        5 000 and 10 000 rows of atlast_10k (scripts/exp_synth.py, exp_synth_stairs.py): 512-row blocks, a third of the
+        rows as head start, 2 workgroups from 8192 rows and 3 below."""
         if self.plan is None:
             raise RuntimeError("no screens bound: call set_screens() or generate_screens() first")
         if out is None:
@@ -739,11 +739,11 @@ class DevicePath:
         self.wait_screens(main)
         big = self.D >= 8192
         if block_rows is None:
-            block_rows = 1024 if big else 512
+            block_rows = 512
         if resident_wgs_per_cu is None:
             resident_wgs_per_cu = 2 if big else 3
         if head_rows is None:
-            head_rows = int(0.35 * self.D)
+            head_rows = int((0.3 if big else 0.35) * self.D)
         if writer_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record(main)
