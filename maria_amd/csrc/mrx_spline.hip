@@ -1635,7 +1635,8 @@ int mrx_spline_upsample(mrx_ctx* ctx, const float* d_ym, int D, int Ta,
 static int mrx_synth_ctl(mrx_ctx* ctx, int** out) {
   if (!ctx->d_synth_ctl) {
     MRX_HIP(ctx, hipMalloc(&ctx->d_synth_ctl, sizeof(int) * kSynthCtlInts * mrx_ctx::kSynthCtlSlots));
-    MRX_HIP(ctx, hipMemset(ctx->d_synth_ctl, 0, sizeof(int) * kSynthCtlInts * mrx_ctx::kSynthCtlSlots));
+    MRX_HIP(ctx, hipMemsetAsync(ctx->d_synth_ctl, 0, sizeof(int) * kSynthCtlInts * mrx_ctx::kSynthCtlSlots, ctx->stream));
+    MRX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // (once per context: later launches may come on other streams)
   }
   *out = ctx->d_synth_ctl + (size_t)kSynthCtlInts * ctx->synth_ctl_next;
   ctx->synth_ctl_next = (ctx->synth_ctl_next + 1) % mrx_ctx::kSynthCtlSlots;
