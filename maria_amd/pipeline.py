@@ -728,7 +728,7 @@ class DevicePath:
         the hand-over between them on the device.  Same bits as the two-call forms.  ``block_rows``: detectors per
         block, the unit of the hand-over; ``head_rows``: rows sampled by a grid that fills the chip before the writers
         enter; ``resident_wgs_per_cu``: sampler workgroups per CU beside the writers.  Defaults from sweeps on 2 512,
-        5 000 and 10 000 rows of atlast_10k (scripts/exp_synth.py, exp_synth_stairs.py): 512-row blocks, a third of the
+        5 000 and 10 000 rows of atlast_10k (scripts/exp_synth.py): 512-row blocks, a third of the
         rows as head start, 2 workgroups from 8192 rows and 3 below."""
         if self.plan is None:
             raise RuntimeError("no screens bound: call set_screens() or generate_screens() first")
