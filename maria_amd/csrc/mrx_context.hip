@@ -129,6 +129,7 @@ int mrx_destroy(mrx_ctx* ctx) {
     if (slot.d_resp) (void)hipFree(slot.d_resp);
   if (ctx->d_reduce) (void)hipFree(ctx->d_reduce);
   if (ctx->d_synth_ctl) (void)hipFree(ctx->d_synth_ctl);
+  if (ctx->d_bin_order) (void)hipFree(ctx->d_bin_order);
   for (hipStream_t st : ctx->side_streams)
     if (st) (void)hipStreamDestroy(st);
   for (hipEvent_t ev : ctx->side_ev)

@@ -53,6 +53,7 @@ struct mrx_ctx {
   } fresp[kFRespSlots];
   int fresp_next = 0;
   int options[MRX_OPT_COUNT] = {0};
+  uint32_t* d_bin_order = nullptr;  // routed binning: contributions per region + the regions by falling total (mrx_map.hip)
   // tile queues + per-block counters of the launches that take their work from a queue (mrx_spline.hip: mrx_synth_ctl)
   static constexpr int kSynthCtlSlots = 8;
   int* d_synth_ctl = nullptr;

@@ -559,6 +559,8 @@ struct BucketArgs {
   int n_tiles;
   int tile_det, tile_entries;  // BinTile<>::kDet, kEntries of the form in use
   uint32_t* tab;       // [R][n_tiles]: (first entry of the region in the tile's slot) << 16 | count
+  uint32_t* totals;    // [R]: contributions per region in this chunk (pass A adds, bin_order_kernel reads)
+  const int* order;    // [R]: regions by falling total (pass B takes the heavy ones first: its tail is then made of light ones)
   void* entries;       // [n_tiles][tile_entries] BinEntryT<entry_bytes>
 };
 
@@ -671,7 +673,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) 
   for (int r = r_lo; r < r_hi; ++r) {
     const uint32_t c = hist[r];
     hist[r] = run;  // the region's cursor from here on
-    if (c) k.tab[(size_t)r * k.n_tiles + tile] = (run << 16) | c;
+    if (c) {
+      k.tab[(size_t)r * k.n_tiles + tile] = (run << 16) | c;
+      atomicAdd(&k.totals[r], c);
+    }
     run += c;
   }
   __syncthreads();
@@ -712,6 +717,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) 
   }
 }
 
+// between the passes: the regions by falling number of contributions (rank by counting: R <= 2048), so that pass B's
+// grid meets the regions under the scan's centre -- several times the mean -- first and ends on light ones
+__global__ __launch_bounds__(1024) void bin_order_kernel(const uint32_t* __restrict__ totals, int R, int* __restrict__ order) {
+  __shared__ uint32_t t[kBinMaxRegions];
+  for (int i = threadIdx.x; i < R; i += blockDim.x) t[i] = totals[i];
+  __syncthreads();
+  for (int i = threadIdx.x; i < R; i += blockDim.x) {
+    const uint32_t mine = t[i];
+    int rank = 0;
+    for (int j = 0; j < R; ++j) rank += (t[j] > mine) || (t[j] == mine && j < i);
+    order[rank] = i;
+  }
+}
+
 // pass B: block (region, split): the region's segments of the split's tiles into LDS, then the
 // block of 64 x 32 pixels into the map
 template <int kEntryBytes>
@@ -728,7 +747,7 @@ __global__ __launch_bounds__(kBlock) void bin_accumulate_kernel(MapArgs g, BinAr
   // number of regions per map row, an XCD would own whole columns of the map -- and the columns
   // under the scan's centre hold several times the samples of those at its rim (measured: 20 ms
   // against 9 ms for this kernel).  Rotating by the split spreads every column over the XCDs.
-  const int r = (int)((blockIdx.x + blockIdx.y) % (unsigned)k.R);
+  const int r = k.order[(blockIdx.x + blockIdx.y) % (unsigned)k.R];
   for (int i = threadIdx.x; i < g.S * 2 * kBinRegionPx; i += kBlock) bin_acc[i] = 0.0;
   const int per = (k.n_tiles + splits - 1) / splits;
   const int t0 = blockIdx.y * per, t1 = min(k.n_tiles, t0 + per);
@@ -1282,7 +1301,11 @@ int mrx_bin_map_bucketed(mrx_ctx* ctx, const mrx_sky_map* map, const float* d_to
   MRX_LDS_CAP(ctx, pass_a, q.lds_a);
   MRX_LDS_CAP(ctx, pass_b, lds_b);
   // enough workgroups per region to fill the chip: the regions under the scan hold most samples
-  // (round 4, onto 1024^2: 8192 items 28.4 ms, 16384 26.8, 32768 25.6, 65536 25.3, 131072 26.2 for the call)
+  // (round 4, onto 1024^2, regions in dispatch order: 8192 items 28.4 ms, 16384 26.8, 32768 25.6, 65536 25.3, 131072 26.2 for
+  //  the call; heaviest regions first: 23.6 / 22.5 / 22.6 / 22.3 / 23.1 from 16384 to 262144)
+  if (!ctx->d_bin_order) MRX_HIP(ctx, hipMalloc(&ctx->d_bin_order, sizeof(uint32_t) * 2 * kBinMaxRegions));
+  k.totals = ctx->d_bin_order;
+  k.order = reinterpret_cast<const int*>(ctx->d_bin_order + kBinMaxRegions);
   int splits = 65536 / k.R;
   splits = splits < 1 ? 1 : splits;
   for (int c0 = 0; c0 < cols_total; c0 += cols) {
@@ -1295,7 +1318,9 @@ int mrx_bin_map_bucketed(mrx_ctx* ctx, const mrx_sky_map* map, const float* d_to
     // (the table behind the entries, 16-byte aligned whatever the entry size)
     k.tab = reinterpret_cast<uint32_t*>(static_cast<char*>(d_work) + (((size_t)k.n_tiles * q.tile_entries * entry_bytes + 15) & ~(size_t)15));
     MRX_HIP(ctx, hipMemsetAsync(k.tab, 0, (size_t)k.R * k.n_tiles * sizeof(uint32_t), ctx->stream));
+    MRX_HIP(ctx, hipMemsetAsync(k.totals, 0, (size_t)k.R * sizeof(uint32_t), ctx->stream));
     hipLaunchKernelGGL(pass_a, dim3(nc, tiles_y), dim3(kBlock), q.lds_a, ctx->stream, g, b, k);
+    hipLaunchKernelGGL(bin_order_kernel, dim3(1), dim3(1024), 0, ctx->stream, k.totals, k.R, const_cast<int*>(k.order));
     const int sp = splits < k.n_tiles ? splits : k.n_tiles;
     hipLaunchKernelGGL(pass_b, dim3(k.R, sp), dim3(kBlock), lds_b, ctx->stream, g, b, k, sp);
     MRX_CHECK_LAUNCH(ctx);
