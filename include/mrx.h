@@ -31,12 +31,12 @@
 extern "C" {
 #endif
 
-#define MRX_VERSION 141 /* 0.2.0 (120): mrx_spline_upsample_fused, mrx_allgather_tod_p2p, mrx_exchange_screens,
+#define MRX_VERSION 142 /* 0.2.0 (120): mrx_spline_upsample_fused, mrx_allgather_tod_p2p, mrx_exchange_screens,
                            mrx_resample_columns; MRX_OPT_SAMPLE_TILES retired.  130: mrx_screen_amplitudes,
                            mrx_screen_desc.d_amp, mrx_screen_generate_3d(..., d_amp), mrx_streams_concurrent.
                            131: mrx_coarse_to_krj_keep_tail.  140: mrx_screen_desc.periodic_beam,
                            mrx_noise_generate_krj, the noise generator's two-rate form.  141: mrx_atm_synthesize,
-                           MRX_FLAG_HANDOVER */
+                           MRX_FLAG_HANDOVER.  142: mrx_atm_synthesize_krj, MRX_OPT_WRITER_PER_TILE */
 
 typedef enum mrx_status {
   MRX_OK = 0,
@@ -300,6 +300,29 @@ int mrx_atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d_az
                        const float* d_mueller00, int D, double pwv0, float* d_coarse, int block_rows,
                        int head_rows, uint32_t* d_flags, double ta0, double dta, const double* d_t, int T,
                        const float* d_scale, const int32_t* d_rows, float* d_out, size_t ld_out);
+
+/* mrx_atm_synthesize with TOD.to("K_RJ") applied on the coarse grid (tod/tod.py:106-142 before the spline, as
+ * mrx_coarse_to_krj does between the two calls -- same functions, same operands, same bits): the sampler role divides
+ * every coarse sample by den_band(d)(el_det(d, j)) before it stores it, and the writer role then writes K_RJ at the
+ * pW writer's cost.  Use it where mrx_coarse_to_krj applies (the caller bounds the form's error:
+ * DevicePath.coarse_krj_bound).
+ *  d_cal_dx, d_cal_dy [D]   detector offsets as the calibration holds them (mrx_coarse_to_krj's d_dx, d_dy)
+ *  d_cal_axis_el [n_el], d_cal_values [n_bands][n_el], n_el, n_bands   as mrx_coarse_to_krj; the cell table
+ *                           (16 (n_el - 1) n_bands bytes) must fit the launch's LDS beside the sampler's:
+ *                           MRX_ERR_UNSUPPORTED otherwise
+ *  d_tail_pw, tail_knots, ld_tail   as mrx_coarse_to_krj_keep_tail: the last tail_knots knots of every detector IN
+ *                           pW, element (k, d) at d_tail_pw[k * ld_tail + d] (d: the row in this call's D), for the
+ *                           samples past the last knot, which take the per-sample form; NULL / 0: not kept
+ *  T                        the samples the writer role writes: those up to the last knot when a tail is kept
+ *  d_coarse                 holds K_RJ afterwards */
+int mrx_atm_synthesize_krj(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d_az, const float* d_el,
+                           int Ta, const float* d_dx, const float* d_dy, const int32_t* d_band,
+                           const float* d_mueller00, int D, double pwv0, float* d_coarse, int block_rows,
+                           int head_rows, uint32_t* d_flags, double ta0, double dta, const double* d_t, int T,
+                           const float* d_scale, const int32_t* d_rows, float* d_out, size_t ld_out,
+                           const float* d_cal_dx, const float* d_cal_dy, const float* d_cal_axis_el,
+                           const float* d_cal_values, int n_el, int n_bands, float* d_tail_pw, int tail_knots,
+                           size_t ld_tail);
 
 /* mrx_spline_upsample fused with TOD.to("K_RJ") (tod/tod.py:106-142): each sample
  * is divided by den_b(el) = (0.5 if polarized else 1) * k_B * 1e12 *

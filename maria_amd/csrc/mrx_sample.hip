@@ -400,9 +400,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kT == 1 
     int nby) {
   extern __shared__ __align__(16) float4 lds_px[];
   // one block of D rows, nobody to tell: the body is mrx_sample_px.h's
+  PxNoHooks hooks;
   px_sample_items<kLdsTables, kT, kPipe, false>(fast, lpx, n_layers, offpx, tables, n_tables, table_data, table_floats, az, el, Ta,
                                          dxs, dys, band, mueller00, D, pwv0, pwv_out, loading, flags, chunk, nby, D, 1, 0, 1,
-                                         (int)blockIdx.x, (int)gridDim.x, lds_px, [](int) {});
+                                         (int)blockIdx.x, (int)gridDim.x, lds_px, hooks);
 }
 
 // ---- plan construction ------------------------------------------------------

@@ -208,7 +208,10 @@ __device__ __forceinline__ float band_loading_px(const mrx_table_dev& tb, const 
 // index and grid size, one detector block, nothing to signal) and the sampler role of the one-launch synthesis
 // (atm_tod_kernel, mrx_spline.hip).  The detectors come in `n_blocks` blocks of `block_rows` rows (the last one
 // shorter); block b's loading is its own time-major array loading + Ta * (b * block_rows) of [Ta][rows of b], and
-// `done(b)` is called by every thread after each finished work item of block b (its stores issued, not yet waited for).
+// `hooks.item(b, d)` is called by every thread at the start of a work item of block b with its detector's row in the
+// whole shard, `hooks.value(loading, (cos, sin, ..) of the step's boresight, step, row, real)` gives what is stored for
+// a sample, and `hooks.done(b)` is called by every thread after each finished work item (its stores issued, not yet
+// waited for).  PxNoHooks: the loading as it is, nobody to tell.
 // kWriteThrough (the synthesis role): the loading leaves the CU as 16-byte write-through (sc1) stores -- four steps of
 // a wave are turned in LDS so that a lane holds four neighbouring detectors of one step -- into rows of pitch
 // round_up(rows of b, 32) floats, every 128-byte line written whole by one store instruction (lanes past the last
@@ -217,7 +220,13 @@ __device__ __forceinline__ float band_loading_px(const mrx_table_dev& tb, const 
 // 0.18 ms of a 1.9-ms step).  Otherwise plain 4-byte stores at pitch = rows.
 // Parameters are passed one by one, not in a struct: the callers hand their `const __restrict__` kernel arguments
 // through, which is what lets the compiler keep the wave-uniform loads (layer records, anchors' inputs) on the scalar unit.
-template <bool kLdsTables, int kT, bool kPipe, bool kWriteThrough, typename Done>
+struct PxNoHooks {
+  __device__ __forceinline__ void item(int, int) {}
+  __device__ __forceinline__ float value(float v, const float4&, int, int, bool) const { return v; }
+  __device__ __forceinline__ void done(int) {}
+};
+
+template <bool kLdsTables, int kT, bool kPipe, bool kWriteThrough, typename Hooks>
 __device__ __forceinline__ void px_sample_items(
     const mrx_layer_fast* __restrict__ fast, const mrx_layer_px* __restrict__ lpx, int n_layers,
     const double2* __restrict__ offpx, const mrx_table_dev* __restrict__ tables, int n_tables,
@@ -225,7 +234,7 @@ __device__ __forceinline__ void px_sample_items(
     const float* __restrict__ el, int Ta, const float* __restrict__ dxs_all, const float* __restrict__ dys_all,
     const int32_t* __restrict__ band_all, const float* __restrict__ mueller00_all, int D_all, double pwv0,
     double* __restrict__ pwv_out_all, float* __restrict__ loading_all, uint32_t* __restrict__ flags, int chunk,
-    int nby, int block_rows, int n_blocks, int blk_begin, int blk_end, int wg, int n_wgs, float4* lds_px, Done done) {
+    int nby, int block_rows, int n_blocks, int blk_begin, int blk_end, int wg, int n_wgs, float4* lds_px, Hooks& hooks) {
   // [chunk * n_layers anchors of 32 bytes: (fraction e, fraction c, middle e, middle c), byte offset of the anchor's
   //  cell, padding][band tables]
   __shared__ float4 bore[kMaxChunk];   // per step: cos/sin of (el - pi/2), cos/sin of az
@@ -309,6 +318,7 @@ __device__ __forceinline__ void px_sample_items(
     const int d = bx * kPxBlock + threadIdx.x;
     const bool live = d < D;
     const int dd = live ? d : D - 1;  // keep addresses valid; stores are masked
+    hooks.item(blk, (int)row0 + dd);
     // ---- per-detector constants (coords/transforms.py:14-23), float32 ------
     const float dx = dxs[dd], dy = dys[dd];
     const float r = sqrtf(dx * dx + dy * dy);
@@ -422,9 +432,11 @@ __device__ __forceinline__ void px_sample_items(
         bool table_oob;
         const float out = band_loading_px(tb, tdata, (float)pwv, theta[tt], m00, table_oob);
         if (t < Ta) iflags |= (off ? MRX_FLAG_SCREEN_OOB : 0u) | (table_oob ? MRX_FLAG_TABLE_OOB : 0u) | (out != out ? MRX_FLAG_NAN : 0u);
+        // what is stored: the loading itself, or what the caller's hook makes of it (K_RJ on the coarse grid)
+        const float kept = hooks.value(out, bore[it + tt], t, (int)row0 + dd, live && t < Ta);
         if (kWriteThrough) {
           const int u = (it + tt) & 3, lane = threadIdx.x & 63;
-          turn[u * 64 + lane] = out;
+          turn[u * 64 + lane] = kept;
           __builtin_amdgcn_wave_barrier();  // (the read below takes other lanes' values: keep it behind the write)
           if (u == 3 || it + tt == chunk - 1 || t >= Ta - 1) {
             // lane 4k + j takes step j of the group, detectors 4k .. 4k+3 (same wave: LDS keeps the order)
@@ -440,13 +452,13 @@ __device__ __forceinline__ void px_sample_items(
           }
         } else if (live && t < Ta) {
           const size_t o = (size_t)t * D + d;
-          loading[o] = out;
+          loading[o] = kept;
           if (pwv_out) pwv_out[o] = pwv;
         }
       }
     }  // chunk loop
     if (live) myflags |= iflags;
-    done(blk);
+    hooks.done(blk);
   }  // item loop
   if (myflags) atomicOr(flags, myflags);
 }

@@ -652,6 +652,8 @@ class DevicePath:
     def coarse_loading(self):
         """[D, Ta] float32 coarse loading in the caller's detector order (device tensor)."""
         if getattr(self, "_synthesized", False):  # the last run was one launch: blocks of [Ta][pitch] (mrx_atm_synthesize)
+            if getattr(self, "_synthesized_krj", False):
+                raise RuntimeError("the last run() wrote its coarse loading in K_RJ: call sample() (pW) before coarse_loading()")
             br, parts = self._synth_block_rows, []
             for lo in range(0, self.D, br):
                 n = min(br, self.D - lo)
@@ -688,13 +690,16 @@ class DevicePath:
         (the pW writer then writes K_RJ), per sample by mrx_spline_upsample_krj otherwise."""
         if out is None:
             out = torch.empty((self.D, self.T), dtype=torch.float32, device=self.device)
-        if blocks is None and not krj and self.synthesize_applies():
+        coarse_form = krj and krj != "sample" and self.coarse_krj_bound() <= self.COARSE_KRJ_LIMIT
+        if blocks is None and (not krj or (coarse_form and not getattr(self, "_synth_krj_unsupported", False))) and self.synthesize_applies():
             try:
-                return self.synthesize(out, writer_events=writer_events)
+                return self.synthesize(out, writer_events=writer_events, krj=bool(krj))
             except MrxError as e:
                 if e.code != -4:  # MRX_ERR_UNSUPPORTED
                     raise
-                self._synth_unsupported = True  # (a layer off a uniform axis, a literal option, cubic tables: the two-call forms)
+                # (a layer off a uniform axis, a literal option, cubic tables -- or, in K_RJ, a cell table too large for the
+                #  launch's LDS: the two-call forms)
+                setattr(self, "_synth_krj_unsupported" if krj else "_synth_unsupported", True)
         if blocks is None:
             blocks = self.default_blocks()
         if krj and not self.coarse_krj_bound() <= self.COARSE_KRJ_LIMIT:
@@ -723,13 +728,15 @@ class DevicePath:
         return (not self.keep_pwv and self.D >= 2048 and work < 0.3 and not getattr(self, "_synth_unsupported", False)
                 and getattr(self, "_la", None) is None)
 
-    def synthesize(self, out=None, block_rows=None, resident_wgs_per_cu=None, head_rows=None, writer_events=None):
+    def synthesize(self, out=None, block_rows=None, resident_wgs_per_cu=None, head_rows=None, writer_events=None, krj=False):
         """Atmosphere -> TOD in ONE launch (mrx_atm_synthesize): the sampler and the writer as two roles of one grid,
         the hand-over between them on the device.  Same bits as the two-call forms.  ``block_rows``: detectors per
         block, the unit of the hand-over; ``head_rows``: rows sampled by a grid that fills the chip before the writers
         enter; ``resident_wgs_per_cu``: sampler workgroups per CU beside the writers.  Defaults from sweeps on 2 512,
         5 000 and 10 000 rows of atlast_10k (scripts/exp_synth.py): 512-row blocks, a third of the
-        rows as head start, 2 workgroups from 8192 rows and 3 below."""
+        rows as head start, 2 workgroups from 8192 rows and 3 below.  ``krj``: the TOD in K_RJ by the coarse-grid form
+        (mrx_atm_synthesize_krj: the division in the sampler role's epilogue; set_calibration first, and the caller has
+        checked coarse_krj_bound() as run() does); the samples past the last knot take the per-sample form afterwards."""
         if self.plan is None:
             raise RuntimeError("no screens bound: call set_screens() or generate_screens() first")
         if out is None:
@@ -751,15 +758,25 @@ class DevicePath:
             self._coarse_blocks = torch.empty(self.Ta * ((self.D + 31) // 32 * 32), dtype=torch.float32, device=self.device)
         saved = self.ctx.get_option(_lib.OPT_SAMPLE_WGS_PER_CU)
         self.ctx.set_option(_lib.OPT_SAMPLE_WGS_PER_CU, int(resident_wgs_per_cu))
+        args = [self.plan, ptr(self.d_az), ptr(self.d_el), self.Ta, ptr(self.d_dx), ptr(self.d_dy),
+                ptr(self.d_band), ptr(self.d_m00), self.D, self.pwv0, ptr(self._coarse_blocks), int(block_rows), int(head_rows),
+                ptr(self.d_flags), self.ta0, self.dta, ptr(self.d_t), self._krj_split() if krj else self.T,
+                None if self.d_gain is None else ptr(self.d_gain), None if self.d_rows is None else ptr(self.d_rows),
+                ptr(out), out.stride(0)]
+        tail = None
+        if krj:
+            c = self._cal
+            if self._krj_split() < self.T:  # the samples past the last knot: per sample, from the last knots in pW
+                if getattr(self, "_synth_tail", None) is None:
+                    self._synth_tail = torch.empty((self._krj_tail_knots(), self.D), dtype=torch.float32, device=self.device)
+                tail = self._synth_tail
+            args += [ptr(c["dx"]), ptr(c["dy"]), ptr(c["axis"]), ptr(c["values"]), c["n_el"], c["n_bands"],
+                     ptr(tail), 0 if tail is None else tail.shape[0], 0 if tail is None else tail.stride(0)]
         try:
             with _range("Sampling turbulence + Computing atmospheric emission + Upsampling atmospheric loading"):
-                self.ctx.call(
-                    "mrx_atm_synthesize", self.plan, ptr(self.d_az), ptr(self.d_el), self.Ta, ptr(self.d_dx), ptr(self.d_dy),
-                    ptr(self.d_band), ptr(self.d_m00), self.D, self.pwv0, ptr(self._coarse_blocks), int(block_rows), int(head_rows),
-                    ptr(self.d_flags), self.ta0, self.dta, ptr(self.d_t), self.T,
-                    None if self.d_gain is None else ptr(self.d_gain), None if self.d_rows is None else ptr(self.d_rows),
-                    ptr(out), out.stride(0),
-                )
+                self.ctx.call("mrx_atm_synthesize_krj" if krj else "mrx_atm_synthesize", *args)
+                if tail is not None:
+                    self._krj_tail(tail, self.D, slice(0, self.D), out, ptr(self.d_rows), self.ctx)
         finally:
             self.ctx.set_option(_lib.OPT_SAMPLE_WGS_PER_CU, saved)
         if writer_events is not None:
@@ -768,6 +785,7 @@ class DevicePath:
         br = int(block_rows) if int(block_rows) > 0 else self.D
         self._synth_block_rows = min((br + 255) // 256 * 256, (self.D + 31) // 32 * 32)  # as the library rounds it
         self._synthesized = True
+        self._synthesized_krj = bool(krj)  # (the coarse blocks then hold K_RJ, not pW)
         self._pipelined = False
         self._pwv_stale = True
         return out

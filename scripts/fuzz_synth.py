@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 import numpy as np
 import torch
 from helpers import attach_numpy_screens
+from test_gpu_calibration import _cal_tables
 from maria_amd import synthetic
 from maria_amd._lib import Context
 from maria_amd.pipeline import DevicePath
@@ -30,8 +31,16 @@ for trial in range(trials):
                                                     timestep=timestep, seed=int(rng.integers(1 << 30)), gain=bool(rng.random() < 0.5)))
     path = DevicePath(p, device="cuda:0", ctx=ctx)
     path.clear_flags()
-    want = path.run(blocks=1)
-    coarse = path.coarse_loading().clone()
+    krj = False
+    if rng.random() < 0.4:  # K_RJ on the coarse grid in the same launch (mrx_atm_synthesize_krj), where its bound allows
+        _, el_full = synthetic.daisy_scan(p["t"])
+        roll = rng.uniform(0, 2 * np.pi)
+        R = np.array([[np.cos(roll), -np.sin(roll)], [np.sin(roll), np.cos(roll)]])
+        nb = len(p["tables"])
+        path.set_calibration(_cal_tables(nb), 273.15, 1.0, el_full, p["offsets"] @ R.T, [bool(rng.random() < 0.5) for _ in range(nb)])
+        krj = bool(path.coarse_krj_bound() <= path.COARSE_KRJ_LIMIT)
+    want = path.run(blocks=1, krj=krj)
+    coarse = None if krj else path.coarse_loading().clone()
     torch.cuda.synchronize()
     f0 = path.check_flags() if False else int(path.d_flags.item())
     block_rows = int(rng.choice([0, 256, 512, 768, 1024, 4096]))
@@ -41,11 +50,11 @@ for trial in range(trials):
     ok = True
     for _ in range(reps):
         got = torch.full_like(want, float("nan"))
-        path.synthesize(got, block_rows=block_rows, head_rows=head_rows, resident_wgs_per_cu=wgs)
+        path.synthesize(got, block_rows=block_rows, head_rows=head_rows, resident_wgs_per_cu=wgs, krj=krj)
         torch.cuda.synchronize()
-        ok = ok and bool(torch.equal(got, want)) and bool(torch.equal(path.coarse_loading(), coarse)) and int(path.d_flags.item()) == f0
+        ok = ok and bool(torch.equal(got, want)) and (krj or bool(torch.equal(path.coarse_loading(), coarse))) and int(path.d_flags.item()) == f0
     tag = "ok " if ok else "BAD"
     bad += not ok
-    print(f"{tag} trial {trial}: D {path.D} Ta {path.Ta} T {path.T} layers {n_layers} bands {n_bands} block_rows {block_rows} head {head_rows} wgs {wgs} reps {reps} flags {f0}", flush=True)
+    print(f"{tag} trial {trial}: D {path.D} Ta {path.Ta} T {path.T} layers {n_layers} bands {n_bands} block_rows {block_rows} head {head_rows} wgs {wgs} reps {reps} flags {f0} krj {krj}", flush=True)
 print(f"fuzz_synth seed {seed}: {bad} bad of {trials}")
 sys.exit(1 if bad else 0)

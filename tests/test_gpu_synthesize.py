@@ -122,6 +122,38 @@ def test_flags_travel_and_unsupported_plans_are_refused(gpu_ctx):
     assert torch.equal(good.synthesize(), want)
 
 
+def test_krj_on_the_coarse_grid_in_the_same_launch(gpu_ctx):
+    """mrx_atm_synthesize_krj: TOD.to("K_RJ") (tod/tod.py:106-142) applied to the coarse loading in the sampler role's
+    epilogue -- the same bits as mrx_coarse_to_krj between the two calls, tail past the last knot included; two bands,
+    one polarised, rolled calibration offsets, a gain."""
+    import torch
+
+    from maria_amd import synthetic
+    from test_gpu_calibration import _cal_tables
+
+    p = small_problem(n_det=700, n_bands=2, n_layers=3, gain=True)
+    _, el_full = synthetic.daisy_scan(p["t"])
+    roll = np.radians(17.0)
+    R = np.array([[np.cos(roll), -np.sin(roll)], [np.sin(roll), np.cos(roll)]])
+    path = _path(p, gpu_ctx)
+    path.set_calibration(_cal_tables(2), 273.15, 1.0, el_full, p["offsets"] @ R.T, [False, True])
+    assert 0 < path.coarse_krj_bound() <= path.COARSE_KRJ_LIMIT
+    want = path.run(blocks=1, krj=True)
+    torch.cuda.synchronize()
+    assert 0 < path._krj_split() < path.T
+    for block_rows, head_rows, wgs in ((256, 0, 3), (512, 256, 2), (0, 0, 4)):
+        got = torch.full_like(want, float("nan"))
+        path.synthesize(got, block_rows=block_rows, head_rows=head_rows, resident_wgs_per_cu=wgs, krj=True)
+        torch.cuda.synchronize()
+        assert path.check_flags() == 0
+        assert torch.equal(got, want), (block_rows, head_rows, wgs)
+    with pytest.raises(RuntimeError, match="K_RJ"):
+        path.coarse_loading()
+    # and pW again afterwards
+    pw = path.run(blocks=1)
+    assert torch.equal(path.synthesize(), pw)
+
+
 def test_full_size_default_run_is_the_one_launch_form_and_bit_identical(gpu_ctx):
     """atlast_10k at full size: run() takes the one-launch form by default; its TOD equals the stages back to back
     word for word, twenty times over with the launch shapes the sweeps covered (hand-overs under load, every
