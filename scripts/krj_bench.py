@@ -29,9 +29,10 @@ for rep in range(1):
 def per_sample():
     path.sample(); path.prepare(); path.upsample_krj(tod)
 print("coarse K_RJ bound %.3g (limit %.3g)" % (path.coarse_krj_bound(), path.COARSE_KRJ_LIMIT))
-print("TOD synthesis in K_RJ: per-sample writer %.3f ms | coarse form, serial %.3f ms | coarse form, pipelined %.3f ms | pW pipelined %.3f ms" % (
-    timeit(per_sample, 10)[0], timeit(lambda: path.run(tod, blocks=1, krj=True), 10)[0], timeit(lambda: path.run(tod, krj=True), 10)[0],
-    timeit(lambda: path.run(tod), 10)[0]), flush=True)
+print("TOD synthesis in K_RJ: per-sample writer %.3f ms | coarse form, serial %.3f ms | coarse form, two streams %.3f ms | coarse form, one launch %.3f ms | pW two streams %.3f ms | pW one launch %.3f ms" % (
+    timeit(per_sample, 10)[0], timeit(lambda: path.run(tod, blocks=1, krj=True), 10)[0],
+    timeit(lambda: path.run(tod, blocks=path.default_blocks(), krj=True), 10)[0], timeit(lambda: path.run(tod, krj=True), 10)[0],
+    timeit(lambda: path.run(tod, blocks=path.default_blocks()), 10)[0], timeit(lambda: path.run(tod), 10)[0]), flush=True)
 a = path.run(torch.empty_like(tod), krj=True)
 per_sample()
 print("max relative deviation of the coarse form from the per-sample writer: %.3g" % float(((a - tod).abs() / tod.abs()).max()))
