@@ -122,6 +122,45 @@ def test_flags_travel_and_unsupported_plans_are_refused(gpu_ctx):
     assert torch.equal(good.synthesize(), want)
 
 
+def test_screens_beyond_the_pixel_kernels_addressing_take_the_general_kernel(gpu_ctx):
+    """The pixel-coordinate sampler forms a 32-bit byte offset with a 24-bit row multiply: a screen side of 2^22 nodes or
+    more (or a screen of 4 GiB) must not reach it.  Such a plan is not `all_pixel`: the one-launch form -- which has no
+    other sampler -- refuses it, mrx_atm_sample takes the general kernel and flags what leaves the (here tiny) screen
+    instead of reading wrong pixels."""
+    import torch
+
+    from maria_amd import _lib
+
+    def wide(n_c):
+        p = small_problem(n_det=40, n_layers=1)
+        lay = p["layers"][0]
+        dc = float(lay["cross_section"][1] - lay["cross_section"][0])
+        lay["extrusion"] = np.asarray(lay["extrusion"])[:8]
+        lay["cross_section"] = float(lay["cross_section"][0]) + dc * np.arange(n_c)
+        lay["values"] = np.zeros((8, n_c), np.float32)
+        return p
+
+    below = _path(wide((1 << 22) - 8), gpu_ctx)
+    below.clear_flags()
+    below.synthesize()  # accepted: the pixel kernel's range
+    torch.cuda.synchronize()
+    below.clear_flags()
+    del below
+    torch.cuda.empty_cache()
+    beyond = _path(wide((1 << 22) + 8), gpu_ctx)
+    with pytest.raises(_lib.MrxError) as e:
+        beyond.synthesize()
+    assert e.value.code == -4
+    beyond.clear_flags()
+    beyond.sample()  # the general kernel: no fault, and the lines of sight that leave the 8 rows are flagged
+    torch.cuda.synchronize()
+    with pytest.raises(RuntimeError, match="introduced nans"):
+        beyond.check_flags()
+    beyond.clear_flags()
+    del beyond
+    torch.cuda.empty_cache()
+
+
 def test_krj_on_the_coarse_grid_in_the_same_launch(gpu_ctx):
     """mrx_atm_synthesize_krj: TOD.to("K_RJ") (tod/tod.py:106-142) applied to the coarse loading in the sampler role's
     epilogue -- the same bits as mrx_coarse_to_krj between the two calls, tail past the last knot included; two bands,
