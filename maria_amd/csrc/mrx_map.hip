@@ -21,6 +21,8 @@
 // available through MRX_OPT_POINTING_CHAIN and agrees to float32 rounding of the angles).
 // Bound by arithmetic (float64 weights and sums, as the reference's sparse product), not
 // by memory.
+#include <type_traits>
+
 #include "mrx_internal.h"
 
 namespace {
@@ -514,8 +516,12 @@ constexpr uint32_t kBinNone = 0xffffffffu;
 
 template <bool kBil>
 struct BinTile {
-  static constexpr int kDet = kBil ? 8 : 16;     // detectors per tile
-  static constexpr int kSpt = kBil ? 1 : 4;      // samples per thread
+#ifndef MRX_BIN_DET
+#define MRX_BIN_DET 16
+#define MRX_BIN_SPT 4
+#endif
+  static constexpr int kDet = kBil ? 8 : MRX_BIN_DET;     // detectors per tile (< 32: five bits of an entry)
+  static constexpr int kSpt = kBil ? 1 : MRX_BIN_SPT;     // samples per thread
   static constexpr int kCorners = kBil ? 4 : 1;
   static constexpr int kSamples = kBlock * kSpt;
   static constexpr int kEntries = kDet * kSamples * kCorners;  // 16 384 / 8 192 contributions per tile at most
@@ -592,7 +598,10 @@ __device__ __forceinline__ void bin_corners(const MapArgs& g, const BucketArgs& 
 
 template <bool kChain, bool kBil, bool kW>
 // (168 registers instead of 174: measured 21.3 -> 19.7 ms)
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) void bin_bucket_kernel(MapArgs g, BinArgs b, BucketArgs k) {
+#ifndef MRX_BIN_WAVES
+#define MRX_BIN_WAVES 3
+#endif
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_BIN_WAVES, MRX_BIN_WAVES))) void bin_bucket_kernel(MapArgs g, BinArgs b, BucketArgs k) {
   using Tile = BinTile<kBil>;
   using Entry = BinEntryT<bin_entry_bytes(kBil, kW)>;
   constexpr int kDet = Tile::kDet, kSpt = Tile::kSpt, kCorners = Tile::kCorners;
@@ -604,10 +613,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) 
   // as the cursors that lets THREE workgroups share a CU's LDS instead of two (the kernel waits on its pointing
   // arithmetic and its LDS atomics: occupancy is what it lacks; pass A 16.9 -> 13.1 ms onto 1024^2).  A thread's four
   // words of one detector are neighbours in both arrays: one 8-byte and one 4-byte LDS access each way.
-  constexpr int kGroup = kSpt * kCorners;  // 4 in both forms
-  static_assert(kGroup == 4, "four sort words per thread and detector");
-  uint2* lo16 = reinterpret_cast<uint2*>(bucket_lds);            // [kEntries / 4] 4 x uint16, by (detector, thread)
-  uint32_t* hi8 = bucket_lds + Tile::kEntries / 2;               // [kEntries / 4] 4 x uint8
+  constexpr int kGroup = kSpt * kCorners;  // sort words per thread and detector: 4, or 2
+  static_assert(kGroup == 4 || kGroup == 2, "two or four sort words per thread and detector");
+  using Lo = std::conditional_t<kGroup == 4, uint2, uint32_t>;     // kGroup x uint16
+  using Hi = std::conditional_t<kGroup == 4, uint32_t, uint16_t>;  // kGroup x uint8
+  Lo* lo16 = reinterpret_cast<Lo*>(bucket_lds);                   // [kEntries / kGroup], by (detector, thread)
+  Hi* hi8 = reinterpret_cast<Hi*>(bucket_lds + Tile::kEntries / 2);  // [kEntries / kGroup]
   uint32_t* hist = bucket_lds + Tile::kEntries / 2 + Tile::kEntries / 4;  // [R]: counts, then (after the scan) cursors
   float2* oxy = reinterpret_cast<float2*>(hist + k.R);  // bilinear: [kDet][kSamples] offsets of the samples
   const int d0 = blockIdx.y * kDet;
@@ -651,9 +662,14 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) 
       for (int c = 0; c < kCorners; ++c) grp[q * kCorners + c] = word[c];
     }
     // (kBinNone >> 16 = 0xffff: its high byte reads 0xff, which no region's does -- R <= 2048 leaves 6 bits there)
-    lo16[dl * kBlock + threadIdx.x] = make_uint2((grp[0] & 0xffffu) | (grp[1] << 16), (grp[2] & 0xffffu) | (grp[3] << 16));
-    hi8[dl * kBlock + threadIdx.x] = ((grp[0] >> 16) & 0xffu) | (((grp[1] >> 16) & 0xffu) << 8) | (((grp[2] >> 16) & 0xffu) << 16) |
-                                     (((grp[3] >> 16) & 0xffu) << 24);
+    if constexpr (kGroup == 4) {
+      lo16[dl * kBlock + threadIdx.x] = make_uint2((grp[0] & 0xffffu) | (grp[1] << 16), (grp[2] & 0xffffu) | (grp[3] << 16));
+      hi8[dl * kBlock + threadIdx.x] = ((grp[0] >> 16) & 0xffu) | (((grp[1] >> 16) & 0xffu) << 8) | (((grp[2] >> 16) & 0xffu) << 16) |
+                                       (((grp[3] >> 16) & 0xffu) << 24);
+    } else {
+      lo16[dl * kBlock + threadIdx.x] = (grp[0] & 0xffffu) | (grp[1] << 16);
+      hi8[dl * kBlock + threadIdx.x] = (uint16_t)(((grp[0] >> 16) & 0xffu) | (((grp[1] >> 16) & 0xffu) << 8));
+    }
   }
   __syncthreads();
   // exclusive scan of the histogram: where each region's contributions start in the tile's slot
@@ -685,10 +701,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(3, 3))) 
   for (int dl = 0; dl < nd; ++dl) {
     const int d = d0 + dl;
     const int chan = b.channel ? min(max(b.channel[d], 0), g.C - 1) : 0;
-    const uint2 l2 = lo16[dl * kBlock + threadIdx.x];
-    const uint32_t h4 = hi8[dl * kBlock + threadIdx.x];
-    const uint32_t grp[kGroup] = {(l2.x & 0xffffu) | ((h4 & 0xffu) << 16), (l2.x >> 16) | (((h4 >> 8) & 0xffu) << 16),
-                                  (l2.y & 0xffffu) | (((h4 >> 16) & 0xffu) << 16), (l2.y >> 16) | ((h4 >> 24) << 16)};
+    uint32_t grp[kGroup];
+    if constexpr (kGroup == 4) {
+      const uint2 l2 = lo16[dl * kBlock + threadIdx.x];
+      const uint32_t h4 = hi8[dl * kBlock + threadIdx.x];
+      grp[0] = (l2.x & 0xffffu) | ((h4 & 0xffu) << 16);
+      grp[1] = (l2.x >> 16) | (((h4 >> 8) & 0xffu) << 16);
+      grp[2] = (l2.y & 0xffffu) | (((h4 >> 16) & 0xffu) << 16);
+      grp[3] = (l2.y >> 16) | ((h4 >> 24) << 16);
+    } else {
+      const uint32_t l2 = lo16[dl * kBlock + threadIdx.x];
+      const uint32_t h2 = hi8[dl * kBlock + threadIdx.x];
+      grp[0] = (l2 & 0xffffu) | ((h2 & 0xffu) << 16);
+      grp[1] = (l2 >> 16) | ((h2 >> 8) << 16);
+    }
 #pragma unroll
     for (int q = 0; q < kSpt; ++q) {
       if (sb + q >= k.s1) continue;
