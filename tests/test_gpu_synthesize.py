@@ -228,6 +228,38 @@ def test_full_size_default_run_is_the_one_launch_form_and_bit_identical(gpu_ctx)
     torch.cuda.empty_cache()
 
 
+def test_hand_over_beside_other_work_on_the_chip(gpu_ctx):
+    """The hand-over under uneven load: another stream streams through 8 GB (and a third one spins arithmetic) while the
+    launch runs, so that the roles' workgroups are dispatched late and unevenly and every cache is busy with other lines;
+    every word of the TOD still equals the two calls', ten times."""
+    import torch
+
+    p = config_problem("atlast_10k", n_det=6000)
+    path = _path(p, gpu_ctx)
+    path.generate_screens()
+    want = path.run(blocks=1)
+    torch.cuda.synchronize()
+    got = torch.empty_like(want)
+    big = torch.ones(1 << 30, dtype=torch.float32, device="cuda:0")  # 4 GB read + 4 GB written per pass
+    small = torch.rand(1 << 22, dtype=torch.float32, device="cuda:0")
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    for rep in range(10):
+        got.fill_(float("nan"))
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s1):
+            for _ in range(1 + rep % 3):
+                big.mul_(1.0000001)
+        with torch.cuda.stream(s2):
+            for _ in range(20):
+                small = torch.sin(small) * 1.0001 + 0.1
+        path.synthesize(got, block_rows=512, head_rows=(rep % 4) * 1024, resident_wgs_per_cu=2 + rep % 2)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want), rep
+    assert path.check_flags() == 0
+    del big, got, want
+    torch.cuda.empty_cache()
+
+
 def test_the_writer_on_its_own_takes_tiles_from_a_queue(gpu_ctx):
     """mrx_spline_upsample_fused is a resident grid over a tile queue: many launches in a row (the queue is left
     zero by the launch itself) on a shape with more tiles than workgroups, against the two-call form's spline."""
