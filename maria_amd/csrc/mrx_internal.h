@@ -164,7 +164,7 @@ inline int mrx_lds_cap(mrx_ctx* ctx, const void* fn, size_t bytes) {
     if (rc__ != MRX_OK) return rc__;                                                       \
   } while (0)
 
-// The last stage of the two-rate noise generator (mrx_noise.hip builds the slow part, mrx_spline.hip holds the writer
+// The last stage of the two-rate noise generator (mrx_noise.hip builds the slow part, the writer sits behind it in the same file
 // next to the K_RJ machinery it shares with mrx_tod_to_krj): see noise_two_rate_kernel.
 struct mrx_two_rate_args {
   const float* lo;          // [rows of this launch][ld_lo]: pink + correlated pink parts at fs / rate; sample t' at lo[t' + 1]
@@ -200,6 +200,11 @@ int mrx_noise_two_rate_write(mrx_ctx* ctx, hipStream_t stream, const mrx_two_rat
 // four white normals for samples 4 q .. 4 q + 3 of row `id`: the counter every white draw of the noise generator uses
 constexpr uint32_t kMrxTagWhite = 0x57484954u;      // 'WHIT'
 constexpr uint32_t kMrxTagModeWhite = 0x4d57484du;  // 'MWHM': the modes' white series (two-rate form)
+
+// threads per workgroup of every tiled kernel (one entity, whichever header brings the name in)
+namespace mrx_dev_common {
+constexpr int kBlock = 256;
+}
 
 static inline int mrx_ceil_div(long long a, long long b) {
   return (int)((a + b - 1) / b);

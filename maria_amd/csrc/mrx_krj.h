@@ -1,0 +1,286 @@
+// TOD.to("K_RJ") on the device: the per-detector constants, the calibration table as the kernels hold it in LDS and
+// the per-tile elevation model shared by the K_RJ writers and conversions (mrx_krj.hip), the sampler role of the
+// one-launch synthesis (mrx_synth.hip) and the two-rate noise writer (mrx_noise.hip).
+#pragma once
+
+#include "mrx_tile.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------
+// Evaluation fused with TOD.to("K_RJ") (tod/tod.py:106-142,
+// calibration/functions.py:73-90): every sample is divided by
+//     den_b(el) = (0.5 if polarized else 1) k_B  Int tau_b(nu) exp(-opacity) dnu
+// looked up at the detector's own full-rate elevation (tod.py:90-93), which is
+// recomputed here from the full-rate boresight elevation and the detector
+// offsets exactly as coords/transforms.py:14-28 does (float32): el = asin(im),
+// im = sin(r)cos(p) sin(a) + cos(r) cos(a), a = el_bore - pi/2.  den_b is the
+// band's transmission-integral table collapsed by the host at the observation's
+// scalar (base temperature, zenith pwv) onto the elevation axis
+// (band/band.py:235-255), so the lookup is a 1-D lerp with jax's index rule.
+// Same tiling as spline_upsample_kernel (knot image fixed at 256 knots).
+struct CalDet {
+  float a_re;  // sin(r) cos(p)
+  float a_im;  // cos(r)
+  int band;
+  float scale;
+  float dy, sdy, cdy;  // vertical offset and its sine / cosine
+  // el_det - el_bore as a linear function of el_bore around the tile's middle boresight
+  // elevation (it does not depend on the azimuth): el_det(s) = eb + dm + slope (eb - ebm).
+  // Curvature over a tile's elevation range (~0.02 rad) is below 1e-7 rad.  exact = 1 near the
+  // zenith, where the detector elevation is not smooth in eb: every sample takes the full formula.
+  float dm, slope, ebm;
+  int exact;
+};
+
+// detector elevation (transforms.py:20-28): im = sin(el) as the chain computes
+// it, then el = asin(im) by one Newton step from el0 = el_bore + dy, whose
+// sine and cosine follow from the angle-addition formulas (no inverse
+// trigonometry per sample); |el - el0| <= r^2 tan(el)/2 ~ 3e-4 rad, so the
+// second-order step is exact to float32 rounding.  eb: boresight elevation,
+// ca / sa: cos / sin of (eb - pi/2).
+__device__ __forceinline__ float det_elevation(const CalDet& c, float eb, float ca, float sa) {
+  const float im = __fadd_rn(__fmul_rn(c.a_re, sa), __fmul_rn(c.a_im, ca));
+  const float s0 = ca * c.cdy - sa * c.sdy;   // sin(el_bore + dy)
+  const float c0 = -sa * c.cdy - ca * c.sdy;  // cos(el_bore + dy)
+  const float rc0 = __builtin_amdgcn_rcpf(c0);
+  const float dl1 = (im - s0) * rc0;
+  float el = (eb + c.dy) + dl1 * (1.0f + 0.5f * dl1 * s0 * rc0);
+  // within ~15 deg of the zenith the expansion loses accuracy: take asin there
+  const bool steep = !(c0 > 0.25f);
+  if (__builtin_amdgcn_ballot_w64(steep) != 0)
+    if (steep) el = asinf(im);
+  return el;
+}
+
+// the linear model of CalDet around the boresight elevation ebm (see CalDet)
+constexpr float kModelHalfRange = 2.0e-2f;  // wide enough that float32 rounding of the differences stays below 1e-7 rad over a tile
+
+__device__ __forceinline__ void set_elevation_model(CalDet& c, float ebm) {
+  constexpr float h = kModelHalfRange;
+  float e[3];
+  bool steep = false;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const float eb = ebm + (float)(k - 1) * h;
+    const float a = eb - 1.57079637050628662109375f;
+    const float ca = cosf(a), sa = sinf(a);
+    steep |= !(-sa * c.cdy - ca * c.sdy > 0.3f);  // cos(el_bore + dy): within ~17 deg of the zenith
+    e[k] = det_elevation(c, eb, ca, sa) - eb;
+  }
+  c.ebm = ebm;
+  c.dm = e[1];
+  c.slope = (e[2] - e[0]) * (0.5f / h);
+  c.exact = steep ? 1 : 0;
+}
+
+__device__ __forceinline__ CalDet make_cal_det(float dx, float dy, int band, float scale) {
+  const float r = sqrtf(dx * dx + dy * dy);
+  const float p = atan2f(-dx, -dy);
+  CalDet c;
+  c.a_re = __fmul_rn(sinf(r), cosf(p));
+  c.a_im = cosf(r);
+  c.band = band;
+  c.scale = scale;
+  c.dy = dy;
+  c.sdy = sinf(dy);
+  c.cdy = cosf(dy);
+  return c;
+}
+
+// The calibration table as the kernels hold it in LDS: per band, per cell i of the elevation
+// axis one float4 (x_i, den_i, 1/(x_{i+1} - x_i), den_{i+1}), so that one 16-byte LDS read
+// serves a lookup.  n_el - 1 cells per band.
+__device__ __forceinline__ void stage_cal_cells(float4* cells, const float* __restrict__ axis,
+                                                const float* __restrict__ values, int n_el, int n_bands) {
+  const int nc = n_el - 1;
+  for (int i = threadIdx.x; i < nc * n_bands; i += kBlock) {
+    const int b = i / nc, k = i - b * nc;
+    const float x0 = axis[k], x1 = axis[k + 1];
+    cells[i] = make_float4(x0, values[b * n_el + k], 1.0f / (x1 - x0), values[b * n_el + k + 1]);
+  }
+}
+
+// den at elevation el with jax's _find_indices / linear weights on the elevation axis
+// (NaN off the axis): arithmetic guess from the first cell's step (am's axis is uniform but
+// for its last node, which the clamp absorbs), corrected by a short walk when the guess is off
+// (non-uniform axis, a sample within rounding of a node)
+__device__ __forceinline__ float den_lookup(float el, const float4* C, int n_el, float el_first,
+                                            float el_last, float el_inv) {
+  const int nc = n_el - 1;
+  int i = min(max((int)fminf(fmaxf((el - el_first) * el_inv, -1.0f), 2.0e9f), 0), nc - 1);
+  while (i < nc - 1 && C[i + 1].x < el) ++i;  // searchsorted(side="left") - 1: x_i < el <= x_{i+1}
+  while (i > 0 && C[i].x >= el) --i;
+  const float4 c = C[i];
+  const float wt = (el - c.x) * c.z;
+  float den = 0.0f + c.y * (1.0f - wt);
+  den = den + c.w * wt;
+  return (el >= el_first && el <= el_last) ? den : __builtin_nanf("");
+}
+
+// Per-thread part of the K_RJ conversion that does not depend on the detector row.
+struct KrjSamples {
+  float eb0, eb3;  // boresight elevation of the thread's first and last sample
+  float x0, x3;    // the same minus the tile's reference elevation (CalDet::ebm)
+  int curved;      // some thread of the workgroup: its four boresight elevations are NOT linear in the sample index to 1e-6 rad
+};
+
+// The K_RJ values of a thread's 4 consecutive samples of one detector.  den is piecewise
+// linear in the elevation, and the elevation is linear in the sample index to ~5e-8 rad over 4
+// samples (10 ms of scanning, over which den itself moves by ~3e-6 of its value): when the
+// first and last sample share a cell of the axis, den -- or its reciprocal, equal to second
+// order, 1e-11 -- of the inner two is interpolated between the outer ones (float32 rounding
+// apart, the value jax computes); otherwise -- a node between them, a guess that missed, an
+// elevation off the axis -- every sample is looked up on its own at the interpolated
+// elevation.  `sv` already carries the detector's scale.
+template <bool kInverse = false, bool kCurved = false>
+__device__ __forceinline__ void krj_row(const CalDet& c, const float4* C, int n_el, float el_first,
+                                        float el_last, float el_inv, const KrjSamples& k,
+                                        const float (&sv)[kSamplesPerThread], float (&o)[kSamplesPerThread],
+                                        const float* __restrict__ bore_el, int sb, int T) {
+  constexpr int kL = kSamplesPerThread - 1;
+  if constexpr (kCurved) {
+    // Low sample rates or tight fast scans (20 Hz, a 0.1 deg daisy at 0.8 deg/s: 3e-4 rad of curvature over a thread's
+    // four samples, 1e-4 of den) -- every sample at its own boresight elevation.  The workgroup takes this instance of
+    // its row loop when any of its threads sees more than 1e-6 rad (KrjSamples::curved); never at the rates the
+    // interpolation below was built for (400 Hz: 6e-8 rad).
+    // (one sample at a time, its elevation reloaded: unrolled, or with the four values kept in registers, this
+    // instance would set the kernel's register count -- 98 instead of 96 costs a wave per SIMD and 12 %)
+#pragma unroll 1
+    for (int q = 0; q < kSamplesPerThread; ++q) {
+      const float ebq = bore_el[min(sb + q, T - 1)];
+      float el;
+      if (c.exact) {
+        // (the hardware sine and cosine, in revolutions: 1e-6 rad here, where den hardly moves with the elevation;
+        // cosf / sinf inlined would set the kernel's register count)
+        const float rev = (ebq - 1.57079637050628662109375f) * 0.15915494309189535f;
+        el = det_elevation(c, ebq, __builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
+      } else {
+        el = fmaf(c.slope, ebq - c.ebm, ebq + c.dm);
+      }
+      const float den = den_lookup(el, C, n_el, el_first, el_last, el_inv);
+      const float val = kInverse ? sv[q] * den : sv[q] * __builtin_amdgcn_rcpf(den);
+      o[0] = q == 0 ? val : o[0];
+      o[1] = q == 1 ? val : o[1];
+      o[2] = q == 2 ? val : o[2];
+      o[3] = q == 3 ? val : o[3];
+    }
+    return;
+  }
+  float e0, e3;
+  if (c.exact) {  // uniform over the workgroup (one detector row at a time), and rare
+    // (sine and cosine of the boresight elevation on the spot, by the hardware instructions in revolutions -- 1e-6 rad,
+    // where den hardly moves with the elevation: kept per thread for every row they were four registers of a kernel
+    // that sits at a wave-per-SIMD boundary)
+    const float r0 = (k.eb0 - 1.57079637050628662109375f) * 0.15915494309189535f, r3 = (k.eb3 - 1.57079637050628662109375f) * 0.15915494309189535f;
+    e0 = det_elevation(c, k.eb0, __builtin_amdgcn_cosf(r0), __builtin_amdgcn_sinf(r0));
+    e3 = det_elevation(c, k.eb3, __builtin_amdgcn_cosf(r3), __builtin_amdgcn_sinf(r3));
+  } else {
+    e0 = fmaf(c.slope, k.x0, k.eb0 + c.dm);
+    e3 = fmaf(c.slope, k.x3, k.eb3 + c.dm);
+  }
+  const int i0 = min(max((int)fminf(fmaxf((e0 - el_first) * el_inv, -1.0f), 2.0e9f), 0), n_el - 2);
+  const float4 cell = C[i0];
+  const float w0 = (e0 - cell.x) * cell.z, w3 = (e3 - cell.x) * cell.z;
+  // both ends inside cell i0 (0 < w <= 1; the first cell closed below) and on the axis.  A
+  // sample within rounding of a node may be taken for either neighbour: den is continuous there.
+  const float wmin = fminf(w0, w3), wmax = fmaxf(w0, w3);
+  const bool fast = (wmin > 0.0f || (i0 == 0 && wmin >= 0.0f)) && wmax <= 1.0f &&
+                    fminf(e0, e3) >= el_first && fmaxf(e0, e3) <= el_last;
+  float d0 = 0.0f + cell.y * (1.0f - w0);
+  d0 = d0 + cell.w * w0;
+  float d3 = 0.0f + cell.y * (1.0f - w3);
+  d3 = d3 + cell.w * w3;
+  if (kInverse) {
+    const float step = (d3 - d0) * (1.0f / (float)kL);
+#pragma unroll
+    for (int q = 0; q < kSamplesPerThread; ++q) o[q] = sv[q] * (q == 0 ? d0 : q == kL ? d3 : fmaf((float)q, step, d0));
+  } else {
+    const float r0 = __builtin_amdgcn_rcpf(d0), r3 = __builtin_amdgcn_rcpf(d3);
+    const float step = (r3 - r0) * (1.0f / (float)kL);
+#pragma unroll
+    for (int q = 0; q < kSamplesPerThread; ++q) o[q] = sv[q] * (q == 0 ? r0 : q == kL ? r3 : fmaf((float)q, step, r0));
+  }
+  if (__builtin_amdgcn_ballot_w64(!fast) != 0) {
+    if (!fast) {
+      const float de = (e3 - e0) * (1.0f / (float)kL);
+#pragma unroll 1
+      for (int q = 0; q < kSamplesPerThread; ++q) {
+        const float el = q == 0 ? e0 : q == kL ? e3 : e0 + (float)q * de;
+        const float den = den_lookup(el, C, n_el, el_first, el_last, el_inv);
+        o[q] = kInverse ? sv[q] * den : sv[q] * __builtin_amdgcn_rcpf(den);
+      }
+    }
+  }
+}
+
+// Shared prologue of the two K_RJ kernels, per workgroup: stage the cell table, reduce the
+// boresight elevation range of the tile's 1024 samples (red[8] = lo, red[9] = hi) and return
+// this thread's sample constants.  Ends with a barrier.
+__device__ __forceinline__ KrjSamples krj_prologue(float4* cells, float* red, const float* __restrict__ bore_el,
+                                                   int T, int sb, const float* __restrict__ cal_axis,
+                                                   const float* __restrict__ cal_values, int n_el, int n_bands) {
+  KrjSamples k;
+  k.eb0 = bore_el[min(sb, T - 1)];
+  k.eb3 = bore_el[min(sb + kSamplesPerThread - 1, T - 1)];
+  float eb_lo, eb_hi;
+  {
+    static_assert(kSamplesPerThread == 4, "the curvature check below is written for four samples");
+    const float eb1 = bore_el[min(sb + 1, T - 1)], eb2 = bore_el[min(sb + 2, T - 1)];
+    const float third = (k.eb3 - k.eb0) * (1.0f / 3.0f);
+    k.curved = !(fabsf(eb1 - (k.eb0 + third)) <= 1.0e-6f && fabsf(eb2 - (k.eb0 + 2.0f * third)) <= 1.0e-6f);  // (a NaN: per sample too)
+    eb_lo = fminf(fminf(k.eb0, eb1), fminf(eb2, k.eb3));
+    eb_hi = fmaxf(fmaxf(k.eb0, eb1), fmaxf(eb2, k.eb3));
+  }
+  // (the samples are monotone enough that the ends of the threads' 4-sample runs bound the
+  // range to ~1e-7 rad): lanes -> waves -> workgroup
+  float lo = eb_lo, hi = eb_hi;
+#pragma unroll
+  for (int m = 32; m > 0; m >>= 1) {
+    lo = fminf(lo, __shfl_xor(lo, m, 64));
+    hi = fmaxf(hi, __shfl_xor(hi, m, 64));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    red[2 * (threadIdx.x >> 6)] = lo;
+    red[2 * (threadIdx.x >> 6) + 1] = hi;
+  }
+  stage_cal_cells(cells, cal_axis, cal_values, n_el, n_bands);
+  __syncthreads();
+  lo = fminf(fminf(red[0], red[2]), fminf(red[4], red[6]));
+  hi = fmaxf(fmaxf(red[1], red[3]), fmaxf(red[5], red[7]));
+  const float ebm = 0.5f * (lo + hi);
+  k.x0 = k.eb0 - ebm;
+  k.x3 = k.eb3 - ebm;
+  if (threadIdx.x == 0) {
+    red[8] = lo;
+    red[9] = hi;
+  }
+  k.curved = __syncthreads_or(k.curved);  // (the barrier this prologue ends with)
+  return k;
+}
+
+// Per group of 16 detector rows: their constants and the tile's elevation model.  The caller
+// puts a barrier between this and the rows' use of cdet[].  Returns nothing; cdet[16].exact
+// of the LAST entry's neighbour slot red[10] is set when any row needs the full formula.
+__device__ __forceinline__ void krj_stage_rows(CalDet* cdet, float* red, const float* __restrict__ dxs,
+                                               const float* __restrict__ dys, const int32_t* __restrict__ band,
+                                               const float* __restrict__ scale, int n_bands, int d0, int nd) {
+  if ((int)threadIdx.x < kTileDet) {
+    const float lo = red[8], hi = red[9];
+    bool exact = false;
+    if ((int)threadIdx.x < nd) {
+      const int d = d0 + threadIdx.x;
+      CalDet c = make_cal_det(dxs[d], dys[d], min(max(band[d], 0), n_bands - 1), scale ? scale[d] : 1.0f);
+      set_elevation_model(c, 0.5f * (lo + hi));
+      // the model is a finite difference over ebm +- 0.02 rad: a tile whose boresight sweeps
+      // farther (slow sample rates, fast elevation slews) takes the full formula per sample
+      if (!(hi - lo <= 2.0f * kModelHalfRange)) c.exact = 1;
+      cdet[threadIdx.x] = c;
+      exact = c.exact != 0;
+    }
+    const bool any = __builtin_amdgcn_ballot_w64(exact) != 0;  // the 16 lanes sit in wave 0
+    if (threadIdx.x == 0) red[10] = any ? 1.0f : 0.0f;
+  }
+}
+
+}  // namespace

@@ -54,6 +54,7 @@
 #include "mrx_internal.h"
 
 #include "mrx_spectral.h"
+#include "mrx_krj.h"  // the two-rate writer's K_RJ division (the machinery of mrx_tod_to_krj)
 
 
 namespace {
@@ -837,7 +838,148 @@ int ilog2(long long n) {
   return (1LL << l) == n ? l : -1;
 }
 
+// ---- the writer of the two-rate noise generator (mrx_noise.hip: noise_generate_two_rate) -------------------
+// noise[d,t] = amp(d,t) ( sqrt(fs) w[d,t] + sqrt(c) sqrt(fs) sum_m B[d,m] w'[m,t] + P_d(t) ) [/ den(el(d,t)): K_RJ]
+// White noise is drawn here, per sample (Philox keyed by row and sample index, as the white-only path draws it);
+// the modes' white parts come from a table of n_modes unit series shared by all detectors; P_d -- the detector's own
+// pink part plus the modes' pink parts -- was synthesised in the frequency domain at fs / rate (its spectrum above
+// that Nyquist frequency holds less than 2 % of the white level: mrx_noise.hip picks the rate so) and is
+// interpolated to the full rate with the four-point Catmull-Rom cubic; the K_RJ division is the one of
+// mrx_tod_to_krj (same per-tile elevation model, same lookup).  Tile: 16 rows x 1024 samples; a thread owns 4
+// consecutive samples -- one interval of the slow series at rate 4, two at rate 2.
+typedef float nvfloat4 __attribute__((ext_vector_type(4)));
+typedef float nvfloat4u __attribute__((ext_vector_type(4), aligned(4)));  // 16 bytes at any 4-byte address: one global_load_dwordx4
+
+template <bool kKrj, int kModes>  // kModes: 0, 5 (up to five modes: the reference's spatial basis) or 8
+__global__ __launch_bounds__(kBlock) void noise_two_rate_kernel(const mrx_two_rate_args a) {
+  extern __shared__ __align__(16) float4 cal_cells[];  // K_RJ: [n_bands][n_el - 1]
+  __shared__ CalDet cdet[kTileDet];
+  __shared__ float red[12];
+  __shared__ float coef[kTileDet][8];  // w_corr sqrt(fs) B[row][m]
+  const int s_tile = blockIdx.x * kTileSamples;
+  const int r0 = blockIdx.y * kTileDet;  // within the launch
+  const int nd = min(kTileDet, a.rows - r0);
+  const int sb = s_tile + threadIdx.x * kSamplesPerThread;
+  KrjSamples ks{};
+  if constexpr (kKrj) {
+    ks = krj_prologue(cal_cells, red, a.bore_el, a.T, sb, a.cal_axis, a.cal_values, a.n_el, a.n_bands);
+    krj_stage_rows(cdet, red, a.dx, a.dy, a.band, nullptr, a.n_bands, a.row0 + r0, nd);
+  }
+  for (int i = threadIdx.x; i < kTileDet * 8; i += kBlock) {
+    const int dl = i >> 3, m = i & 7;
+    coef[dl][m] = (dl < nd && m < a.n_modes) ? a.w_corr * a.sqrt_fs * a.basis[(size_t)(a.row0 + r0 + dl) * a.n_modes + m] : 0.0f;
+  }
+  __syncthreads();
+  if (sb >= a.T) return;
+  // the modes' white parts of this thread's four samples
+  float mw[kModes > 0 ? kModes : 1][kSamplesPerThread];
+#pragma unroll
+  for (int m = 0; m < kModes; ++m) {
+#pragma unroll
+    for (int q = 0; q < kSamplesPerThread; ++q) mw[m][q] = 0.0f;
+    if (m < a.n_modes) {  // (uniform)
+      const float* src = a.mode_white + (size_t)m * a.ld_mw + sb;  // ld_mw and the buffer are padded to whole groups of 4
+      const nvfloat4 v = *reinterpret_cast<const nvfloat4*>(src);
+      mw[m][0] = v[0]; mw[m][1] = v[1]; mw[m][2] = v[2]; mw[m][3] = v[3];
+    }
+  }
+  const bool full = sb + kSamplesPerThread <= a.T && (a.ld & 3) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
+  const float el_first = kKrj ? cal_cells[0].x : 0.0f, el_last = kKrj ? a.cal_axis[a.n_el - 1] : 0.0f, el_inv = kKrj ? cal_cells[0].z : 0.0f;
+  // Catmull-Rom weights of (P[-1], P[0], P[1], P[2]) at u = 1/4, 1/2, 3/4 (u = 0: P[0] itself)
+  constexpr float kW14[4] = {-0.0703125f, 0.8671875f, 0.2265625f, -0.0234375f};
+  constexpr float kW12[4] = {-0.0625f, 0.5625f, 0.5625f, -0.0625f};
+  constexpr float kW34[4] = {-0.0234375f, 0.2265625f, 0.8671875f, -0.0703125f};
+  auto rows_loop = [&](auto curved) {
+#pragma unroll 2
+    for (int dl = 0; dl < nd; ++dl) {
+      const int row = a.row0 + r0 + dl;  // row of the call
+      // the slow part: samples t' - 1 .. t' + 2 (.. t' + 3 at rate 2) around the thread's interval(s), stored one to the right
+      const float* lo = a.lo + (size_t)(r0 + dl) * a.ld_lo;
+      float p[kSamplesPerThread];
+      if (a.rate == 4) {
+        const nvfloat4u q = *reinterpret_cast<const nvfloat4u*>(lo + (sb >> 2));
+        const float p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3];
+        p[0] = p1;
+        p[1] = kW14[0] * p0 + kW14[1] * p1 + kW14[2] * p2 + kW14[3] * p3;
+        p[2] = kW12[0] * p0 + kW12[1] * p1 + kW12[2] * p2 + kW12[3] * p3;
+        p[3] = kW34[0] * p0 + kW34[1] * p1 + kW34[2] * p2 + kW34[3] * p3;
+      } else {
+        const nvfloat4u q = *reinterpret_cast<const nvfloat4u*>(lo + (sb >> 1));
+        const float p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3], p4 = lo[(sb >> 1) + 4];
+        p[0] = p1;
+        p[1] = kW12[0] * p0 + kW12[1] * p1 + kW12[2] * p2 + kW12[3] * p3;
+        p[2] = p2;
+        p[3] = kW12[0] * p1 + kW12[1] * p2 + kW12[2] * p3 + kW12[3] * p4;
+      }
+      const mrx_dev::U4 rnd = mrx_dev::philox4x32_10(
+          mrx_dev::U4{(uint32_t)(sb >> 2), a.id0 + (uint32_t)row, 0u, kMrxTagWhite}, a.key0, a.key1);
+      const float2 g0 = mrx_dev::box_muller(rnd.x, rnd.y), g1 = mrx_dev::box_muller(rnd.z, rnd.w);
+      float v[kSamplesPerThread] = {a.sqrt_fs * g0.x + p[0], a.sqrt_fs * g0.y + p[1], a.sqrt_fs * g1.x + p[2], a.sqrt_fs * g1.y + p[3]};
+#pragma unroll
+      for (int m = 0; m < kModes; ++m) {
+        const float cm = coef[dl][m];
+#pragma unroll
+        for (int q = 0; q < kSamplesPerThread; ++q) v[q] = fmaf(cm, mw[m][q], v[q]);
+      }
+      const float sc = a.scale ? a.scale[row] : 1.0f;
+      float sv[kSamplesPerThread];
+      if (a.loading) {  // total NEP of a sample: NEP + NEP_per_loading x loading (sim/noise.py:35-37)
+        const float* L = a.loading + (size_t)row * a.ld_loading + sb;
+#pragma unroll
+        for (int q = 0; q < kSamplesPerThread; ++q) sv[q] = v[q] * (sc + a.per_loading * (sb + q < a.T ? L[q] : 0.0f));
+      } else {
+#pragma unroll
+        for (int q = 0; q < kSamplesPerThread; ++q) sv[q] = v[q] * sc;
+      }
+      float o[kSamplesPerThread];
+      if constexpr (kKrj) {
+        const CalDet c = cdet[dl];
+        krj_row<false, decltype(curved)::value>(c, cal_cells + c.band * (a.n_el - 1), a.n_el, el_first, el_last, el_inv, ks, sv, o,
+                                                a.bore_el, sb, a.T);
+      } else {
+#pragma unroll
+        for (int q = 0; q < kSamplesPerThread; ++q) o[q] = sv[q];
+      }
+      float* dst = a.out + (size_t)row * a.ld + sb;
+      if (full) {
+        nvfloat4 x = {o[0], o[1], o[2], o[3]};
+        nvfloat4* d4 = reinterpret_cast<nvfloat4*>(dst);
+        if (a.accumulate) x += *d4;
+        __builtin_nontemporal_store(x, d4);
+      } else {
+#pragma unroll
+        for (int q = 0; q < kSamplesPerThread; ++q)
+          if (sb + q < a.T) dst[q] = a.accumulate ? dst[q] + o[q] : o[q];
+      }
+    }
+  };
+  if (kKrj && ks.curved) rows_loop(std::true_type{}); else rows_loop(std::false_type{});  // (uniform)
+}
+
 }  // namespace
+
+int mrx_noise_two_rate_write(mrx_ctx* ctx, hipStream_t stream, const mrx_two_rate_args& a) {
+  const dim3 grid(mrx_ceil_div(a.T, kTileSamples), mrx_ceil_div(a.rows, kTileDet));
+  MRX_REQUIRE(ctx, grid.y <= 65535u, "too many rows for one launch");
+  if (a.bore_el) {
+    MRX_REQUIRE(ctx, a.n_el >= 2 && a.n_bands >= 1 && (size_t)(a.n_el - 1) * a.n_bands <= 6144,
+                "calibration tables need 2 <= n_el and (n_el-1)*n_bands <= 6144");
+    const size_t lds = sizeof(float4) * (size_t)(a.n_el - 1) * a.n_bands;
+#define MRX_TWO_RATE(K, M)                                                                     \
+  do {                                                                                         \
+    MRX_LDS_CAP(ctx, (noise_two_rate_kernel<K, M>), lds);                                      \
+    hipLaunchKernelGGL((noise_two_rate_kernel<K, M>), grid, dim3(kBlock), lds, stream, a);     \
+  } while (0)
+    if (a.n_modes == 0) MRX_TWO_RATE(true, 0); else if (a.n_modes <= 5) MRX_TWO_RATE(true, 5); else MRX_TWO_RATE(true, 8);
+  } else {
+    const size_t lds = 0;
+    if (a.n_modes == 0) MRX_TWO_RATE(false, 0); else if (a.n_modes <= 5) MRX_TWO_RATE(false, 5); else MRX_TWO_RATE(false, 8);
+#undef MRX_TWO_RATE
+  }
+  MRX_CHECK_LAUNCH(ctx);
+  return MRX_OK;
+}
+
 
 extern "C" {
 

@@ -1,5 +1,5 @@
 // The pixel-coordinate sampler (atm_sample_px_kernel's body) and the device-side plan it reads, shared by the
-// sampling TU (mrx_sample.hip: the kernel on its own) and the synthesis TU (mrx_spline.hip: the same body as the
+// sampling TU (mrx_sample.hip: the kernel on its own) and the synthesis TU (mrx_synth.hip: the same body as the
 // sampler role of the one-launch atmosphere -> TOD kernel).  Arithmetic follows the reference's rounding points
 // (see mrx_sample.hip's header): everything here is compiled WITHOUT floating-point contraction, whatever the
 // including TU's flags say -- a * b + c rounds twice, like numpy / XLA; fused multiply-adds are written out.
@@ -206,7 +206,7 @@ __device__ __forceinline__ float band_loading_px(const mrx_table_dev& tb, const 
 
 // The work of one sampler workgroup, `wg` of `n_wgs`: the body of atm_sample_px_kernel (which calls it with its block
 // index and grid size, one detector block, nothing to signal) and the sampler role of the one-launch synthesis
-// (atm_tod_kernel, mrx_spline.hip).  The detectors come in `n_blocks` blocks of `block_rows` rows (the last one
+// (atm_tod_kernel, mrx_synth.hip).  The detectors come in `n_blocks` blocks of `block_rows` rows (the last one
 // shorter); block b's loading is its own time-major array loading + Ta * (b * block_rows) of [Ta][rows of b], and
 // `hooks.item(b, d)` is called by every thread at the start of a work item of block b with its detector's row in the
 // whole shard, `hooks.value(loading, (cos, sin, ..) of the step's boresight, step, row, real)` gives what is stored for

@@ -6,7 +6,7 @@
 
 namespace mrx_dev {
 
-constexpr int kBlock = 256;
+using ::mrx_dev_common::kBlock;
 
 // ---- Philox-4x32-10 (Salmon et al., SC'11) ---------------------------------
 struct U4 {
