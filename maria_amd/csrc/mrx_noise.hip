@@ -998,15 +998,29 @@ int mrx_noise_period(int T, int* n1, int* n2) {
   return MRX_OK;
 }
 
+constexpr int kTwoRateMinT = 32768;  // shorter series keep the one-rate form (two_rate_factor)
+
 int mrx_noise_work_floats(int T, int n_modes, int batch, size_t* floats) {
   int n1, n2;
   int rc = mrx_noise_period(T, &n1, &n2);
   if (rc != MRX_OK || !floats || batch < 1 || n_modes < 0) return rc != MRX_OK ? rc : MRX_ERR_INVALID;
-  const size_t n = (size_t)n1 * n2;
-  // mode spectra [n_modes][N] + one complex series [N] per pair of detectors
-  // window means (8 doubles for the modes, a double2 per pair), mode spectra [n_modes][N], one
+  const size_t pairs = ((size_t)batch + 1) / 2, m = (size_t)n_modes;
+  // one-rate form: window means (8 doubles for the modes, a double2 per pair), mode spectra [n_modes][N], one
   // complex series [N] per pair of detectors
-  *floats = 16 + (2 * n + 4) * ((size_t)(batch + 1) / 2) + 2 * n * (size_t)n_modes + 16;
+  size_t need = 32 + (2 * (size_t)n1 * n2 + 4) * pairs + 2 * (size_t)n1 * n2 * m;
+  // two-rate form (noise_generate_impl picks it from the sample rate and the knee, which this function does not
+  // see: the size covers every rate it can pick): the same for the slow series of T / rate + 4 samples, plus the
+  // slow series themselves [2 pairs][ld_lo] and the modes' white table [n_modes][ld_mw].  The period is a power of
+  // two, so for T at or just below one the slow series' period can equal the full one and this form needs MORE
+  // than the one-rate form for batches of a few rows (a band or a shard with a handful of detectors: ADVICE r4).
+  for (int rate = 2; rate <= 4 && T >= kTwoRateMinT; rate <<= 1) {
+    const int Ts = (T + rate - 1) / rate + 4;
+    int s1, s2;
+    if (mrx_noise_period(Ts, &s1, &s2) != MRX_OK) continue;
+    const size_t n = (size_t)s1 * s2, ld_lo = ((size_t)Ts + 3) & ~(size_t)3, ld_mw = ((size_t)T + 3) & ~(size_t)3;
+    need = std::max(need, 32 + 2 * n * m + m * ld_mw + 16 + (2 * n + 4 + 2 * ld_lo) * pairs);
+  }
+  *floats = need;
   return MRX_OK;
 }
 
@@ -1026,7 +1040,7 @@ struct NoiseKrj {
 // interpolation's roll-off just below is smaller still) -- 4 at 400 Hz with a knee of 1 Hz, 1 (the one-rate form)
 // at 50 Hz.  Short series and option bit 8 of MRX_OPT_NOISE_GENERIC keep the one-rate form.
 static int two_rate_factor(const mrx_ctx* ctx, int T, double sample_rate, double knee) {
-  if ((ctx->options[MRX_OPT_NOISE_GENERIC] & 8) || !(knee > 0.0) || T < 32768) return 1;
+  if ((ctx->options[MRX_OPT_NOISE_GENERIC] & 8) || !(knee > 0.0) || T < kTwoRateMinT) return 1;
   for (int rate = 4; rate >= 2; rate >>= 1)
     if (2.0 * rate * knee / sample_rate <= 0.0205) return rate;  // (2 %, with room for a rate of 399.99 Hz read off a time axis)
   return 1;

@@ -310,14 +310,17 @@ class DevicePath:
         return self._amp[key]
 
     def sampled_margins_px(self):
-        """Per layer, the smallest distance in pixels between any line of sight of this shard and an edge of the
-        layer's grid, over the whole observation: (margin along the extrusion axis, margin across).  Host-side and
+        """Per layer, the smallest distance in pixels between any line of sight of the observation and an edge of the
+        layer's grid: (margin along the extrusion axis, margin across).  Of the WHOLE focal plane, not of this path's
+        detector shard: the margins decide how a screen is generated (the beam as a stencil or as a factor of the
+        spectrum, generate_screens), screens are shared by all shards -- regenerated by every rank or, layer-sharded,
+        made by one rank for all --, and a shard's TOD must not depend on how the detectors were cut.  Host-side and
         conservative: the boresight track with a ring of 24 directions around the focal plane's outermost detector,
         pushed out to circumscribe the circle, through the float64 form of the pointing
         (coords/transforms.py:10-29) and the layer's projection (atmosphere/atmosphere.py:346-347)."""
         if getattr(self, "_margins", None) is None:
             p = self.problem
-            off = np.asarray(p["offsets"], float)[self.det_slice]
+            off = np.asarray(p["offsets"], float)
             rad = float(np.hypot(off[:, 0], off[:, 1]).max()) if len(off) else 0.0
             ang = np.linspace(0.0, 2.0 * np.pi, 24, endpoint=False)
             ring = np.r_[np.zeros((1, 2)), (rad / np.cos(np.pi / 24) * 1.001 + 1e-9) * np.c_[np.cos(ang), np.sin(ang)]]

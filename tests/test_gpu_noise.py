@@ -394,3 +394,23 @@ def test_two_rate_form(gpu_ctx, fs, knee, rate):
     lnep = _generate(gpu_ctx, D, T, fs, knee, corr=c, basis=B, scale=scale, seed=31, loading=loading, per_loading=0.7)
     want = two * ((torch.as_tensor(scale, dtype=torch.float32, device="cuda:0")[:, None] + 0.7 * loading) / torch.as_tensor(scale, dtype=torch.float32, device="cuda:0")[:, None])
     assert torch.allclose(lnep, want, rtol=2e-6, atol=1e-5 * float(two.abs().max()))
+
+
+@pytest.mark.parametrize("T", [32768, 65536 - 3, 131072])
+@pytest.mark.parametrize("fs,knee", [(400.0, 1.5), (400.0, 1.0)])  # rate 2, rate 4
+def test_work_buffer_size_covers_the_two_rate_form_for_small_batches(gpu_ctx, T, fs, knee):
+    """mrx_noise_work_floats sees neither the sample rate nor the knee, so its size holds every form the generator can
+    pick: for T at or just below a power of two the slow series' period equals the full one and the two-rate form
+    needs MORE than the one-rate form for a batch of a few rows -- a band or a shard with two detectors used to fail
+    with 'work buffer too small' although the caller followed the API."""
+    from maria_amd import noise as mnoise
+    from maria_amd import synthetic
+
+    D = 2
+    off = synthetic.hex_pack(D, np.radians(0.1))
+    B = mnoise.spatial_basis(off, k=5, n_side=16, scale=max(mnoise.diameter(off), 1e-3))
+    x = _generate(gpu_ctx, D, T, fs, knee, corr=0.3, basis=B, batch=D).cpu().numpy().astype(np.float64)
+    assert np.isfinite(x).all()
+    # the top of the band is white at the model's level: own part + the modes through this row of the basis
+    p = (np.abs(np.fft.rfft(x, axis=1)) ** 2)[:, np.fft.rfftfreq(T, 1 / fs) > 0.4 * fs].mean(axis=1)
+    np.testing.assert_allclose(p / (T * fs * (1 + 0.3 * (B**2).sum(axis=1))), 1.0, rtol=0.1)

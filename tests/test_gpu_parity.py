@@ -497,3 +497,27 @@ def test_overlapping_runs_are_bit_identical_to_separate_ones(gpu_ctx):
         torch.cuda.synchronize()
         assert torch.equal(out, ref), k
     assert not torch.equal(outs[0], outs[1])
+
+
+def test_screen_form_does_not_depend_on_the_shard(gpu_ctx):
+    """How a screen is generated (the beam as a stencil or folded into the spectrum, whose rim pixels differ) is decided
+    from the margins of the WHOLE focal plane: a shard of inner detectors keeps farther from the edges than the array
+    does, and must still make -- and sample -- the screens every other shard makes."""
+    import torch
+
+    from maria_amd import synthetic
+    from maria_amd.pipeline import DevicePath
+
+    p = synthetic.config_problem("atlast_10k", n_det=1024, duration=30.0)
+    off = np.asarray(p["offsets"], float)
+    inner = slice(0, 64)  # hex_pack orders ring by ring: the first detectors are the central ones
+    assert np.hypot(*off[inner].T).max() < 0.5 * np.hypot(*off.T).max()
+    whole = DevicePath(p, device="cuda:0", ctx=gpu_ctx)
+    part = DevicePath(p, device="cuda:0", ctx=gpu_ctx, det_slice=inner)
+    assert part.sampled_margins_px() == whole.sampled_margins_px()
+    sw = [s.clone() for s in whole.generate_screens()]
+    sp = part.generate_screens()
+    assert part._beam_in_spectrum == whole._beam_in_spectrum
+    for a, b in zip(sw, sp):
+        assert torch.equal(a, b)
+    assert torch.equal(part.run(), whole.run()[inner])
