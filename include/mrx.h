@@ -116,7 +116,9 @@ enum {
                               up to 4, each with at least 128 detectors of the work buffer) */
   MRX_OPT_SCREEN_STOCKHAM = 9, /* 1: the screen generator's transforms as LDS Stockham passes even
                                   where the register transforms apply (tests, A/B runs) */
-  MRX_OPT_COUNT = 10
+  MRX_OPT_SYNTH_WGS_PER_CU = 10, /* mrx_atm_synthesize: resident workgroups per CU of its one grid (1..5; 0 = as many as
+                                    fit, 5).  Timing sweeps, and the tests' way to vary who runs beside whom */
+  MRX_OPT_COUNT = 11
 };
 int mrx_set_option(mrx_ctx* ctx, int option, int value);
 const char* mrx_last_error(const mrx_ctx* ctx);
@@ -271,34 +273,36 @@ int mrx_spline_upsample_fused(mrx_ctx* ctx, const float* d_y, int D, int Ta,
                               float* d_out, size_t ld_out);
 
 /* Atmosphere -> TOD for one observation in ONE launch: mrx_atm_sample followed by
- * mrx_spline_upsample_fused, block of detectors by block of detectors -- the reference's
- * _simulate_atmosphere from the layer loop to the interpolation at the sample rate
- * (atmosphere/atmosphere.py:317-373, sim/atmosphere.py:43-82) --, with the hand-over from the
- * sampler to the writer on the device: the first workgroups of the grid sample the blocks in
- * order and count their finished work items per block, the others write TOD tiles and wait
- * (poll, acquire) for the block a tile belongs to.  The writer of the first block starts
- * after block_rows rows have been sampled instead of after a whole launch, and no launch
- * boundary or stream event separates the blocks.  Bit-identical to the two calls.
- *  block_rows        detectors per block, rounded up to a multiple of 256 (<= 0: one block); at
- *                    most 1024 blocks, 4 * Ta * block_rows < 2^31
- *  head_rows         detectors (rounded up to whole blocks) that ALL sampler workgroups -- a grid that
- *                    fills the chip -- sample before the writers enter; the rest is sampled by
- *                    MRX_OPT_SAMPLE_WGS_PER_CU workgroups per CU (unset: 2) beside the writers.  The
- *                    sampler beside a writer runs at half its speed alone: a head start of about a
- *                    third of the rows keeps the writers from catching up (0 = none)
+ * mrx_spline_upsample_fused -- the reference's _simulate_atmosphere from the layer loop to the
+ * interpolation at the sample rate (atmosphere/atmosphere.py:317-373, sim/atmosphere.py:43-82) --,
+ * with the hand-over from the sampling to the writing on the device, TIME CHUNK by time chunk: one
+ * resident grid takes sampler work items (a time chunk of 256 detectors) and TOD tiles (1024 samples
+ * of 32 rows) from two queues; a tile is written once the two or three chunks around its samples are
+ * in (a counter per chunk; write-through stores, an sc1 poll, a workgroup barrier, sc1 loads), and a
+ * workgroup whose tile is not ready samples one work item instead of waiting, so the two kinds of
+ * work balance themselves and the launch cannot stall whatever is resident.  The first TOD tile
+ * starts after the first chunks instead of after a whole sampling launch, all detectors of a chunk
+ * share one pass over the screens' footprint, and no launch boundary or stream event separates
+ * anything.  Bit-identical to the two calls.
+ *  block_rows        detectors per block of the coarse array, rounded up to a multiple of 256; <= 0:
+ *                    the library's choice -- one block where 4 * Ta * rows < 2^31, the most that fit
+ *                    otherwise (a block's coarse array is addressed with 32-bit offsets)
+ *  sampler_wgs       workgroups that ONLY sample while work items remain (they write afterwards);
+ *                    <= 0: MRX_OPT_SAMPLE_WGS_PER_CU per CU (unset: 2).  The others write and sample
+ *                    where they would wait
  *  d_coarse          f32, out (scratch the caller may read), 128-byte aligned, Ta * round_up(D, 32)
  *                    floats: the coarse loading in pW, block b (rows b*block_rows ...) as its own
  *                    time-major array at d_coarse + Ta * b * block_rows, [Ta][pitch] with
  *                    pitch = its rows rounded up to 32 (the columns past the last row: padding)
  *  other arguments   as mrx_atm_sample (d_az ... pwv0, d_flags) and mrx_spline_upsample
- *                    (ta0 ... ld_out)
+ *                    (ta0 ... ld_out); MRX_OPT_SAMPLE_CHUNK: coarse steps per time chunk (unset: 32)
  * MRX_ERR_UNSUPPORTED (nothing launched) for plans or options the pixel-coordinate sampler
  * does not take -- a layer on a non-uniform axis, MRX_OPT_AXIS_LITERAL, MRX_OPT_POINTING_CHAIN,
  * bicubic band tables --: use the two calls there.  MRX_FLAG_HANDOVER in d_flags: see above. */
 int mrx_atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d_az, const float* d_el,
                        int Ta, const float* d_dx, const float* d_dy, const int32_t* d_band,
                        const float* d_mueller00, int D, double pwv0, float* d_coarse, int block_rows,
-                       int head_rows, uint32_t* d_flags, double ta0, double dta, const double* d_t, int T,
+                       int sampler_wgs, uint32_t* d_flags, double ta0, double dta, const double* d_t, int T,
                        const float* d_scale, const int32_t* d_rows, float* d_out, size_t ld_out);
 
 /* mrx_atm_synthesize with TOD.to("K_RJ") applied on the coarse grid (tod/tod.py:106-142 before the spline, as
@@ -318,7 +322,7 @@ int mrx_atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d_az
 int mrx_atm_synthesize_krj(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d_az, const float* d_el,
                            int Ta, const float* d_dx, const float* d_dy, const int32_t* d_band,
                            const float* d_mueller00, int D, double pwv0, float* d_coarse, int block_rows,
-                           int head_rows, uint32_t* d_flags, double ta0, double dta, const double* d_t, int T,
+                           int sampler_wgs, uint32_t* d_flags, double ta0, double dta, const double* d_t, int T,
                            const float* d_scale, const int32_t* d_rows, float* d_out, size_t ld_out,
                            const float* d_cal_dx, const float* d_cal_dy, const float* d_cal_axis_el,
                            const float* d_cal_values, int n_el, int n_bands, float* d_tail_pw, int tail_knots,

@@ -23,11 +23,14 @@ FLAG_HANDOVER = 8
 OPT_POINTING_CHAIN = 0
 OPT_AXIS_LITERAL = 1
 OPT_SAMPLE_TIMES = 2
+OPT_SAMPLE_CHUNK = 3
+OPT_UPSAMPLE_GROUPS = 4
 OPT_SAMPLE_WGS_PER_CU = 6
 OPT_NOISE_GENERIC = 5
 OPT_WRITER_PER_TILE = 7
 OPT_NOISE_LANES = 8
 OPT_SCREEN_STOCKHAM = 9
+OPT_SYNTH_WGS_PER_CU = 10
 
 _STATUS = {
     0: "MRX_OK",

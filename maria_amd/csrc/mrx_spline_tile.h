@@ -325,24 +325,43 @@ __device__ __forceinline__ void fused_writer_tile(
 }
 
 
-constexpr int kSynthMaxBlocks = 1024;
-// the control block of a launch: [0] tile queue, [16] workgroups that have left, [32 + b] finished work items of
-// block b (each on a line of its own kind: the queue is hammered by every writer, the counters by the samplers).
-// All zero between launches: the last workgroup to leave clears what the launch used, so a launch needs no memset.
-constexpr int kSynthCtlInts = 32 + kSynthMaxBlocks;
+// The raw knots [lo, hi] that the tile of time tile `sx` reads over all its passes (what fused_writer_tile stages:
+// every pass widens its knot range by kFHalo + 3 either side and, at an end of the axis, to the knots the not-a-knot
+// terms are derived from).  For a writer that must know which coarse samples it depends on (mrx_synth.hip).
+__device__ __forceinline__ void fused_tile_knots(const double* __restrict__ t, int T, int n, double ta0, double inv_dta,
+                                                 int sx, int& lo, int& hi) {
+  const int s_tile = sx * kTileSamples;
+  const int s_last = min(s_tile + kTileSamples, T) - 1;
+  const int j_first = interval_of((t[s_tile] - ta0) * inv_dta, n);
+  const int j_end = interval_of((t[s_last] - ta0) * inv_dta, n) + 1;
+  lo = max(min(j_first, n - 3) - 3 - kFHalo, 0);
+  hi = min(max(j_end, 2) + 3 + kFHalo, n - 1);
+}
+
+// The control block of a launch that takes its work from queues: [0] the tile queue, [16] workgroups that have left,
+// [32] the sampler's work-item queue (the one-launch synthesis), [64 + s] finished work items of hand-over unit s
+// (a detector block's time chunk: mrx_synth.hip) -- each kind on lines of its own: the tile queue is hammered by every
+// writer, the counters by the samplers.  All zero between launches: the last workgroup to leave clears what the
+// launch used, so a launch needs no memset.
+constexpr int kCtlTiles = 0, kCtlLeft = 16, kCtlItems = 32, kCtlDone = 64;
+constexpr int kSynthMaxSlots = 32768;
+constexpr int kSynthCtlInts = kCtlDone + kSynthMaxSlots;
 
 // Leaves the control block as it was found: the workgroup whose exit is the grid's last (atomicInc wraps the exit
-// count to 0 by itself) zeroes the queue and the block counters -- nobody reads them any more, and the next launch
-// on the stream starts after this one has ended.
-__device__ __forceinline__ void synth_leave(int* ctl, int n_blocks) {
+// count to 0 by itself) zeroes the queues and the first n_slots counters -- nobody reads them any more, and the next
+// launch on the stream starts after this one has ended.
+__device__ __forceinline__ void synth_leave(int* ctl, int n_slots) {
   __syncthreads();
   __shared__ int s_last;
-  if (threadIdx.x == 0) s_last = atomicInc(reinterpret_cast<unsigned*>(ctl + 16), gridDim.x - 1) == gridDim.x - 1;
+  if (threadIdx.x == 0) s_last = atomicInc(reinterpret_cast<unsigned*>(ctl + kCtlLeft), gridDim.x - 1) == gridDim.x - 1;
   __syncthreads();
   if (s_last) {
-    if (threadIdx.x == 0) __hip_atomic_store(ctl, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    for (int b = threadIdx.x; b < n_blocks; b += kBlock)
-      __hip_atomic_store(ctl + 32 + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+      __hip_atomic_store(ctl + kCtlTiles, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(ctl + kCtlItems, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    for (int b = threadIdx.x; b < n_slots; b += kBlock)
+      __hip_atomic_store(ctl + kCtlDone + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 

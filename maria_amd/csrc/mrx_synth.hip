@@ -9,44 +9,50 @@
 namespace {
 
 // ---------------------------------------------------------------------------
-// Atmosphere -> TOD in ONE launch (mrx_atm_synthesize): the sampler and the writer as two ROLES of one grid, the
-// hand-over on the device.  Replaces, for one observation, screens -> [sampler of block b on a side stream |
-// writer of block b behind an event] x blocks: there the writer of block 0 cannot start before the whole first
-// block is sampled (0.2 ms of the 2.3-ms step of atlast_10k with HBM idle) and every launch boundary drains and
-// refills the chip (4-14 per step).
+// Atmosphere -> TOD in ONE launch (mrx_atm_synthesize): sampling and writing as two kinds of work that ONE resident
+// grid takes from two queues, the hand-over between them on the device, in units of a TIME CHUNK.
 //
-//   * the first `n_sampler_wgs` workgroups (lowest block indices: the dispatcher hands them out first, so they are
-//     resident before any writer -- and they never wait for anything, so the grid always drains) run
-//     px_sample_items over the detector blocks in order: block b's coarse loading is its own [Ta][rows] array;
-//   * the loading leaves the sampler's CUs as write-through (sc1) 16-byte stores, every 128-byte line written whole
-//     by one store instruction (px_sample_items<..., kWriteThrough>); after each finished work item every wave
-//     drains its stores (s_waitcnt vmcnt(0)), the workgroup meets at a barrier, and ONE lane adds 1 to done[b]
-//     (agent scope, relaxed);
-//   * every other workgroup is a writer: it takes tile numbers from a queue (one agent-scope atomic per tile; tiles
-//     are numbered block by block, time tile fastest -- the order the two-dimensional grid of
-//     spline_upsample_fused_kernel is dispatched in), and before its FIRST tile of a block one lane polls done[b]
-//     (global_load_dword sc1, s_sleep between) until all of the block's items are in, then the workgroup meets at a
-//     barrier; the tile stages its knots with sc1 loads (past the CU's L1), then fused_writer_tile as in the
-//     stand-alone kernel.
-// The per-XCD L2s are not coherent and a CU's L1 is not refreshed by other CUs' stores.  Write-through stores +
-// drained waves + one agent-scope add per workgroup on the producer's side, an sc1 poll + a workgroup barrier + sc1
-// loads on the consumer's, is one of the forms MI355X_MICROARCH.md lists as measured valid on gfx950 (its table of
-// hand-offs without fences, third row).  The first version used the fenced form (release fence per work item, acquire
-// per writer and block): correct too, but a release writes back the XCD's whole L2 under a streaming writer --
-// 0.18 ms of a 1.9-ms step in fences, 0.15-0.3 more in waits.
-// A poll gives up after `poll_limit` tries and raises MRX_FLAG_HANDOVER (the host then fails the call): a bound,
-// not a path -- it cannot trigger while the sampler role is resident.
-// Results: the same bits as mrx_atm_sample + mrx_spline_upsample_fused per block (same bodies, same order of
-// operations; tests/test_gpu_synthesize.py).
-// kKrj (mrx_atm_synthesize_krj): TOD.to("K_RJ") on the coarse grid, in the sampler role's epilogue -- what
+// The observation's work is
+//   * sampler items: (detector block b, time chunk c of `chunk` coarse steps, group of 256 detectors) -- the body of
+//     atm_sample_px_kernel (px_sample_items) --, handed out chunk by chunk: block b's coarse loading is its own
+//     time-major array [Ta][pitch];
+//   * writer tiles: (block b, time tile of 1024 samples, group of 32 rows) -- fused_writer_tile, the body of
+//     spline_upsample_fused_kernel --, handed out time tile by time tile.  A tile reads the ~66 knots around its
+//     samples (fused_tile_knots), i.e. two or three time chunks of its block.
+// Round 4's form handed over whole detector blocks: the writers of block b waited for ALL coarse steps of its 512 rows,
+// so the sampler role was the launch's critical path until its last block (it runs at half its speed beside the
+// writers), a third of the rows had to be sampled before the first writer started (HBM idle for 0.25 ms of 2.0), and
+// every detector block re-read the screens' whole track (5-8 GB a step at 16 x 4096^2).  Handing over time chunks,
+// the writers follow the samplers a few chunks behind, all detectors of a chunk share one pass over the screens'
+// footprint, and the two kinds of work balance themselves:
+//   * the first `n_dedicated` workgroups sample until the item queue is empty, then write;
+//   * every other workgroup takes a tile; if a chunk its tile needs is not sampled yet it takes ONE sampler item
+//     instead of waiting (whichever chunk is next in the queue: sampling never waits for anything), then looks again.
+//     So the launch cannot deadlock whatever is resident -- a single workgroup would finish it alone --, at the start
+//     every workgroup samples one item (the head start, as long as the first items take), and where the samplers fall
+//     behind (16 layers: as much sampling as writing) the writers make up the difference, an item at a time.
+// Hand-over (unchanged from round 4 but for its unit): the loading leaves the sampling CUs as write-through (sc1)
+// 16-byte stores, every 128-byte line written whole by one store instruction (px_sample_items<..., kWriteThrough>);
+// after a work item every wave drains its stores (s_waitcnt vmcnt(0)), the workgroup meets at a barrier and ONE
+// lane adds 1 to done[b][c] (agent scope, relaxed).  Before a tile, 16 lanes of the workgroup's first wave read the
+// next 16 counters past the workgroup's own watermark (global_load_dword sc1; chunks complete roughly in order),
+// the workgroup meets at a barrier, and the tile stages its knots with sc1 loads (past the CU's L1).  The per-XCD
+// L2s are not coherent and a CU's L1 is not refreshed by other CUs' stores: write-through stores + drained waves +
+// one agent-scope add per workgroup on the producer's side, an sc1 poll + a workgroup barrier + sc1 loads on the
+// consumer's, is the third row of MI355X_MICROARCH.md's table of hand-offs measured valid on gfx950 without fences --
+// in every cell but one: that row was measured with ONE workgroup per CU and this launch runs up to five.  What
+// stands in for that cell: no consumer touches a line of a chunk before its counter matches (first touch is an sc1
+// load behind the barrier, so no stale copy of it can sit in this CU's L1 from this launch, and sc1 loads do not
+// read the L1 anyway), chunks share no line, and tests/test_gpu_synthesize.py changes the data between launches so
+// that a byte left over from an earlier launch is a wrong byte (DESIGN 3.0 has the cost of the guide's fallback,
+// an agent acquire per tile).
+// A tile that waits with the item queue empty polls (s_sleep between) and gives up after `poll_limit` tries, raising
+// MRX_FLAG_HANDOVER (the host then fails the call): a bound, not a path.
+// Results: the same bits as mrx_atm_sample + mrx_spline_upsample_fused (same bodies, same order of operations;
+// tests/test_gpu_synthesize.py).
+// kKrj (mrx_atm_synthesize_krj): TOD.to("K_RJ") on the coarse grid, in the sampler's epilogue -- what
 // coarse_krj_kernel does to a finished block between the two calls (same functions, same operands: the same bits),
 // the last knots kept aside in pW for the samples past the last knot.
-// who samples what: blocks [end[p-1], end[p]) by the first wgs[p] sampler workgroups (wgs descending)
-struct SynthPhases {
-  int n;
-  int end[4];
-  int wgs[4];
-};
 
 // The calibration of the K_RJ form (DevicePath.set_calibration: the band's denominators on the elevation axis).
 struct SynthCal {
@@ -86,10 +92,11 @@ struct SynthHooks {
     if (cal.tail && real && t >= cal.tail_first) cal.tail[(size_t)(t - cal.tail_first) * cal.ld_tail + d] = v;
     return v * __builtin_amdgcn_rcpf(den);
   }
-  __device__ __forceinline__ void done(int blk) {
+  int slot = 0;  // the hand-over unit of the work item in progress: block * nby + time chunk
+  __device__ __forceinline__ void done(int) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's (write-through) stores of the item are out
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctl + 32 + blk, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(ctl + kCtlDone + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 };
 
@@ -100,82 +107,140 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_WRIT
     const float* __restrict__ table_data, int table_floats, const float* __restrict__ az,
     const float* __restrict__ el, int Ta, const float* __restrict__ dxs, const float* __restrict__ dys,
     const int32_t* __restrict__ band, const float* __restrict__ mueller00, int D, double pwv0,
-    float* loading,  // written by the sampler role, read by the writer role: no __restrict__, no const
-    uint32_t* __restrict__ flags, int chunk, int nby, int block_rows, int n_blocks, int n_sampler_wgs,
-    SynthPhases phases, double ta0, double inv_dta, const double* __restrict__ t, int T,
+    float* loading,  // written by sampler items, read by writer tiles: no __restrict__, no const
+    uint32_t* __restrict__ flags, int chunk, int nby, int block_rows, int n_blocks, int n_dedicated,
+    double ta0, double inv_dta, const double* __restrict__ t, int T,
     const float* __restrict__ scale, const int32_t* __restrict__ rows, float* __restrict__ out, size_t ld, int vec_ok,
     int batches, int* ctl, int poll_limit, SynthCal cal) {
   extern __shared__ __align__(16) unsigned char synth_lds[];
-  if ((int)blockIdx.x < n_sampler_wgs) {
-    SynthHooks<kKrj> hooks;
-    hooks.ctl = ctl;
-    hooks.band = band;
-    hooks.cal = cal;
-    if (kKrj) {
-      // the cell table behind the anchors, the band tables and the four turned steps (16-byte aligned)
-      float4* cells = reinterpret_cast<float4*>(synth_lds) + 2 * chunk * n_layers + (kLdsTables ? (table_floats + 3) / 4 : 0) + kBlock;
-      stage_cal_cells(cells, cal.axis, cal.values, cal.n_el, cal.n_bands);
-      __syncthreads();
-      hooks.cells = cells;
-      hooks.el_first = cells[0].x;
-      hooks.el_last = cal.axis[cal.n_el - 1];
-      hooks.el_inv = cells[0].z;
-    }
-    // phases: the first blocks by ALL sampler workgroups (nothing else is resident yet: the chip is theirs), the next
-    // ones by fewer and fewer of them -- those that leave make room for writers --, the rest by the first few
-    int b0 = 0;
-    for (int ph = 0; ph < phases.n; ++ph) {
-      const int nw = phases.wgs[ph];
-      if ((int)blockIdx.x >= nw) break;
-      const int b1 = phases.end[ph];
-      if (b1 > b0)
-        mrx_px::px_sample_items<kLdsTables, 1, true, true>(
-            fast, lpx, n_layers, offpx, tables, n_tables, table_data, table_floats, az, el, Ta, dxs, dys, band, mueller00,
-            D, pwv0, nullptr, loading, flags, chunk, nby, block_rows, n_blocks, b0, b1, (int)blockIdx.x, nw,
-            reinterpret_cast<float4*>(synth_lds), hooks);
-      b0 = max(b0, b1);
-    }
-    synth_leave(ctl, n_blocks);
-    return;
+  __shared__ int s_word[4];  // what the first wave found out for the workgroup: [0] tile / item, [1] watermark, [2] the tile's last unit
+  SynthHooks<kKrj> hooks;
+  hooks.ctl = ctl;
+  hooks.band = band;
+  hooks.cal = cal;
+  // the cell table of the K_RJ form behind the anchors, the band tables and the four turned steps (16-byte aligned)
+  float4* const cells = reinterpret_cast<float4*>(synth_lds) + 2 * chunk * n_layers + (kLdsTables ? (table_floats + 3) / 4 : 0) + kBlock;
+  if (kKrj) {  // (what stage_cal_cells puts into cells[0].x and .z)
+    hooks.cells = cells;
+    hooks.el_first = cal.axis[0];
+    hooks.el_last = cal.axis[cal.n_el - 1];
+    hooks.el_inv = 1.0f / (cal.axis[1] - cal.axis[0]);
   }
+  // ---- the two kinds of work, as numbers ----
   constexpr int kRows = kTileDet * kG;
-  __shared__ int s_next;
-  const int nsx = (T + kTileSamples - 1) / kTileSamples;
   const int rows_per_tile = kRows * batches;
-  const int last_rows = D - (n_blocks - 1) * block_rows;
-  const int tiles_full = nsx * ((block_rows + rows_per_tile - 1) / rows_per_tile);
-  const int total = tiles_full * (n_blocks - 1) + nsx * ((last_rows + rows_per_tile - 1) / rows_per_tile);
-  int have = -1;  // blocks up to this one are known to be sampled
+  const int last = n_blocks - 1;
+  const int last_rows = D - last * block_rows;
+  const int nsx = (T + kTileSamples - 1) / kTileSamples;
+  const int nrg_full = (block_rows + rows_per_tile - 1) / rows_per_tile, nrg_last = (last_rows + rows_per_tile - 1) / rows_per_tile;
+  const int tiles_full = nsx * nrg_full;
+  const int n_tiles = tiles_full * last + nsx * nrg_last;
+  const int nbx_full = (block_rows + mrx_px::kPxBlock - 1) / mrx_px::kPxBlock, nbx_last = (last_rows + mrx_px::kPxBlock - 1) / mrx_px::kPxBlock;
+  const int items_full = nby * nbx_full;
+  const int n_items = items_full * last + nby * nbx_last;
+  const int n_slots = n_blocks * nby;
+
+  bool sampling = (int)blockIdx.x < n_dedicated;  // (workgroup-uniform, like everything that steers the loop)
+  bool items_left = true;
+  int tile = -1;   // the tile in hand, not yet written
+  int have = 0;    // hand-over units 0 .. have - 1 are known to be sampled (blocks in order, chunks in order)
+  int tries = 0;
   for (;;) {
-    if (threadIdx.x == 0) s_next = __hip_atomic_fetch_add(ctl, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __syncthreads();  // (also: the previous tile's readers of the LDS images are done)
-    const int tile = s_next;
-    if (tile >= total) break;
-    const int blk = min(tile / tiles_full, n_blocks - 1);
-    const int rem = tile - blk * tiles_full;
-    const int by = rem / nsx, sx = rem - by * nsx;
-    const int Db = blk == n_blocks - 1 ? last_rows : block_rows;
-    if (blk > have) {  // workgroup-uniform
-      if (threadIdx.x == 0) {
-        const int want = nby * ((Db + mrx_px::kPxBlock - 1) / mrx_px::kPxBlock);
-        int tries = 0;
-        while (__hip_atomic_load(ctl + 32 + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
-          if (++tries > poll_limit) {
-            atomicOr(flags, MRX_FLAG_HANDOVER);
-            break;
+    __syncthreads();  // everybody is done with the previous turn's LDS: the images, the tables, s_word
+    bool take_item = sampling;
+    if (!sampling) {
+      // ---- a tile: take one if none is in hand, then see whether its chunks are sampled ----
+      if (threadIdx.x < 64) {  // the first wave
+        int tl = tile, need = 0;
+        if (tl < 0) {
+          if (threadIdx.x == 0) tl = __hip_atomic_fetch_add(ctl + kCtlTiles, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          tl = __builtin_amdgcn_readfirstlane(tl);
+        }
+        int hv = have;
+        if (tl < n_tiles) {
+          const int blk = min(tl / tiles_full, last);
+          const int rem = tl - blk * tiles_full;
+          const int sx = rem / (blk == last ? nrg_last : nrg_full);
+          int lo, hi;
+          fused_tile_knots(t, T, Ta, ta0, inv_dta, sx, lo, hi);
+          need = blk * nby + hi / chunk;  // the last unit the tile reads (a tile's knots lie in one block)
+          // the watermark: 16 counters a look, on while all 16 are complete and the tile's are not reached
+          while (hv <= need) {
+            const int sl = hv + (int)threadIdx.x;
+            bool ok = false;
+            if (threadIdx.x < 16 && sl < n_slots) {
+              const int want = sl / nby == last ? nbx_last : nbx_full;
+              ok = __hip_atomic_load(ctl + kCtlDone + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
+            }
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(ok) & 0xffffull;
+            const int adv = m == 0xffffull ? 16 : __builtin_ctzll(~m);
+            hv += adv;
+            if (adv < 16) break;
           }
-          __builtin_amdgcn_s_sleep(32);
+        }
+        if (threadIdx.x == 0) {
+          s_word[0] = tl;
+          s_word[1] = hv;
+          s_word[2] = need;
         }
       }
-      __syncthreads();  // between the poll and EVERY load of the block's bytes, the polling wave's own too
-      have = blk;
+      __syncthreads();  // between the poll and EVERY load of the chunks' bytes, the polling wave's own too
+      tile = s_word[0];
+      have = s_word[1];
+      const int need = s_word[2];
+      if (tile >= n_tiles) break;  // (the queue is empty: nothing in hand, nothing left)
+      bool ready = have > need;
+      if (!ready && !items_left) {  // the chunk is being sampled by others: wait for it
+        if (++tries > poll_limit) {
+          if (threadIdx.x == 0) atomicOr(flags, MRX_FLAG_HANDOVER);
+          ready = true;
+        } else {
+          __builtin_amdgcn_s_sleep(32);
+          continue;
+        }
+      }
+      if (ready) {
+        const int blk = min(tile / tiles_full, last);
+        const int rem = tile - blk * tiles_full;
+        const int nrg = blk == last ? nrg_last : nrg_full;
+        const int sx = rem / nrg, by = rem - sx * nrg;
+        const int Db = blk == last ? last_rows : block_rows;
+        const size_t row0 = (size_t)blk * block_rows;
+        fused_writer_tile<kHasScale, kMaxKnots, kG, true>(loading + (size_t)Ta * row0, (Db + 31) & ~31, Db, Ta, ta0, inv_dta, t, T,
+                                                           kHasScale ? scale + row0 : nullptr, rows ? rows + row0 : nullptr,
+                                                           rows ? out : out + row0 * ld, ld, vec_ok, batches, sx, by, synth_lds);
+        tile = -1;
+        tries = 0;
+        continue;
+      }
+      take_item = true;  // instead of waiting: one item of whatever is next to be sampled
+      __syncthreads();   // (s_word is read: the item's number goes there next)
     }
-    const size_t row0 = (size_t)blk * block_rows;
-    fused_writer_tile<kHasScale, kMaxKnots, kG, true>(loading + (size_t)Ta * row0, (Db + 31) & ~31, Db, Ta, ta0, inv_dta, t, T,
-                                                       kHasScale ? scale + row0 : nullptr, rows ? rows + row0 : nullptr,
-                                                       rows ? out : out + row0 * ld, ld, vec_ok, batches, sx, by, synth_lds);
+    if (take_item) {
+      if (threadIdx.x == 0) s_word[0] = __hip_atomic_fetch_add(ctl + kCtlItems, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      const int item = s_word[0];
+      if (item >= n_items) {  // everything is sampled or being sampled: from here on this workgroup writes
+        items_left = false;
+        sampling = false;
+        continue;
+      }
+      // items: block by block, time chunk by time chunk, the chunk's detector groups side by side
+      const int blk = min(item / items_full, last);
+      const int rem = item - blk * items_full;
+      const int nbx = blk == last ? nbx_last : nbx_full;
+      const int by = rem / nbx, bx = rem - by * nbx;
+      hooks.slot = blk * nby + by;
+      if (kKrj) stage_cal_cells(cells, cal.axis, cal.values, cal.n_el, cal.n_bands);  // (the item starts with a barrier)
+      // px_sample_items walks the items of "workgroup w of W" in its own order -- XCD w mod 8 takes the chunks
+      // w mod 8, + 8, ... -- and W = 2^30 makes that walk exactly ONE item long: the one numbered (by, bx)
+      mrx_px::px_sample_items<kLdsTables, 1, true, true>(
+          fast, lpx, n_layers, offpx, tables, n_tables, table_data, table_floats, az, el, Ta, dxs, dys, band, mueller00,
+          D, pwv0, nullptr, loading, flags, chunk, nby, block_rows, n_blocks, blk, blk + 1, ((by >> 3) * nbx + bx) * 8 + (by & 7),
+          1 << 30, reinterpret_cast<float4*>(synth_lds), hooks);
+    }
   }
-  synth_leave(ctl, n_blocks);
+  synth_leave(ctl, n_slots);
 }
 
 }  // namespace
@@ -184,7 +249,7 @@ extern "C" {
 
 static int atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d_az, const float* d_el, int Ta,
                           const float* d_dx, const float* d_dy, const int32_t* d_band, const float* d_mueller00, int D,
-                          double pwv0, float* d_coarse, int block_rows, int head_rows, uint32_t* d_flags, double ta0,
+                          double pwv0, float* d_coarse, int block_rows, int sampler_wgs, uint32_t* d_flags, double ta0,
                           double dta, const double* d_t, int T, const float* d_scale, const int32_t* d_rows, float* d_out,
                           size_t ld_out, const SynthCal* krj) {
   if (!ctx) return MRX_ERR_INVALID;
@@ -205,13 +270,17 @@ static int atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d
   if (!plan->all_pixel || literal || plan->any_cubic || plan->n_layers > mrx_px::kMaxAnchors)
     return mrx_fail(ctx, MRX_ERR_UNSUPPORTED, "mrx_atm_synthesize: this plan or option set takes the two-call form");
   const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
-  if (block_rows <= 0) block_rows = D;
+  // detector blocks: one where the block's coarse array stays below 2 GiB (the sampler addresses it as a raw buffer)
+  {
+    const long long cap = ((1LL << 31) - 4096) / (4LL * Ta) / kBlock * kBlock;  // rows of whole groups of 256 lanes
+    MRX_REQUIRE(ctx, cap >= kBlock, "Ta too large: 256 rows of the coarse loading must stay below 2 GiB");
+    if (block_rows <= 0 || block_rows > cap) block_rows = (int)std::min<long long>(cap, (long long)mrx_ceil_div(D, kBlock) * kBlock);
+  }
   block_rows = std::min(mrx_ceil_div(block_rows, kBlock) * kBlock, mrx_ceil_div(D, 32) * 32);  // whole groups of 256 lanes; rows of whole lines
   const int n_blocks = mrx_ceil_div(D, block_rows);
-  MRX_REQUIRE(ctx, n_blocks <= kSynthMaxBlocks, "too many detector blocks");
   MRX_REQUIRE(ctx, (long long)Ta * block_rows * 4 < (1LL << 31), "a block's coarse array must stay below 2 GiB");
   MRX_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(d_coarse) & 127u) == 0, "d_coarse must be 128-byte aligned");
-  // ---- writer role: mrx_spline_upsample_fused's choices ----
+  // ---- writer tiles: mrx_spline_upsample_fused's choices ----
   const int vec_ok = (ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15u) == 0);
   const double knots_per_tile = (double)kTileSamples * (double)Ta / (double)T;
   const bool small = knots_per_tile + 6.0 <= 64.0;
@@ -226,42 +295,21 @@ static int atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d
                                    ((D - (long long)(n_blocks - 1) * block_rows) + rows_per_tile - 1) / rows_per_tile);
   MRX_REQUIRE(ctx, n_tiles <= 0x7fffffffLL - 65536, "too many tiles for one launch");
   const size_t lds_w = small ? FusedLds<64, 2>::kBytes : FusedLds<256, 1>::kBytes;
-  // ---- sampler role: mrx_atm_sample's choices for a resident grid ----
+  // ---- sampler items: the time chunk is the unit of the hand-over ----
   int chunk = ctx->options[MRX_OPT_SAMPLE_CHUNK];
-  if (chunk <= 0) {
-    chunk = mrx_px::kMaxChunk;
-    const long long want = 24LL * n_cu;
-    while (chunk > 1 && (long long)mrx_ceil_div(D, kBlock) * mrx_ceil_div(Ta, chunk) < want) chunk /= 2;
-  }
+  if (chunk <= 0) chunk = 32;  // (16 / 32 / 64 steps: DESIGN 6 -- shorter chunks start the writers sooner and cost more item prologues)
   chunk = chunk < 1 ? 1 : chunk > mrx_px::kMaxChunk ? mrx_px::kMaxChunk : chunk;
   while (chunk > 1 && chunk * plan->n_layers > mrx_px::kMaxAnchors) chunk /= 2;
-  // the launch has ONE dynamic LDS size and a CU's LDS is what bounds its writers: the sampler's anchors stay under
-  // the writer's images (16 layers at 64 steps a work item took 37 KB -- and a writer's place on every CU)
+  // the launch has ONE dynamic LDS size and a CU's LDS is what bounds its workgroups: the sampler's anchors stay under
+  // the writer's images (16 layers at 64 steps a work item took 37 KB -- and a workgroup's place on every CU)
   const size_t lds_turn = sizeof(float) * 4 * kBlock;  // four steps of every lane (px_sample_items<..., kWriteThrough>)
   while (chunk > 8 && 2 * sizeof(float4) * (size_t)chunk * plan->n_layers + lds_turn > lds_w) chunk /= 2;
+  while (chunk < mrx_px::kMaxChunk && (long long)n_blocks * mrx_ceil_div(Ta, chunk) > kSynthMaxSlots) chunk *= 2;
   const int nby = mrx_ceil_div(Ta, chunk);
+  MRX_REQUIRE(ctx, (long long)n_blocks * nby <= kSynthMaxSlots, "too many (detector block, time chunk) units for one launch");
   const long long n_items = (long long)nby * ((long long)(n_blocks - 1) * mrx_ceil_div(block_rows, kBlock) +
                                               mrx_ceil_div(D - (n_blocks - 1) * block_rows, kBlock));
-  MRX_REQUIRE(ctx, n_items <= 0x7fffffffLL, "too many work items for one launch");
-  int per_cu = ctx->options[MRX_OPT_SAMPLE_WGS_PER_CU];
-  if (per_cu <= 0 || per_cu >= 8) per_cu = 2;
-  long long wgs_s = std::min(n_items, (long long)per_cu * n_cu);
-  if (wgs_s >= 8) wgs_s &= ~7LL;
-  // the head start: the first blocks by a grid that fills the chip (MRX_WRITER_WAVES workgroups per CU)
-  const int head_blocks = std::max(0, std::min(mrx_ceil_div(std::max(head_rows, 0), block_rows), n_blocks));
-  const long long wgs_full = std::max(wgs_s, std::min(n_items, (long long)MRX_WRITER_WAVES * n_cu) & ~7LL);
-  SynthPhases phases = {};
-  // (a staircase -- the head's blocks in shares to 5, 4, 3 workgroups per CU, writers entering as each step leaves --
-  //  measured no better than one step: 1.98-2.05 against 1.93-1.98 ms)
-  if (head_blocks > 0) {
-    phases.n = 2;
-    phases.end[0] = head_blocks; phases.wgs[0] = (int)wgs_full;
-    phases.end[1] = n_blocks;    phases.wgs[1] = (int)wgs_s;
-  } else {
-    phases.n = 1;
-    phases.end[0] = n_blocks; phases.wgs[0] = (int)wgs_s;
-  }
-  const long long wgs_head = phases.wgs[0];
+  MRX_REQUIRE(ctx, n_items <= 0x7fffffffLL - 65536, "too many work items for one launch");
   const size_t lds_anchor = 2 * sizeof(float4) * (size_t)chunk * plan->n_layers;
   const size_t lds_tables = sizeof(float) * (size_t)((plan->table_floats + 3) / 4 * 4);
   // band tables in LDS only where they fit under the writer's images too
@@ -270,15 +318,25 @@ static int atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d
   if (lds_anchor + (lds_tab ? lds_tables : 0) + lds_turn + lds_cal > lds_w)
     return mrx_fail(ctx, MRX_ERR_UNSUPPORTED, "mrx_atm_synthesize: the calibration table does not fit beside the sampler's LDS: use the two calls");
   const size_t lds = lds_w;
-  // writers: as many as fit a CU once the samplers have left (the surplus is dispatched as those exit)
-  const long long per_cu_w = std::max<long long>(1, std::min<long long>(MRX_WRITER_WAVES, (long long)(ctx->lds_per_cu > 0 ? ctx->lds_per_cu : 160 * 1024) / (long long)(lds + 1552)));
-  const long long wgs_w = std::min(n_tiles, per_cu_w * n_cu);
+  // ---- the grid: as many workgroups as a CU holds, all resident, each taking tiles and items until both queues are
+  // empty; the first `dedicated` only sample while items remain (MRX_OPT_SAMPLE_WGS_PER_CU per CU, or the caller's number)
+  long long per_cu = std::max<long long>(1, std::min<long long>(MRX_WRITER_WAVES, (long long)(ctx->lds_per_cu > 0 ? ctx->lds_per_cu : 160 * 1024) / (long long)(lds + 1600)));
+  if (ctx->options[MRX_OPT_SYNTH_WGS_PER_CU] > 0) per_cu = std::min<long long>(per_cu, ctx->options[MRX_OPT_SYNTH_WGS_PER_CU]);
+  const long long wgs = std::min(n_tiles + n_items, per_cu * n_cu);
+  long long dedicated = sampler_wgs;
+  if (dedicated <= 0) {
+    int s_per_cu = ctx->options[MRX_OPT_SAMPLE_WGS_PER_CU];
+    if (s_per_cu <= 0 || s_per_cu >= 8) s_per_cu = 2;
+    dedicated = (long long)s_per_cu * n_cu;
+  }
+  dedicated = std::min(dedicated, std::max(0LL, wgs - 1));  // (somebody has to write while items remain: or all would sample first)
+  if (ctx->options[MRX_OPT_SAMPLE_WGS_PER_CU] >= 8) dedicated = 0;  // (A/B: nobody only samples)
   int* ctl = nullptr;
   {
     const int rc = mrx_synth_ctl(ctx, &ctl);
     if (rc != MRX_OK) return rc;
   }
-  const dim3 grid((unsigned)(wgs_head + wgs_w));
+  const dim3 grid((unsigned)wgs);
   const int poll_limit = 1 << 22;  // x >= 0.5 us a try: seconds
   const SynthCal cal = krj ? *krj : SynthCal{};
 #define MRX_LAUNCH_SYNTH(L, S, K, G, J)                                                                           \
@@ -287,7 +345,7 @@ static int atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d
     hipLaunchKernelGGL((atm_tod_kernel<L, S, K, G, J>), grid, dim3(kBlock), lds, ctx->stream, plan->d_fast,       \
                        plan->d_px, plan->n_layers, plan->d_offpx, plan->d_tables, plan->n_tables,                 \
                        plan->d_table_data, plan->table_floats, d_az, d_el, Ta, d_dx, d_dy, d_band, d_mueller00,   \
-                       D, pwv0, d_coarse, d_flags, chunk, nby, block_rows, n_blocks, (int)wgs_head, phases, ta0, 1.0 / dta,           \
+                       D, pwv0, d_coarse, d_flags, chunk, nby, block_rows, n_blocks, (int)dedicated, ta0, 1.0 / dta, \
                        d_t, T, d_scale, d_rows, d_out, ld_out, vec_ok, batches, ctl, poll_limit, cal);           \
   } while (0)
 #define MRX_LAUNCH_SYNTH_J(L, S, K, G) do { if (krj) MRX_LAUNCH_SYNTH(L, S, K, G, true); else MRX_LAUNCH_SYNTH(L, S, K, G, false); } while (0)
@@ -306,17 +364,17 @@ static int atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d
 
 int mrx_atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d_az, const float* d_el, int Ta,
                        const float* d_dx, const float* d_dy, const int32_t* d_band, const float* d_mueller00, int D,
-                       double pwv0, float* d_coarse, int block_rows, int head_rows, uint32_t* d_flags, double ta0,
+                       double pwv0, float* d_coarse, int block_rows, int sampler_wgs, uint32_t* d_flags, double ta0,
                        double dta, const double* d_t, int T, const float* d_scale, const int32_t* d_rows, float* d_out,
                        size_t ld_out) {
   MRX_ENTER(ctx);
-  return atm_synthesize(ctx, plan, d_az, d_el, Ta, d_dx, d_dy, d_band, d_mueller00, D, pwv0, d_coarse, block_rows, head_rows,
+  return atm_synthesize(ctx, plan, d_az, d_el, Ta, d_dx, d_dy, d_band, d_mueller00, D, pwv0, d_coarse, block_rows, sampler_wgs,
                         d_flags, ta0, dta, d_t, T, d_scale, d_rows, d_out, ld_out, nullptr);
 }
 
 int mrx_atm_synthesize_krj(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d_az, const float* d_el, int Ta,
                            const float* d_dx, const float* d_dy, const int32_t* d_band, const float* d_mueller00, int D,
-                           double pwv0, float* d_coarse, int block_rows, int head_rows, uint32_t* d_flags, double ta0,
+                           double pwv0, float* d_coarse, int block_rows, int sampler_wgs, uint32_t* d_flags, double ta0,
                            double dta, const double* d_t, int T, const float* d_scale, const int32_t* d_rows, float* d_out,
                            size_t ld_out, const float* d_cal_dx, const float* d_cal_dy, const float* d_cal_axis_el,
                            const float* d_cal_values, int n_el, int n_bands, float* d_tail_pw, int tail_knots, size_t ld_tail) {
@@ -326,7 +384,7 @@ int mrx_atm_synthesize_krj(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* 
   MRX_REQUIRE(ctx, n_el >= 2 && n_bands >= 1, "calibration tables need 2 <= n_el, 1 <= n_bands");
   MRX_REQUIRE(ctx, tail_knots >= 0 && tail_knots <= Ta && (!d_tail_pw || ld_tail >= (size_t)D), "bad tail window");
   SynthCal cal{d_cal_dx, d_cal_dy, d_cal_axis_el, d_cal_values, n_el, n_bands, tail_knots > 0 ? d_tail_pw : nullptr, Ta - tail_knots, ld_tail};
-  return atm_synthesize(ctx, plan, d_az, d_el, Ta, d_dx, d_dy, d_band, d_mueller00, D, pwv0, d_coarse, block_rows, head_rows,
+  return atm_synthesize(ctx, plan, d_az, d_el, Ta, d_dx, d_dy, d_band, d_mueller00, D, pwv0, d_coarse, block_rows, sampler_wgs,
                         d_flags, ta0, dta, d_t, T, d_scale, d_rows, d_out, ld_out, &cal);
 }
 

@@ -722,24 +722,22 @@ class DevicePath:
         return out
 
     def synthesize_applies(self):
-        """Does run() take the one-launch form by default?  From 2048 rows (below, the stages back to back are as
-        fast: 0.36 ms for 1 250 rows either way) and where the writer has more to do than the sampler (atlast_10k:
-        2.0 against 2.2 ms pipelined on two streams; with the 16 layers of atlast_50k the two-stream form stays ahead,
-        9.5 against 10.5 ms: there the sampler wants four workgroups per CU at 80 registers beside a writer at 94, and one
-        kernel has one register budget)."""
-        work = len(self.problem["layers"]) * self.Ta / max(self.T, 1)
-        return (not self.keep_pwv and self.D >= 2048 and work < 0.3 and not getattr(self, "_synth_unsupported", False)
+        """Does run() take the one-launch form by default?  Wherever the library's form applies (every layer on a
+        uniform axis, the default cell rule and pointing, linear tables: the call itself says so) but for callers that
+        want the coarse pwv kept and runs that overlap successive observations on streams (enable_lookahead)."""
+        return (not self.keep_pwv and self.D >= 2048 and not getattr(self, "_synth_unsupported", False)
                 and getattr(self, "_la", None) is None)
 
-    def synthesize(self, out=None, block_rows=None, resident_wgs_per_cu=None, head_rows=None, writer_events=None, krj=False):
-        """Atmosphere -> TOD in ONE launch (mrx_atm_synthesize): the sampler and the writer as two roles of one grid,
-        the hand-over between them on the device.  Same bits as the two-call forms.  ``block_rows``: detectors per
-        block, the unit of the hand-over; ``head_rows``: rows sampled by a grid that fills the chip before the writers
-        enter; ``resident_wgs_per_cu``: sampler workgroups per CU beside the writers.  Defaults from sweeps on 2 512,
-        5 000 and 10 000 rows of atlast_10k (scripts/exp_synth.py): 512-row blocks, a third of the
-        rows as head start, 2 workgroups from 8192 rows and 3 below.  ``krj``: the TOD in K_RJ by the coarse-grid form
-        (mrx_atm_synthesize_krj: the division in the sampler role's epilogue; set_calibration first, and the caller has
-        checked coarse_krj_bound() as run() does); the samples past the last knot take the per-sample form afterwards."""
+    def synthesize(self, out=None, block_rows=None, sampler_wgs_per_cu=None, chunk=None, writer_events=None, krj=False):
+        """Atmosphere -> TOD in ONE launch (mrx_atm_synthesize): sampler work items and TOD tiles as two queues of
+        one resident grid, the hand-over between them on the device, time chunk by time chunk.  Same bits as the
+        two-call forms.  ``block_rows``: detectors per block of the coarse array (default: the library's -- one block
+        where it stays below 2 GiB); ``sampler_wgs_per_cu``: workgroups per CU that only sample while items remain
+        (default 2; 8 or more: none -- every workgroup writes and samples only where it would wait);
+        ``chunk``: coarse steps per time chunk, the unit of the hand-over (default: the library's, 32).
+        ``krj``: the TOD in K_RJ by the coarse-grid form (mrx_atm_synthesize_krj: the division in the sampler's
+        epilogue; set_calibration first, and the caller has checked coarse_krj_bound() as run() does); the samples
+        past the last knot take the per-sample form afterwards."""
         if self.plan is None:
             raise RuntimeError("no screens bound: call set_screens() or generate_screens() first")
         if out is None:
@@ -747,22 +745,20 @@ class DevicePath:
         main = torch.cuda.current_stream(self.device)
         self.ctx.set_stream(main)
         self.wait_screens(main)
-        big = self.D >= 8192
         if block_rows is None:
-            block_rows = 512
-        if resident_wgs_per_cu is None:
-            resident_wgs_per_cu = 2 if big else 3
-        if head_rows is None:
-            head_rows = int((0.3 if big else 0.35) * self.D)
+            block_rows = 0
         if writer_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record(main)
         if getattr(self, "_coarse_blocks", None) is None:
             self._coarse_blocks = torch.empty(self.Ta * ((self.D + 31) // 32 * 32), dtype=torch.float32, device=self.device)
-        saved = self.ctx.get_option(_lib.OPT_SAMPLE_WGS_PER_CU)
-        self.ctx.set_option(_lib.OPT_SAMPLE_WGS_PER_CU, int(resident_wgs_per_cu))
+        saved = (self.ctx.get_option(_lib.OPT_SAMPLE_WGS_PER_CU), self.ctx.get_option(_lib.OPT_SAMPLE_CHUNK))
+        if sampler_wgs_per_cu is not None:
+            self.ctx.set_option(_lib.OPT_SAMPLE_WGS_PER_CU, int(sampler_wgs_per_cu))
+        if chunk is not None:
+            self.ctx.set_option(_lib.OPT_SAMPLE_CHUNK, int(chunk))
         args = [self.plan, ptr(self.d_az), ptr(self.d_el), self.Ta, ptr(self.d_dx), ptr(self.d_dy),
-                ptr(self.d_band), ptr(self.d_m00), self.D, self.pwv0, ptr(self._coarse_blocks), int(block_rows), int(head_rows),
+                ptr(self.d_band), ptr(self.d_m00), self.D, self.pwv0, ptr(self._coarse_blocks), int(block_rows), 0,
                 ptr(self.d_flags), self.ta0, self.dta, ptr(self.d_t), self._krj_split() if krj else self.T,
                 None if self.d_gain is None else ptr(self.d_gain), None if self.d_rows is None else ptr(self.d_rows),
                 ptr(out), out.stride(0)]
@@ -781,17 +777,25 @@ class DevicePath:
                 if tail is not None:
                     self._krj_tail(tail, self.D, slice(0, self.D), out, ptr(self.d_rows), self.ctx)
         finally:
-            self.ctx.set_option(_lib.OPT_SAMPLE_WGS_PER_CU, saved)
+            self.ctx.set_option(_lib.OPT_SAMPLE_WGS_PER_CU, saved[0])
+            self.ctx.set_option(_lib.OPT_SAMPLE_CHUNK, saved[1])
         if writer_events is not None:
             ev[1].record(main)
             writer_events.append(ev)
-        br = int(block_rows) if int(block_rows) > 0 else self.D
-        self._synth_block_rows = min((br + 255) // 256 * 256, (self.D + 31) // 32 * 32)  # as the library rounds it
+        self._synth_block_rows = self.synth_block_rows(int(block_rows))
         self._synthesized = True
         self._synthesized_krj = bool(krj)  # (the coarse blocks then hold K_RJ, not pW)
         self._pipelined = False
         self._pwv_stale = True
         return out
+
+    def synth_block_rows(self, block_rows=0):
+        """Rows per block of the coarse array as mrx_atm_synthesize lays it out: the caller's number in whole groups of
+        256 detectors, or -- 0 -- everything in one block where 4 Ta rows stays below 2 GiB (the most that do otherwise)."""
+        cap = ((1 << 31) - 4096) // (4 * self.Ta) // 256 * 256
+        if block_rows <= 0 or block_rows > cap:
+            block_rows = min(cap, (self.D + 255) // 256 * 256)
+        return min((block_rows + 255) // 256 * 256, (self.D + 31) // 32 * 32)
 
     def default_blocks(self):
         """Detector blocks of the pipelined run: about 0.65e9 samples each from 4096 rows up -- 4 for atlast_10k

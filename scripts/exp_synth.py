@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
 """Experiment: the one-launch synthesis (mrx_atm_synthesize) against the pipelined two-stream run: bits and time.
-Usage: python scripts/exp_synth.py <config> [block_rows...]"""
+Usage: python scripts/exp_synth.py <config> [block_rows...]
+  SYNTH_WGS=0,1,2,3   dedicated sampler workgroups per CU (8: none)     SYNTH_CHUNK=16,32,64   steps per time chunk
+  SYNTH_PER_CU=0      resident workgroups per CU (0: as many as fit)    SYNTH_DETS=n           detectors"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
-from maria_amd import synthetic
+from maria_amd import _lib, synthetic
 from maria_amd.pipeline import DevicePath
 from scripts.kbench import timeit
 
 config = sys.argv[1] if len(sys.argv) > 1 else "atlast_10k"
-rows = [int(b) for b in sys.argv[2:]] or [256, 512, 1024]
+rows = [int(b) for b in sys.argv[2:]] or [0]
 n_det = synthetic.CONFIGS[config]["n_det"] // (8 if config == "atlast_50k" else 1)
 if os.environ.get("SYNTH_DETS"):
     n_det = int(os.environ["SYNTH_DETS"])
@@ -20,19 +22,24 @@ ref = torch.empty((path.D, path.T), dtype=torch.float32, device="cuda:0")
 path.run(ref, blocks=1)
 torch.cuda.synchronize()
 tod = torch.empty_like(ref)
-heads = [int(h) for h in os.environ.get("SYNTH_HEADS", "0").split(",")]
-for br in rows:
-  for head in heads:
-    for wgs in [int(w) for w in os.environ.get('SYNTH_WGS', '3,4').split(',')]:
+ints = lambda name, default: [int(x) for x in os.environ.get(name, default).split(",")]
+for per_cu in ints("SYNTH_PER_CU", "0"):
+  path.ctx.set_option(_lib.OPT_SYNTH_WGS_PER_CU, per_cu)
+  for br in rows:
+    for chunk in ints("SYNTH_CHUNK", "32"):
+      for wgs in ints("SYNTH_WGS", "2"):
         tod.fill_(float("nan"))
-        path.synthesize(tod, block_rows=br, resident_wgs_per_cu=wgs, head_rows=head * br)
+        kw = dict(block_rows=br, sampler_wgs_per_cu=wgs, chunk=chunk)
+        path.synthesize(tod, **kw)
         torch.cuda.synchronize()
         flags = int(path.d_flags.item())
         same = bool(torch.equal(tod, ref))
         nbad = 0 if same else int((tod != ref).sum().item())
-        med, mn = timeit(lambda: path.synthesize(tod, block_rows=br, resident_wgs_per_cu=wgs, head_rows=head * br), 6)
-        print(f"{config} synthesize block_rows {br} head {head} wgs {wgs}: identical {same} (differing {nbad}) flags {flags}  median {med:.3f} ms min {mn:.3f}", flush=True)
-med, mn = timeit(lambda: path.run(tod, blocks=path.default_blocks()), 6)
-print(f"{config} pipelined run (default blocks {path.default_blocks()}): median {med:.3f} ms min {mn:.3f}", flush=True)
-med, mn = timeit(lambda: path.run(tod, blocks=1), 4)
-print(f"{config} serial run: median {med:.3f} ms min {mn:.3f}", flush=True)
+        med, mn = timeit(lambda: path.synthesize(tod, **kw), 8)
+        print(f"{config} D {path.D} synthesize per_cu {per_cu} block_rows {br} chunk {chunk} samplers {wgs}: identical {same} (differing {nbad}) flags {flags}  median {med:.3f} ms min {mn:.3f}", flush=True)
+path.ctx.set_option(_lib.OPT_SYNTH_WGS_PER_CU, 0)
+if not os.environ.get("SYNTH_ONLY"):
+    med, mn = timeit(lambda: path._run_pipelined(tod, path.default_blocks()) if path.default_blocks() > 1 else path.run(tod, blocks=1), 6)
+    print(f"{config} pipelined run (default blocks {path.default_blocks()}): median {med:.3f} ms min {mn:.3f}", flush=True)
+    med, mn = timeit(lambda: path.run(tod, blocks=1), 4)
+    print(f"{config} serial run: median {med:.3f} ms min {mn:.3f}", flush=True)
