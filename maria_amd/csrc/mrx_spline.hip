@@ -422,7 +422,7 @@ int mrx_spline_upsample_fused(mrx_ctx* ctx, const float* d_y, int D, int Ta,
   // tile of 1024 samples then spans <= 58 knots + the widening at the ends); the 256-knot
   // image one group (ratios down to ~4.2); below that the kernel's per-sample path runs
   const double knots_per_tile = (double)kTileSamples * (double)Ta / (double)T;
-  const bool small = knots_per_tile + 6.0 <= 64.0;
+  const bool small = knots_per_tile + 6.0 <= (double)kSmallKnots;
   const int rows_per_batch = small ? 2 * kTileDet : kTileDet;
   int batches = ctx->options[MRX_OPT_UPSAMPLE_GROUPS];
   // rows per workgroup and occupancy do not matter (round 3, 10 000 x 240 000 alone: 1.77-1.79 ms = 5.35-5.41 TB/s
@@ -437,7 +437,7 @@ int mrx_spline_upsample_fused(mrx_ctx* ctx, const float* d_y, int D, int Ta,
   const long long nsx = mrx_ceil_div(T, kTileSamples);
   const long long n_tiles = nsx * mrx_ceil_div(D, rows_per_batch * batches);
   MRX_REQUIRE(ctx, n_tiles <= 0x7fffffffLL - 65536, "too many tiles for one launch");
-  const size_t lds = small ? FusedLds<64, 2>::kBytes : FusedLds<256, 1>::kBytes;
+  const size_t lds = small ? FusedLds<kSmallKnots, 2>::kBytes : FusedLds<256, 1>::kBytes;
   const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
   const long long per_cu = std::max<long long>(1, std::min<long long>(MRX_WRITER_WAVES, (long long)(ctx->lds_per_cu > 0 ? ctx->lds_per_cu : 160 * 1024) / (long long)(lds + 64)));
   const bool per_tile = ctx->options[MRX_OPT_WRITER_PER_TILE] != 0;
@@ -455,9 +455,9 @@ int mrx_spline_upsample_fused(mrx_ctx* ctx, const float* d_y, int D, int Ta,
                      d_rows, d_out, ld_out, vec_ok, batches, (int)nsx, (int)n_tiles, ctl)
 #define MRX_LAUNCH_UPF(S, K, G) do { if (per_tile) MRX_LAUNCH_UPF_Q(S, K, G, false); else MRX_LAUNCH_UPF_Q(S, K, G, true); } while (0)
   if (d_scale) {
-    if (small) MRX_LAUNCH_UPF(true, 64, 2); else MRX_LAUNCH_UPF(true, 256, 1);
+    if (small) MRX_LAUNCH_UPF(true, kSmallKnots, 2); else MRX_LAUNCH_UPF(true, 256, 1);
   } else {
-    if (small) MRX_LAUNCH_UPF(false, 64, 2); else MRX_LAUNCH_UPF(false, 256, 1);
+    if (small) MRX_LAUNCH_UPF(false, kSmallKnots, 2); else MRX_LAUNCH_UPF(false, 256, 1);
   }
 #undef MRX_LAUNCH_UPF_Q
 #undef MRX_LAUNCH_UPF

@@ -52,11 +52,21 @@ constexpr int kFHalo = 16;
 #define MRX_WRITER_WAVES 5  // occupancy target of the fused writer (see the kernel): 6 -> 80 registers, 2 spilled
 #endif
 
+// The small image (upsampling ratios from ~20 up: a tile of 1024 samples then spans <= 52 knots + the widening at the
+// ends) evaluates its samples in Horner form from per-interval coefficients (see fused_writer_tile, 3.): 58 knots is
+// what lets the coefficient image of 32 rows x 57 intervals (29 184 bytes) lie over the solve's two images, so that
+// the workgroup keeps its 30 KB and the CU its five workgroups.
+constexpr int kSmallKnots = 58;
+
 template <int kMaxKnots, int kG>
 struct FusedLds {
   static constexpr int kRows = kTileDet * kG;
-  static constexpr size_t kBytes = sizeof(float2) * kRows * (kMaxKnots + 1) +
-                                   sizeof(float) * kRows * ((kMaxKnots + 2 * kFHalo + 6) | 1) + sizeof(int) * kRows;
+  static constexpr bool kHorner = kMaxKnots <= 64;
+  static constexpr size_t kSolveBytes = sizeof(float2) * kRows * (kMaxKnots + 1) + sizeof(float) * kRows * ((kMaxKnots + 2 * kFHalo + 6) | 1);
+  static constexpr size_t kCoefBytes = kHorner ? sizeof(float4) * kRows * (kMaxKnots - 1) : 0;
+  static constexpr size_t kImageBytes = (((kSolveBytes > kCoefBytes ? kSolveBytes : kCoefBytes) + 15) / 16) * 16;
+  // the images, then per row its place in the TOD (row x ld, 8 bytes)
+  static constexpr size_t kBytes = kImageBytes + sizeof(unsigned long long) * kRows;
 };
 
 // One tile of the fused writer: time tile `sx` (kTileSamples samples), row group `by` (batches x kRows rows of the
@@ -76,16 +86,22 @@ __device__ __forceinline__ void fused_writer_tile(
   constexpr int kSegKnots = kMaxKnots - 2;          // knots of one segment before the widening at the ends
   float2* tile = reinterpret_cast<float2*>(fused_lds);                 // [kRows][kPitch]
   float* yraw = reinterpret_cast<float*>(tile + kRows * kPitch);       // [kRows][kWPitch]
-  int* row_lds = reinterpret_cast<int*>(yraw + kRows * kWPitch);       // [kRows]
-  auto row_of = [&](int dl, int d) -> size_t { return rows ? (size_t)row_lds[dl] : (size_t)d; };
+  // Horner form (the small image): after the solve, the knots (y, m) of a row become per-INTERVAL coefficients
+  //   S(u) = c0 + u (c1 + u (c2 + u c3)),  c0 = y_j, c1 = (y_{j+1} - y_j) - 2 m_j - m_{j+1}, c2 = 3 m_j, c3 = m_{j+1} - m_j
+  // (the same cubic as y_j + [u (y_{j+1} - y_j) + ((1-u)^3 - (1-u)) m_j + (u^3 - u) m_{j+1}], expanded in u; the
+  // detector's scale goes into the coefficients), one float4 per (row, interval) in an image that lies OVER the solve's
+  // two: a sample then costs one 16-byte LDS read and three fused multiply-adds instead of two 8-byte reads, five
+  // operations and a multiply by the scale -- the row loop was 85 % of the writer's vector instructions (40 per row and
+  // thread), and the launch that writes beside the sampler is bound by vector issue (SIMDs 92 % busy).
+  constexpr bool kHorner = FusedLds<kMaxKnots, kG>::kHorner;
+  constexpr int kCPitch = kMaxKnots - 1;  // intervals of a row (odd for the small image: 57)
+  float4* coef = reinterpret_cast<float4*>(fused_lds);                 // [kRows][kCPitch], over tile and yraw
+  // where a row starts in the TOD, in floats: staged per pass, read back in the row loop (one 64-bit add per lane and
+  // row; computed there from the row number it was a 64-bit multiply per lane and row)
+  unsigned long long* row_off = reinterpret_cast<unsigned long long*>(fused_lds + FusedLds<kMaxKnots, kG>::kImageBytes);  // [kRows]
   const int s_tile = sx * kTileSamples;
   const int sb = s_tile + threadIdx.x * kSamplesPerThread;
-
-  // the thread's sample times: loaded now (in flight during the staging below), turned into interval
-  // and weights after the solve -- 8 registers live through the prologue instead of 24
-  double tq[kSamplesPerThread];
-#pragma unroll
-  for (int q = 0; q < kSamplesPerThread; ++q) tq[q] = t[min(sb + q, T - 1)];
+  float* const out_sb = out + sb;  // the thread's four samples in row 0
 
   // knot range of the tile (workgroup-uniform; t ascending).  It normally fits the image: one
   // segment.  A tile that spans more knots (upsampling ratio below ~1024 / kMaxKnots) is
@@ -111,8 +127,19 @@ __device__ __forceinline__ void fused_writer_tile(
       const int K = jmax - jmin + 1;  // <= kMaxKnots
       const int w0 = max(jmin - 3 - kFHalo, 0), w1 = min(jmax + 3 + kFHalo, n - 1);
       const int Wn = w1 - w0 + 1;
+      // the thread's sample times: loaded now (in flight during the staging below), turned into interval and weights
+      // after the solve -- 8 registers live through the prologue instead of 24 -- and loaded again in every pass (a
+      // tile is one pass but for several row batches or small upsampling ratios; the empty asm keeps the loads from
+      // being hoisted): kept across the row loop they were 8 registers of a kernel that sits at its bound
+      double tq[kSamplesPerThread];
+      {
+        int sbq = sb;
+        asm volatile("" : "+v"(sbq));
+#pragma unroll
+        for (int q = 0; q < kSamplesPerThread; ++q) tq[q] = t[min(sbq + q, T - 1)];
+      }
       if (g > 0 || ja > j_first) __syncthreads();  // the previous pass is done with the images
-      if (rows && (int)threadIdx.x < nd) row_lds[threadIdx.x] = rows[d0 + threadIdx.x];
+      if ((int)threadIdx.x < nd) row_off[threadIdx.x] = (unsigned long long)(rows ? rows[d0 + threadIdx.x] : d0 + (int)threadIdx.x) * ld;
       {  // kRows lanes cover the rows of one knot: 64 or 128 contiguous bytes; 8 loads in flight per thread
         const int dl = threadIdx.x & (kRows - 1);
         const int d = d0 + dl;
@@ -280,6 +307,72 @@ __device__ __forceinline__ void fused_writer_tile(
       }
       }
       // ---- 3. evaluation -------------------------------------------------------------
+      if constexpr (kHorner) {
+        // (y, m) per knot -> (c0 .. c3) per interval, through registers (the coefficient image lies over the knots): a
+        // thread takes kSpan CONSECUTIVE intervals of one row -- kSpan + 1 knots, 2 (kSpan + 1) registers across the
+        // barrier (one interval in kBlock / kRows, as the combine step deals them, would hold 4 kSpan)
+        constexpr int kSpan = (kCPitch + kBlock / kRows - 1) / (kBlock / kRows);  // 8 for the small image
+        {
+          const int dl = threadIdx.x & (kRows - 1);
+          const int k0 = (threadIdx.x / kRows) * kSpan;  // wave-uniform but for the two halves of a wave
+          const float gsc = kHasScale ? scale[min(d0 + dl, D - 1)] : 1.0f;
+          float2 kn[kSpan + 1];
+#pragma unroll
+          for (int i = 0; i <= kSpan; ++i) kn[i] = tile[dl * kPitch + min(k0 + i, K - 1)];
+          __syncthreads();  // every thread has read its knots
+#pragma unroll
+          for (int i = 0; i < kSpan; ++i)
+            if (k0 + i < K - 1) {
+              const float2 s0 = kn[i], s1 = kn[i + 1];
+              float4 c = make_float4(s0.x, ((s1.x - s0.x) - 2.0f * s0.y) - s1.y, 3.0f * s0.y, s1.y - s0.y);
+              if (kHasScale) c = make_float4(gsc * c.x, gsc * c.y, gsc * c.z, gsc * c.w);
+              coef[dl * kCPitch + k0 + i] = c;
+            }
+          __syncthreads();
+        }
+        // interval and position within it, float64 once per sample (u < 0 or > 1: extrapolation, the same cubic)
+        int r[kSamplesPerThread], jq[kSamplesPerThread];
+        float u[kSamplesPerThread];
+#pragma unroll
+        for (int q = 0; q < kSamplesPerThread; ++q) {
+          const double x = (tq[q] - ta0) * inv_dta;
+          jq[q] = interval_of(x, n);
+          r[q] = min(max(jq[q] - jmin, 0), K - 2);  // in range even if t is unsorted
+          u[q] = (float)(x - (double)(jmin + r[q]));
+        }
+        if (full) {
+#pragma unroll 4
+          for (int dl = 0; dl < nd; ++dl) {
+            const float4* row = coef + dl * kCPitch;
+            float o[kSamplesPerThread];
+#pragma unroll
+            for (int q = 0; q < kSamplesPerThread; ++q) {
+              const float4 cf = row[r[q]];
+              o[q] = fmaf(u[q], fmaf(u[q], fmaf(u[q], cf.w, cf.z), cf.y), cf.x);
+            }
+            const vfloat4 v = {o[0], o[1], o[2], o[3]};
+            // (nt: beside the sampler it is the policy that costs least -- 2.17 ms against 2.43 plain, 2.47 sc1, 2.28 sc1 nt)
+            __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(out_sb + row_off[dl]));
+          }
+        } else {
+          // a sample belongs to the segment that holds its interval (every sample of a
+          // single-segment tile does, whatever its interval)
+          bool mine[kSamplesPerThread];
+#pragma unroll
+          for (int q = 0; q < kSamplesPerThread; ++q)
+            mine[q] = sb + q < T && (single || (jq[q] >= ja && jq[q] < jb));
+          for (int dl = 0; dl < nd; ++dl) {
+            const float4* row = coef + dl * kCPitch;
+            float* dst = out_sb + row_off[dl];
+#pragma unroll
+            for (int q = 0; q < kSamplesPerThread; ++q)
+              if (mine[q]) {
+                const float4 cf = row[r[q]];
+                dst[q] = fmaf(u[q], fmaf(u[q], fmaf(u[q], cf.w, cf.z), cf.y), cf.x);
+              }
+          }
+        }
+      } else {
       SampleWeights w;
       sample_weights_at(tq, n, ta0, inv_dta, w);
       int r[kSamplesPerThread];
@@ -300,13 +393,9 @@ __device__ __forceinline__ void fused_writer_tile(
             for (int q = 0; q < kSamplesPerThread; ++q) o[q] *= gsc;
           }
           const vfloat4 v = {o[0], o[1], o[2], o[3]};
-          // (nt: beside the sampler it is the policy that costs least -- 2.17 ms against 2.43 plain, 2.47 sc1, 2.28 sc1 nt)
-          __builtin_nontemporal_store(
-              v, reinterpret_cast<vfloat4*>(out + row_of(dl, d0 + dl) * ld + sb));
+          __builtin_nontemporal_store(v, reinterpret_cast<vfloat4*>(out_sb + row_off[dl]));
         }
       } else {
-        // a sample belongs to the segment that holds its interval (every sample of a
-        // single-segment tile does, whatever its interval)
         bool mine[kSamplesPerThread];
 #pragma unroll
         for (int q = 0; q < kSamplesPerThread; ++q)
@@ -314,11 +403,12 @@ __device__ __forceinline__ void fused_writer_tile(
         for (int dl = 0; dl < nd; ++dl) {
           const float2* row = tile + dl * kPitch;
           const float gsc = kHasScale ? scale[d0 + dl] : 1.0f;
-          float* dst = out + row_of(dl, d0 + dl) * ld + sb;
+          float* dst = out_sb + row_off[dl];
 #pragma unroll
           for (int q = 0; q < kSamplesPerThread; ++q)
             if (mine[q]) dst[q] = gsc * spline_eval(w, q, row[r[q]], row[r[q] + 1]);
         }
+      }
       }
     }
   }

@@ -8,6 +8,10 @@
 
 namespace {
 
+#ifndef MRX_SYNTH_PIPE
+#define MRX_SYNTH_PIPE 1  // the sampler's layer loop as the three-stage gather ring (0: the plain loop)
+#endif
+
 // ---------------------------------------------------------------------------
 // Atmosphere -> TOD in ONE launch (mrx_atm_synthesize): sampling and writing as two kinds of work that ONE resident
 // grid takes from two queues, the hand-over between them on the device, in units of a TIME CHUNK.
@@ -234,7 +238,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_WRIT
       if (kKrj) stage_cal_cells(cells, cal.axis, cal.values, cal.n_el, cal.n_bands);  // (the item starts with a barrier)
       // px_sample_items walks the items of "workgroup w of W" in its own order -- XCD w mod 8 takes the chunks
       // w mod 8, + 8, ... -- and W = 2^30 makes that walk exactly ONE item long: the one numbered (by, bx)
-      mrx_px::px_sample_items<kLdsTables, 1, true, true>(
+      mrx_px::px_sample_items<kLdsTables, 1, MRX_SYNTH_PIPE != 0, true>(
           fast, lpx, n_layers, offpx, tables, n_tables, table_data, table_floats, az, el, Ta, dxs, dys, band, mueller00,
           D, pwv0, nullptr, loading, flags, chunk, nby, block_rows, n_blocks, blk, blk + 1, ((by >> 3) * nbx + bx) * 8 + (by & 7),
           1 << 30, reinterpret_cast<float4*>(synth_lds), hooks);
@@ -283,7 +287,7 @@ static int atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d
   // ---- writer tiles: mrx_spline_upsample_fused's choices ----
   const int vec_ok = (ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15u) == 0);
   const double knots_per_tile = (double)kTileSamples * (double)Ta / (double)T;
-  const bool small = knots_per_tile + 6.0 <= 64.0;
+  const bool small = knots_per_tile + 6.0 <= (double)kSmallKnots;
   const int rows_per_batch = small ? 2 * kTileDet : kTileDet;
   int batches = ctx->options[MRX_OPT_UPSAMPLE_GROUPS];
   if (batches <= 0) batches = 1;
@@ -294,7 +298,7 @@ static int atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d
   const long long n_tiles = nsx * ((long long)(n_blocks - 1) * ((block_rows + rows_per_tile - 1) / rows_per_tile) +
                                    ((D - (long long)(n_blocks - 1) * block_rows) + rows_per_tile - 1) / rows_per_tile);
   MRX_REQUIRE(ctx, n_tiles <= 0x7fffffffLL - 65536, "too many tiles for one launch");
-  const size_t lds_w = small ? FusedLds<64, 2>::kBytes : FusedLds<256, 1>::kBytes;
+  const size_t lds_w = small ? FusedLds<kSmallKnots, 2>::kBytes : FusedLds<256, 1>::kBytes;
   // ---- sampler items: the time chunk is the unit of the hand-over ----
   int chunk = ctx->options[MRX_OPT_SAMPLE_CHUNK];
   if (chunk <= 0) chunk = 32;  // (16 / 32 / 64 steps: DESIGN 6 -- shorter chunks start the writers sooner and cost more item prologues)
@@ -349,7 +353,7 @@ static int atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d
                        d_t, T, d_scale, d_rows, d_out, ld_out, vec_ok, batches, ctl, poll_limit, cal);           \
   } while (0)
 #define MRX_LAUNCH_SYNTH_J(L, S, K, G) do { if (krj) MRX_LAUNCH_SYNTH(L, S, K, G, true); else MRX_LAUNCH_SYNTH(L, S, K, G, false); } while (0)
-#define MRX_LAUNCH_SYNTH_S(L, S) do { if (small) MRX_LAUNCH_SYNTH_J(L, S, 64, 2); else MRX_LAUNCH_SYNTH_J(L, S, 256, 1); } while (0)
+#define MRX_LAUNCH_SYNTH_S(L, S) do { if (small) MRX_LAUNCH_SYNTH_J(L, S, kSmallKnots, 2); else MRX_LAUNCH_SYNTH_J(L, S, 256, 1); } while (0)
   if (lds_tab) {
     if (d_scale) MRX_LAUNCH_SYNTH_S(true, true); else MRX_LAUNCH_SYNTH_S(true, false);
   } else {

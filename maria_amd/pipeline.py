@@ -728,13 +728,14 @@ class DevicePath:
         return (not self.keep_pwv and self.D >= 2048 and not getattr(self, "_synth_unsupported", False)
                 and getattr(self, "_la", None) is None)
 
-    def synthesize(self, out=None, block_rows=None, sampler_wgs_per_cu=None, chunk=None, writer_events=None, krj=False):
+    def synthesize(self, out=None, block_rows=None, sampler_wgs_per_cu=None, chunk=None, writer_events=None, krj=False, sampler_wgs=0):
         """Atmosphere -> TOD in ONE launch (mrx_atm_synthesize): sampler work items and TOD tiles as two queues of
         one resident grid, the hand-over between them on the device, time chunk by time chunk.  Same bits as the
         two-call forms.  ``block_rows``: detectors per block of the coarse array (default: the library's -- one block
         where it stays below 2 GiB); ``sampler_wgs_per_cu``: workgroups per CU that only sample while items remain
         (default 2; 8 or more: none -- every workgroup writes and samples only where it would wait);
-        ``chunk``: coarse steps per time chunk, the unit of the hand-over (default: the library's, 32).
+        ``chunk``: coarse steps per time chunk, the unit of the hand-over (default: the library's, 32);
+        ``sampler_wgs``: the dedicated samplers as a number of workgroups instead of per CU (0: not given).
         ``krj``: the TOD in K_RJ by the coarse-grid form (mrx_atm_synthesize_krj: the division in the sampler's
         epilogue; set_calibration first, and the caller has checked coarse_krj_bound() as run() does); the samples
         past the last knot take the per-sample form afterwards."""
@@ -758,7 +759,7 @@ class DevicePath:
         if chunk is not None:
             self.ctx.set_option(_lib.OPT_SAMPLE_CHUNK, int(chunk))
         args = [self.plan, ptr(self.d_az), ptr(self.d_el), self.Ta, ptr(self.d_dx), ptr(self.d_dy),
-                ptr(self.d_band), ptr(self.d_m00), self.D, self.pwv0, ptr(self._coarse_blocks), int(block_rows), 0,
+                ptr(self.d_band), ptr(self.d_m00), self.D, self.pwv0, ptr(self._coarse_blocks), int(block_rows), int(sampler_wgs),
                 ptr(self.d_flags), self.ta0, self.dta, ptr(self.d_t), self._krj_split() if krj else self.T,
                 None if self.d_gain is None else ptr(self.d_gain), None if self.d_rows is None else ptr(self.d_rows),
                 ptr(out), out.stride(0)]

@@ -29,7 +29,7 @@ for per_cu in ints("SYNTH_PER_CU", "0"):
     for chunk in ints("SYNTH_CHUNK", "32"):
       for wgs in ints("SYNTH_WGS", "2"):
         tod.fill_(float("nan"))
-        kw = dict(block_rows=br, sampler_wgs_per_cu=wgs, chunk=chunk)
+        kw = dict(block_rows=br, sampler_wgs_per_cu=wgs, chunk=chunk) if wgs < 16 else dict(block_rows=br, sampler_wgs=wgs, chunk=chunk)
         path.synthesize(tod, **kw)
         torch.cuda.synchronize()
         flags = int(path.d_flags.item())
