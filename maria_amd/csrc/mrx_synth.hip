@@ -301,7 +301,14 @@ static int atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d
   const size_t lds_w = small ? FusedLds<kSmallKnots, 2>::kBytes : FusedLds<256, 1>::kBytes;
   // ---- sampler items: the time chunk is the unit of the hand-over ----
   int chunk = ctx->options[MRX_OPT_SAMPLE_CHUNK];
-  if (chunk <= 0) chunk = 32;  // (16 / 32 / 64 steps: DESIGN 6 -- shorter chunks start the writers sooner and cost more item prologues)
+  if (chunk <= 0) {
+    // 32 steps where that makes a few work items per resident workgroup (atlast_10k: 7 520 items, 2.00 ms against 2.04 at
+    // 64 steps and 2.08 at 16), shorter chunks for small shards, whose few detector groups would otherwise leave most
+    // of the chip without an item while the first chunks are sampled (2 512 rows: 0.54 ms at 16 steps, 0.58 at 32;
+    // 1 264 rows: 0.32 against 0.37)
+    chunk = 32;
+    while (chunk > 8 && (long long)mrx_ceil_div(Ta, chunk) * mrx_ceil_div(D, kBlock) < 5LL * MRX_WRITER_WAVES * n_cu / 2) chunk /= 2;
+  }
   chunk = chunk < 1 ? 1 : chunk > mrx_px::kMaxChunk ? mrx_px::kMaxChunk : chunk;
   while (chunk > 1 && chunk * plan->n_layers > mrx_px::kMaxAnchors) chunk /= 2;
   // the launch has ONE dynamic LDS size and a CU's LDS is what bounds its workgroups: the sampler's anchors stay under
