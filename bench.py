@@ -243,24 +243,57 @@ def fluct_err(a, b):
 def frontend_timing(device):
     """Wall clock of Simulation(atlast_10k-shaped instrument, device_output=True): set-up (Atmosphere.initialize:
     hull, rotation search, layer geometry, device upload -- atmosphere/atmosphere.py:81-281) and run()
-    (sim/simulation.py:201-272) atmosphere-only and with the detector noise, K_RJ (the reference's default units)."""
+    (sim/simulation.py:201-272), K_RJ (the reference's default units): atmosphere only, with the detector noise, and
+    the north star's literal call -- Simulation(instrument, plans, site, map=...) (sim/simulation.py:76-92) with a
+    1024^2 map in the ra/dec frame -- without and with the noise.  ``atmosphere_ms`` of a map row is the span of the
+    atmosphere's own launches inside that run (events around _simulate_atmosphere + _compute_atmospheric_loading)."""
     import numpy as np
     import torch
 
+    from maria_amd import map as mmap
     from maria_amd.instrument import Band, Detectors, Instrument, Site
-    from maria_amd.sim import Plan, Simulation
+    from maria_amd.sim import Plan, Simulation, sky_transform_stack
 
     band = Band(center=150e9, width=30e9, shape="top_hat", name="f150")
     inst = Instrument(Detectors.hexagon(10000, 2.0, [band], primary_size=50.0))
     plan = Plan.daisy(start_time=1.7e9, duration=600.0, sample_rate=400.0, scan_center=(45.0, 60.0), radius=0.5, speed=0.5)
-    out = {"instrument": f"{inst.dets.n} det hexagon, 2 deg field, 1 band; daisy 600 s @ 400 Hz; units K_RJ; device_output"}
-    for name, noise in (("atmosphere", False), ("atmosphere_noise", True)):
+    site = Site(altitude=5000.0)
+    # the scanned patch's centre in the map's frame: xyz(az, el) @ M[t] = xyz(ra, dec)
+    M = sky_transform_stack(plan.time[::4000], site.latitude, site.longitude)
+    az, el = plan.phi[::4000], plan.theta[::4000]
+    xyz = np.einsum("ti,tij->tj", np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)], axis=1), M).mean(axis=0)
+    centre = (float(np.degrees(np.arctan2(xyz[1], xyz[0]) % (2 * np.pi))), float(np.degrees(np.arcsin(xyz[2] / np.linalg.norm(xyz)))))
+    n = 1024
+    X, Y = np.meshgrid(np.linspace(-1, 1, n), np.linspace(-1, 1, n))
+    sky = mmap.ProjectionMap((1e-3 * (np.exp(-((X - 0.2) ** 2 + (Y + 0.1) ** 2) / 0.05) + 0.3 * np.sin(9 * X) * np.cos(7 * Y))).astype(np.float32),
+                             nu=150e9, width=4.0, center=centre, frame="ra/dec")
+    out = {"instrument": f"{inst.dets.n} det hexagon, 2 deg field, 1 band; daisy 600 s @ 400 Hz; units K_RJ; device_output; "
+                         f"map rows: {n}^2 K_RJ map, 4 deg wide, ra/dec frame"}
+    for name, noise, with_map in (("atmosphere", False, False), ("atmosphere_noise", True, False),
+                                  ("atmosphere_map", False, True), ("atmosphere_map_noise", True, True)):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        sim = Simulation(inst, plan, Site(altitude=5000.0), atmosphere="2d", noise=noise, device_output=True, noise_seed=1,
-                         progress_bars=False)
+        sim = Simulation(inst, plan, site, atmosphere="2d", map=sky if with_map else None, noise=noise, device_output=True,
+                         noise_seed=1, progress_bars=False)
         torch.cuda.synchronize()
         init_s = time.perf_counter() - t0
+        atm_spans = []
+        if with_map:  # the atmosphere's share of the run: events around its two stages (screens; sampling + TOD)
+            first, second = sim._simulate_atmosphere, sim._compute_atmospheric_loading
+
+            def timed_first(*a, **k):
+                e0 = torch.cuda.Event(enable_timing=True)
+                e0.record()
+                atm_spans.append([e0, None])
+                return first(*a, **k)
+
+            def timed_second(*a, **k):
+                r = second(*a, **k)
+                atm_spans[-1][1] = torch.cuda.Event(enable_timing=True)
+                atm_spans[-1][1].record()
+                return r
+
+            sim._simulate_atmosphere, sim._compute_atmospheric_loading = timed_first, timed_second
         walls, spans = [], []
         for _ in range(9):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -276,6 +309,8 @@ def frontend_timing(device):
         # (median of 8 runs after the first; single runs show 50-80 ms host stalls on a shared box)
         out[name] = {"init_s": init_s, "run_ms": 1e3 * float(np.median(walls[1:])), "run_ms_min": 1e3 * float(np.min(walls[1:])),
                      "first_run_ms": 1e3 * walls[0], "gpu_span_ms": float(np.median(spans[1:]))}
+        if atm_spans:
+            out[name]["atmosphere_ms"] = float(np.median([a.elapsed_time(b) for a, b in atm_spans[1:]]))
         del sim
         torch.cuda.empty_cache()
     return out

@@ -294,8 +294,12 @@ int mrx_spline_upsample_fused(mrx_ctx* ctx, const float* d_y, int D, int Ta,
  *                    floats: the coarse loading in pW, block b (rows b*block_rows ...) as its own
  *                    time-major array at d_coarse + Ta * b * block_rows, [Ta][pitch] with
  *                    pitch = its rows rounded up to 32 (the columns past the last row: padding)
+ *  d_pwv             f64, out, or NULL: the zenith-scaled pwv of every coarse sample (what mrx_atm_sample's
+ *                    d_pwv receives: atmosphere.py:373; the map mixin's calibration reads it,
+ *                    sim/map.py:117-135), block b as its own time-major array [Ta][rows of b] at
+ *                    d_pwv + Ta * b * block_rows -- one [Ta][D] array where the rows are one block
  *  other arguments   as mrx_atm_sample (d_az ... pwv0, d_flags) and mrx_spline_upsample
- *                    (ta0 ... ld_out); MRX_OPT_SAMPLE_CHUNK: coarse steps per time chunk (unset: 32)
+ *                    (ta0 ... ld_out); MRX_OPT_SAMPLE_CHUNK: coarse steps per time chunk (unset: by size)
  * MRX_ERR_UNSUPPORTED (nothing launched) for plans or options the pixel-coordinate sampler
  * does not take -- a layer on a non-uniform axis, MRX_OPT_AXIS_LITERAL, MRX_OPT_POINTING_CHAIN,
  * bicubic band tables --: use the two calls there.  MRX_FLAG_HANDOVER in d_flags: see above. */
@@ -303,7 +307,7 @@ int mrx_atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d_az
                        int Ta, const float* d_dx, const float* d_dy, const int32_t* d_band,
                        const float* d_mueller00, int D, double pwv0, float* d_coarse, int block_rows,
                        int sampler_wgs, uint32_t* d_flags, double ta0, double dta, const double* d_t, int T,
-                       const float* d_scale, const int32_t* d_rows, float* d_out, size_t ld_out);
+                       const float* d_scale, const int32_t* d_rows, float* d_out, size_t ld_out, double* d_pwv);
 
 /* mrx_atm_synthesize with TOD.to("K_RJ") applied on the coarse grid (tod/tod.py:106-142 before the spline, as
  * mrx_coarse_to_krj does between the two calls -- same functions, same operands, same bits): the sampler role divides
@@ -326,7 +330,7 @@ int mrx_atm_synthesize_krj(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* 
                            const float* d_scale, const int32_t* d_rows, float* d_out, size_t ld_out,
                            const float* d_cal_dx, const float* d_cal_dy, const float* d_cal_axis_el,
                            const float* d_cal_values, int n_el, int n_bands, float* d_tail_pw, int tail_knots,
-                           size_t ld_tail);
+                           size_t ld_tail, double* d_pwv);
 
 /* mrx_spline_upsample fused with TOD.to("K_RJ") (tod/tod.py:106-142): each sample
  * is divided by den_b(el) = (0.5 if polarized else 1) * k_B * 1e12 *

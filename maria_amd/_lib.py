@@ -172,9 +172,9 @@ SIGNATURES = {
     "mrx_spline_prepare": (_i, [_vp, _vp, _i, _i, _vp]),
     "mrx_spline_upsample": (_i, [_vp, _vp, _i, _i, _d, _d, _vp, _i, _vp, _vp, _vp, _sz]),
     "mrx_spline_upsample_fused": (_i, [_vp, _vp, _i, _i, _d, _d, _vp, _i, _vp, _vp, _vp, _sz]),
-    "mrx_atm_synthesize": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _d, _vp, _i, _i, _vp, _d, _d, _vp, _i, _vp, _vp, _vp, _sz]),
+    "mrx_atm_synthesize": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _d, _vp, _i, _i, _vp, _d, _d, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "mrx_atm_synthesize_krj": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _d, _vp, _i, _i, _vp, _d, _d, _vp, _i, _vp, _vp, _vp, _sz,
-                                    _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _sz]),
+                                    _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _sz, _vp]),
     "mrx_spline_upsample_krj": (_i, [_vp, _vp, _i, _i, _d, _d, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _sz]),
     "mrx_coarse_to_krj": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "mrx_coarse_to_krj_keep_tail": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _sz]),

@@ -435,6 +435,7 @@ __device__ __forceinline__ void px_sample_items(
         // what is stored: the loading itself, or what the caller's hook makes of it (K_RJ on the coarse grid)
         const float kept = hooks.value(out, bore[it + tt], t, (int)row0 + dd, live && t < Ta);
         if (kWriteThrough) {
+          if (pwv_out && live && t < Ta) pwv_out[(size_t)t * D + d] = pwv;  // (plain stores: nobody reads it in this launch)
           const int u = (it + tt) & 3, lane = threadIdx.x & 63;
           turn[u * 64 + lane] = kept;
           __builtin_amdgcn_wave_barrier();  // (the read below takes other lanes' values: keep it behind the write)

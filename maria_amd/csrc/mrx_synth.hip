@@ -111,6 +111,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_WRIT
     const float* __restrict__ table_data, int table_floats, const float* __restrict__ az,
     const float* __restrict__ el, int Ta, const float* __restrict__ dxs, const float* __restrict__ dys,
     const int32_t* __restrict__ band, const float* __restrict__ mueller00, int D, double pwv0,
+    double* __restrict__ pwv_out,  // the zenith-scaled pwv per coarse sample, block b as [Ta][rows of b], or null
     float* loading,  // written by sampler items, read by writer tiles: no __restrict__, no const
     uint32_t* __restrict__ flags, int chunk, int nby, int block_rows, int n_blocks, int n_dedicated,
     double ta0, double inv_dta, const double* __restrict__ t, int T,
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_WRIT
       // w mod 8, + 8, ... -- and W = 2^30 makes that walk exactly ONE item long: the one numbered (by, bx)
       mrx_px::px_sample_items<kLdsTables, 1, MRX_SYNTH_PIPE != 0, true>(
           fast, lpx, n_layers, offpx, tables, n_tables, table_data, table_floats, az, el, Ta, dxs, dys, band, mueller00,
-          D, pwv0, nullptr, loading, flags, chunk, nby, block_rows, n_blocks, blk, blk + 1, ((by >> 3) * nbx + bx) * 8 + (by & 7),
+          D, pwv0, pwv_out, loading, flags, chunk, nby, block_rows, n_blocks, blk, blk + 1, ((by >> 3) * nbx + bx) * 8 + (by & 7),
           1 << 30, reinterpret_cast<float4*>(synth_lds), hooks);
     }
   }
@@ -255,7 +256,7 @@ static int atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d
                           const float* d_dx, const float* d_dy, const int32_t* d_band, const float* d_mueller00, int D,
                           double pwv0, float* d_coarse, int block_rows, int sampler_wgs, uint32_t* d_flags, double ta0,
                           double dta, const double* d_t, int T, const float* d_scale, const int32_t* d_rows, float* d_out,
-                          size_t ld_out, const SynthCal* krj) {
+                          size_t ld_out, const SynthCal* krj, double* d_pwv) {
   if (!ctx) return MRX_ERR_INVALID;
   MRX_REQUIRE(ctx, D >= 0 && Ta >= 0 && T >= 0, "negative size");
   if (D == 0 || T == 0) return MRX_OK;
@@ -356,7 +357,7 @@ static int atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d
     hipLaunchKernelGGL((atm_tod_kernel<L, S, K, G, J>), grid, dim3(kBlock), lds, ctx->stream, plan->d_fast,       \
                        plan->d_px, plan->n_layers, plan->d_offpx, plan->d_tables, plan->n_tables,                 \
                        plan->d_table_data, plan->table_floats, d_az, d_el, Ta, d_dx, d_dy, d_band, d_mueller00,   \
-                       D, pwv0, d_coarse, d_flags, chunk, nby, block_rows, n_blocks, (int)dedicated, ta0, 1.0 / dta, \
+                       D, pwv0, d_pwv, d_coarse, d_flags, chunk, nby, block_rows, n_blocks, (int)dedicated, ta0, 1.0 / dta, \
                        d_t, T, d_scale, d_rows, d_out, ld_out, vec_ok, batches, ctl, poll_limit, cal);           \
   } while (0)
 #define MRX_LAUNCH_SYNTH_J(L, S, K, G) do { if (krj) MRX_LAUNCH_SYNTH(L, S, K, G, true); else MRX_LAUNCH_SYNTH(L, S, K, G, false); } while (0)
@@ -377,10 +378,10 @@ int mrx_atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d_az
                        const float* d_dx, const float* d_dy, const int32_t* d_band, const float* d_mueller00, int D,
                        double pwv0, float* d_coarse, int block_rows, int sampler_wgs, uint32_t* d_flags, double ta0,
                        double dta, const double* d_t, int T, const float* d_scale, const int32_t* d_rows, float* d_out,
-                       size_t ld_out) {
+                       size_t ld_out, double* d_pwv) {
   MRX_ENTER(ctx);
   return atm_synthesize(ctx, plan, d_az, d_el, Ta, d_dx, d_dy, d_band, d_mueller00, D, pwv0, d_coarse, block_rows, sampler_wgs,
-                        d_flags, ta0, dta, d_t, T, d_scale, d_rows, d_out, ld_out, nullptr);
+                        d_flags, ta0, dta, d_t, T, d_scale, d_rows, d_out, ld_out, nullptr, d_pwv);
 }
 
 int mrx_atm_synthesize_krj(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d_az, const float* d_el, int Ta,
@@ -388,7 +389,8 @@ int mrx_atm_synthesize_krj(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* 
                            double pwv0, float* d_coarse, int block_rows, int sampler_wgs, uint32_t* d_flags, double ta0,
                            double dta, const double* d_t, int T, const float* d_scale, const int32_t* d_rows, float* d_out,
                            size_t ld_out, const float* d_cal_dx, const float* d_cal_dy, const float* d_cal_axis_el,
-                           const float* d_cal_values, int n_el, int n_bands, float* d_tail_pw, int tail_knots, size_t ld_tail) {
+                           const float* d_cal_values, int n_el, int n_bands, float* d_tail_pw, int tail_knots, size_t ld_tail,
+                           double* d_pwv) {
   MRX_ENTER(ctx);
   if (!ctx) return MRX_ERR_INVALID;
   MRX_REQUIRE(ctx, d_cal_dx && d_cal_dy && d_cal_axis_el && d_cal_values, "null calibration pointer");
@@ -396,7 +398,7 @@ int mrx_atm_synthesize_krj(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* 
   MRX_REQUIRE(ctx, tail_knots >= 0 && tail_knots <= Ta && (!d_tail_pw || ld_tail >= (size_t)D), "bad tail window");
   SynthCal cal{d_cal_dx, d_cal_dy, d_cal_axis_el, d_cal_values, n_el, n_bands, tail_knots > 0 ? d_tail_pw : nullptr, Ta - tail_knots, ld_tail};
   return atm_synthesize(ctx, plan, d_az, d_el, Ta, d_dx, d_dy, d_band, d_mueller00, D, pwv0, d_coarse, block_rows, sampler_wgs,
-                        d_flags, ta0, dta, d_t, T, d_scale, d_rows, d_out, ld_out, &cal);
+                        d_flags, ta0, dta, d_t, T, d_scale, d_rows, d_out, ld_out, &cal, d_pwv);
 }
 
 }  // extern "C"

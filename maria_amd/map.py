@@ -71,7 +71,7 @@ def collapse_temperature(table, axis_T, base_temperature):
 
 def sample_map(ctx, values, eta, xi, center, az, el, offsets, stokes_weights, out=None, transform=None, bilinear=True,
                cal_tables=None, cal_axis_pwv=None, cal_axis_el=None, coarse_pwv=None, ta0=0.0, dta=1.0, t=None,
-               cal_scalars=None, device="cuda:0"):
+               cal_scalars=None, device="cuda:0", sync=True):
     """``mrx_map_sample`` for the detectors of one band (sim/map.py:76-172).
 
     values [C, S, n_eta, n_xi] K_RJ (smoothed, parity applied); eta, xi the map axes in radians;
@@ -79,7 +79,10 @@ def sample_map(ctx, values, eta, xi, center, az, el, offsets, stokes_weights, ou
     [D, S]; transform [T, 3, 3] float64 or None (az/el-frame map).  Calibration: either
     ``cal_tables`` [C, npwv, nel] (collapsed at the base temperature) with the pwv / elevation axes,
     the coarse zenith-scaled pwv [Ta, D] (device tensor or array), its time grid and the sample
-    times ``t``; or ``cal_scalars`` [C].  Returns the [D, T] float32 device tensor in pW."""
+    times ``t``; or ``cal_scalars`` [C].  Arrays or device tensors throughout (tensors of the right type are used as
+    they are).  ``sync=False``: return without waiting for the kernel -- for callers whose inputs outlive the launch
+    or live on the launch's stream (torch's allocator then orders their reuse).  Returns the [D, T] float32 device
+    tensor in pW."""
     from ._lib import MrxMapCal, MrxSkyMap
 
     dev = torch.device(device)
@@ -87,20 +90,19 @@ def sample_map(ctx, values, eta, xi, center, az, el, offsets, stokes_weights, ou
     f64 = lambda a: a.to(dev, torch.float64).contiguous() if isinstance(a, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(a, np.float64)).to(dev)  # noqa: E731
     values = np.asarray(values) if not isinstance(values, torch.Tensor) else values
     C_, S_, n_eta, n_xi = values.shape
-    offsets = np.asarray(offsets, float)
     D, T = len(offsets), len(az)
     eta, xi = np.asarray(eta, float), np.asarray(xi, float)
     deta, dxi = (eta[-1] - eta[0]) / (n_eta - 1), (xi[-1] - xi[0]) / (n_xi - 1)
     if not (np.allclose(np.diff(eta), deta, rtol=1e-6, atol=0) and np.allclose(np.diff(xi), dxi, rtol=1e-6, atol=0)):
         raise ValueError("map axes must be uniform (np.linspace, map/projection.py:122-123)")
     keep = dict(values=f32(values), az=f32(az), el=f32(el), dx=f32(offsets[:, 0]), dy=f32(offsets[:, 1]),
-                w=f64(np.asarray(stokes_weights)[:, :S_]))
+                w=f64(stokes_weights[:, :S_]))
     sky = MrxSkyMap(ptr(keep["values"]), C_, S_, n_eta, n_xi, float(eta[0]), float(deta), float(xi[0]), float(dxi),
                     float(center[0]), float(center[1]), 1 if bilinear else 0, 0)
     cal = MrxMapCal()
     if cal_tables is not None:
         keep.update(tab=f32(cal_tables), ap=f32(cal_axis_pwv), ae=f32(cal_axis_el), pwv=f64(coarse_pwv), t=f64(t))
-        assert keep["tab"].shape == (C_, len(cal_axis_pwv), len(cal_axis_el)) and keep["pwv"].shape[1] == D
+        assert tuple(keep["tab"].shape) == (C_, len(cal_axis_pwv), len(cal_axis_el)) and keep["pwv"].shape[1] == D
         cal.d_table, cal.d_axis_pwv, cal.d_axis_el = ptr(keep["tab"]), ptr(keep["ap"]), ptr(keep["ae"])
         cal.n_pwv, cal.n_el = len(cal_axis_pwv), len(cal_axis_el)
         cal.d_pwv, cal.Ta, cal.ta0, cal.dta, cal.d_t = ptr(keep["pwv"]), keep["pwv"].shape[0], float(ta0), float(dta), ptr(keep["t"])
@@ -114,7 +116,8 @@ def sample_map(ctx, values, eta, xi, center, az, el, offsets, stokes_weights, ou
         out = torch.empty((D, T), dtype=torch.float32, device=dev)
     ctx.call("mrx_map_sample", C.byref(sky), C.byref(cal), ptr(keep["az"]), ptr(keep["el"]), T, ptr(keep.get("tr")),
              ptr(keep["dx"]), ptr(keep["dy"]), ptr(keep["w"]), D, ptr(out), out.stride(0))
-    torch.cuda.current_stream(dev).synchronize()  # the temporaries in `keep` may go once the kernel is done
+    if sync:
+        torch.cuda.current_stream(dev).synchronize()  # the temporaries in `keep` may go once the kernel is done
     return out
 
 

@@ -593,6 +593,7 @@ class DevicePath:
             self.pwv0, ptr(self.d_pwv) if (self.keep_pwv or want_pwv) else None, ptr(self.d_loading), ptr(self.d_flags),
         )
         self._pwv_stale = not (self.keep_pwv or want_pwv)
+        self._pwv_blocked = False
 
     def prepare(self, krj=False):
         """Second derivatives of the coarse loading (``krj``: of the coarse loading in K_RJ that
@@ -676,6 +677,12 @@ class DevicePath:
             self.d_pwv = torch.empty((self.Ta, self.D), dtype=torch.float64, device=self.device)
         if self._pwv_stale:
             self.sample(want_pwv=True)
+        if getattr(self, "_pwv_blocked", False) and self._synth_block_rows < self.D:  # the one-launch form's blocks
+            br, flat, parts = self._synth_block_rows, self.d_pwv.view(-1), []
+            for lo in range(0, self.D, br):
+                n = min(br, self.D - lo)
+                parts.append(flat[self.Ta * lo : self.Ta * (lo + n)].view(self.Ta, n))
+            return torch.cat(parts, dim=1).T.index_select(0, self._d_inverse)
         return self.d_pwv.T.index_select(0, self._d_inverse)
 
     def run(self, out=None, blocks=None, writer_events=None, krj=False):
@@ -725,10 +732,9 @@ class DevicePath:
         """Does run() take the one-launch form by default?  Wherever the library's form applies (every layer on a
         uniform axis, the default cell rule and pointing, linear tables: the call itself says so) from 1024 rows (640 rows:
         0.22 ms against 0.21 for the stages back to back; 1 264: 0.32 against 0.34; 2 512: 0.54 against 0.65; 10 000: 2.0
-        against 2.3) but for callers that want the coarse pwv kept and runs that overlap successive observations on
-        streams (enable_lookahead)."""
-        return (not self.keep_pwv and self.D >= 1024 and not getattr(self, "_synth_unsupported", False)
-                and getattr(self, "_la", None) is None)
+        against 2.3) but for runs that overlap successive observations on streams (enable_lookahead).  ``keep_pwv`` rides
+        along: the sampler's float64 pwv is the launch's optional second output."""
+        return self.D >= 1024 and not getattr(self, "_synth_unsupported", False) and getattr(self, "_la", None) is None
 
     def synthesize(self, out=None, block_rows=None, sampler_wgs_per_cu=None, chunk=None, writer_events=None, krj=False, sampler_wgs=0):
         """Atmosphere -> TOD in ONE launch (mrx_atm_synthesize): sampler work items and TOD tiles as two queues of
@@ -774,6 +780,8 @@ class DevicePath:
                 tail = self._synth_tail
             args += [ptr(c["dx"]), ptr(c["dy"]), ptr(c["axis"]), ptr(c["values"]), c["n_el"], c["n_bands"],
                      ptr(tail), 0 if tail is None else tail.shape[0], 0 if tail is None else tail.stride(0)]
+        # keep_pwv: the sampler's second output, block by block like the loading (coarse_pwv() puts the blocks together)
+        args.append(ptr(self.d_pwv) if self.keep_pwv else None)
         try:
             with _range("Sampling turbulence + Computing atmospheric emission + Upsampling atmospheric loading"):
                 self.ctx.call("mrx_atm_synthesize_krj" if krj else "mrx_atm_synthesize", *args)
@@ -789,7 +797,8 @@ class DevicePath:
         self._synthesized = True
         self._synthesized_krj = bool(krj)  # (the coarse blocks then hold K_RJ, not pW)
         self._pipelined = False
-        self._pwv_stale = True
+        self._pwv_stale = not self.keep_pwv
+        self._pwv_blocked = self.keep_pwv  # (d_pwv holds blocks of [Ta][rows], not one [Ta][D] array)
         return out
 
     def synth_block_rows(self, block_rows=0):

@@ -305,10 +305,9 @@ class Simulation:
     def _simulate_atmosphere(self, obs):
         lo, hi = self._rows(obs.instrument.dets.n)
         det_slice = None if self.shard is None else slice(lo, hi)
-        if self.map is None:  # screens only: DevicePath.run() samples and writes in one pipelined call
-            obs.atmosphere.new_realisation(instrument=obs.instrument, det_slice=det_slice)
-        else:
-            obs.atmosphere.simulate_pwv(instrument=obs.instrument, det_slice=det_slice)
+        # screens only: DevicePath.run() samples and writes in one call -- with a map too: the coarse pwv its calibration
+        # reads (sim/map.py:117-135) is the sampler's second output there (keep_pwv)
+        obs.atmosphere.new_realisation(instrument=obs.instrument, det_slice=det_slice)
 
     def _gather(self, obs, tod):
         """All-gather a shard's TOD along the detector axis (equal row blocks, so the gathered
@@ -355,21 +354,8 @@ class Simulation:
         out = torch.empty((path.D, path.T), dtype=torch.float32, device=path.device)
         if units == "K_RJ":
             self._set_calibration(obs, metadata)
-        if self.map is None:  # nothing sampled yet (see _simulate_atmosphere)
-            path.run(out, krj=units == "K_RJ")
-            path.check_flags()  # RuntimeError "introduced nans" like atmosphere.py:368-369
-            return out
-        if units == "K_RJ":
-            if path.coarse_krj_bound() <= path.COARSE_KRJ_LIMIT:
-                # the conversion on the coarse grid, then the pW writer (HBM-bound): the two orders of
-                # "divide" and "interpolate" differ by less than a quarter of the parity tolerance here
-                path.coarse_to_krj()
-                path.upsample_fused(out, krj=True)
-            else:
-                path.prepare()
-                path.upsample_krj(out)
-        else:
-            path.upsample_fused(out)
+        path.run(out, krj=units == "K_RJ")  # (nothing is sampled yet: see _simulate_atmosphere)
+        path.check_flags()  # RuntimeError "introduced nans" like atmosphere.py:368-369
         return out
 
     def _sample_maps(self, obs, rows=None):
@@ -394,53 +380,75 @@ class Simulation:
             ctx = self._noise_ctx
             ctx.set_stream(torch.cuda.current_stream(device))
         T = len(obs.coords.t)
-        out = torch.zeros((dets.n, T), dtype=torch.float32, device=device)
-        transform = None
-        if self.map.frame == "ra/dec":
-            transform = sky_transform_stack(obs.coords.t, obs.site.latitude, obs.site.longitude)
-        stokes_rows = mmap.mueller_row(dets.gamma)[:, ["IQUV".index(s) for s in self.map.stokes]]
-        for b, band in enumerate(dets.bands):
-            idx = np.nonzero(dets.band_index == b)[0]
-            if len(idx) == 0:
-                continue
+        # what does not change from run to run lives on the device, per observation and per band: the boresight, the
+        # sample times, the horizon -> equatorial transform (14 ms of host arithmetic and 17 MB a run when it was made
+        # per call), the smoothed map channels, the collapsed calibration tables, the detectors' offsets and weights
+        key = (str(device), lo, hi, id(self.map))
+        cache = getattr(obs, "_map_cache", None)
+        if cache is None or cache.get("key") != key:
+            f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(device)  # noqa: E731
+            f64 = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float64)).to(device)  # noqa: E731
+            cache = {"key": key, "az": f32(obs.boresight._baz), "el": f32(obs.boresight._bel), "t": f64(obs.coords.t), "bands": {}}
+            cache["transform"] = (f64(sky_transform_stack(obs.coords.t, obs.site.latitude, obs.site.longitude).reshape(T, 9))
+                                  if self.map.frame == "ra/dec" else None)
+            stokes_rows = mmap.mueller_row(dets.gamma)[:, ["IQUV".index(s) for s in self.map.stokes]]
+            covered = np.zeros(dets.n, bool)
+            for b, band in enumerate(dets.bands):
+                idx = np.nonzero(dets.band_index == b)[0]
+                if len(idx) == 0:
+                    continue
+                # ideally one beam per channel; the reference smooths once per band (map.py:101-104)
+                fwhm = float(compute_angular_fwhm(fwhm_0=dets.primary_size.mean(), z=np.inf, nu=band.center))
+                smoothed = self.map.smooth(fwhm, ctx=ctx, device=device)  # [S, C, eta, xi]
+                channels, tables, scalars = [], [], []
+                for c, (nu_min, nu_max) in enumerate(self.map.nu_bin_bounds):
+                    if band.nu.max() < nu_min or nu_max < band.nu.min():  # map.py:112-113
+                        continue
+                    channels.append(c)
+                    if atm is not None:  # band/band.py:250-255
+                        sp = atm.spectrum
+                        mask = (sp.side_nu >= nu_min) & (sp.side_nu < nu_max)
+                        nu = sp.side_nu[mask]
+                        grid = np.trapezoid(band.passband(nu) * np.exp(-sp._opacity[..., mask]), x=nu, axis=-1)
+                        tables.append(mmap.collapse_temperature(grid, sp.side_base_temperature, atm.weather.temperature[0]))
+                    else:  # band/band.py:246-248
+                        nu = band.nu[(band.nu >= nu_min) & (band.nu < nu_max)]
+                        scalars.append(float(np.trapezoid(band.passband(nu), x=nu)))
+                if not channels:
+                    logger.warning(f"No load from map for band {band.name}")
+                    continue
+                covered[idx] = True
+                sm = smoothed if isinstance(smoothed, torch.Tensor) else torch.as_tensor(np.ascontiguousarray(smoothed, np.float32))
+                entry = dict(idx=idx, contiguous=bool((np.diff(idx) == 1).all()),
+                             values=sm.to(device, torch.float32)[:, channels].transpose(0, 1).contiguous(),  # [C, S, eta, xi]
+                             offsets=f32(offsets[idx]), stokes=f64(stokes_rows[idx]), idx_dev=torch.as_tensor(idx, device=device))
+                if atm is not None:
+                    sp = atm.spectrum
+                    entry.update(tab=f32(np.stack(tables)), ap=f32(sp.side_zenith_pwv), ae=f32(sp.side_elevation))
+                else:
+                    entry.update(scalars=scalars)
+                cache["bands"][b] = entry
+            cache["all_rows"] = bool(covered.all())
+            obs._map_cache = cache
+        # rows of bands that see no channel of the map stay zero (sim/map.py:112-113); where every row is written
+        # nothing is cleared first (a [D, T] fill is 9.6 GB at the headline size)
+        out = (torch.empty if cache["all_rows"] else torch.zeros)((dets.n, T), dtype=torch.float32, device=device)
+        for b, e in cache["bands"].items():
             # the reference masks rows by band name (sim/map.py:90-95): a band's rows need not be neighbours.  Contiguous
             # rows are written in place; scattered ones into a buffer of their own, copied to their rows below
-            contiguous = bool((np.diff(idx) == 1).all())
-            # ideally one beam per channel; the reference smooths once per band (map.py:101-104)
-            fwhm = float(compute_angular_fwhm(fwhm_0=dets.primary_size.mean(), z=np.inf, nu=band.center))
-            smoothed = self.map.smooth(fwhm, ctx=ctx, device=device)  # [S, C, eta, xi]
-            channels, tables, scalars = [], [], []
-            for c, (nu_min, nu_max) in enumerate(self.map.nu_bin_bounds):
-                if band.nu.max() < nu_min or nu_max < band.nu.min():  # map.py:112-113
-                    continue
-                channels.append(c)
-                if atm is not None:  # band/band.py:250-255
-                    sp = atm.spectrum
-                    mask = (sp.side_nu >= nu_min) & (sp.side_nu < nu_max)
-                    nu = sp.side_nu[mask]
-                    grid = np.trapezoid(band.passband(nu) * np.exp(-sp._opacity[..., mask]), x=nu, axis=-1)
-                    tables.append(mmap.collapse_temperature(grid, sp.side_base_temperature, atm.weather.temperature[0]))
-                else:  # band/band.py:246-248
-                    nu = band.nu[(band.nu >= nu_min) & (band.nu < nu_max)]
-                    scalars.append(float(np.trapezoid(band.passband(nu), x=nu)))
-            if not channels:
-                logger.warning(f"No load from map for band {band.name}")
-                continue
-            values = np.ascontiguousarray(np.swapaxes(np.asarray(smoothed)[:, channels], 0, 1))  # [C, S, eta, xi]
-            kw = {}
+            idx = e["idx"]
             if atm is not None:
-                sp = atm.spectrum
-                pwv = path.coarse_pwv()[torch.as_tensor(idx, device=device)].T.contiguous()  # [Ta, D_band]
-                kw = dict(cal_tables=np.stack(tables), cal_axis_pwv=sp.side_zenith_pwv, cal_axis_el=sp.side_elevation,
-                          coarse_pwv=pwv, ta0=path.ta0, dta=path.dta, t=obs.coords.t)
+                pwv = path.coarse_pwv()[e["idx_dev"]].T.contiguous()  # [Ta, D_band]
+                kw = dict(cal_tables=e["tab"], cal_axis_pwv=e["ap"], cal_axis_el=e["ae"], coarse_pwv=pwv, ta0=path.ta0,
+                          dta=path.dta, t=cache["t"])
             else:
-                kw = dict(cal_scalars=scalars)
-            dst = out[int(idx[0]) : int(idx[-1]) + 1] if contiguous else torch.zeros((len(idx), T), dtype=torch.float32, device=device)
-            mmap.sample_map(ctx, values, self.map.eta, self.map.xi, self.map.center, obs.boresight._baz, obs.boresight._bel,
-                            offsets[idx], stokes_rows[idx], out=dst,
-                            transform=transform, bilinear=bool(self.map_kwargs["bilinear_sampling"]), device=device, **kw)
-            if not contiguous:
-                out.index_copy_(0, torch.as_tensor(idx, device=device), dst)
+                kw = dict(cal_scalars=e["scalars"])
+            dst = out[int(idx[0]) : int(idx[-1]) + 1] if e["contiguous"] else torch.empty((len(idx), T), dtype=torch.float32, device=device)
+            mmap.sample_map(ctx, e["values"], self.map.eta, self.map.xi, self.map.center, cache["az"], cache["el"],
+                            e["offsets"], e["stokes"], out=dst, transform=cache["transform"],
+                            bilinear=bool(self.map_kwargs["bilinear_sampling"]), device=device, sync=False, **kw)
+            if not e["contiguous"]:
+                out.index_copy_(0, e["idx_dev"], dst)
         return out
 
     def _simulate_noise(self, obs, loading=None, rows=None, krj=None):

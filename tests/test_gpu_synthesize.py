@@ -126,6 +126,32 @@ def test_caller_row_order_and_strided_output(gpu_ctx):
     assert bool((wide[:, path.T :] == 7.0).all())
 
 
+def test_coarse_pwv_is_the_launchs_second_output(gpu_ctx):
+    """keep_pwv (the map mixin's calibration reads the coarse zenith-scaled pwv, sim/map.py:117-135): the one launch
+    writes it beside the loading -- the float64 values mrx_atm_sample writes, in one block of rows and in several --
+    and run() keeps the one-launch form for such a path."""
+    import torch
+
+    p = small_problem(n_det=1100, n_layers=3, n_bands=2, gain=True)
+    path = _path(p, gpu_ctx, keep_pwv=True)
+    assert path.synthesize_applies()
+    want = path.run(blocks=1)
+    pwv = path.coarse_pwv().clone()
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(pwv).all()) and float(pwv.std()) > 0
+    for block_rows in (0, 256, 512):
+        path.d_pwv.fill_(float("nan"))
+        got = path.synthesize(block_rows=block_rows)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want)
+        assert torch.equal(path.coarse_pwv(), pwv), block_rows
+    path.d_pwv.fill_(float("nan"))
+    assert torch.equal(path.run(), want) and path._synthesized
+    assert torch.equal(path.coarse_pwv(), pwv)
+    path.sample()  # and the two-call form's own layout again afterwards
+    assert torch.equal(path.coarse_pwv(), pwv)
+
+
 def test_flags_travel_and_unsupported_plans_are_refused(gpu_ctx):
     """A line of sight off its screen is flagged as by mrx_atm_sample (atmosphere.py:368-369); the literal cell
     rule, the float32 pointing chain and non-uniform axes are the two-call form's: MRX_ERR_UNSUPPORTED, nothing
