@@ -401,6 +401,52 @@ def test_bin_mapper_recovers_the_sampled_map(gpu_ctx):
     assert abs(np.sum(rec[good]) / np.sum(expect[good]) - 1) < 0.05
 
 
+def test_recover_map_as_the_reference_asserts_it(gpu_ctx):
+    """The one numeric pin the reference's tests hold on the map chain (maria/tests/map/test_recover_map.py:15-69): 300
+    positions x 3 bands (90 / 150 / 220 GHz) behind a beam-free dish (primary_size 1000 m), field of view = half the
+    map, a 60 s daisy of radius width / 3 at 50 Hz, no noise, no atmosphere; the TOD (default units K_RJ) binned by
+    BinMapper at the input map's centre, width and resolution; and, per band,
+        sqrt(nansum(w (m1 - m0)^2) / nansum(w)) < 1e-3   [K_RJ]
+    between the binned map m1 and the input m0.  The reference's input is a downloaded cluster map (mean subtracted);
+    here a synthetic one of the same kind -- a beta-model decrement of 5 mK with arcminute-scale structure, mean
+    subtracted -- and, since a bound of 1e-3 K says little about a 5-mK map, the same residual is also held below 1 %
+    of the map's peak."""
+    from maria_amd import map as mmap
+    from maria_amd.instrument import Band, Detectors, Instrument, Site
+    from maria_amd.mappers import BinMapper
+    from maria_amd.sim import Plan, Simulation, sky_transform_stack
+
+    bands = [Band(center=90e9, width=30e9, name="f090"), Band(center=150e9, width=40e9, name="f150"), Band(center=220e9, width=50e9, name="f220")]
+    n, width = 128, 1.0  # degrees
+    res = width / (n - 1)
+    X, Y = np.meshgrid(np.linspace(-1, 1, n), np.linspace(-1, 1, n))
+    rng = np.random.default_rng(8)
+    field = np.fft.irfft2(np.fft.rfft2(rng.standard_normal((n, n))) * np.exp(-0.5 * (np.hypot(*np.meshgrid(np.fft.rfftfreq(n), np.fft.fftfreq(n))) * 12.0) ** 2), s=(n, n))
+    data = -5e-3 * (1 + ((X - 0.1) ** 2 + (Y + 0.05) ** 2) / 0.04) ** -1.0 + 4e-4 * field / field.std()
+    data = (data - data.mean()).astype(np.float32)
+    inst = Instrument(Detectors.hexagon(300, width / 2, bands, primary_size=1000.0))
+    plan = Plan.daisy(start_time=1.7e9, duration=60.0, sample_rate=50.0, scan_center=(120.0, 55.0), radius=width / 3, speed=0.5)
+    site = Site(altitude=5190.0)
+    centre = _centre(plan.phi.astype(np.float32), plan.theta.astype(np.float32), sky_transform_stack(plan.time, site.latitude, site.longitude))
+    sky = mmap.ProjectionMap(data, nu=150e9, width=width, center=np.degrees(centre), frame="ra/dec")
+    sim = Simulation(inst, plan, site, map=sky, noise=False)
+    (tod,) = sim.run()
+    assert tod.units == "K_RJ" and set(tod.fields) == {"map"}
+    # the input map's own grid: n pixels of its resolution around its centre
+    mapper = BinMapper([tod], center=np.degrees(centre), width=(n + 0.5) * res, resolution=res, stokes="I",
+                       nu=[b.center for b in bands], frame="ra/dec", units="K_RJ")
+    out = mapper.run()
+    assert out.data.shape[-2:] == (n, n) and np.allclose(out.xi, sky.xi, atol=1e-12) and np.allclose(out.eta, sky.eta, atol=1e-12)
+    m0 = sky.data[0, 0]
+    m1 = out.data[0, :]                      # [band, eta, xi]
+    w = mapper.products["weight"][0, -1]     # (the reference weighs every band with the last channel's hits)
+    assert (w > 0).mean() > 0.5
+    relsqres = np.sqrt(np.nansum(w * (m1 - m0) ** 2, axis=(-1, -2)) / np.nansum(w))
+    print("weighted rms residual per band [K_RJ]:", relsqres, "map peak", np.abs(m0).max())
+    assert relsqres.shape == (3,) and np.all(relsqres < 1e-3)       # the reference's assertion
+    assert np.all(relsqres < 0.01 * np.abs(m0).max())              # ... and one that a 5-mK map can fail
+
+
 def test_end_to_end_polarised_multifrequency_pipeline(gpu_ctx):
     """The shape of the reference's end-to-end tests (tests/sim/test_pipeline.py:21-54,
     test_polarization.py, test_multifrequency.py): atmosphere + map + noise in the default
