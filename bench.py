@@ -84,6 +84,8 @@ def parse_args(argv=None):
     ap.add_argument("--gather-reps", type=int, default=3)
     ap.add_argument("--blocks", type=int, default=None, help="detector blocks of the pipelined TOD synthesis (default: DevicePath.default_blocks(); 1 = serial)")
     ap.add_argument("--block-shares", default=None, help="A/B: relative sizes of the detector blocks, e.g. 1,2,2,2 (default: equal blocks)")
+    ap.add_argument("--synth-wgs-per-cu", type=int, default=0,
+                    help="A/B: resident workgroups per CU of the one-launch synthesis (MRX_OPT_SYNTH_WGS_PER_CU; 0 = as many as fit)")
     ap.add_argument("--lookahead", action="store_true",
                     help="A/B: let successive steps overlap (DevicePath.enable_lookahead: the next step's screens and first samplers run "
                     "beside this step's last writers; the timer brackets all K steps behind a sync either way).  Measured in round 4: "
@@ -431,7 +433,7 @@ def run(args):
     writer_events = []
     # the form DevicePath.run() takes by itself: ONE launch (mrx_atm_synthesize: sampler and writer as two roles of one
     # grid) where it applies, else detector blocks pipelined on two streams, else the stages back to back
-    one_launch = args.blocks is None and not args.block_shares and not args.lookahead and path.synthesize_applies()
+    one_launch = args.blocks is None and not args.block_shares and path.synthesize_applies()
     n_blocks = 1 if one_launch else args.blocks if args.blocks is not None else path.default_blocks()
     if args.block_shares:
         path.block_shares = [int(x) for x in args.block_shares.split(",")]
@@ -471,7 +473,10 @@ def run(args):
     screens()
     # successive steps overlap like the observations of one Simulation.run() (sim/simulation.py:201-211): the same
     # launches, ordered by events instead of by one stream
-    lookahead = args.lookahead and n_blocks > 1 and path.enable_lookahead()
+    lookahead = args.lookahead and path.enable_lookahead()
+    if args.synth_wgs_per_cu:
+        from maria_amd import _lib as _mlib
+        path.ctx.set_option(_mlib.OPT_SYNTH_WGS_PER_CU, args.synth_wgs_per_cu)
     for _ in range(args.warmup):
         step()
     barrier()

@@ -11,6 +11,9 @@ namespace {
 #ifndef MRX_SYNTH_PIPE
 #define MRX_SYNTH_PIPE 1  // the sampler's layer loop as the three-stage gather ring (0: the plain loop)
 #endif
+#ifndef MRX_SYNTH_ACQUIRE
+#define MRX_SYNTH_ACQUIRE 0  // 1: the guide's fallback for the consumer -- an agent acquire per tile, plain loads (A/B)
+#endif
 
 // ---------------------------------------------------------------------------
 // Atmosphere -> TOD in ONE launch (mrx_atm_synthesize): sampling and writing as two kinds of work that ONE resident
@@ -188,6 +191,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_WRIT
           s_word[1] = hv;
           s_word[2] = need;
         }
+#if MRX_SYNTH_ACQUIRE
+        if (hv > need) {  // (the polling wave, once its poll has matched: invalidates this CU's L1)
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+#endif
       }
       __syncthreads();  // between the poll and EVERY load of the chunks' bytes, the polling wave's own too
       tile = s_word[0];
@@ -211,7 +220,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_WRIT
         const int sx = rem / nrg, by = rem - sx * nrg;
         const int Db = blk == last ? last_rows : block_rows;
         const size_t row0 = (size_t)blk * block_rows;
-        fused_writer_tile<kHasScale, kMaxKnots, kG, true>(loading + (size_t)Ta * row0, (Db + 31) & ~31, Db, Ta, ta0, inv_dta, t, T,
+        fused_writer_tile<kHasScale, kMaxKnots, kG, MRX_SYNTH_ACQUIRE == 0>(loading + (size_t)Ta * row0, (Db + 31) & ~31, Db, Ta, ta0, inv_dta, t, T,
                                                            kHasScale ? scale + row0 : nullptr, rows ? rows + row0 : nullptr,
                                                            rows ? out : out + row0 * ld, ld, vec_ok, batches, sx, by, synth_lds);
         tile = -1;

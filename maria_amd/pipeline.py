@@ -449,9 +449,6 @@ class DevicePath:
         if la is not None:
             which = la["count"] % 2
             target, gen_ctx = la["screens"][which], la["ctx"]
-            if la["count"] == 0:  # everything the caller queued so far (uploads, the amplitude tables) comes first
-                la["first"].record(torch.cuda.current_stream(dev))
-                la["stream"].wait_event(la["first"])
             if la["sampled"][which]:
                 la["stream"].wait_event(la["samplers_done"][which])
 
@@ -567,12 +564,21 @@ class DevicePath:
         plans = [(self.plan, self._layers, self._layer_bufs), self._make_plan(other)]
         ev = lambda: torch.cuda.Event()  # noqa: E731
         self._la = dict(stream=stream, ctx=ctx3, screens=[self._gen_screens, other], plans=plans, count=0, current=0,
-                        first=ev(), screens_done=[ev(), ev()], samplers_done=[ev(), ev()], sampled=[False, False],
+                        screens_done=[ev(), ev()], samplers_done=[ev(), ev()], sampled=[False, False],
                         writer_done={}, probe=probe)
         # the set bound now holds valid screens (generated above, on the caller's stream)
         self._la["screens_done"][0].record(main)
         self._la["count"] = 1
         return True
+
+    def _mark_sampled(self, stream=None):
+        """enable_lookahead: everything queued on ``stream`` (default: the current one) so far has read the bound set of
+        screens -- the screens' stream may refill that set behind it.  Every reader of the bound screens ends with this
+        (sample(), the serial and K_RJ forms of run(), synthesize(); the two-stream pipeline marks its side stream)."""
+        la = getattr(self, "_la", None)
+        if la is not None:
+            la["samplers_done"][la["current"]].record(stream or torch.cuda.current_stream(self.device))
+            la["sampled"][la["current"]] = True
 
     def wait_screens(self, stream=None):
         """Order ``stream`` (default: the current one) behind the generation of the screens now bound."""
@@ -594,6 +600,7 @@ class DevicePath:
         )
         self._pwv_stale = not (self.keep_pwv or want_pwv)
         self._pwv_blocked = False
+        self._mark_sampled()
 
     def prepare(self, krj=False):
         """Second derivatives of the coarse loading (``krj``: of the coarse loading in K_RJ that
@@ -697,7 +704,10 @@ class DevicePath:
         ``keep_pwv``: its consumers want whole coarse arrays); ``blocks=1`` runs the stages back
         to back on the caller's stream.  ``krj``: the TOD in K_RJ (set_calibration first): the
         conversion is applied to the coarse loading before the spline when coarse_krj_bound() allows
-        (the pW writer then writes K_RJ), per sample by mrx_spline_upsample_krj otherwise."""
+        (the pW writer then writes K_RJ), per sample by mrx_spline_upsample_krj otherwise.
+        Everything is queued, nothing waited for: call check_flags() before trusting the TOD -- a line of sight off its
+        screen (the reference's RuntimeError), an emission table left, or a hand-over that gave up inside the one launch
+        (MRX_FLAG_HANDOVER: the TOD is then invalid) are reported there.  Simulation.run_obs does."""
         if out is None:
             out = torch.empty((self.D, self.T), dtype=torch.float32, device=self.device)
         coarse_form = krj and krj != "sample" and self.coarse_krj_bound() <= self.COARSE_KRJ_LIMIT
@@ -732,9 +742,8 @@ class DevicePath:
         """Does run() take the one-launch form by default?  Wherever the library's form applies (every layer on a
         uniform axis, the default cell rule and pointing, linear tables: the call itself says so) from 1024 rows (640 rows:
         0.22 ms against 0.21 for the stages back to back; 1 264: 0.32 against 0.34; 2 512: 0.54 against 0.65; 10 000: 2.0
-        against 2.3) but for runs that overlap successive observations on streams (enable_lookahead).  ``keep_pwv`` rides
-        along: the sampler's float64 pwv is the launch's optional second output."""
-        return self.D >= 1024 and not getattr(self, "_synth_unsupported", False) and getattr(self, "_la", None) is None
+        against 2.3).  ``keep_pwv`` rides along: the sampler's float64 pwv is the launch's optional second output."""
+        return self.D >= 1024 and not getattr(self, "_synth_unsupported", False)
 
     def synthesize(self, out=None, block_rows=None, sampler_wgs_per_cu=None, chunk=None, writer_events=None, krj=False, sampler_wgs=0):
         """Atmosphere -> TOD in ONE launch (mrx_atm_synthesize): sampler work items and TOD tiles as two queues of
@@ -793,6 +802,7 @@ class DevicePath:
         if writer_events is not None:
             ev[1].record(main)
             writer_events.append(ev)
+        self._mark_sampled(main)  # (enable_lookahead: the screens' stream may refill this set once this launch is through)
         self._synth_block_rows = self.synth_block_rows(int(block_rows))
         self._synthesized = True
         self._synthesized_krj = bool(krj)  # (the coarse blocks then hold K_RJ, not pW)
@@ -979,6 +989,8 @@ class DevicePath:
         if la is not None:  # the screens' stream may refill this set once these samplers are through
             la["samplers_done"][la["current"]].record(side)
             la["sampled"][la["current"]] = True
+        else:  # (the serial and K_RJ forms sample on streams the caller's stream is ordered behind by now)
+            self._mark_sampled(main)
         if krj and krj != "sample" and self._krj_split() < self.T:
             if serial:
                 self._krj_tail(st["tail"], self.D, slice(0, self.D), out, ptr(self.d_rows), self.ctx)
