@@ -33,30 +33,63 @@ __device__ __forceinline__ int reflect_index(int i, int n) {
 // conversion per element instead of one per tap) and follow scipy's symmetric
 // summation: centre tap, then (left + right) * w_k.
 
-// pass along x (contiguous axis): one workgroup = 256 consecutive outputs of a row
-constexpr int kXCols = kBlock;
+// pass along x (contiguous axis): one workgroup = 1024 consecutive outputs of a row, a thread 4 consecutive ones from
+// ONE sliding window of 2 radius + 4 values: the window comes out of LDS 16 bytes a read (conflict-free: a lane's four
+// values sit in four banks of their own), every value meets four taps -- the window step's and the three before it --
+// and four float64 accumulators, one per output.  One output per thread read its 2 radius + 1 values one by one, as
+// float64: 16 bytes of LDS traffic per tap and output, which bound the pass (round 1); this form reads 1 byte.
+// wz holds the tap row with 3 zeros on either side, as in the y pass.
+constexpr int kXPerThread = 4;
+constexpr int kXCols = kBlock * kXPerThread;
 
 __global__ __launch_bounds__(kBlock) void gauss_x_kernel(
     const float* __restrict__ in, float* __restrict__ out, int ny, int nx,
     const double* __restrict__ taps, int radius) {
   extern __shared__ double ldsd[];
+  const int ntap = 2 * radius + 1;
   const int span = kXCols + 2 * radius;
+  double* wz = ldsd;                                             // [3 zeros][ntap taps][3 zeros]
+  float* img = reinterpret_cast<float*>(ldsd + ((ntap + 6 + 1) & ~1));  // 16-byte aligned: [span + 4]
   const int y = blockIdx.y;
   const int x0 = blockIdx.x * kXCols;
   const float* src = in + (size_t)y * nx;
-  for (int i = threadIdx.x; i < span; i += kBlock)
-    ldsd[i] = (double)src[reflect_index(x0 - radius + i, nx)];
+  for (int i = threadIdx.x; i < span + 4; i += kBlock)
+    img[i] = i < span ? src[reflect_index(x0 - radius + i, nx)] : 0.0f;
+  for (int k = threadIdx.x; k < ntap + 6; k += kBlock)
+    wz[k] = (k >= 3 && k < ntap + 3) ? taps[k - 3] : 0.0;
   __syncthreads();
-  const int x = x0 + threadIdx.x;
+  const int x = x0 + threadIdx.x * kXPerThread;
   if (x >= nx) return;
-  // the pass is LDS-bound (35 data reads per output): keep the taps out of LDS,
-  // they are wave-uniform and come through the scalar cache
-  const double* c = ldsd + threadIdx.x + radius;
-  const double* tw = taps + radius;
-  double acc = tw[0] * c[0];
-#pragma unroll 8
-  for (int k = 1; k <= radius; ++k) acc += (c[-k] + c[k]) * tw[k];
-  out[(size_t)y * nx + x] = (float)acc;
+  // outputs x .. x + 3 read img[4 tid .. 4 tid + 2 radius + 3]; window step k: value img[4 tid + k], taps wz[k + 3 - j]
+  const float4* c4 = reinterpret_cast<const float4*>(img + threadIdx.x * kXPerThread);
+  double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
+  double t1 = 0.0, t2 = 0.0, t3 = 0.0;  // wz[k + 2], wz[k + 1], wz[k]
+  const int steps = ntap + 3;            // (the last group of four reads up to 3 values past the window: zero taps)
+  for (int k = 0; k < steps; k += 4) {
+    const float4 q = c4[k >> 2];
+    const float v[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const double t0 = k + i < steps ? wz[k + i + 3] : 0.0;
+      const double vv = (double)v[i];
+      acc0 += t0 * vv;
+      acc1 += t1 * vv;
+      acc2 += t2 * vv;
+      acc3 += t3 * vv;
+      t3 = t2;
+      t2 = t1;
+      t1 = t0;
+    }
+  }
+  float* dst = out + (size_t)y * nx + x;
+  if (x + 3 < nx && (nx & 3) == 0) {
+    *reinterpret_cast<float4*>(dst) = make_float4((float)acc0, (float)acc1, (float)acc2, (float)acc3);
+  } else {
+    const double acc[4] = {acc0, acc1, acc2, acc3};
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (x + j < nx) dst[j] = (float)acc[j];
+  }
 }
 
 // pass along y: tile of tile_rows outputs x 64 columns; 4 row groups of threads.
@@ -195,7 +228,7 @@ int smooth_axis1(mrx_ctx* ctx, const float* in, float* out, int ny, int nx,
   const double* d_taps = nullptr;
   int rc = get_taps(ctx, sigma, truncate, &radius, &d_taps);
   if (rc != MRX_OK) return rc;
-  const size_t lds = (size_t)(kXCols + 2 * radius) * sizeof(double);
+  const size_t lds = (size_t)((2 * radius + 1 + 6 + 1) & ~1) * sizeof(double) + (size_t)(kXCols + 2 * radius + 4) * sizeof(float);
   if ((rc = raise_lds_cap(ctx)) != MRX_OK) return rc;
   if (lds > kMaxLds)
     return mrx_fail(ctx, MRX_ERR_UNSUPPORTED,
