@@ -35,7 +35,7 @@ Prints ONE JSON line on rank 0, including
                   upsample) --, timed live with events on the launch stream
   second_kernel : the same for the sampler (VALU / vector-memory-latency bound)
   cpu_baseline  : the numpy/scipy oracle on a detector subset, on one host core and on
-                  min(64, physical cores) processes; parity of the GPU rows against it, on the
+                  as many processes as the job has cores (physical cores, or the cgroup's CPU quota); parity of the GPU rows against it, on the
                   loading and on the fluctuation alone (per-detector mean removed)
   frontend      : wall time of what a user calls, Simulation(...).run(), set-up and run
 """
@@ -68,7 +68,7 @@ def parse_args(argv=None):
                     "weak = the named configuration per GPU (default for atlast_50k)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-dets", type=int, default=2048, help="detector rows of the one-core CPU-baseline sample")
-    ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the all-core CPU baseline (0 = min(64, physical cores))")
+    ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the all-core CPU baseline (0 = the physical cores, or the cgroup's CPU quota where smaller)")
     ap.add_argument("--no-frontend", action="store_true", help="skip the Simulation(...).run() wall-clock section")
     ap.add_argument("--no-screens-in-step", action="store_true", help="time TOD synthesis only (screens generated once)")
     ap.add_argument("--shard-screens", action="store_true",
@@ -163,6 +163,31 @@ def _physical_cores():
     except OSError:
         pass
     return max(1, (os.cpu_count() or 2) // 2)
+
+
+def _cpu_quota():
+    """CPUs this process may keep busy: the cgroup's quota (cpu.max, or the v1 files) where one is set -- a GPU box leases
+    16 CPUs' worth per GPU although it shows the host's 256 --, else the affinity mask."""
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+        if q != "max":
+            return max(1, int(-(-int(q) // int(p))))
+    except (OSError, ValueError):
+        pass
+    try:
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+            q = int(f.read())
+        with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+            p = int(f.read())
+        if q > 0:
+            return max(1, -(-q // p))
+    except (OSError, ValueError):
+        pass
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
 
 
 def cpu_baseline(problem, screens, rows):
@@ -645,7 +670,7 @@ def run(args):
             "kind": "port",
             "sample": f"first {n_sub} of {D} detector rows, full {T} samples, screens given (sampling + emission + cubic "
             f"upsample; numpy/scipy with BLAS/OpenMP pools limited to 1 thread): {cpu_s1:.2f} s",
-            "host_cpus": os.cpu_count(),
+            "host_cpus": os.cpu_count(), "cpu_quota": _cpu_quota(),
             "physical_cores": _physical_cores(),
             "cpu_model": _cpu_model(),
             "parity_max_rel_err_vs_gpu": err,
@@ -654,11 +679,13 @@ def run(args):
         }
         del ref, got
         try:
-            n_procs = args.cpu_procs or min(64, _physical_cores())
+            # all the cores this job may use: the physical cores, or the cgroup's CPU quota where that is smaller (one
+            # process per core; more processes than the quota only take turns)
+            n_procs = args.cpu_procs or max(1, min(_physical_cores(), _cpu_quota()))
             allc = cpu_baseline_all_cores(args.config, n_total, scr, n_procs)
             result["cpu_baseline"]["all_cores"] = {
                 "value": allc["rows"] * T / allc["seconds_slowest_process"], "unit": "detector-samples/s", "cores": n_procs,
-                "seconds": allc["seconds_slowest_process"],
+                "cpu_quota": _cpu_quota(), "seconds": allc["seconds_slowest_process"],
                 "sample": f"{n_procs} processes x 512 detector rows each (rows taken cyclically), full {T} samples, one "
                 "numpy/scipy thread per process, timed behind a common barrier; rate = all rows / slowest process",
             }
