@@ -118,7 +118,11 @@ enum {
                                   where the register transforms apply (tests, A/B runs) */
   MRX_OPT_SYNTH_WGS_PER_CU = 10, /* mrx_atm_synthesize: resident workgroups per CU of its one grid (1..5; 0 = as many as
                                     fit, 5).  Timing sweeps, and the tests' way to vary who runs beside whom */
-  MRX_OPT_COUNT = 11
+  MRX_OPT_SYNTH_TILE_ORDER = 11, /* mrx_atm_synthesize: 0 = the tiles of a detector block time tile by time tile (all its row groups
+                                    side by side: the writers follow the samplers a few chunks behind); 1 = row group by row group, the
+                                    time tiles of a row group in a row (the order the chip stores fastest; a block's tiles then wait
+                                    for the whole block: give block_rows) */
+  MRX_OPT_COUNT = 12
 };
 int mrx_set_option(mrx_ctx* ctx, int option, int value);
 const char* mrx_last_error(const mrx_ctx* ctx);
@@ -285,8 +289,10 @@ int mrx_spline_upsample_fused(mrx_ctx* ctx, const float* d_y, int D, int Ta,
  * share one pass over the screens' footprint, and no launch boundary or stream event separates
  * anything.  Bit-identical to the two calls.
  *  block_rows        detectors per block of the coarse array, rounded up to a multiple of 256; <= 0:
- *                    the library's choice -- one block where 4 * Ta * rows < 2^31, the most that fit
- *                    otherwise (a block's coarse array is addressed with 32-bit offsets)
+ *                    the library's choice (mrx_atm_synthesize_block_rows tells) -- blocks of about 5 000
+ *                    rows while the plan's screens fit the Infinity Cache, one block beyond (every block
+ *                    walks the screens' track again), never more than 4 * Ta * rows < 2^31 allows (a block's
+ *                    coarse array is addressed with 32-bit offsets)
  *  sampler_wgs       workgroups that ONLY sample while work items remain (they write afterwards);
  *                    <= 0: MRX_OPT_SAMPLE_WGS_PER_CU per CU (unset: 2).  The others write and sample
  *                    where they would wait
@@ -308,6 +314,10 @@ int mrx_atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d_az
                        const float* d_mueller00, int D, double pwv0, float* d_coarse, int block_rows,
                        int sampler_wgs, uint32_t* d_flags, double ta0, double dta, const double* d_t, int T,
                        const float* d_scale, const int32_t* d_rows, float* d_out, size_t ld_out, double* d_pwv);
+
+/* The rows per block mrx_atm_synthesize lays d_coarse (and d_pwv) out in for `block_rows` (<= 0: the library's
+ * choice, which depends on the plan's screens: see the call) -- for a caller that reads the coarse arrays back. */
+int mrx_atm_synthesize_block_rows(mrx_ctx* ctx, const mrx_atm_plan* plan, int D, int Ta, int block_rows, int* rows_out);
 
 /* mrx_atm_synthesize with TOD.to("K_RJ") applied on the coarse grid (tod/tod.py:106-142 before the spline, as
  * mrx_coarse_to_krj does between the two calls -- same functions, same operands, same bits): the sampler role divides

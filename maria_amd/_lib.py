@@ -31,6 +31,7 @@ OPT_WRITER_PER_TILE = 7
 OPT_NOISE_LANES = 8
 OPT_SCREEN_STOCKHAM = 9
 OPT_SYNTH_WGS_PER_CU = 10
+OPT_SYNTH_TILE_ORDER = 11
 
 _STATUS = {
     0: "MRX_OK",
@@ -172,6 +173,7 @@ SIGNATURES = {
     "mrx_spline_prepare": (_i, [_vp, _vp, _i, _i, _vp]),
     "mrx_spline_upsample": (_i, [_vp, _vp, _i, _i, _d, _d, _vp, _i, _vp, _vp, _vp, _sz]),
     "mrx_spline_upsample_fused": (_i, [_vp, _vp, _i, _i, _d, _d, _vp, _i, _vp, _vp, _vp, _sz]),
+    "mrx_atm_synthesize_block_rows": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "mrx_atm_synthesize": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _d, _vp, _i, _i, _vp, _d, _d, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "mrx_atm_synthesize_krj": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _d, _vp, _i, _i, _vp, _d, _d, _vp, _i, _vp, _vp, _vp, _sz,
                                     _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _sz, _vp]),

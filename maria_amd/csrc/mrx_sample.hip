@@ -630,7 +630,11 @@ int mrx_atm_plan_create(mrx_ctx* ctx, const mrx_layer* layers, int n_layers,
   if (ok()) e = hipGetLastError();
   if (ok()) e = hipStreamSynchronize(ctx->stream);  // host vectors go away
   p->all_pixel = n_layers > 0;
-  for (auto& f : hfast) p->all_pixel = p->all_pixel && f.pixel != 0;
+  p->screen_bytes = 0;
+  for (auto& f : hfast) {
+    p->all_pixel = p->all_pixel && f.pixel != 0;
+    p->screen_bytes += 4ull * (unsigned long long)f.n_e * (unsigned long long)f.n_c;
+  }
   if (!ok()) {
     plan_free(p);
     return mrx_fail(ctx, MRX_ERR_HIP, "plan upload failed: %s",

@@ -72,6 +72,7 @@ struct mrx_atm_plan {
   int n_layers = 0, n_tables = 0, n_t = 0;
   int table_floats = 0;
   bool all_pixel = false;  // every layer passed the uniform check: atm_sample_px_kernel applies
+  unsigned long long screen_bytes = 0;  // of all layers' screens together
   bool any_cubic = false;  // a band table carries the bicubic cells of interpolation_method="cubic"
 };
 

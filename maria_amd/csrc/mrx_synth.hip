@@ -119,9 +119,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_WRIT
     uint32_t* __restrict__ flags, int chunk, int nby, int block_rows, int n_blocks, int n_dedicated,
     double ta0, double inv_dta, const double* __restrict__ t, int T,
     const float* __restrict__ scale, const int32_t* __restrict__ rows, float* __restrict__ out, size_t ld, int vec_ok,
-    int batches, int* ctl, int poll_limit, SynthCal cal) {
+    int batches, int tile_order, int* ctl, int poll_limit, SynthCal cal) {
   extern __shared__ __align__(16) unsigned char synth_lds[];
-  __shared__ int s_word[4];  // what the first wave found out for the workgroup: [0] tile / item, [1] watermark, [2] the tile's last unit
+  __shared__ int s_word[8];  // what the first wave found out for the workgroup: [0] tile / item, [1] watermark, [2] the tile's last unit, [3..5] its (block, time tile, row group)
   SynthHooks<kKrj> hooks;
   hooks.ctl = ctl;
   hooks.band = band;
@@ -164,11 +164,20 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_WRIT
           if (threadIdx.x == 0) tl = __hip_atomic_fetch_add(ctl + kCtlTiles, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           tl = __builtin_amdgcn_readfirstlane(tl);
         }
-        int hv = have;
+        int hv = have, blk = 0, sx = 0, rg = 0;
         if (tl < n_tiles) {
-          const int blk = min(tl / tiles_full, last);
+          // (the integer divisions of this decode are a few dozen vector instructions each -- there is no scalar one --:
+          // done here once for the workgroup, not by every wave)
+          blk = last == 0 ? 0 : min(tl / tiles_full, last);
           const int rem = tl - blk * tiles_full;
-          const int sx = rem / (blk == last ? nrg_last : nrg_full);
+          const int nrg = blk == last ? nrg_last : nrg_full;
+          if (tile_order == 0) {  // time tile by time tile, the block's row groups side by side
+            sx = rem / nrg;
+            rg = rem - sx * nrg;
+          } else {  // row group by row group, its time tiles in a row
+            rg = rem / nsx;
+            sx = rem - rg * nsx;
+          }
           int lo, hi;
           fused_tile_knots(t, T, Ta, ta0, inv_dta, sx, lo, hi);
           need = blk * nby + hi / chunk;  // the last unit the tile reads (a tile's knots lie in one block)
@@ -177,7 +186,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_WRIT
             const int sl = hv + (int)threadIdx.x;
             bool ok = false;
             if (threadIdx.x < 16 && sl < n_slots) {
-              const int want = sl / nby == last ? nbx_last : nbx_full;
+              const int want = sl >= last * nby ? nbx_last : nbx_full;
               ok = __hip_atomic_load(ctl + kCtlDone + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
             }
             const unsigned long long m = __builtin_amdgcn_ballot_w64(ok) & 0xffffull;
@@ -190,6 +199,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_WRIT
           s_word[0] = tl;
           s_word[1] = hv;
           s_word[2] = need;
+          s_word[3] = blk;
+          s_word[4] = sx;
+          s_word[5] = rg;
         }
 #if MRX_SYNTH_ACQUIRE
         if (hv > need) {  // (the polling wave, once its poll has matched: invalidates this CU's L1)
@@ -214,10 +226,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_WRIT
         }
       }
       if (ready) {
-        const int blk = min(tile / tiles_full, last);
-        const int rem = tile - blk * tiles_full;
-        const int nrg = blk == last ? nrg_last : nrg_full;
-        const int sx = rem / nrg, by = rem - sx * nrg;
+        const int blk = s_word[3], sx = s_word[4], by = s_word[5];
         const int Db = blk == last ? last_rows : block_rows;
         const size_t row0 = (size_t)blk * block_rows;
         fused_writer_tile<kHasScale, kMaxKnots, kG, MRX_SYNTH_ACQUIRE == 0>(loading + (size_t)Ta * row0, (Db + 31) & ~31, Db, Ta, ta0, inv_dta, t, T,
@@ -261,6 +270,32 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_WRIT
 
 extern "C" {
 
+// Rows per block of the coarse array (and of the hand-over): the caller's number in whole groups of 256 lanes, or the
+// library's choice.
+static int synth_block_rows(mrx_ctx* ctx, const mrx_atm_plan* plan, int D, int Ta, int block_rows, int* out) {
+  // one block where the block's coarse array stays below 2 GiB (the sampler addresses it as a raw buffer)
+  {
+    const long long cap = ((1LL << 31) - 4096) / (4LL * Ta) / kBlock * kBlock;  // rows of whole groups of 256 lanes
+    MRX_REQUIRE(ctx, cap >= kBlock, "Ta too large: 256 rows of the coarse loading must stay below 2 GiB");
+    if (block_rows <= 0) {
+      // The library's choice.  The tiles of a block are written time tile by time tile, all its row groups side by side;
+      // cut into blocks of about 5 000 rows the launch measured 3-7 % faster than in one (atlast_10k's shape at 7 000,
+      // 8 000, 10 000 and 20 000 rows: 1.41 / 1.61 / 1.93 / 3.88 ms against 1.50 / 1.68 / 2.08 / 3.98; blocks of 2 048 to
+      // 6 912 rows alike) -- but every block walks the screens' track again, which is free only while the screens stay
+      // in the 256 MiB Infinity Cache (8 x 2048^2: 134 MB): 16 x 4096^2 (1.07 GB) in blocks of 3 328 rows took 9.45 ms
+      // against 9.22 in one block, 12 500 rows of that shape 17.2 / 17.4 in two / three blocks against 17.0 in one
+      const long long all = (long long)mrx_ceil_div(D, kBlock) * kBlock;
+      long long want = all;
+      if (plan->screen_bytes <= (192ull << 20) && D > 6400) want = (long long)mrx_ceil_div(mrx_ceil_div(D, mrx_ceil_div(D, 5120)), kBlock) * kBlock;
+      block_rows = (int)std::min(cap, want);
+    } else if (block_rows > cap) {
+      block_rows = (int)cap;
+    }
+  }
+  *out = std::min(mrx_ceil_div(block_rows, kBlock) * kBlock, mrx_ceil_div(D, 32) * 32);  // whole groups of 256 lanes; rows of whole lines
+  return MRX_OK;
+}
+
 static int atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d_az, const float* d_el, int Ta,
                           const float* d_dx, const float* d_dy, const int32_t* d_band, const float* d_mueller00, int D,
                           double pwv0, float* d_coarse, int block_rows, int sampler_wgs, uint32_t* d_flags, double ta0,
@@ -284,13 +319,10 @@ static int atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d
   if (!plan->all_pixel || literal || plan->any_cubic || plan->n_layers > mrx_px::kMaxAnchors)
     return mrx_fail(ctx, MRX_ERR_UNSUPPORTED, "mrx_atm_synthesize: this plan or option set takes the two-call form");
   const int n_cu = ctx->n_cu > 0 ? ctx->n_cu : 256;
-  // detector blocks: one where the block's coarse array stays below 2 GiB (the sampler addresses it as a raw buffer)
   {
-    const long long cap = ((1LL << 31) - 4096) / (4LL * Ta) / kBlock * kBlock;  // rows of whole groups of 256 lanes
-    MRX_REQUIRE(ctx, cap >= kBlock, "Ta too large: 256 rows of the coarse loading must stay below 2 GiB");
-    if (block_rows <= 0 || block_rows > cap) block_rows = (int)std::min<long long>(cap, (long long)mrx_ceil_div(D, kBlock) * kBlock);
+    const int rc = synth_block_rows(ctx, plan, D, Ta, block_rows, &block_rows);
+    if (rc != MRX_OK) return rc;
   }
-  block_rows = std::min(mrx_ceil_div(block_rows, kBlock) * kBlock, mrx_ceil_div(D, 32) * 32);  // whole groups of 256 lanes; rows of whole lines
   const int n_blocks = mrx_ceil_div(D, block_rows);
   MRX_REQUIRE(ctx, (long long)Ta * block_rows * 4 < (1LL << 31), "a block's coarse array must stay below 2 GiB");
   MRX_REQUIRE(ctx, (reinterpret_cast<uintptr_t>(d_coarse) & 127u) == 0, "d_coarse must be 128-byte aligned");
@@ -367,7 +399,7 @@ static int atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d
                        plan->d_px, plan->n_layers, plan->d_offpx, plan->d_tables, plan->n_tables,                 \
                        plan->d_table_data, plan->table_floats, d_az, d_el, Ta, d_dx, d_dy, d_band, d_mueller00,   \
                        D, pwv0, d_pwv, d_coarse, d_flags, chunk, nby, block_rows, n_blocks, (int)dedicated, ta0, 1.0 / dta, \
-                       d_t, T, d_scale, d_rows, d_out, ld_out, vec_ok, batches, ctl, poll_limit, cal);           \
+                       d_t, T, d_scale, d_rows, d_out, ld_out, vec_ok, batches, ctx->options[MRX_OPT_SYNTH_TILE_ORDER], ctl, poll_limit, cal); \
   } while (0)
 #define MRX_LAUNCH_SYNTH_J(L, S, K, G) do { if (krj) MRX_LAUNCH_SYNTH(L, S, K, G, true); else MRX_LAUNCH_SYNTH(L, S, K, G, false); } while (0)
 #define MRX_LAUNCH_SYNTH_S(L, S) do { if (small) MRX_LAUNCH_SYNTH_J(L, S, kSmallKnots, 2); else MRX_LAUNCH_SYNTH_J(L, S, 256, 1); } while (0)
@@ -381,6 +413,13 @@ static int atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d
 #undef MRX_LAUNCH_SYNTH
   MRX_CHECK_LAUNCH(ctx);
   return MRX_OK;
+}
+
+int mrx_atm_synthesize_block_rows(mrx_ctx* ctx, const mrx_atm_plan* plan, int D, int Ta, int block_rows, int* rows_out) {
+  MRX_ENTER(ctx);
+  if (!ctx) return MRX_ERR_INVALID;
+  MRX_REQUIRE(ctx, plan && rows_out && D > 0 && Ta > 0, "need a plan, D > 0, Ta > 0 and an output");
+  return synth_block_rows(ctx, plan, D, Ta, block_rows, rows_out);
 }
 
 int mrx_atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d_az, const float* d_el, int Ta,

@@ -812,12 +812,11 @@ class DevicePath:
         return out
 
     def synth_block_rows(self, block_rows=0):
-        """Rows per block of the coarse array as mrx_atm_synthesize lays it out: the caller's number in whole groups of
-        256 detectors, or -- 0 -- everything in one block where 4 Ta rows stays below 2 GiB (the most that do otherwise)."""
-        cap = ((1 << 31) - 4096) // (4 * self.Ta) // 256 * 256
-        if block_rows <= 0 or block_rows > cap:
-            block_rows = min(cap, (self.D + 255) // 256 * 256)
-        return min((block_rows + 255) // 256 * 256, (self.D + 31) // 32 * 32)
+        """Rows per block of the coarse array as mrx_atm_synthesize lays it out (the library tells:
+        mrx_atm_synthesize_block_rows): the caller's number in whole groups of 256 detectors, or -- 0 -- its own choice."""
+        rows = C.c_int()
+        self.ctx.call("mrx_atm_synthesize_block_rows", self.plan, self.D, self.Ta, int(block_rows), C.byref(rows))
+        return rows.value
 
     def default_blocks(self):
         """Detector blocks of the pipelined run: about 0.65e9 samples each from 4096 rows up -- 4 for atlast_10k

@@ -23,7 +23,9 @@ path.run(ref, blocks=1)
 torch.cuda.synchronize()
 tod = torch.empty_like(ref)
 ints = lambda name, default: [int(x) for x in os.environ.get(name, default).split(",")]
-for per_cu in ints("SYNTH_PER_CU", "0"):
+for order in ints("SYNTH_ORDER", "0"):
+ path.ctx.set_option(_lib.OPT_SYNTH_TILE_ORDER, order)
+ for per_cu in ints("SYNTH_PER_CU", "0"):
   path.ctx.set_option(_lib.OPT_SYNTH_WGS_PER_CU, per_cu)
   for br in rows:
     for chunk in ints("SYNTH_CHUNK", "32"):
@@ -36,8 +38,9 @@ for per_cu in ints("SYNTH_PER_CU", "0"):
         same = bool(torch.equal(tod, ref))
         nbad = 0 if same else int((tod != ref).sum().item())
         med, mn = timeit(lambda: path.synthesize(tod, **kw), 8)
-        print(f"{config} D {path.D} synthesize per_cu {per_cu} block_rows {br} chunk {chunk} samplers {wgs}: identical {same} (differing {nbad}) flags {flags}  median {med:.3f} ms min {mn:.3f}", flush=True)
+        print(f"{config} D {path.D} synthesize order {order} per_cu {per_cu} block_rows {br} chunk {chunk} samplers {wgs}: identical {same} (differing {nbad}) flags {flags}  median {med:.3f} ms min {mn:.3f}", flush=True)
 path.ctx.set_option(_lib.OPT_SYNTH_WGS_PER_CU, 0)
+path.ctx.set_option(_lib.OPT_SYNTH_TILE_ORDER, 0)
 if not os.environ.get("SYNTH_ONLY"):
     med, mn = timeit(lambda: path._run_pipelined(tod, path.default_blocks()) if path.default_blocks() > 1 else path.run(tod, blocks=1), 6)
     print(f"{config} pipelined run (default blocks {path.default_blocks()}): median {med:.3f} ms min {mn:.3f}", flush=True)
