@@ -41,6 +41,9 @@ for order in ints("SYNTH_ORDER", "0"):
         print(f"{config} D {path.D} synthesize order {order} per_cu {per_cu} block_rows {br} chunk {chunk} samplers {wgs}: identical {same} (differing {nbad}) flags {flags}  median {med:.3f} ms min {mn:.3f}", flush=True)
 path.ctx.set_option(_lib.OPT_SYNTH_WGS_PER_CU, 0)
 path.ctx.set_option(_lib.OPT_SYNTH_TILE_ORDER, 0)
+path.sample()
+med, mn = timeit(lambda: path.upsample_fused(tod), 6)
+print(f"{config} D {path.D} writer alone (mrx_spline_upsample_fused): median {med:.3f} ms min {mn:.3f}", flush=True)
 if not os.environ.get("SYNTH_ONLY"):
     med, mn = timeit(lambda: path._run_pipelined(tod, path.default_blocks()) if path.default_blocks() > 1 else path.run(tod, blocks=1), 6)
     print(f"{config} pipelined run (default blocks {path.default_blocks()}): median {med:.3f} ms min {mn:.3f}", flush=True)
