@@ -645,6 +645,23 @@ int mrx_map_sample(mrx_ctx* ctx, const mrx_sky_map* map, const mrx_map_cal* cal,
                    const float* d_dx, const float* d_dy, const double* d_stokes_w, int D,
                    float* d_out, size_t ld_out);
 
+/* mrx_map_sample with the gain and TOD.to("K_RJ") (tod/tod.py:106-142) on its store:
+ *   d_out[d][s] = S(d, s) * d_scale[d] / den_band(d)(el(d, s)),
+ * S the pW field mrx_map_sample writes, the division exactly as mrx_tod_to_krj performs it on a finished field (the same
+ * per-tile elevation model from the same 1024 samples, the same lookup) -- the same bits as mrx_map_sample followed by
+ * mrx_tod_to_krj with that d_scale, without the second pass over the field.
+ *  d_scale                      [D] float32 or NULL (1): the gain error (sim/simulation.py:239-247)
+ *  d_bore_el                    [T] float32 full-rate boresight elevation
+ *  d_krj_dx, d_krj_dy, d_band   [D] float32 offsets and int32 band index of this call's rows, as mrx_tod_to_krj takes them
+ *  d_cal_axis_el, d_cal_values  [n_el], [n_bands][n_el] float32: the bands' collapsed transmission integrals
+ * MRX_ERR_UNSUPPORTED (nothing launched) with MRX_OPT_POINTING_CHAIN: sample in pW and convert there. */
+int mrx_map_sample_krj(mrx_ctx* ctx, const mrx_sky_map* map, const mrx_map_cal* cal,
+                       const float* d_az, const float* d_el, int T, const double* d_transform,
+                       const float* d_dx, const float* d_dy, const double* d_stokes_w, int D,
+                       const float* d_scale, const float* d_bore_el, const float* d_krj_dx, const float* d_krj_dy,
+                       const int32_t* d_band, const float* d_cal_axis_el, const float* d_cal_values, int n_el, int n_bands,
+                       float* d_out, size_t ld_out);
+
 /* BinMapper.run for one TOD (mappers/bin_mapper.py:84-120): the transpose of the pointing
  * matrix of mrx_map_sample, map_sum += (W * D) @ P and map_wgt += W @ |P|, as float64 atomic
  * adds into the caller's (zeroed or running) maps; the map itself is sum / wgt.  `map` gives

@@ -204,6 +204,7 @@ SIGNATURES = {
     "mrx_screen_amplitudes": (_i, [_vp, _i, _i, _i, _d, _d, _d, _d, C.POINTER(_d), C.POINTER(_d), _i, _d, _d, _d, _vp, _vp, _sz]),
     "mrx_screen_psd_sum": (_i, [_vp, _i, _i, _d, _d, _d, _d, C.POINTER(_d)]),
     "mrx_map_sample": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _sz]),
+    "mrx_map_sample_krj": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _sz]),
     "mrx_bin_map": (_i, [_vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
     "mrx_bin_map_work_bytes": (_i, [_vp, _i, _i, _vp, _vp]),
     "mrx_bin_map_bucketed": (_i, [_vp, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz]),

@@ -5,6 +5,16 @@
 
 #include "mrx_tile.h"
 
+// The K_RJ division must round alike wherever it is inlined -- tod_krj_kernel, the spline writers, the noise writer, the
+// one-launch sampler, the map sampler -- because callers compare their fields bit for bit (a field written in K_RJ against
+// the same field converted afterwards), and those kernels live in translation units built with different contraction
+// rules (mrx_map.hip: -ffp-contract=off).  "Let the compiler fuse" is not a rule two translation units apply alike (the
+// same source gave 15 fused multiply-adds in one and 12 in the other, and a per-row elevation model 1e-7 rad apart: one
+// value in fifteen a float32 ulp off).  So every function here states `contract(off)` for its own body -- the statement
+// form of the pragma, which leaves nothing behind for the including file -- and writes the fused operations it wants as
+// fmaf: IEEE operations in a fixed order, the same bits wherever they are inlined.
+#define MRX_KRJ_FP _Pragma("clang fp contract(off)")
+
 namespace {
 
 // ---------------------------------------------------------------------------
@@ -39,13 +49,22 @@ struct CalDet {
 // trigonometry per sample); |el - el0| <= r^2 tan(el)/2 ~ 3e-4 rad, so the
 // second-order step is exact to float32 rounding.  eb: boresight elevation,
 // ca / sa: cos / sin of (eb - pi/2).
+// sin(el_det) as the float32 chain forms it (transforms.py:20-28): two products and a sum, each rounded.  ca / sa: cos / sin
+// of (boresight elevation - pi/2).  One definition for every kernel that divides by den(el_det) -- here, coarse_krj_kernel
+// and the one-launch sampler (mrx_synth.hip), whose fields are compared bit for bit.
+__device__ __forceinline__ float det_sin_elevation(float a_re, float a_im, float ca, float sa) {
+  MRX_KRJ_FP
+  return a_re * sa + a_im * ca;
+}
+
 __device__ __forceinline__ float det_elevation(const CalDet& c, float eb, float ca, float sa) {
-  const float im = __fadd_rn(__fmul_rn(c.a_re, sa), __fmul_rn(c.a_im, ca));
-  const float s0 = ca * c.cdy - sa * c.sdy;   // sin(el_bore + dy)
-  const float c0 = -sa * c.cdy - ca * c.sdy;  // cos(el_bore + dy)
+  MRX_KRJ_FP
+  const float im = det_sin_elevation(c.a_re, c.a_im, ca, sa);
+  const float s0 = fmaf(ca, c.cdy, -(sa * c.sdy));   // sin(el_bore + dy)
+  const float c0 = -fmaf(sa, c.cdy, ca * c.sdy);     // cos(el_bore + dy)
   const float rc0 = __builtin_amdgcn_rcpf(c0);
   const float dl1 = (im - s0) * rc0;
-  float el = (eb + c.dy) + dl1 * (1.0f + 0.5f * dl1 * s0 * rc0);
+  float el = fmaf(dl1, 1.0f + 0.5f * dl1 * s0 * rc0, eb + c.dy);
   // within ~15 deg of the zenith the expansion loses accuracy: take asin there
   const bool steep = !(c0 > 0.25f);
   if (__builtin_amdgcn_ballot_w64(steep) != 0)
@@ -57,6 +76,7 @@ __device__ __forceinline__ float det_elevation(const CalDet& c, float eb, float 
 constexpr float kModelHalfRange = 2.0e-2f;  // wide enough that float32 rounding of the differences stays below 1e-7 rad over a tile
 
 __device__ __forceinline__ void set_elevation_model(CalDet& c, float ebm) {
+  MRX_KRJ_FP
   constexpr float h = kModelHalfRange;
   float e[3];
   bool steep = false;
@@ -65,7 +85,7 @@ __device__ __forceinline__ void set_elevation_model(CalDet& c, float ebm) {
     const float eb = ebm + (float)(k - 1) * h;
     const float a = eb - 1.57079637050628662109375f;
     const float ca = cosf(a), sa = sinf(a);
-    steep |= !(-sa * c.cdy - ca * c.sdy > 0.3f);  // cos(el_bore + dy): within ~17 deg of the zenith
+    steep |= !(-fmaf(sa, c.cdy, ca * c.sdy) > 0.3f);  // cos(el_bore + dy): within ~17 deg of the zenith
     e[k] = det_elevation(c, eb, ca, sa) - eb;
   }
   c.ebm = ebm;
@@ -75,10 +95,11 @@ __device__ __forceinline__ void set_elevation_model(CalDet& c, float ebm) {
 }
 
 __device__ __forceinline__ CalDet make_cal_det(float dx, float dy, int band, float scale) {
-  const float r = sqrtf(dx * dx + dy * dy);
+  MRX_KRJ_FP
+  const float r = sqrtf(fmaf(dx, dx, dy * dy));
   const float p = atan2f(-dx, -dy);
   CalDet c;
-  c.a_re = __fmul_rn(sinf(r), cosf(p));
+  c.a_re = sinf(r) * cosf(p);
   c.a_im = cosf(r);
   c.band = band;
   c.scale = scale;
@@ -93,6 +114,7 @@ __device__ __forceinline__ CalDet make_cal_det(float dx, float dy, int band, flo
 // serves a lookup.  n_el - 1 cells per band.
 __device__ __forceinline__ void stage_cal_cells(float4* cells, const float* __restrict__ axis,
                                                 const float* __restrict__ values, int n_el, int n_bands) {
+  MRX_KRJ_FP
   const int nc = n_el - 1;
   for (int i = threadIdx.x; i < nc * n_bands; i += kBlock) {
     const int b = i / nc, k = i - b * nc;
@@ -107,14 +129,14 @@ __device__ __forceinline__ void stage_cal_cells(float4* cells, const float* __re
 // (non-uniform axis, a sample within rounding of a node)
 __device__ __forceinline__ float den_lookup(float el, const float4* C, int n_el, float el_first,
                                             float el_last, float el_inv) {
+  MRX_KRJ_FP
   const int nc = n_el - 1;
   int i = min(max((int)fminf(fmaxf((el - el_first) * el_inv, -1.0f), 2.0e9f), 0), nc - 1);
   while (i < nc - 1 && C[i + 1].x < el) ++i;  // searchsorted(side="left") - 1: x_i < el <= x_{i+1}
   while (i > 0 && C[i].x >= el) --i;
   const float4 c = C[i];
   const float wt = (el - c.x) * c.z;
-  float den = 0.0f + c.y * (1.0f - wt);
-  den = den + c.w * wt;
+  const float den = fmaf(c.w, wt, c.y * (1.0f - wt));  // jax: 0 + y (1 - wt), then + w wt
   return (el >= el_first && el <= el_last) ? den : __builtin_nanf("");
 }
 
@@ -138,6 +160,7 @@ __device__ __forceinline__ void krj_row(const CalDet& c, const float4* C, int n_
                                         float el_last, float el_inv, const KrjSamples& k,
                                         const float (&sv)[kSamplesPerThread], float (&o)[kSamplesPerThread],
                                         const float* __restrict__ bore_el, int sb, int T) {
+  MRX_KRJ_FP
   constexpr int kL = kSamplesPerThread - 1;
   if constexpr (kCurved) {
     // Low sample rates or tight fast scans (20 Hz, a 0.1 deg daisy at 0.8 deg/s: 3e-4 rad of curvature over a thread's
@@ -187,10 +210,8 @@ __device__ __forceinline__ void krj_row(const CalDet& c, const float4* C, int n_
   const float wmin = fminf(w0, w3), wmax = fmaxf(w0, w3);
   const bool fast = (wmin > 0.0f || (i0 == 0 && wmin >= 0.0f)) && wmax <= 1.0f &&
                     fminf(e0, e3) >= el_first && fmaxf(e0, e3) <= el_last;
-  float d0 = 0.0f + cell.y * (1.0f - w0);
-  d0 = d0 + cell.w * w0;
-  float d3 = 0.0f + cell.y * (1.0f - w3);
-  d3 = d3 + cell.w * w3;
+  const float d0 = fmaf(cell.w, w0, cell.y * (1.0f - w0));  // (den_lookup's arithmetic)
+  const float d3 = fmaf(cell.w, w3, cell.y * (1.0f - w3));
   if (kInverse) {
     const float step = (d3 - d0) * (1.0f / (float)kL);
 #pragma unroll
@@ -206,7 +227,7 @@ __device__ __forceinline__ void krj_row(const CalDet& c, const float4* C, int n_
       const float de = (e3 - e0) * (1.0f / (float)kL);
 #pragma unroll 1
       for (int q = 0; q < kSamplesPerThread; ++q) {
-        const float el = q == 0 ? e0 : q == kL ? e3 : e0 + (float)q * de;
+        const float el = q == 0 ? e0 : q == kL ? e3 : fmaf((float)q, de, e0);
         const float den = den_lookup(el, C, n_el, el_first, el_last, el_inv);
         o[q] = kInverse ? sv[q] * den : sv[q] * __builtin_amdgcn_rcpf(den);
       }
@@ -220,6 +241,7 @@ __device__ __forceinline__ void krj_row(const CalDet& c, const float4* C, int n_
 __device__ __forceinline__ KrjSamples krj_prologue(float4* cells, float* red, const float* __restrict__ bore_el,
                                                    int T, int sb, const float* __restrict__ cal_axis,
                                                    const float* __restrict__ cal_values, int n_el, int n_bands) {
+  MRX_KRJ_FP
   KrjSamples k;
   k.eb0 = bore_el[min(sb, T - 1)];
   k.eb3 = bore_el[min(sb + kSamplesPerThread - 1, T - 1)];
@@ -228,7 +250,7 @@ __device__ __forceinline__ KrjSamples krj_prologue(float4* cells, float* red, co
     static_assert(kSamplesPerThread == 4, "the curvature check below is written for four samples");
     const float eb1 = bore_el[min(sb + 1, T - 1)], eb2 = bore_el[min(sb + 2, T - 1)];
     const float third = (k.eb3 - k.eb0) * (1.0f / 3.0f);
-    k.curved = !(fabsf(eb1 - (k.eb0 + third)) <= 1.0e-6f && fabsf(eb2 - (k.eb0 + 2.0f * third)) <= 1.0e-6f);  // (a NaN: per sample too)
+    k.curved = !(fabsf(eb1 - (k.eb0 + third)) <= 1.0e-6f && fabsf(eb2 - fmaf(2.0f, third, k.eb0)) <= 1.0e-6f);  // (a NaN: per sample too)
     eb_lo = fminf(fminf(k.eb0, eb1), fminf(eb2, k.eb3));
     eb_hi = fmaxf(fmaxf(k.eb0, eb1), fmaxf(eb2, k.eb3));
   }
@@ -265,6 +287,7 @@ __device__ __forceinline__ KrjSamples krj_prologue(float4* cells, float* red, co
 __device__ __forceinline__ void krj_stage_rows(CalDet* cdet, float* red, const float* __restrict__ dxs,
                                                const float* __restrict__ dys, const int32_t* __restrict__ band,
                                                const float* __restrict__ scale, int n_bands, int d0, int nd) {
+  MRX_KRJ_FP
   if ((int)threadIdx.x < kTileDet) {
     const float lo = red[8], hi = red[9];
     bool exact = false;

@@ -158,7 +158,7 @@ __global__ __launch_bounds__(kBlock) void coarse_krj_kernel(
       if (j >= j1) break;
       // coords/transforms.py:20-28 in float32: im = sin(el_det), el_det = asin(im)
       const float2 cs = trig[j - j0];
-      const float im = __fadd_rn(__fmul_rn(c.a_re, cs.y), __fmul_rn(c.a_im, cs.x));
+      const float im = det_sin_elevation(c.a_re, c.a_im, cs.x, cs.y);
       const float den = den_lookup(asinf(im), C, n_el, el_first, el_last, el_inv);
       out[(size_t)j * D + d] = v[k] * __builtin_amdgcn_rcpf(den);
       if (tail && j >= tail_first) tail[(size_t)(j - tail_first) * ld_tail + d] = v[k];  // (uniform: j is the block's)

@@ -24,18 +24,14 @@
 #include <type_traits>
 
 #include "mrx_internal.h"
+#include "mrx_krj.h"  // the tile (mrx_tile.h: 16 rows x 1024 samples, 4 a thread) and TOD.to("K_RJ") on the sampler's store
 
 namespace {
 
-constexpr int kBlock = 256;
-constexpr int kTileDet = 16;
-constexpr int kSamplesPerThread = 4;
-constexpr int kTileSamples = kBlock * kSamplesPerThread;
+static_assert(kBlock == 256 && kTileDet == 16 && kSamplesPerThread == 4 && kTileSamples == 1024, "the map kernels are written for the TOD tile");
 constexpr int kMaxStokes = 4;
 constexpr float kHalfPiF = 1.57079637050628662109375f;
 constexpr float kTwoPiF = 6.283185482025146484375f;
-
-typedef float vfloat4 __attribute__((ext_vector_type(4)));
 
 // One map axis: node i sits at first + i * step (np.linspace, map/projection.py:122-123;
 // step of either sign -- eta is descending after the parity flip).
@@ -82,6 +78,19 @@ struct MapArgs {
   float* out;
   size_t ld;
   int vec_ok;
+};
+
+// TOD.to("K_RJ") on the sampler's store (mrx_map_sample_krj): the arguments of mrx_tod_to_krj for the rows of this call
+struct MapKrj {
+  const float* bore_el;     // [T]
+  const float* dx;          // [D]
+  const float* dy;          // [D]
+  const int32_t* band;      // [D]
+  const float* scale;       // [D] or null
+  const float* cal_axis;    // [n_el]
+  const float* cal_values;  // [n_bands][n_el]
+  int n_el, n_bands;
+  int cells_offset;         // of the cell table in the dynamic LDS, in float4
 };
 
 struct DetConst {
@@ -891,13 +900,18 @@ __global__ __launch_bounds__(kBlock) void bin_accumulate_kernel(MapArgs g, BinAr
   }
 }
 
-template <bool kChain, bool kCal, int kS>
+// kKrj: the field leaves in K_RJ -- every row's four values times the row's scale, divided by den_band(el_det) exactly as
+// tod_krj_kernel divides a finished field (mrx_krj.h: the same per-tile elevation model from the same 1024 samples, the same
+// lookup), instead of a second pass that reads and writes the field again (3.9 of 18.3 ms at 10 000 x 240 000).
+template <bool kChain, bool kCal, int kS, bool kKrj = false>
 // without the per-sample atmospheric calibration the kernel fits 168 registers (three waves per
 // SIMD: 16.8 -> 14.8 ms at 10 000 x 240 000); with it the cap costs spills (26.8 -> 34.4 ms)
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kChain ? (kCal ? 2 : 3) : (kCal ? 3 : 5), kChain ? (kCal ? 2 : 3) : 8))) void map_sample_kernel(MapArgs g, int groups) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kChain ? (kCal ? 2 : 3) : (kCal ? 3 : 5), kChain ? (kCal ? 2 : 3) : 8))) void map_sample_kernel(MapArgs g, int groups, MapKrj kj) {
   __shared__ DetConst dets[kTileDet];
   __shared__ float2 edge[2][kBlock];  // (first, last) raw value of every thread, double-buffered
-  extern __shared__ float cal_lds[];   // calibration axes and tables (a few KB)
+  extern __shared__ __align__(16) float cal_lds[];   // calibration axes and tables (a few KB); K_RJ: the cell table behind them
+  __shared__ CalDet cdet[kKrj ? kTileDet : 1];
+  __shared__ float red[12];
   CalLds cl{};
   if (kCal) {
     for (int i = threadIdx.x; i < g.n_pwv; i += kBlock) cal_lds[i] = g.cal_pwv[i];
@@ -942,7 +956,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kChain ?
       sc_halo.s = min(max(sh, 0), g.T - 1);
     }
   }
+  float4* const cal_cells = reinterpret_cast<float4*>(cal_lds) + kj.cells_offset;
+  KrjSamples ks{};
+  if constexpr (kKrj) ks = krj_prologue(cal_cells, red, kj.bore_el, g.T, sb, kj.cal_axis, kj.cal_values, kj.n_el, kj.n_bands);  // (ends with a barrier)
   __syncthreads();
+  const float el_first = kKrj ? cal_cells[0].x : 0.0f, el_last = kKrj ? kj.cal_axis[kj.n_el - 1] : 0.0f, el_inv = kKrj ? cal_cells[0].z : 0.0f;
   if (kCal) {
     cl.pwv = make_rgi_axis(cal_lds, g.n_pwv);
     cl.el = make_rgi_axis(cal_lds + g.n_pwv, g.n_el);
@@ -974,8 +992,9 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kChain ?
   const int d0 = (blockIdx.y * groups + grp) * kTileDet;
   if (d0 >= g.D) break;
   const int nd = min(kTileDet, g.D - d0);
-  __syncthreads();  // the previous group is done with dets[] and edge[]
+  __syncthreads();  // the previous group is done with dets[], cdet[] and edge[]
   if ((int)threadIdx.x < nd) dets[threadIdx.x] = make_det_const(g, d0 + threadIdx.x);
+  if constexpr (kKrj) krj_stage_rows(cdet, red, kj.dx, kj.dy, kj.band, kj.scale, kj.n_bands, d0, nd);
   __syncthreads();
   for (int dl = 0; dl < nd; ++dl) {
     const DetConst dc = dets[dl];
@@ -1050,6 +1069,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kChain ?
       const float next = q == kSamplesPerThread - 1 ? right : r[q + 1];
       o[q] = fmaf(r[q], 0.5f, (prev + next) * 0.25f);
     }
+    if constexpr (kKrj) {
+      const CalDet c = cdet[dl];
+      float sv[kSamplesPerThread];
+#pragma unroll
+      for (int q = 0; q < kSamplesPerThread; ++q) sv[q] = c.scale * o[q];
+      const float4* C = cal_cells + c.band * (kj.n_el - 1);
+      // (curved: a workgroup whose boresight elevation is not linear over a thread's four samples -- low sample rates --
+      // looks every sample up at its own elevation; uniform)
+      if (ks.curved) krj_row<false, true>(c, C, kj.n_el, el_first, el_last, el_inv, ks, sv, o, kj.bore_el, sb, g.T);
+      else krj_row<false, false>(c, C, kj.n_el, el_first, el_last, el_inv, ks, sv, o, kj.bore_el, sb, g.T);
+    }
     float* dst = g.out + (size_t)d * g.ld + sb;
     if (full) {
       const vfloat4 v = {o[0], o[1], o[2], o[3]};
@@ -1065,14 +1095,11 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kChain ?
 
 }  // namespace
 
-extern "C" {
-
-int mrx_map_sample(mrx_ctx* ctx, const mrx_sky_map* map, const mrx_map_cal* cal,
-                   const float* d_az, const float* d_el, int T, const double* d_transform,
-                   const float* d_dx, const float* d_dy, const double* d_stokes_w, int D,
-                   float* d_out, size_t ld_out) {
-  MRX_ENTER(ctx);
-  if (!ctx) return MRX_ERR_INVALID;
+// mrx_map_sample (krj == nullptr) and mrx_map_sample_krj
+static int map_sample(mrx_ctx* ctx, const mrx_sky_map* map, const mrx_map_cal* cal,
+                      const float* d_az, const float* d_el, int T, const double* d_transform,
+                      const float* d_dx, const float* d_dy, const double* d_stokes_w, int D,
+                      float* d_out, size_t ld_out, const MapKrj* krj) {
   MRX_REQUIRE(ctx, D >= 0 && T >= 0, "negative size");
   if (D == 0 || T == 0) return MRX_OK;
   MRX_REQUIRE(ctx, map && cal && d_az && d_el && d_dx && d_dy && d_stokes_w && d_out, "null pointer");
@@ -1142,33 +1169,79 @@ int mrx_map_sample(mrx_ctx* ctx, const mrx_sky_map* map, const mrx_map_cal* cal,
     lds = sizeof(float) * ((size_t)cal->n_pwv + cal->n_el + (size_t)map->n_channels * cal->n_pwv * cal->n_el);
     MRX_REQUIRE(ctx, lds <= 48 * 1024, "calibration tables of all channels must fit in 48 KiB");
   }
+  MapKrj kj{};
+  if (krj) {  // the cell table of TOD.to("K_RJ") behind the sampler's own tables, on a 16-byte boundary
+    kj = *krj;
+    lds = (lds + 15) / 16 * 16;
+    kj.cells_offset = (int)(lds / 16);
+    lds += sizeof(float4) * (size_t)(kj.n_el - 1) * kj.n_bands;
+    MRX_REQUIRE(ctx, lds <= 60 * 1024, "the calibration tables (sampling and K_RJ) must fit in 60 KiB");
+  }
   MRX_REQUIRE(ctx, (long long)map->n_eta * map->n_xi < (1LL << 29), "a map plane must hold fewer than 2^29 pixels");
   const bool chain = ctx->options[MRX_OPT_POINTING_CHAIN] != 0, has_cal = cal->d_table != nullptr;
+  if (krj && chain)
+    return mrx_fail(ctx, MRX_ERR_UNSUPPORTED, "mrx_map_sample_krj: not with MRX_OPT_POINTING_CHAIN (sample in pW, then mrx_tod_to_krj)");
   // (the kernel's static LDS -- sample records, edge exchange -- is up to 46 KiB: with large calibration
   // tables the sum passes the 64 KiB a launch gets by default)
-#define MRX_LAUNCH_MAP(CH, CA, S)                                                                              \
+#define MRX_LAUNCH_MAP(CH, CA, S, K)                                                                           \
   do {                                                                                                         \
-    if (lds + 47 * 1024 > 64 * 1024)                                                                           \
-      MRX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(map_sample_kernel<CH, CA, S>),           \
+    if (lds + 48 * 1024 > 64 * 1024)                                                                           \
+      MRX_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(map_sample_kernel<CH, CA, S, K>),        \
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                 \
-    hipLaunchKernelGGL((map_sample_kernel<CH, CA, S>), grid, dim3(kBlock), lds, ctx->stream, g, groups);       \
+    hipLaunchKernelGGL((map_sample_kernel<CH, CA, S, K>), grid, dim3(kBlock), lds, ctx->stream, g, groups, kj); \
   } while (0)
-#define MRX_LAUNCH_MAP_S(CH, CA)                    \
-  switch (map->n_stokes) {                          \
-    case 1: MRX_LAUNCH_MAP(CH, CA, 1); break;       \
-    case 2: MRX_LAUNCH_MAP(CH, CA, 2); break;       \
-    case 3: MRX_LAUNCH_MAP(CH, CA, 3); break;       \
-    default: MRX_LAUNCH_MAP(CH, CA, 4); break;      \
+#define MRX_LAUNCH_MAP_S(CH, CA, K)                    \
+  switch (map->n_stokes) {                             \
+    case 1: MRX_LAUNCH_MAP(CH, CA, 1, K); break;       \
+    case 2: MRX_LAUNCH_MAP(CH, CA, 2, K); break;       \
+    case 3: MRX_LAUNCH_MAP(CH, CA, 3, K); break;       \
+    default: MRX_LAUNCH_MAP(CH, CA, 4, K); break;      \
   }
   if (chain) {
-    if (has_cal) { MRX_LAUNCH_MAP_S(true, true); } else { MRX_LAUNCH_MAP_S(true, false); }
+    if (has_cal) { MRX_LAUNCH_MAP_S(true, true, false); } else { MRX_LAUNCH_MAP_S(true, false, false); }
+  } else if (krj) {
+    if (has_cal) { MRX_LAUNCH_MAP_S(false, true, true); } else { MRX_LAUNCH_MAP_S(false, false, true); }
   } else {
-    if (has_cal) { MRX_LAUNCH_MAP_S(false, true); } else { MRX_LAUNCH_MAP_S(false, false); }
+    if (has_cal) { MRX_LAUNCH_MAP_S(false, true, false); } else { MRX_LAUNCH_MAP_S(false, false, false); }
   }
 #undef MRX_LAUNCH_MAP_S
 #undef MRX_LAUNCH_MAP
   MRX_CHECK_LAUNCH(ctx);
   return MRX_OK;
+}
+
+extern "C" {
+
+int mrx_map_sample(mrx_ctx* ctx, const mrx_sky_map* map, const mrx_map_cal* cal,
+                   const float* d_az, const float* d_el, int T, const double* d_transform,
+                   const float* d_dx, const float* d_dy, const double* d_stokes_w, int D,
+                   float* d_out, size_t ld_out) {
+  MRX_ENTER(ctx);
+  if (!ctx) return MRX_ERR_INVALID;
+  return map_sample(ctx, map, cal, d_az, d_el, T, d_transform, d_dx, d_dy, d_stokes_w, D, d_out, ld_out, nullptr);
+}
+
+int mrx_map_sample_krj(mrx_ctx* ctx, const mrx_sky_map* map, const mrx_map_cal* cal,
+                       const float* d_az, const float* d_el, int T, const double* d_transform,
+                       const float* d_dx, const float* d_dy, const double* d_stokes_w, int D,
+                       const float* d_scale, const float* d_bore_el, const float* d_krj_dx, const float* d_krj_dy,
+                       const int32_t* d_band, const float* d_cal_axis_el, const float* d_cal_values, int n_el, int n_bands,
+                       float* d_out, size_t ld_out) {
+  MRX_ENTER(ctx);
+  if (!ctx) return MRX_ERR_INVALID;
+  MRX_REQUIRE(ctx, d_bore_el && d_krj_dx && d_krj_dy && d_band && d_cal_axis_el && d_cal_values, "null K_RJ pointer");
+  MRX_REQUIRE(ctx, n_el >= 2 && n_bands >= 1, "need n_el >= 2 and n_bands >= 1");
+  MapKrj kj{};
+  kj.bore_el = d_bore_el;
+  kj.dx = d_krj_dx;
+  kj.dy = d_krj_dy;
+  kj.band = d_band;
+  kj.scale = d_scale;
+  kj.cal_axis = d_cal_axis_el;
+  kj.cal_values = d_cal_values;
+  kj.n_el = n_el;
+  kj.n_bands = n_bands;
+  return map_sample(ctx, map, cal, d_az, d_el, T, d_transform, d_dx, d_dy, d_stokes_w, D, d_out, ld_out, &kj);
 }
 
 static int bin_map_args(mrx_ctx* ctx, const mrx_sky_map* map, const float* d_tod, size_t ld_tod,

@@ -94,7 +94,7 @@ struct SynthHooks {
   // coarse_krj_kernel's arithmetic: im = sin(el_det) from the step's (cos, sin) of (boresight elevation - pi/2)
   __device__ __forceinline__ float value(float v, const float4& bt, int t, int d, bool real) const {
     if (!kKrj) return v;
-    const float im = __fadd_rn(__fmul_rn(a_re, bt.y), __fmul_rn(a_im, bt.x));
+    const float im = det_sin_elevation(a_re, a_im, bt.x, bt.y);
     const float den = den_lookup(asinf(im), C, cal.n_el, el_first, el_last, el_inv);
     if (cal.tail && real && t >= cal.tail_first) cal.tail[(size_t)(t - cal.tail_first) * cal.ld_tail + d] = v;
     return v * __builtin_amdgcn_rcpf(den);

@@ -71,7 +71,7 @@ def collapse_temperature(table, axis_T, base_temperature):
 
 def sample_map(ctx, values, eta, xi, center, az, el, offsets, stokes_weights, out=None, transform=None, bilinear=True,
                cal_tables=None, cal_axis_pwv=None, cal_axis_el=None, coarse_pwv=None, ta0=0.0, dta=1.0, t=None,
-               cal_scalars=None, device="cuda:0", sync=True):
+               cal_scalars=None, device="cuda:0", sync=True, krj=None, scale=None):
     """``mrx_map_sample`` for the detectors of one band (sim/map.py:76-172).
 
     values [C, S, n_eta, n_xi] K_RJ (smoothed, parity applied); eta, xi the map axes in radians;
@@ -82,7 +82,13 @@ def sample_map(ctx, values, eta, xi, center, az, el, offsets, stokes_weights, ou
     times ``t``; or ``cal_scalars`` [C].  Arrays or device tensors throughout (tensors of the right type are used as
     they are).  ``sync=False``: return without waiting for the kernel -- for callers whose inputs outlive the launch
     or live on the launch's stream (torch's allocator then orders their reuse).  Returns the [D, T] float32 device
-    tensor in pW."""
+    tensor in pW.
+
+    ``krj``: the field in K_RJ instead (``mrx_map_sample_krj``: ``TOD.to("K_RJ")`` on the sampler's store, the same bits
+    as ``mrx_tod_to_krj`` of the pW field) -- a dict of device tensors for THESE rows: ``bore_el`` [T], ``dx``, ``dy``
+    [D] float32, ``band`` [D] int32, ``axis`` [n_el], ``values`` [n_bands, n_el] float32 (``DevicePath.krj_row_tables()``,
+    its per-row arrays indexed by the band's rows); ``scale`` [D] float32: the gain error, multiplied in before the
+    division (with ``krj`` only)."""
     from ._lib import MrxMapCal, MrxSkyMap
 
     dev = torch.device(device)
@@ -114,8 +120,22 @@ def sample_map(ctx, values, eta, xi, center, az, el, offsets, stokes_weights, ou
         keep["tr"] = f64(np.asarray(transform).reshape(T, 9) if not isinstance(transform, torch.Tensor) else transform.reshape(T, 9))
     if out is None:
         out = torch.empty((D, T), dtype=torch.float32, device=dev)
-    ctx.call("mrx_map_sample", C.byref(sky), C.byref(cal), ptr(keep["az"]), ptr(keep["el"]), T, ptr(keep.get("tr")),
-             ptr(keep["dx"]), ptr(keep["dy"]), ptr(keep["w"]), D, ptr(out), out.stride(0))
+    if krj is None:
+        if scale is not None:
+            raise ValueError("scale goes with krj (the pW field takes its gain from the caller)")
+        ctx.call("mrx_map_sample", C.byref(sky), C.byref(cal), ptr(keep["az"]), ptr(keep["el"]), T, ptr(keep.get("tr")),
+                 ptr(keep["dx"]), ptr(keep["dy"]), ptr(keep["w"]), D, ptr(out), out.stride(0))
+    else:
+        keep.update(k_el=f32(krj["bore_el"]), k_dx=f32(krj["dx"]), k_dy=f32(krj["dy"]), k_axis=f32(krj["axis"]), k_values=f32(krj["values"]),
+                    k_band=krj["band"].to(dev, torch.int32).contiguous(), k_scale=None if scale is None else f32(scale))
+        n_el = int(keep["k_axis"].numel())
+        n_bands = int(keep["k_values"].numel()) // n_el
+        assert keep["k_el"].numel() == T and keep["k_dx"].numel() == D and keep["k_dy"].numel() == D and keep["k_band"].numel() == D
+        assert keep["k_scale"] is None or keep["k_scale"].numel() == D
+        ctx.call("mrx_map_sample_krj", C.byref(sky), C.byref(cal), ptr(keep["az"]), ptr(keep["el"]), T, ptr(keep.get("tr")),
+                 ptr(keep["dx"]), ptr(keep["dy"]), ptr(keep["w"]), D, ptr(keep["k_scale"]), ptr(keep["k_el"]), ptr(keep["k_dx"]),
+                 ptr(keep["k_dy"]), ptr(keep["k_band"]), ptr(keep["k_axis"]), ptr(keep["k_values"]), n_el, n_bands,
+                 ptr(out), out.stride(0))
     if sync:
         torch.cuda.current_stream(dev).synchronize()  # the temporaries in `keep` may go once the kernel is done
     return out

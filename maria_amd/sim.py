@@ -358,9 +358,11 @@ class Simulation:
         path.check_flags()  # RuntimeError "introduced nans" like atmosphere.py:368-369
         return out
 
-    def _sample_maps(self, obs, rows=None):
+    def _sample_maps(self, obs, rows=None, krj=None, gain=None):
         """sim/map.py:76-172 on the device: one ``mrx_map_sample`` per band, [D, T] pW
-        (``rows = (lo, hi)``: only this shard's detector rows)."""
+        (``rows = (lo, hi)``: only this shard's detector rows).  ``krj`` (``DevicePath.krj_row_tables()``): the field in
+        K_RJ instead, ``gain`` [D] multiplied in, both on the sampler's own store (``mrx_map_sample_krj``: the bits of
+        the pW field times the gain, converted by ``DevicePath.to_krj``, without the two passes over the field)."""
         import torch
 
         from . import map as mmap
@@ -443,6 +445,12 @@ class Simulation:
                           dta=path.dta, t=cache["t"])
             else:
                 kw = dict(cal_scalars=e["scalars"])
+            if krj is not None:  # the calibration's per-row arrays for this band's rows (kept while the tables are the same objects)
+                if e.get("krj_of") is not krj["dx"]:
+                    e["krj_rows"] = {k: krj[k].index_select(0, e["idx_dev"]) for k in ("dx", "dy", "band")}
+                    e["krj_of"] = krj["dx"]
+                kw.update(krj=dict(e["krj_rows"], bore_el=krj["bore_el"], axis=krj["axis"], values=krj["values"]),
+                          scale=None if gain is None else gain.index_select(0, e["idx_dev"]))
             dst = out[int(idx[0]) : int(idx[-1]) + 1] if e["contiguous"] else torch.empty((len(idx), T), dtype=torch.float32, device=device)
             mmap.sample_map(ctx, e["values"], self.map.eta, self.map.xi, self.map.center, cache["az"], cache["el"],
                             e["offsets"], e["stokes"], out=dst, transform=cache["transform"],
@@ -480,6 +488,8 @@ class Simulation:
         """sim/simulation.py:213-272 (followed by ``.to(units)`` of :206), for this process's
         detector rows."""
         import torch
+
+        from . import _lib
 
         obs.loading = {}
         all_dets = obs.instrument.dets
@@ -525,7 +535,19 @@ class Simulation:
             loading = self._compute_atmospheric_loading(
                 obs, gain=gain if has_gain and not loading_nep else None,
                 units="pW" if loading_nep else units, metadata=metadata)
-        map_loading = self._sample_maps(obs, rows) if self.map is not None else None  # pW
+        # The map field: in pW, gain and TOD.to("K_RJ") applied below -- or, in the default units with an atmosphere to
+        # calibrate by and no noise that wants the loadings in pW first, written in K_RJ with the gain by the sampler
+        # itself (mrx_map_sample_krj; not with the literal pointing chain, which that entry refuses)
+        map_loading, map_done = None, False
+        if self.map is not None:
+            if (units == "K_RJ" and has_atm and not loading_nep
+                    and not obs.atmosphere._device_path().ctx.get_option(_lib.OPT_POINTING_CHAIN)):
+                self._set_calibration(obs, metadata)
+                d_gain_rows = torch.as_tensor(gain.astype(np.float32), device=device) if has_gain else None
+                map_loading = self._sample_maps(obs, rows, krj=obs.atmosphere._device_path().krj_row_tables(), gain=d_gain_rows)
+                map_done = True
+            else:
+                map_loading = self._sample_maps(obs, rows)  # pW
         noise = None
         if self.noise:
             total = None
@@ -543,7 +565,7 @@ class Simulation:
             noise = self._simulate_noise(obs, loading=total, rows=rows, krj=noise_krj)
         if has_gain:  # the gain error applies to every field but the noise (simulation.py:243-245)
             d_gain = torch.as_tensor(gain.astype(np.float32), device=device)[:, None]
-            if map_loading is not None:
+            if map_loading is not None and not map_done:
                 map_loading *= d_gain
             if loading is not None and loading_nep:
                 loading *= d_gain
@@ -553,7 +575,7 @@ class Simulation:
             if loading_nep:
                 self._set_calibration(obs, metadata)
                 path.to_krj(loading)
-            if map_loading is not None:  # (the noise was written in K_RJ)
+            if map_loading is not None and not map_done:  # (the noise was written in K_RJ)
                 path.to_krj(map_loading)
         elif units == "K_RJ":
             den = torch.as_tensor(self._band_denominators(all_dets)[lo:hi].astype(np.float32), device=device)[:, None]

@@ -178,6 +178,67 @@ def test_map_sampling_with_atmospheric_transmission(gpu_ctx, pointing_mode):
     assert np.isnan(got2).all()
 
 
+@pytest.mark.parametrize("atm_cal", [True, False], ids=["cal_tables", "cal_scalars"])
+@pytest.mark.parametrize("rate,D,T,el_lo", [(400.0, 37, 3001, 20.0), (20.0, 37, 3001, 20.0), (400.0, 16, 4096, 20.0), (50.0, 5, 1027, 60.0)],
+                         ids=["400Hz", "20Hz_per_sample_branch", "whole_tiles", "off_the_axis"])
+def test_map_field_written_in_krj_equals_sampling_then_tod_to_krj(gpu_ctx, atm_cal, rate, D, T, el_lo):
+    """mrx_map_sample_krj -- the gain and TOD.to("K_RJ") on the sampler's own store -- against mrx_map_sample, a float32
+    multiply by the gain and mrx_tod_to_krj in turn: bit for bit (its header's promise), with and without the sampler's
+    own atmospheric calibration, two bands, ragged rows and samples, a scan slow enough that a thread's four samples are
+    not on a line in elevation (the per-sample branch of the division) and an elevation axis the detectors leave (NaN as
+    jax fills, in the same samples)."""
+    import torch
+
+    from maria_amd import map as mmap
+    from maria_amd import synthetic
+    from maria_amd._lib import ptr
+
+    rng = np.random.default_rng(int(rate) + D + T)
+    t = 1.7e9 + np.arange(T) / rate
+    az, el = synthetic.daisy_scan(t)
+    az, el = az.astype(np.float32), el.astype(np.float32)
+    off = synthetic.hex_pack(max(D, 2), np.radians(0.4))[:D]
+    centre = _centre(az, el, None)
+    eta, xi = np.linspace(0.02, -0.02, 9), np.linspace(-0.02, 0.02, 9)
+    values = _blob_map(2, 1, 9, 9, eta, xi, rng)
+    w = np.ones((D, 1)) * 0.5
+    kw = {}
+    if atm_cal:
+        axis_pwv, axis_el_s = np.linspace(0.0, 6.0, 13), np.radians(np.linspace(20.0, 90.0, 15))
+        tabs = np.stack([(1.5e10 + 4e9 * c) * np.exp(-(0.05 + 0.03 * c + 0.04 * axis_pwv[:, None]) / np.sin(axis_el_s)[None, :]) for c in range(2)])
+        ta = np.arange(t[0], t[-1] + 1.0, 0.5)
+        coarse = 1.2 + 0.3 * np.cumsum(rng.normal(0, 0.05, (D, len(ta))), axis=1)
+        kw = dict(cal_tables=tabs.astype(np.float32), cal_axis_pwv=axis_pwv, cal_axis_el=axis_el_s, coarse_pwv=coarse.T, ta0=ta[0], dta=0.5, t=t)
+    else:
+        kw = dict(cal_scalars=[1.0e10, 1.3e10])
+    dev = "cuda:0"
+    f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(dev)  # noqa: E731
+    # TOD.to("K_RJ")'s tables: an elevation axis with a node at 60 degrees, the middle of the scan (rows straddle it), starting
+    # at el_lo degrees (60: the detectors below the boresight's lowest point are off the axis)
+    n_el, n_bands = 29, 2
+    axis = np.radians(np.linspace(el_lo, 90.0, n_el))
+    den = np.stack([(2.0e-2 + 5e-3 * b) * np.exp(-(0.04 + 0.02 * b) / np.sin(axis)) for b in range(n_bands)])
+    krj = dict(bore_el=f32(el), dx=f32(off[:, 0]), dy=f32(off[:, 1]), band=torch.as_tensor(rng.integers(0, n_bands, D).astype(np.int32)).to(dev),
+               axis=f32(axis), values=f32(den))
+    scale = f32(rng.uniform(0.9, 1.1, D))
+    for sc in (scale, None):
+        ref = mmap.sample_map(gpu_ctx, values, eta, xi, centre, az, el, off, w, **kw)
+        if sc is not None:
+            ref *= sc[:, None]
+        gpu_ctx.call("mrx_tod_to_krj", ptr(ref), ref.stride(0), D, T, None, None, ptr(krj["bore_el"]), ptr(krj["dx"]), ptr(krj["dy"]),
+                     ptr(krj["band"]), ptr(krj["axis"]), ptr(krj["values"]), n_el, n_bands)
+        got = mmap.sample_map(gpu_ctx, values, eta, xi, centre, az, el, off, w, krj=krj, scale=sc, **kw)
+        nan_ref, nan_got = torch.isnan(ref), torch.isnan(got)
+        assert torch.equal(nan_ref, nan_got)
+        assert torch.equal(torch.where(nan_ref, torch.zeros_like(ref), ref), torch.where(nan_got, torch.zeros_like(got), got)), \
+            float((got - ref).abs().nan_to_num().max())
+        assert bool(torch.isfinite(ref).any()) and float(ref[torch.isfinite(ref)].abs().max()) > 0
+        if el_lo > 20.0:
+            assert bool(nan_ref.any()) and not bool(nan_ref.all())  # the case is what it says: some samples off the axis
+        else:
+            assert not bool(nan_ref.any())
+
+
 @pytest.mark.parametrize("frame", ["az/el", "ra/dec"])
 def test_simulation_with_map(gpu_ctx, frame):
     """Simulation(map=...): tod.data["map"] against the oracle chain fed with the same
@@ -238,6 +299,8 @@ def test_simulation_with_map(gpu_ctx, frame):
     (tod2,) = sim2.run()
     factor = tod2.data["atmosphere"].astype(np.float64) / tod.data["atmosphere"]
     np.testing.assert_allclose(tod2.data["map"], got * factor, rtol=3e-6, atol=1e-7 * np.abs(got * factor).max())
+    # ... and written in K_RJ by the sampler itself (mrx_map_sample_krj): the very bits of the pW field converted afterwards
+    np.testing.assert_array_equal(tod2.data["map"], tod.to("K_RJ").data["map"])
 
 
 @pytest.mark.parametrize("shape,chunked,bilinear", [((12, 16), False, 0), ((70, 150), False, 0), ((70, 150), True, 0), ((33, 64), True, 0),
