@@ -39,10 +39,11 @@ struct Axis {
   int n;
   double first, inv_step;
   float lo, hi;  // float32 bounds just beyond the axis (one pixel either side): offsets are clamped into them first
+  double u_last;  // the largest double below n - 1 (axis_cell)
 };
 
 __host__ __device__ inline Axis make_axis(int n, double first, double step) {
-  Axis a{n, first, 1.0 / step, 0.0f, 0.0f};
+  Axis a{n, first, 1.0 / step, 0.0f, 0.0f, (double)(n - 1) * (1.0 - 1.1102230246251565e-16)};
   const double x0 = first - 1.5 * step, x1 = first + ((double)n + 0.5) * step;
   a.lo = (float)(x0 < x1 ? x0 : x1);
   a.hi = (float)(x0 < x1 ? x1 : x0);
@@ -125,6 +126,30 @@ __device__ __forceinline__ void axis_weights(const Axis& a, float x, bool biline
     // np.digitize on the midpoints: the nearest node
     i0 = i1 = min(max((int)floor(u + 0.5), 0), a.n - 1);
     p = 0.0f;
+  }
+}
+
+// The same for the map SAMPLER, as one cell: i0 in [0, n - 2] and the weight p in [0, 1] of node i0 + 1 -- the value
+// (1 - p) v[i0] + p v[i0 + 1] is axis_weights' everywhere: inside the axis the same floor and the same fraction of the
+// same float64 u; at a node p = 0; before the first node (0, p = 0) = v[0]; from the last node on (n - 2, p = 1) =
+// v[n - 1], where axis_weights says (n - 1, n - 1, 0).  What it saves the kernel -- which is bound by its instruction
+// count (173 vector instructions a sample, the SIMDs 85 % busy issuing them) -- is the integer clamps and selects of two
+// indices (u is clamped instead, NaN to the low end by fmax's rule; just below n - 1, so that the floor stays <= n - 2)
+// and, in sample_value, the special case of the last column for its corner pairs: 26 -> 16 issue slots an axis.
+__device__ __forceinline__ void axis_cell(const Axis& a, float x, bool bilinear, int& i0, float& p) {
+  const double u = ((double)x - a.first) * a.inv_step;
+  if (bilinear) {  // workgroup-uniform
+    asm volatile("" ::: "memory");  // keep this a branch (see axis_weights)
+    const double uc = fmin(fmax(u, 0.0), a.u_last);
+    const double fl = floor(uc);
+    i0 = (int)fl;
+    p = (float)(uc - fl);
+  } else {
+    asm volatile("" ::: "memory");
+    // np.digitize on the midpoints: the nearest node, as the cell that holds it with weight 0 or 1
+    const int i = (int)fmin(fmax(floor(u + 0.5), 0.0), (double)(a.n - 1));
+    i0 = min(i, a.n - 2);
+    p = i > a.n - 2 ? 1.0f : 0.0f;
   }
 }
 
@@ -258,24 +283,21 @@ template <bool kCal, int kS>
 __device__ __forceinline__ float sample_value(const MapArgs& g, const CalLds& cl, const Axis& ax_eta, const Axis& ax_xi,
                                               const DetConst& dc, int d, const SampleConst& sc, float ox,
                                               float oy, float el_d, double y0, double y1, const float* fixed_cal = nullptr) {
-  int e0, e1, x0, x1;
+  int e0, x0;
   float pe, px;
-  axis_weights(ax_eta, oy, g.bilinear, e0, e1, pe);
-  axis_weights(ax_xi, ox, g.bilinear, x0, x1, px);
+  axis_cell(ax_eta, oy, g.bilinear, e0, pe);
+  axis_cell(ax_xi, ox, g.bilinear, x0, px);
   // float32 weights and sums (round 3): the reference's float64 sparse product P @ map is rounded to
   // float32 per channel anyway (map.py:155); a float32 evaluation is within 2e-7 of it
   const float qe = 1.0f - pe;
   CalCell cell{};
   if (kCal && !fixed_cal) cell = cal_cell(cl, (float)fma(sc.u, y1 - y0, y0), el_d);  // (pwv demoted to float32 by the jax interpolator)
   const int plane = g.n_eta * g.n_xi;  // < 2^29: checked by the host (byte offsets in 32 bits)
-  // The two corners of a row as ONE 8-byte load (x, x + 1): x is moved to n_xi - 2 when the sample sits in the
-  // last column or beyond (both indices n_xi - 1), where the upper weight 1 selects that column.  Byte offsets
-  // inside a plane as unsigned 32-bit numbers: the loads take the plane's base from scalar registers.
-  const bool at_end = x0 > g.n_xi - 2;
-  const int xa = at_end ? g.n_xi - 2 : x0;
-  const float pxa = at_end ? 1.0f : (x1 > x0 ? px : 0.0f);
-  const float w0a = qe * (1.0f - pxa), w0b = qe * pxa, w1a = pe * (1.0f - pxa), w1b = pe * pxa;
-  const uint32_t o0 = ((uint32_t)(e0 * g.n_xi) + (uint32_t)xa) << 2, o1 = ((uint32_t)(e1 * g.n_xi) + (uint32_t)xa) << 2;
+  // The two corners of a row as ONE 8-byte load (x0, x0 + 1), rows e0 and e0 + 1 (axis_cell: a sample in the last
+  // column or row, or beyond, sits in the last cell with upper weight 1).  Byte offsets inside a plane as unsigned
+  // 32-bit numbers: the loads take the plane's base from scalar registers.
+  const float w0a = qe * (1.0f - px), w0b = qe * px, w1a = pe * (1.0f - px), w1b = pe * px;
+  const uint32_t o0 = ((uint32_t)(e0 * g.n_xi) + (uint32_t)x0) << 2, o1 = o0 + ((uint32_t)g.n_xi << 2);
   typedef __attribute__((address_space(1))) const char gchar;
   typedef float pair4 __attribute__((ext_vector_type(2), aligned(4)));
   typedef __attribute__((address_space(1))) const pair4 gpair;

@@ -692,6 +692,17 @@ class DevicePath:
             return torch.cat(parts, dim=1).T.index_select(0, self._d_inverse)
         return self.d_pwv.T.index_select(0, self._d_inverse)
 
+    def coarse_pwv_time_major(self, rows=None):
+        """[Ta, n] float64, time-major: the zenith-scaled pwv of the caller's rows ``rows`` (a device int64 tensor; None:
+        all of them, in the caller's order) in the layout ``mrx_map_sample`` reads -- one gather along the detector axis of
+        the sampler's own [Ta][D] array (which sits in the path's internal detector order) instead of coarse_pwv()'s
+        transpose, the caller's row selection and a transpose back: four passes over 480 MB at 10 000 x 6 000."""
+        if self.d_pwv is None or self._pwv_stale or (getattr(self, "_pwv_blocked", False) and self._synth_block_rows < self.D):
+            full = self.coarse_pwv()  # (samples if need be; puts the one launch's detector blocks together)
+            return (full if rows is None else full.index_select(0, rows)).T.contiguous()
+        cols = self._d_inverse if rows is None else self._d_inverse.index_select(0, rows)
+        return self.d_pwv.view(self.Ta, self.D).index_select(1, cols)
+
     def run(self, out=None, blocks=None, writer_events=None, krj=False):
         """The whole path for this shard; returns the [D, T] float32 TOD tensor.  The
         stages carry the reference's progress-bar names as profiler ranges (roctx via
@@ -764,7 +775,10 @@ class DevicePath:
         self.ctx.set_stream(main)
         self.wait_screens(main)
         if block_rows is None:
-            block_rows = 0
+            # the library's choice -- but a pwv that is kept (the map mixin reads it) in ONE block where the launch allows:
+            # d_pwv is then the plain [Ta][D] array its reader wants (coarse_pwv_time_major), and taking the blocks apart
+            # again costs more (four passes over the array, ~1 ms at 10 000 x 6 000) than blocks gain the launch (3-7 %)
+            block_rows = (self.D + 255) // 256 * 256 if self.keep_pwv else 0
         if writer_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
             ev[0].record(main)

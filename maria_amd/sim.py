@@ -440,7 +440,7 @@ class Simulation:
             # rows are written in place; scattered ones into a buffer of their own, copied to their rows below
             idx = e["idx"]
             if atm is not None:
-                pwv = path.coarse_pwv()[e["idx_dev"]].T.contiguous()  # [Ta, D_band]
+                pwv = path.coarse_pwv_time_major(e["idx_dev"])  # [Ta, D_band]
                 kw = dict(cal_tables=e["tab"], cal_axis_pwv=e["ap"], cal_axis_el=e["ae"], coarse_pwv=pwv, ta0=path.ta0,
                           dta=path.dta, t=cache["t"])
             else:

@@ -139,17 +139,28 @@ def test_coarse_pwv_is_the_launchs_second_output(gpu_ctx):
     pwv = path.coarse_pwv().clone()
     torch.cuda.synchronize()
     assert bool(torch.isfinite(pwv).all()) and float(pwv.std()) > 0
-    for block_rows in (0, 256, 512):
+    # ... and as the map sampler reads it: time-major, the caller's rows of one band (coarse_pwv_time_major: one gather
+    # from the launch's own array where that is one block, the blocks put together otherwise)
+    rows = torch.as_tensor(np.random.default_rng(3).permutation(path.D)[:700], device=pwv.device)
+
+    def time_major_ok():
+        return (torch.equal(path.coarse_pwv_time_major(rows), pwv.index_select(0, rows).T)
+                and torch.equal(path.coarse_pwv_time_major(), pwv.T))
+
+    assert time_major_ok()
+    for block_rows in (None, 0, 256, 512):
         path.d_pwv.fill_(float("nan"))
         got = path.synthesize(block_rows=block_rows)
         torch.cuda.synchronize()
         assert torch.equal(got, want)
         assert torch.equal(path.coarse_pwv(), pwv), block_rows
+        assert time_major_ok(), block_rows
+        assert (path._synth_block_rows >= path.D) == (block_rows in (None, 0))  # (kept pwv, library's choice: one block)
     path.d_pwv.fill_(float("nan"))
     assert torch.equal(path.run(), want) and path._synthesized
-    assert torch.equal(path.coarse_pwv(), pwv)
+    assert torch.equal(path.coarse_pwv(), pwv) and time_major_ok()
     path.sample()  # and the two-call form's own layout again afterwards
-    assert torch.equal(path.coarse_pwv(), pwv)
+    assert torch.equal(path.coarse_pwv(), pwv) and time_major_ok()
 
 
 def test_flags_travel_and_unsupported_plans_are_refused(gpu_ctx):
