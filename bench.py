@@ -91,6 +91,9 @@ def parse_args(argv=None):
                     "beside this step's last writers; the timer brackets all K steps behind a sync either way).  Measured in round 4: "
                     "2.38 against 2.34 ms (atlast_10k), 11.8 against 11.5 (atlast_50k) -- the sampler chain beside the writers becomes the "
                     "critical path -- so the default stays one step after the other")
+    ap.add_argument("--shard-of", type=int, default=0,
+                    help="development, N = 1 only: run alone on this GPU the rows rank 0 of a run on this many GPUs would take "
+                         "(the per-rank step of an N-GPU run, rehearsed on one; the line says so in config.workload)")
     ap.add_argument("--print-launch", action="store_true", help="print the child launch command of --gpus N as JSON and exit (no GPU needed)")
     return ap.parse_args(argv)
 
@@ -387,6 +390,10 @@ def run(args):
         n_total = n_config if (scaling == "strong" or world == 1) else n_config * world
     problem = synthetic.config_problem(args.config, n_det=n_total)
     lo, hi = shard_bounds(n_total, world, rank)
+    if args.shard_of > 1:
+        if world != 1:
+            raise SystemExit("--shard-of rehearses one rank's rows on one GPU: use it with --gpus 1")
+        lo, hi = shard_bounds(n_total, args.shard_of, 0)
     path = DevicePath(problem, device=device, det_slice=slice(lo, hi))
     D, T, Ta = path.D, path.T, path.Ta
     L = len(problem["layers"])
@@ -577,7 +584,8 @@ def run(args):
         "config": {
             "workload": f"{args.config}: {n_step} det x {T} samples ({problem['fs']:.0f} Hz), Ta={Ta}, "
             f"{L} layers of {len(problem['layers'][0]['extrusion'])}^2 screens, "
-            f"{len(problem['tables'])} band(s), in total over {world} GPU(s)",
+            f"{len(problem['tables'])} band(s), in total over {world} GPU(s)"
+            + (f" -- the rows of rank 0 of a {args.shard_of}-GPU run of {n_total} detectors, run ALONE on one GPU (--shard-of)" if args.shard_of > 1 else ""),
             "n_det_total": n_step,
             "n_det_per_gpu": D,
             "n_samples": T,
