@@ -107,8 +107,13 @@ struct SynthHooks {
   }
 };
 
+// Waves per SIMD the launch is compiled for (= its resident workgroups per CU, LDS permitting): the fused writer's 5, i.e. a
+// budget of 96 registers, which this kernel -- sampler and writer in one -- exceeds by 25-48 (spilled: DESIGN 3.0).
+#ifndef MRX_SYNTH_WAVES
+#define MRX_SYNTH_WAVES MRX_WRITER_WAVES
+#endif
 template <bool kLdsTables, bool kHasScale, int kMaxKnots, int kG, bool kKrj>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_WRITER_WAVES, MRX_WRITER_WAVES))) void atm_tod_kernel(
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_SYNTH_WAVES, MRX_SYNTH_WAVES))) void atm_tod_kernel(
     const mrx_layer_fast* __restrict__ fast, const mrx_layer_px* __restrict__ lpx, int n_layers,
     const double2* __restrict__ offpx, const mrx_table_dev* __restrict__ tables, int n_tables,
     const float* __restrict__ table_data, int table_floats, const float* __restrict__ az,
@@ -349,7 +354,7 @@ static int atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d
     // of the chip without an item while the first chunks are sampled (2 512 rows: 0.54 ms at 16 steps, 0.58 at 32;
     // 1 264 rows: 0.32 against 0.37)
     chunk = 32;
-    while (chunk > 8 && (long long)mrx_ceil_div(Ta, chunk) * mrx_ceil_div(D, kBlock) < 5LL * MRX_WRITER_WAVES * n_cu / 2) chunk /= 2;
+    while (chunk > 8 && (long long)mrx_ceil_div(Ta, chunk) * mrx_ceil_div(D, kBlock) < 5LL * MRX_SYNTH_WAVES * n_cu / 2) chunk /= 2;
   }
   chunk = chunk < 1 ? 1 : chunk > mrx_px::kMaxChunk ? mrx_px::kMaxChunk : chunk;
   while (chunk > 1 && chunk * plan->n_layers > mrx_px::kMaxAnchors) chunk /= 2;
@@ -373,7 +378,7 @@ static int atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d
   const size_t lds = lds_w;
   // ---- the grid: as many workgroups as a CU holds, all resident, each taking tiles and items until both queues are
   // empty; the first `dedicated` only sample while items remain (MRX_OPT_SAMPLE_WGS_PER_CU per CU, or the caller's number)
-  long long per_cu = std::max<long long>(1, std::min<long long>(MRX_WRITER_WAVES, (long long)(ctx->lds_per_cu > 0 ? ctx->lds_per_cu : 160 * 1024) / (long long)(lds + 1600)));
+  long long per_cu = std::max<long long>(1, std::min<long long>(MRX_SYNTH_WAVES, (long long)(ctx->lds_per_cu > 0 ? ctx->lds_per_cu : 160 * 1024) / (long long)(lds + 1600)));
   if (ctx->options[MRX_OPT_SYNTH_WGS_PER_CU] > 0) per_cu = std::min<long long>(per_cu, ctx->options[MRX_OPT_SYNTH_WGS_PER_CU]);
   const long long wgs = std::min(n_tiles + n_items, per_cu * n_cu);
   long long dedicated = sampler_wgs;
