@@ -1180,9 +1180,12 @@ static int map_sample(mrx_ctx* ctx, const mrx_sky_map* map, const mrx_map_cal* c
   g.out = d_out;
   g.ld = ld_out;
   g.vec_ok = (ld_out % 4 == 0) && ((reinterpret_cast<uintptr_t>(d_out) & 15u) == 0);
-  // detector tiles per workgroup (they share the per-sample constants): 4 while that leaves >= 16
+  // detector tiles per workgroup (they share the per-sample constants): MRX_MAP_GROUPS while that leaves >= 16
   // workgroups per CU in the grid
-  int groups = 4;
+#ifndef MRX_MAP_GROUPS
+#define MRX_MAP_GROUPS 4
+#endif
+  int groups = MRX_MAP_GROUPS;
   while (groups > 1 && (long long)mrx_ceil_div(T, kTileSamples) * mrx_ceil_div(D, kTileDet * groups) < 16LL * 256) groups /= 2;
   dim3 grid(mrx_ceil_div(T, kTileSamples), mrx_ceil_div(D, kTileDet * groups));
   MRX_REQUIRE(ctx, grid.y <= 65535u, "D too large for one launch");
