@@ -753,7 +753,13 @@ class DevicePath:
         """Does run() take the one-launch form by default?  Wherever the library's form applies (every layer on a
         uniform axis, the default cell rule and pointing, linear tables: the call itself says so) from 1024 rows (640 rows:
         0.22 ms against 0.21 for the stages back to back; 1 264: 0.32 against 0.34; 2 512: 0.54 against 0.65; 10 000: 2.0
-        against 2.3).  ``keep_pwv`` rides along: the sampler's float64 pwv is the launch's optional second output."""
+        against 2.3).  ``keep_pwv`` rides along: the sampler's float64 pwv is the launch's optional second output.
+
+        The two-call forms stay selectable (same bits, the stages back to back or pipelined on two streams): set
+        ``path.one_launch = False``, or MARIA_AMD_ONE_LAUNCH=0 in the environment for every path of the process
+        (``Simulation`` included) -- the fallback for a device on which the launch's hand-over raises MRX_FLAG_HANDOVER."""
+        if not getattr(self, "one_launch", True) or os.environ.get("MARIA_AMD_ONE_LAUNCH", "1") == "0":
+            return False
         return self.D >= 1024 and not getattr(self, "_synth_unsupported", False)
 
     def synthesize(self, out=None, block_rows=None, sampler_wgs_per_cu=None, chunk=None, writer_events=None, krj=False, sampler_wgs=0):

@@ -163,6 +163,30 @@ def test_coarse_pwv_is_the_launchs_second_output(gpu_ctx):
     assert torch.equal(path.coarse_pwv(), pwv) and time_major_ok()
 
 
+def test_the_two_call_forms_stay_selectable(gpu_ctx, monkeypatch):
+    """``path.one_launch = False`` and MARIA_AMD_ONE_LAUNCH=0 send run() through the two-call forms (the fallback for a
+    device whose hand-over raises MRX_FLAG_HANDOVER): the same TOD, and run() says which form it took."""
+    import torch
+
+    p = small_problem(n_det=1100, n_layers=3, n_bands=2, gain=True)
+    path = _path(p, gpu_ctx)
+    assert path.synthesize_applies()
+    want = path.run().clone()
+    assert path._synthesized
+    path.one_launch = False
+    assert not path.synthesize_applies()
+    got = path.run()
+    assert not path._synthesized and torch.equal(got, want)
+    path.one_launch = True
+    monkeypatch.setenv("MARIA_AMD_ONE_LAUNCH", "0")
+    assert not path.synthesize_applies()
+    got = path.run()
+    assert not path._synthesized and torch.equal(got, want)
+    monkeypatch.delenv("MARIA_AMD_ONE_LAUNCH")
+    assert path.synthesize_applies() and torch.equal(path.run(), want) and path._synthesized
+    assert path.check_flags() == 0
+
+
 def test_flags_travel_and_unsupported_plans_are_refused(gpu_ctx):
     """A line of sight off its screen is flagged as by mrx_atm_sample (atmosphere.py:368-369); the literal cell
     rule, the float32 pointing chain and non-uniform axes are the two-call form's: MRX_ERR_UNSUPPORTED, nothing
