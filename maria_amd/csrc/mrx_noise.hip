@@ -889,23 +889,36 @@ __global__ __launch_bounds__(kBlock) void noise_two_rate_kernel(const mrx_two_ra
   constexpr float kW14[4] = {-0.0703125f, 0.8671875f, 0.2265625f, -0.0234375f};
   constexpr float kW12[4] = {-0.0625f, 0.5625f, 0.5625f, -0.0625f};
   constexpr float kW34[4] = {-0.0234375f, 0.2265625f, 0.8671875f, -0.0703125f};
+  // The rows one after the other, the NEXT row's slow samples (and its scale) fetched while this row is computed: the loop
+  // does not unroll (the compiler says so, six instances out of six), and with the load at the top of every iteration a wave
+  // sat out a memory latency per row -- its waves waited three quarters of their cycles while the white-only path, the same
+  // draws and stores without the load, keeps the vector ALU busy (profiles/r05_noise_mix.txt).
+  const int slow_at = a.rate == 4 ? (sb >> 2) : (sb >> 1);
+  auto fetch_slow = [&](int dl, nvfloat4u& q, float& q4, float& sc) {
+    const float* lo = a.lo + (size_t)(r0 + dl) * a.ld_lo;
+    q = *reinterpret_cast<const nvfloat4u*>(lo + slow_at);
+    q4 = a.rate == 4 ? 0.0f : lo[slow_at + 4];
+    sc = a.scale ? a.scale[a.row0 + r0 + dl] : 1.0f;
+  };
   auto rows_loop = [&](auto curved) {
-#pragma unroll 2
+    nvfloat4u q_next;
+    float q4_next, sc_next;
+    fetch_slow(0, q_next, q4_next, sc_next);
     for (int dl = 0; dl < nd; ++dl) {
       const int row = a.row0 + r0 + dl;  // row of the call
       // the slow part: samples t' - 1 .. t' + 2 (.. t' + 3 at rate 2) around the thread's interval(s), stored one to the right
-      const float* lo = a.lo + (size_t)(r0 + dl) * a.ld_lo;
+      const nvfloat4u q = q_next;
+      const float q4 = q4_next, sc = sc_next;
+      if (dl + 1 < nd) fetch_slow(dl + 1, q_next, q4_next, sc_next);  // (uniform)
       float p[kSamplesPerThread];
       if (a.rate == 4) {
-        const nvfloat4u q = *reinterpret_cast<const nvfloat4u*>(lo + (sb >> 2));
         const float p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3];
         p[0] = p1;
         p[1] = kW14[0] * p0 + kW14[1] * p1 + kW14[2] * p2 + kW14[3] * p3;
         p[2] = kW12[0] * p0 + kW12[1] * p1 + kW12[2] * p2 + kW12[3] * p3;
         p[3] = kW34[0] * p0 + kW34[1] * p1 + kW34[2] * p2 + kW34[3] * p3;
       } else {
-        const nvfloat4u q = *reinterpret_cast<const nvfloat4u*>(lo + (sb >> 1));
-        const float p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3], p4 = lo[(sb >> 1) + 4];
+        const float p0 = q[0], p1 = q[1], p2 = q[2], p3 = q[3], p4 = q4;
         p[0] = p1;
         p[1] = kW12[0] * p0 + kW12[1] * p1 + kW12[2] * p2 + kW12[3] * p3;
         p[2] = p2;
@@ -921,7 +934,6 @@ __global__ __launch_bounds__(kBlock) void noise_two_rate_kernel(const mrx_two_ra
 #pragma unroll
         for (int q = 0; q < kSamplesPerThread; ++q) v[q] = fmaf(cm, mw[m][q], v[q]);
       }
-      const float sc = a.scale ? a.scale[row] : 1.0f;
       float sv[kSamplesPerThread];
       if (a.loading) {  // total NEP of a sample: NEP + NEP_per_loading x loading (sim/noise.py:35-37)
         const float* L = a.loading + (size_t)row * a.ld_loading + sb;
