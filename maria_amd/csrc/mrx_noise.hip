@@ -608,8 +608,11 @@ __global__ __launch_bounds__(kBlock) void noise_fft_combine(
 // pass 2 when n1 == 64 (every period up to 2^19 samples): one thread per j, the
 // 64-point transform over k1 in registers -- no LDS, no barrier.  Lane l of a wave
 // holds samples t = j0 + l + n2 m, so each (m, row) is one 256-byte store per wave.
+#ifndef MRX_FFT64_WAVES
+#define MRX_FFT64_WAVES 2  // waves per SIMD of the 64-point register pass: 256 registers for the 64 complex values and the transform's temporaries
+#endif
 template <bool kExtras>
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 2))) void noise_fft64_combine(
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_FFT64_WAVES, MRX_FFT64_WAVES))) void noise_fft64_combine(
     const float2* __restrict__ A, int n2, CombineArgs g, uint32_t key0, uint32_t key1) {
   const int j = blockIdx.x * kBlock + threadIdx.x;
   if (j >= n2 || j >= g.T) return;
