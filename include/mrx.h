@@ -622,7 +622,10 @@ typedef struct mrx_map_cal {
   const float* d_axis_el;  /* [n_el] */
   int n_pwv, n_el;
   const double* d_pwv;     /* [Ta][D] coarse zenith-scaled pwv, time-major */
-  int Ta, reserved;
+  int Ta;
+  int steps_per_tile;      /* the most coarse steps of the pwv series that 1024 consecutive samples meet (ceil(1025 dt / dta) + 1), or 0 if the
+                            * caller does not know: sizes the LDS table of the calibration's interval form (a tile that meets more
+                            * takes the per-sample form: correct, slower) */
   double ta0, dta;         /* first coarse time and coarse step (s) */
   const double* d_t;       /* [T] full-rate sample times */
   const double* d_scalar;  /* [n_channels] Int passband dnu (device), used when d_table is NULL */

@@ -142,7 +142,7 @@ class MrxMapCal(C.Structure):
         ("n_el", C.c_int32),
         ("d_pwv", C.c_void_p),
         ("Ta", C.c_int32),
-        ("reserved", C.c_int32),
+        ("steps_per_tile", C.c_int32),
         ("ta0", C.c_double),
         ("dta", C.c_double),
         ("d_t", C.c_void_p),

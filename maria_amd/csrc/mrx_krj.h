@@ -41,6 +41,13 @@ struct CalDet {
   // zenith, where the detector elevation is not smooth in eb: every sample takes the full formula.
   float dm, slope, ebm;
   int exact;
+  // lin = 1: over the tile's whole boresight range the row stays inside ONE cell of the table's elevation axis (a cell
+  // is a few degrees, a tile's 1 024 samples sweep a degree or so) and on the axis, and the model above holds -- so
+  // den is ONE linear function of x = el_bore - ebm for every sample of the row in this tile: den = lin_a + lin_b x
+  // (set_linear_den; krj_row then needs neither the cell nor its checks per thread: the division cost ~21 vector
+  // instructions a sample wherever it rode on another kernel's store)
+  float lin_a, lin_b;
+  int lin;
 };
 
 // detector elevation (transforms.py:20-28): im = sin(el) as the chain computes
@@ -92,6 +99,33 @@ __device__ __forceinline__ void set_elevation_model(CalDet& c, float ebm) {
   c.dm = e[1];
   c.slope = (e[2] - e[0]) * (0.5f / h);
   c.exact = steep ? 1 : 0;
+}
+
+// The row's den as one linear function of x = el_bore - ebm over the tile (CalDet::lin).  [lo, hi]: the tile's boresight
+// elevation range (krj_prologue: red[8], red[9]); C: the band's cells.  den_lookup's value at the model's elevation
+// e(x) = (ebm + dm) + (1 + slope) x inside cell i: y_i + (y_{i+1} - y_i) z_i (e - x_i), expanded in x -- it differs from
+// den_lookup's own float32 evaluation by a rounding or two of den (1e-7), alike in every kernel that includes this header.
+__device__ __forceinline__ void set_linear_den(CalDet& c, float lo, float hi, const float4* C, int n_el, float el_first,
+                                               float el_inv) {
+  MRX_KRJ_FP
+  c.lin = 0;
+  c.lin_a = 0.0f;
+  c.lin_b = 0.0f;
+  if (c.exact) return;
+  const float e_lo = fmaf(c.slope, lo - c.ebm, lo + c.dm), e_hi = fmaf(c.slope, hi - c.ebm, hi + c.dm);
+  const float e0 = fminf(e_lo, e_hi), e1 = fmaxf(e_lo, e_hi);
+  const int i0 = min(max((int)fminf(fmaxf((e0 - el_first) * el_inv, -1.0f), 2.0e9f), 0), n_el - 2);
+  const float4 cell = C[i0];
+  const float w0 = (e0 - cell.x) * cell.z, w1 = (e1 - cell.x) * cell.z;
+  // both ends inside the cell with a margin of 1e-4 of its width (the threads' own elevations are rounded separately;
+  // den is continuous at a node anyway) -- hence on the axis; a guess that missed the cell (non-uniform axis) or a NaN
+  // anywhere: not linear, and the row takes the general form below
+  const bool inside = w0 >= 1.0e-4f && w1 <= 1.0f - 1.0e-4f;
+  if (!inside) return;
+  const float g = (cell.w - cell.y) * cell.z;  // d den / d el in the cell
+  c.lin_a = fmaf(g, (c.ebm + c.dm) - cell.x, cell.y);
+  c.lin_b = g * (1.0f + c.slope);
+  c.lin = 1;
 }
 
 __device__ __forceinline__ CalDet make_cal_det(float dx, float dy, int band, float scale) {
@@ -187,6 +221,22 @@ __device__ __forceinline__ void krj_row(const CalDet& c, const float4* C, int n_
       o[1] = q == 1 ? val : o[1];
       o[2] = q == 2 ? val : o[2];
       o[3] = q == 3 ? val : o[3];
+    }
+    return;
+  }
+  if (__builtin_amdgcn_readfirstlane(c.lin) != 0) {  // (a scalar branch: the row is the workgroup's)
+    // the usual row: den is one linear function of the boresight elevation over the whole tile (CalDet::lin) -- its value at
+    // the thread's first and last sample, two reciprocals, and the inner two samples on the chord between them
+    const float d0 = fmaf(c.lin_b, k.x0, c.lin_a), d3 = fmaf(c.lin_b, k.x3, c.lin_a);
+    if (kInverse) {
+      const float step = (d3 - d0) * (1.0f / (float)kL);
+#pragma unroll
+      for (int q = 0; q < kSamplesPerThread; ++q) o[q] = sv[q] * (q == 0 ? d0 : q == kL ? d3 : fmaf((float)q, step, d0));
+    } else {
+      const float r0 = __builtin_amdgcn_rcpf(d0), r3 = __builtin_amdgcn_rcpf(d3);
+      const float step = (r3 - r0) * (1.0f / (float)kL);
+#pragma unroll
+      for (int q = 0; q < kSamplesPerThread; ++q) o[q] = sv[q] * (q == 0 ? r0 : q == kL ? r3 : fmaf((float)q, step, r0));
     }
     return;
   }
@@ -286,7 +336,8 @@ __device__ __forceinline__ KrjSamples krj_prologue(float4* cells, float* red, co
 // of the LAST entry's neighbour slot red[10] is set when any row needs the full formula.
 __device__ __forceinline__ void krj_stage_rows(CalDet* cdet, float* red, const float* __restrict__ dxs,
                                                const float* __restrict__ dys, const int32_t* __restrict__ band,
-                                               const float* __restrict__ scale, int n_bands, int d0, int nd) {
+                                               const float* __restrict__ scale, int n_bands, int d0, int nd,
+                                               const float4* cells, int n_el) {
   MRX_KRJ_FP
   if ((int)threadIdx.x < kTileDet) {
     const float lo = red[8], hi = red[9];
@@ -298,6 +349,7 @@ __device__ __forceinline__ void krj_stage_rows(CalDet* cdet, float* red, const f
       // the model is a finite difference over ebm +- 0.02 rad: a tile whose boresight sweeps
       // farther (slow sample rates, fast elevation slews) takes the full formula per sample
       if (!(hi - lo <= 2.0f * kModelHalfRange)) c.exact = 1;
+      set_linear_den(c, lo, hi, cells + c.band * (n_el - 1), n_el, cells[0].x, cells[0].z);
       cdet[threadIdx.x] = c;
       exact = c.exact != 0;
     }

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
         tile[dl * kPitch + rr] = v;
       }
     }
-    krj_stage_rows(cdet, red, dxs, dys, band, scale, n_bands, d0, nd);
+    krj_stage_rows(cdet, red, dxs, dys, band, scale, n_bands, d0, nd, cal_cells, n_el);
     if (rows && (int)threadIdx.x < nd) row_lds[threadIdx.x] = rows[d0 + threadIdx.x];
     __syncthreads();
     // the loop body is instantiated once per knot source so that each instance
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(kBlock) void tod_krj_kernel(
   const int nd = min(kTileDet, D - d0);
   __shared__ int row_lds[kTileDet];
   KrjSamples ks = krj_prologue(cal_cells, red, bore_el, T, sb, cal_axis, cal_values, n_el, n_bands);
-  krj_stage_rows(cdet, red, dxs, dys, band, scale, n_bands, d0, nd);
+  krj_stage_rows(cdet, red, dxs, dys, band, scale, n_bands, d0, nd, cal_cells, n_el);
   if ((int)threadIdx.x < nd) row_lds[threadIdx.x] = rows ? rows[d0 + threadIdx.x] : d0 + (int)threadIdx.x;
   __syncthreads();
   if (sb >= T) return;

@@ -21,6 +21,7 @@
 // available through MRX_OPT_POINTING_CHAIN and agrees to float32 rounding of the angles).
 // Bound by arithmetic (float64 weights and sums, as the reference's sparse product), not
 // by memory.
+#include <cmath>
 #include <type_traits>
 
 #include "mrx_internal.h"
@@ -39,14 +40,31 @@ struct Axis {
   int n;
   double first, inv_step;
   float lo, hi;  // float32 bounds just beyond the axis (one pixel either side): offsets are clamped into them first
-  double u_last;  // the largest double below n - 1 (axis_cell)
+  double u_last;  // the largest double below n - 1 (axis_cell, nearest pixel)
+  // The sampler's bilinear cell in float32 (axis_cell): u = x inv + c with inv = inv_hi + inv_lo (float32 head and tail of
+  // 1 / step) and c = -first / step = c_int + c_frac (an integer and a fraction in [0, 1), both exact float32 numbers or
+  // rounded at 6e-8).  x_min / x_max: the float32 numbers just inside the axis' ends; k_lo / k_hi: the cells 0 and n - 2
+  // counted from c_int.
+  float inv_hi, inv_lo, c_int, c_frac, x_min, x_max, k_lo, k_hi;
 };
 
-__host__ __device__ inline Axis make_axis(int n, double first, double step) {
+inline Axis make_axis(int n, double first, double step) {  // (host)
   Axis a{n, first, 1.0 / step, 0.0f, 0.0f, (double)(n - 1) * (1.0 - 1.1102230246251565e-16)};
   const double x0 = first - 1.5 * step, x1 = first + ((double)n + 0.5) * step;
   a.lo = (float)(x0 < x1 ? x0 : x1);
   a.hi = (float)(x0 < x1 ? x1 : x0);
+  a.inv_hi = (float)a.inv_step;
+  a.inv_lo = (float)(a.inv_step - (double)a.inv_hi);
+  const double c = -first * a.inv_step, ci = std::floor(c);
+  a.c_int = (float)ci;  // (|c| < 2^24: a map axis has fewer than 2^24 nodes, and the host refuses centres farther off)
+  a.c_frac = (float)(c - ci);
+  const double last = first + (double)(n - 1) * step, e0 = first < last ? first : last, e1 = first < last ? last : first;
+  a.x_min = (float)e0;
+  a.x_max = (float)e1;
+  if ((double)a.x_min < e0) a.x_min = std::nextafterf(a.x_min, INFINITY);
+  if ((double)a.x_max > e1) a.x_max = std::nextafterf(a.x_max, -INFINITY);
+  a.k_lo = -a.c_int;
+  a.k_hi = (float)(n - 2) - a.c_int;
   return a;
 }
 
@@ -79,6 +97,9 @@ struct MapArgs {
   float* out;
   size_t ld;
   int vec_ok;
+  uint32_t map_bytes;  // of all planes (below 4 GiB): the sampler's raw buffer
+  int coef_offset;     // of the calibration's interval table in the dynamic LDS, in floats; < 0: none (more than kCalFastChannels channels)
+  int coef_cap;        // coarse steps per row the table holds
 };
 
 // TOD.to("K_RJ") on the sampler's store (mrx_map_sample_krj): the arguments of mrx_tod_to_krj for the rows of this call
@@ -136,20 +157,37 @@ __device__ __forceinline__ void axis_weights(const Axis& a, float x, bool biline
 // count (173 vector instructions a sample, the SIMDs 85 % busy issuing them) -- is the integer clamps and selects of two
 // indices (u is clamped instead, NaN to the low end by fmax's rule; just below n - 1, so that the floor stays <= n - 2)
 // and, in sample_value, the special case of the last column for its corner pairs: 26 -> 16 issue slots an axis.
-__device__ __forceinline__ void axis_cell(const Axis& a, float x, bool bilinear, int& i0, float& p) {
-  const double u = ((double)x - a.first) * a.inv_step;
-  if (bilinear) {  // workgroup-uniform
-    asm volatile("" ::: "memory");  // keep this a branch (see axis_weights)
-    const double uc = fmin(fmax(u, 0.0), a.u_last);
-    const double fl = floor(uc);
-    i0 = (int)fl;
-    p = (float)(uc - fl);
+template <bool kBil>
+__device__ __forceinline__ void axis_cell_t(const Axis& a, float x, int& i0, float& p) {
+  if (kBil) {
+    // Round 6: float32, no float64 (nine of the axis' eleven instructions were float64, at half rate or less).  With
+    // u = x inv + c split as in Axis: p0 = x inv_hi + c_frac is u - c_int to float32 rounding (3e-5 pixel at pixel 500: good
+    // enough to name the cell, not the weight); k = floor(p0) kept inside the axis; then the weight as
+    // (x inv_hi - k) + (x inv_lo + c_frac): the first bracket is ONE fused multiply-add whose exact value is below one
+    // pixel, so it rounds at 6e-8 of a pixel -- the float64 form's fraction to float32 rounding.  A p0 within rounding of
+    // an integer may name the neighbouring cell: the weight then comes out just below 0 or just above 1, which is the same
+    // interpolated value to 1e-7 of the corner difference.  The offset is first clamped INTO the axis (a NaN goes to the
+    // low end by med3's rule): before the first node (cell 0, p = 0), from the last node on (cell n - 2, p = 1).
+    const float xc = __builtin_amdgcn_fmed3f(x, a.x_min, a.x_max);
+    const float k = __builtin_amdgcn_fmed3f(floorf(fmaf(xc, a.inv_hi, a.c_frac)), a.k_lo, a.k_hi);
+    p = fmaf(xc, a.inv_hi, -k) + fmaf(xc, a.inv_lo, a.c_frac);
+    i0 = (int)(k + a.c_int);
   } else {
-    asm volatile("" ::: "memory");
     // np.digitize on the midpoints: the nearest node, as the cell that holds it with weight 0 or 1
+    const double u = ((double)x - a.first) * a.inv_step;
     const int i = (int)fmin(fmax(floor(u + 0.5), 0.0), (double)(a.n - 1));
     i0 = min(i, a.n - 2);
     p = i > a.n - 2 ? 1.0f : 0.0f;
+  }
+}
+
+__device__ __forceinline__ void axis_cell(const Axis& a, float x, bool bilinear, int& i0, float& p) {
+  if (bilinear) {  // workgroup-uniform
+    asm volatile("" ::: "memory");  // keep this a branch (see axis_weights)
+    axis_cell_t<true>(a, x, i0, p);
+  } else {
+    asm volatile("" ::: "memory");
+    axis_cell_t<false>(a, x, i0, p);
   }
 }
 
@@ -245,6 +283,7 @@ __device__ __forceinline__ void sample_const(const MapArgs& g, int s, bool chain
 struct CalLds {
   RgiAxis pwv, el;   // axes (nodes in LDS)
   const float* tab;  // [C][n_pwv][n_el] (LDS)
+  const float* chan; // without the tables: [C] pW per K_RJ of a channel, 1e12 k_B x the caller's scalar, float32 (LDS)
 };
 
 // the cell of the calibration tables a (zenith pwv, elevation) pair falls in, with jax's index rule and weights
@@ -276,7 +315,12 @@ __device__ __forceinline__ float cal_factor(const MapArgs& g, const CalLds& cl, 
   return __fmul_rn(1.380649e-11f, v);
 }
 
-constexpr int kCalFastChannels = 4;  // channels whose factors a thread keeps in registers (the stretch form below)
+constexpr int kCalFastChannels = 4;  // channels whose factors the interval form below tabulates
+// The interval form of the per-sample calibration (round 6): per row and coarse step of the pwv series that the tile
+// meets, the factor along the step as a parabola in the step's own coordinate (three floats), in LDS as
+// [channel][row][steps][3] (row pitch 3 * cap + 1 floats).  kMaxSteps: the most steps a tile may meet for the form to
+// apply (the knots' boresight table is sized for it); the launcher sizes the coefficients by mrx_map_cal.steps_per_tile.
+constexpr int kMaxSteps = 64, kDefaultSteps = 33;
 
 // kCal with fixed_cal != nullptr: the per-channel factors of this sample are given (interpolated by the caller)
 template <bool kCal, int kS>
@@ -294,31 +338,38 @@ __device__ __forceinline__ float sample_value(const MapArgs& g, const CalLds& cl
   if (kCal && !fixed_cal) cell = cal_cell(cl, (float)fma(sc.u, y1 - y0, y0), el_d);  // (pwv demoted to float32 by the jax interpolator)
   const int plane = g.n_eta * g.n_xi;  // < 2^29: checked by the host (byte offsets in 32 bits)
   // The two corners of a row as ONE 8-byte load (x0, x0 + 1), rows e0 and e0 + 1 (axis_cell: a sample in the last
-  // column or row, or beyond, sits in the last cell with upper weight 1).  Byte offsets inside a plane as unsigned
-  // 32-bit numbers: the loads take the plane's base from scalar registers.
+  // column or row, or beyond, sits in the last cell with upper weight 1).  Round 6: BUFFER loads -- a plane is a raw
+  // buffer whose descriptor lives in scalar registers, the cell's byte offset (one 24-bit multiply-add and a shift)
+  // is the only vector operand and the second row is the same offset with the row pitch as the scalar offset: the
+  // plain loads added the plane's base to a 64-bit vector address twice per plane and sample.
   const float w0a = qe * (1.0f - px), w0b = qe * px, w1a = pe * (1.0f - px), w1b = pe * px;
-  const uint32_t o0 = ((uint32_t)(e0 * g.n_xi) + (uint32_t)x0) << 2, o1 = o0 + ((uint32_t)g.n_xi << 2);
-  typedef __attribute__((address_space(1))) const char gchar;
-  typedef float pair4 __attribute__((ext_vector_type(2), aligned(4)));
-  typedef __attribute__((address_space(1))) const pair4 gpair;
-  gchar* m = (gchar*)g.values;
+  const int o0 = (int)(__umul24((unsigned)e0, (unsigned)g.n_xi) + (unsigned)x0) << 2;  // (e0 < n_eta, n_xi < 2^24)
+  const int pitch4 = g.n_xi << 2;
+  typedef float pair4 __attribute__((ext_vector_type(2)));
+  // ONE descriptor for the whole map (four scalar registers for the kernel's life; a descriptor per plane had the
+  // compiler keep them all and spill scalars by the hundred), the plane as the load's scalar offset: the host refuses
+  // maps of 4 GiB or more.
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)g.values, 0, (int)g.map_bytes, 0x00020000);
   float acc = 0.0f;
-  for (int c = 0; c < g.C; ++c) {
+  auto channel = [&](int c, float pw_per_k, bool first_channel) {
     float val = 0.0f;
 #pragma unroll
     for (int k = 0; k < kS; ++k) {
-      const pair4 r0 = *(gpair*)(m + o0), r1 = *(gpair*)(m + o1);
+      const int soff = (c * kS + k) * (plane << 2);
+      const pair4 r0 = __builtin_bit_cast(pair4, __builtin_amdgcn_raw_buffer_load_b64(rs, o0, soff, 0));
+      const pair4 r1 = __builtin_bit_cast(pair4, __builtin_amdgcn_raw_buffer_load_b64(rs, o0, soff + pitch4, 0));
       const float v = fmaf(w0a, r0.x, fmaf(w0b, r0.y, fmaf(w1a, r1.x, w1b * r1.y)));
-      val = fmaf((float)dc.w[k], v, val);
-      m += (size_t)plane * 4;
+      val = k == 0 ? (float)dc.w[k] * v : fmaf((float)dc.w[k], v, val);  // (0 + x: the sum's first term as it is)
     }
-    float pw_per_k;
-    if (kCal) {
-      pw_per_k = fixed_cal ? fixed_cal[c] : cal_factor(g, cl, cell, c);
-    } else {
-      pw_per_k = (float)(1.380649e-11 * g.scalar[c]);
-    }
-    acc = fmaf(pw_per_k, val, acc);  // float32 accumulator (map.py:155)
+    acc = first_channel ? pw_per_k * val : fmaf(pw_per_k, val, acc);  // float32 accumulator (map.py:155)
+  };
+  if (kCal && fixed_cal) {
+    // (the caller's factors live in registers: a loop over c would pick them with a chain of selects)
+#pragma unroll
+    for (int c = 0; c < kCalFastChannels; ++c)
+      if (c < g.C) channel(c, fixed_cal[c], c == 0);  // (uniform)
+  } else {
+    for (int c = 0; c < g.C; ++c) channel(c, kCal ? cal_factor(g, cl, cell, c) : cl.chan[c], false);
   }
   return acc;
 }
@@ -422,6 +473,102 @@ __device__ __forceinline__ float raw_sample(const MapArgs& g, const CalLds& cl, 
     y1 = g.pwv[(size_t)(sc.jj + 1) * g.D + d];
   }
   return sample_value<kCal, kS>(g, cl, ax_eta, ax_xi, dc, d, sc, ox, oy, el_d, y0, y1);
+}
+
+// Round 6: the kN samples of one thread and one detector row TOGETHER (kN = 4, or 5 with the thread's halo sample), for the
+// composed rotation with per-channel factors that need no lookup per sample (the caller's scalars, or the stretch form's
+// chord).  One sample at a time the kernel was a chain of latencies -- three LDS reads, arithmetic, two gathers from L2,
+// arithmetic, per sample and plane, every wave waiting 59 % of its cycles at 38 % of the vector issue rate
+// (gpurun_out/r6a_pmc_*: 5.6e9 wave-instructions in 2.8e7 cycles of 1024 SIMDs at two cycles each) -- because the sample's
+// code sat behind branches (bilinear or nearest, the far-offset form of asin(r)/r, a guard per channel) that end a basic
+// block, and the compiler schedules inside a block.  Here the branches are out of the samples' way: kBil is a template
+// parameter, the far-offset form is one vote per row, the channel loop is outside the samples -- so a thread's 2 kN kS
+// gathers of a channel are in flight together, behind 3 kN LDS reads issued together.
+//   record(slot): the sample's six matrix entries (LDS); slot[q]: the samples' slots; pw(c, f): fills f[q] with pW per K_RJ
+//   of channel c at sample q; kUnrollC: at most kCalFastChannels channels, unrolled under a guard; else a loop.
+template <bool kBil, int kS, int kN, bool kUnrollC, typename RecordFn, typename PwFn>
+__device__ __forceinline__ void row_samples(const MapArgs& g, const Axis& ax_eta, const Axis& ax_xi, const DetConst& dc,
+                                            const int (&slot)[kN], RecordFn record, PwFn pw, float (&out)[kN]) {
+  float ox[kN], oy[kN], r2[kN];
+  bool far = false;
+#pragma unroll
+  for (int q = 0; q < kN; ++q) {
+    const SampleConst sc = record(slot[q]);
+    // (sample_offsets' composed form: float32, see there)
+    const float dz_re = fmaf(dc.c_re, sc.G[0], fmaf(dc.c_cr, sc.G[2], dc.c_im * sc.G[4]));
+    const float dz_im = fmaf(dc.c_re, sc.G[1], fmaf(dc.c_cr, sc.G[3], dc.c_im * sc.G[5]));
+    r2[q] = fmaf(dz_re, dz_re, dz_im * dz_im);
+    const float f = fmaf(r2[q], fmaf(r2[q], fmaf(r2[q], fmaf(r2[q], 35.0f / 1152.0f, 15.0f / 336.0f), 3.0f / 40.0f), 1.0f / 6.0f), 1.0f);
+    far |= r2[q] >= 0.01f;
+    ox[q] = -dz_re * f;
+    oy[q] = -dz_im * f;
+  }
+  if (__builtin_amdgcn_ballot_w64(far) != 0) {  // beyond 0.1 rad of the map's centre: asin(r)/r itself instead of its series
+#pragma unroll 1
+    for (int q = 0; q < kN; ++q) {
+      const float x = r2[q];
+      if (x >= 0.01f) {
+        const float series = fmaf(x, fmaf(x, fmaf(x, fmaf(x, 35.0f / 1152.0f, 15.0f / 336.0f), 3.0f / 40.0f), 1.0f / 6.0f), 1.0f);
+        const float r = sqrtf(x);
+        const float ratio = (asinf(fminf(r, 1.0f)) / r) / series;
+#pragma unroll
+        for (int k = 0; k < kN; ++k) {  // (registers, not an indexed array)
+          ox[k] = k == q ? ox[k] * ratio : ox[k];
+          oy[k] = k == q ? oy[k] * ratio : oy[k];
+        }
+      }
+    }
+  }
+  int o0[kN];
+  float w0a[kN], w0b[kN], w1a[kN], w1b[kN];
+#pragma unroll
+  for (int q = 0; q < kN; ++q) {
+    int e0, x0;
+    float pe, px;
+    axis_cell_t<kBil>(ax_eta, oy[q], e0, pe);
+    axis_cell_t<kBil>(ax_xi, ox[q], x0, px);
+    const float qe = 1.0f - pe, qx = 1.0f - px;
+    w0a[q] = qe * qx; w0b[q] = qe * px; w1a[q] = pe * qx; w1b[q] = pe * px;
+    o0[q] = (int)(__umul24((unsigned)e0, (unsigned)g.n_xi) + (unsigned)x0) << 2;  // (e0 < n_eta, n_xi < 2^24)
+  }
+  typedef float pair4 __attribute__((ext_vector_type(2)));
+  const int plane4 = (g.n_eta * g.n_xi) << 2, pitch4 = g.n_xi << 2;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)g.values, 0, (int)g.map_bytes, 0x00020000);
+#pragma unroll
+  for (int q = 0; q < kN; ++q) out[q] = 0.0f;
+  float wf[kS];  // the Stokes weights as the float32 numbers the sums take
+#pragma unroll
+  for (int k = 0; k < kS; ++k) wf[k] = (float)dc.w[k];
+  auto channel = [&](int c, bool first_channel) {
+    float val[kN];
+#pragma unroll
+    for (int k = 0; k < kS; ++k) {  // (a plane's 2 kN gathers in flight together; all kS planes' at once would not fit the registers)
+      const int soff = (c * kS + k) * plane4;
+      pair4 r0[kN], r1[kN];
+#pragma unroll
+      for (int q = 0; q < kN; ++q) {
+        r0[q] = __builtin_bit_cast(pair4, __builtin_amdgcn_raw_buffer_load_b64(rs, o0[q], soff, 0));
+        r1[q] = __builtin_bit_cast(pair4, __builtin_amdgcn_raw_buffer_load_b64(rs, o0[q], soff + pitch4, 0));
+      }
+#pragma unroll
+      for (int q = 0; q < kN; ++q) {
+        const float v = fmaf(w0a[q], r0[q].x, fmaf(w0b[q], r0[q].y, fmaf(w1a[q], r1[q].x, w1b[q] * r1[q].y)));
+        val[q] = k == 0 ? wf[k] * v : fmaf(wf[k], v, val[q]);
+      }
+    }
+    float f[kN];
+    pw(c, f);
+#pragma unroll
+    for (int q = 0; q < kN; ++q)
+      out[q] = first_channel ? f[q] * val[q] : fmaf(f[q], val[q], out[q]);  // float32 accumulator (map.py:155)
+  };
+  if (kUnrollC) {
+#pragma unroll
+    for (int c = 0; c < kCalFastChannels; ++c)
+      if (c < g.C) channel(c, c == 0);  // (uniform)
+  } else {
+    for (int c = 0; c < g.C; ++c) channel(c, false);
+  }
 }
 
 __device__ __forceinline__ DetConst make_det_const(const MapArgs& g, int d) {
@@ -925,10 +1072,13 @@ __global__ __launch_bounds__(kBlock) void bin_accumulate_kernel(MapArgs g, BinAr
 // kKrj: the field leaves in K_RJ -- every row's four values times the row's scale, divided by den_band(el_det) exactly as
 // tod_krj_kernel divides a finished field (mrx_krj.h: the same per-tile elevation model from the same 1024 samples, the same
 // lookup), instead of a second pass that reads and writes the field again (3.9 of 18.3 ms at 10 000 x 240 000).
+#ifndef MRX_MAP_CAL_WAVES
+#define MRX_MAP_CAL_WAVES 4
+#endif
 template <bool kChain, bool kCal, int kS, bool kKrj = false>
 // without the per-sample atmospheric calibration the kernel fits 168 registers (three waves per
 // SIMD: 16.8 -> 14.8 ms at 10 000 x 240 000); with it the cap costs spills (26.8 -> 34.4 ms)
-__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kChain ? (kCal ? 2 : 3) : (kCal ? 3 : 5), kChain ? (kCal ? 2 : 3) : 8))) void map_sample_kernel(MapArgs g, int groups, MapKrj kj) {
+__global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kChain ? (kCal ? 2 : 3) : (kCal ? MRX_MAP_CAL_WAVES : kS == 1 ? 5 : 4), kChain ? (kCal ? 2 : 3) : 8))) void map_sample_kernel(MapArgs g, int groups, MapKrj kj) {
   __shared__ DetConst dets[kTileDet];
   __shared__ float2 edge[2][kBlock];  // (first, last) raw value of every thread, double-buffered
   extern __shared__ __align__(16) float cal_lds[];   // calibration axes and tables (a few KB); K_RJ: the cell table behind them
@@ -939,6 +1089,10 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kChain ?
     for (int i = threadIdx.x; i < g.n_pwv; i += kBlock) cal_lds[i] = g.cal_pwv[i];
     for (int i = threadIdx.x; i < g.n_el; i += kBlock) cal_lds[g.n_pwv + i] = g.cal_el[i];
     for (int i = threadIdx.x; i < g.C * g.n_pwv * g.n_el; i += kBlock) cal_lds[g.n_pwv + g.n_el + i] = g.cal[i];
+  } else {
+    // (once per workgroup: per sample and channel this was a float64 product and a conversion)
+    for (int i = threadIdx.x; i < g.C; i += kBlock) cal_lds[i] = (float)(1.380649e-11 * g.scalar[i]);
+    cl.chan = cal_lds;
   }
   const int s_tile = blockIdx.x * kTileSamples;
   const int sb = s_tile + threadIdx.x * kSamplesPerThread;
@@ -949,12 +1103,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kChain ?
   // (slot 0 / 1025: the halo samples of the 3-tap kernel) and the row loop fetches it with three 8-byte
   // reads, instead of five records held in 65 registers per thread (168 -> 63 registers).
   constexpr bool kLdsSc = !kChain;
-  // With the calibration a sample also needs cos / sin of the boresight elevation, its coarse interval and weight there:
-  // kept for every thread's FIRST sample only (the stretch form below looks the factor up there), 4 KB instead of 16 --
-  // 41 KB of records held the kernel to three workgroups per CU; the per-sample fallback recomputes them.
   constexpr int kRec = 6;
   __shared__ __align__(16) float sc_lds[kLdsSc ? kRec * (kTileSamples + 2) : 8];
-  __shared__ float4 sc_cal[kLdsSc && kCal ? kBlock : 1];
+  // the interval form of the calibration (see kMaxSteps): (cos, sin) of (boresight elevation - pi/2) at the start, the middle
+  // and the end of every coarse step the tile meets; a row with a knot off the tables (NaN)
+  __shared__ float2 knot_cs[kLdsSc && kCal ? 2 * kMaxSteps + 1 : 1];
+  __shared__ int bad_row[kLdsSc && kCal ? kTileDet : 1];
   SampleConst sc[kSamplesPerThread], sc_halo;
   const bool first = threadIdx.x == 0, last = threadIdx.x == kBlock - 1;
   if (kLdsSc) {
@@ -963,8 +1117,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kChain ?
       sample_const(g, s_tile - 1 + i, false, one);
 #pragma unroll
       for (int k = 0; k < 6; ++k) sc_lds[kRec * i + k] = one.G[k];
-      if (kCal && i >= 1 && ((i - 1) & (kSamplesPerThread - 1)) == 0 && (i - 1) / kSamplesPerThread < kBlock)
-        sc_cal[(i - 1) / kSamplesPerThread] = make_float4(one.ca, one.sa, __int_as_float(one.jj), (float)one.u);  // (the interpolated pwv is rounded to float32 anyway)
     }
   } else {
 #pragma unroll
@@ -1010,71 +1162,184 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kChain ?
     return one;
   };
   const bool full = (sb + kSamplesPerThread <= g.T) && g.vec_ok;
+  // The interval form of the per-sample calibration (round 6).  The factor -- pW per K_RJ at the sample's zenith pwv and
+  // the detector's elevation, per channel -- along a row: the pwv is piecewise LINEAR between the coarse samples (0.1 s;
+  // sim/atmosphere.py:30-37), the elevation a smooth scan.  Inside one coarse step the factor is therefore smooth, and its
+  // kinks sit at the steps' ends.  So it is looked up ONCE per row at the start, the middle and the end of every coarse
+  // step the tile meets (16 rows x ~26 steps x 3 lookups a group, five a thread, all of a thread's in flight together),
+  // kept in LDS as the parabola through the three in the step's own coordinate, and a sample evaluates its step's
+  // parabola at its place in the step: the kinks are where the reference has them, the elevation's curvature inside a step
+  // is the parabola's (what is left is the third difference over 0.1 s: below 1e-8 of the factor), and a kink of the
+  // TABLES inside a step is missed by less than 1e-7 of the factor.  Rounds 3-5 looked the factor up per thread and row (at
+  // its first sample; a lane shuffle for the chord to the next thread's): a chain of LDS reads, two global loads and a
+  // barrier per ROW -- a third of the kernel's instructions and most of its waiting.  The form applies to whole tiles
+  // that meet at most coef_cap steps (the launcher's table; mrx_map_cal.steps_per_tile) of at least eight samples; a row
+  // with a knot off the tables (NaN: jax's fill) takes the per-sample form, which marks exactly the samples that are off.
+  bool coef_ok = false;
+  int j_lo = 0, n_int = 0, rb = 0;
+  float v0 = 0.0f, dvt = 0.0f, lim = 1.0f;
+  float* const coef = cal_lds + (g.coef_offset >= 0 ? g.coef_offset : 0);
+  const int coef_pitch = 3 * g.coef_cap + 1;
+  if constexpr (kCal && kLdsSc) {
+    auto step_of = [&](int sidx, double& u) {  // sample_const's interval and weight
+      const double tt = g.t[min(max(sidx, 0), g.T - 1)];
+      int jj = (int)floor(fmin(fmax((tt - g.ta0) * g.inv_dta, -1.0), 2.0e9));
+      jj = min(max(jj, 0), g.Ta - 2);
+      u = (tt - (g.ta0 + (double)jj * g.dta)) * g.inv_dta;
+      return jj;
+    };
+    double u_lo, u_hi;
+    j_lo = step_of(s_tile - 1, u_lo);
+    n_int = step_of(s_tile + kTileSamples, u_hi) - j_lo + 1;
+    coef_ok = g.coef_offset >= 0 && s_tile + kTileSamples <= g.T && n_int <= min(g.coef_cap, kMaxSteps) && n_int * 8 <= kTileSamples;  // (uniform)
+    if (coef_ok) {
+      // the thread's samples in units of a step, counted from the start of the step of its earliest sample (the first
+      // thread's halo): v0 at its first sample, dvt a sample (the samples are evenly spaced over a thread's 10 ms)
+      double u_b, u_0, u_3;
+      const int jb = step_of(first ? s_tile - 1 : sb, u_b), j0 = step_of(sb, u_0), j3 = step_of(sb + kSamplesPerThread - 1, u_3);
+      v0 = (float)((double)(j0 - jb) + u_0);
+      dvt = (float)(((double)(j3 - jb) + u_3 - ((double)(j0 - jb) + u_0)) * (1.0 / (kSamplesPerThread - 1)));
+      lim = jb >= g.Ta - 2 ? 3.0e38f : 1.0f;  // (past the last coarse sample the series is extrapolated: still the last step)
+      rb = jb - j_lo;
+      // the boresight at the steps' starts, middles and ends: linear between the two samples around the knot's time
+      const int s_a = max(s_tile - 1, 0), s_b = min(s_tile + kTileSamples, g.T - 1);
+      const double t_a = g.t[s_a], inv_dt = (double)(s_b - s_a) / (g.t[s_b] - t_a);
+      for (int m = threadIdx.x; m < 2 * n_int + 1; m += kBlock) {
+        const double tau = g.ta0 + ((double)j_lo + 0.5 * (double)m) * g.dta;
+        int sidx = min(max(s_a + (int)floor(fmin(fmax((tau - t_a) * inv_dt, -2.0e9), 2.0e9)), 0), g.T - 2);
+        for (int it = 0; it < 8 && sidx < g.T - 2 && g.t[sidx + 1] < tau; ++it) ++sidx;  // (unevenly spaced samples)
+        for (int it = 0; it < 8 && sidx > 0 && g.t[sidx] > tau; ++it) --sidx;
+        const double wt = (tau - g.t[sidx]) / (g.t[sidx + 1] - g.t[sidx]);
+        const float e0 = g.el[sidx], e1 = g.el[sidx + 1];
+        const float a = __fsub_rn((float)((double)e0 + wt * ((double)e1 - (double)e0)), kHalfPiF);
+        knot_cs[m] = make_float2(cosf(a), sinf(a));
+      }
+    }
+  }
   for (int grp = 0; grp < groups; ++grp) {
   const int d0 = (blockIdx.y * groups + grp) * kTileDet;
   if (d0 >= g.D) break;
   const int nd = min(kTileDet, g.D - d0);
   __syncthreads();  // the previous group is done with dets[], cdet[] and edge[]
   if ((int)threadIdx.x < nd) dets[threadIdx.x] = make_det_const(g, d0 + threadIdx.x);
-  if constexpr (kKrj) krj_stage_rows(cdet, red, kj.dx, kj.dy, kj.band, kj.scale, kj.n_bands, d0, nd);
+  if (kCal && kLdsSc && (int)threadIdx.x < kTileDet) bad_row[threadIdx.x] = 0;
+  if constexpr (kKrj) krj_stage_rows(cdet, red, kj.dx, kj.dy, kj.band, kj.scale, kj.n_bands, d0, nd, cal_cells, kj.n_el);
   __syncthreads();
+  // The interval form of the per-sample calibration: this group's rows (see the tile's part above)
+  if constexpr (kCal && kLdsSc) {
+    if (coef_ok) {
+      for (int i = threadIdx.x; i < kTileDet * n_int; i += kBlock) {
+        const int dl = i & (kTileDet - 1), r = i / kTileDet;
+        if (dl >= nd) continue;
+        const int j = j_lo + r, d = d0 + dl;
+        const double y0 = g.pwv[(size_t)j * g.D + d], y1 = g.pwv[(size_t)(j + 1) * g.D + d];
+        float F[3][kCalFastChannels];
+        bool bad = false;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {  // the step's start, middle and end
+          const float2 cs = knot_cs[2 * r + k];
+          const float im = __fadd_rn(__fmul_rn(dets[dl].c_re, cs.y), __fmul_rn(dets[dl].c_cr, cs.x));
+          const CalCell cell = cal_cell(cl, (float)fma(0.5 * (double)k, y1 - y0, y0), asin_poly(im));  // (pwv demoted to float32 by the jax interpolator)
+#pragma unroll
+          for (int c = 0; c < kCalFastChannels; ++c) {
+            F[k][c] = 0.0f;
+            if (c < g.C) {  // (uniform)
+              F[k][c] = cal_factor(g, cl, cell, c);
+              bad |= !(F[k][c] == F[k][c]);
+            }
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < kCalFastChannels; ++c)
+          if (c < g.C) {  // the parabola through (0, F0), (1/2, F1), (1, F2): F0 + w (4 F1 - 3 F0 - F2) + w^2 (2 F0 + 2 F2 - 4 F1)
+            float* rec = coef + (c * kTileDet + dl) * coef_pitch + 3 * r;
+            rec[0] = F[0][c];
+            rec[1] = fmaf(4.0f, F[1][c], fmaf(-3.0f, F[0][c], -F[2][c]));
+            rec[2] = fmaf(-4.0f, F[1][c], 2.0f * (F[0][c] + F[2][c]));
+          }
+        if (bad) bad_row[dl] = 1;
+      }
+      __syncthreads();
+    }
+  }
   for (int dl = 0; dl < nd; ++dl) {
     const DetConst dc = dets[dl];
     const int d = d0 + dl;
     float r[kSamplesPerThread];
-    const int jj0 = kCal ? (kLdsSc ? __float_as_int(sc_cal[threadIdx.x].z) : sc[0].jj) : 0;
-    double y0 = 0.0, y1 = 0.0;
-    if (kCal) {
-      y0 = g.pwv[(size_t)jj0 * g.D + d];
-      y1 = g.pwv[(size_t)(jj0 + 1) * g.D + d];
-    }
     float halo = 0.0f;
-    // The calibration factor -- pW per K_RJ at the sample's zenith pwv and the detector's elevation, per channel --
-    // moves by parts in 1e7 over a thread's four samples (10 ms at 400 Hz): ONE lookup per thread, at its first
-    // sample; the next thread's value comes over by a lane shuffle (the wave's last lane extrapolates its neighbour's
-    // step) and the thread's samples take the chord.  A kink of the tables inside those 10 ms is missed by less
-    // than 1e-8 of the factor.  Any lane off the tables (NaN: jax's fill) sends the row through the per-sample form,
-    // which marks exactly the samples that are off.  (Up to kCalFastChannels channels; not with the literal chain.)
-    bool stretch = false;
+    // Round 6: the thread's four samples TOGETHER (row_samples: their LDS reads, then their gathers, in flight at once);
+    // the tile's halo samples ride along as a fifth sample of waves 0 and 3 (in a branch of their own the first and the
+    // last thread's waves ran a whole sample's chain of latencies alone, once per row)
+    auto batched = [&](auto unroll_c, auto pw) {
+      const int s0 = 1 + threadIdx.x * kSamplesPerThread;
+      const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+      auto run = [&](auto bil) {
+        if (wave == 0 || wave == kBlock / 64 - 1) {
+          const int slot[5] = {s0, s0 + 1, s0 + 2, s0 + 3, first ? 0 : last ? kTileSamples + 1 : s0 + 3};
+          float v[5];
+          row_samples<decltype(bil)::value, kS, 5, decltype(unroll_c)::value>(g, ax_eta, ax_xi, dc, slot, record, pw, v);
+          r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; r[3] = v[3];
+          halo = v[4];
+        } else {
+          const int slot[4] = {s0, s0 + 1, s0 + 2, s0 + 3};
+          row_samples<decltype(bil)::value, kS, 4, decltype(unroll_c)::value>(g, ax_eta, ax_xi, dc, slot, record, pw, r);
+        }
+      };
+      if (g.bilinear) run(std::true_type{}); else run(std::false_type{});  // (uniform)
+    };
+    bool done = false;
     if constexpr (kCal && kLdsSc) {
-      float f0[kCalFastChannels], df[kCalFastChannels];
-      if (g.C <= kCalFastChannels) {  // (uniform)
-        const float4 s0 = sc_cal[threadIdx.x];  // (cos, sin, coarse interval = jj0, weight) at the thread's first sample
-        const float im = __fadd_rn(__fmul_rn(dc.c_re, s0.y), __fmul_rn(dc.c_cr, s0.x));
-        const CalCell cell = cal_cell(cl, (float)fma((double)s0.w, y1 - y0, y0), asin_poly(im));
-        const int lane = threadIdx.x & 63;
-        bool bad = false;
+      if (coef_ok && __builtin_amdgcn_readfirstlane(bad_row[dl]) == 0) {  // (uniform)
+        batched(std::true_type{}, [&](int c, auto& f) {
+          const float* cf = coef + (c * kTileDet + dl) * coef_pitch + 3 * rb;
+          constexpr int n = sizeof(f) / sizeof(f[0]);
 #pragma unroll
-        for (int c = 0; c < kCalFastChannels; ++c) {
-          f0[c] = c < g.C ? cal_factor(g, cl, cell, c) : 0.0f;
-          const float nxt = __shfl_down(f0[c], 1, 64), prv = __shfl_up(f0[c], 1, 64);
-          df[c] = 0.25f * (lane < 63 ? nxt - f0[c] : f0[c] - prv);
-          bad |= !(f0[c] == f0[c]) || !(df[c] == df[c]);
-        }
-        stretch = __builtin_amdgcn_ballot_w64(bad) == 0 && (sb + kSamplesPerThread <= g.T);
-        stretch = __syncthreads_and(stretch);  // (the row's waves take the same form: one barrier pattern below)
-        if (stretch) {
-#pragma unroll
-          for (int q = 0; q < kSamplesPerThread; ++q) {
-            float cf[kCalFastChannels];
-#pragma unroll
-            for (int c = 0; c < kCalFastChannels; ++c) cf[c] = fmaf(df[c], (float)q, f0[c]);
-            r[q] = raw_sample_fixed<kChain, kS>(g, cl, ax_eta, ax_xi, dc, d, record(1 + threadIdx.x * kSamplesPerThread + q), cf);
+          for (int q = 0; q < n; ++q) {
+            // the sample's place in its coarse step: v counts from the start of the thread's first step; past 1 it is the
+            // next step's (one record on).  (The halo sample, q = 4: one sample before the first thread's first, or one
+            // after the last thread's last.)
+            const float v = fmaf(q == 4 ? (first ? -1.0f : 4.0f) : (float)q, dvt, v0);
+            const bool next = v >= lim;
+            const float w = next ? v - 1.0f : v;
+            const float* rec = next ? cf + 3 : cf;
+            f[q] = fmaf(w, fmaf(w, rec[2], rec[1]), rec[0]);
           }
-          if (first || last) {
-            float cf[kCalFastChannels];
-#pragma unroll
-            for (int c = 0; c < kCalFastChannels; ++c) cf[c] = fmaf(df[c], first ? -1.0f : 4.0f, f0[c]);
-            halo = raw_sample_fixed<kChain, kS>(g, cl, ax_eta, ax_xi, dc, d, record(first ? 0 : kTileSamples + 1), cf);
-          }
-        }
+        });
+        done = true;
       }
     }
-    if (!stretch) {
-      auto rec_of = [&](int slot) { return (kCal && kLdsSc) ? with_cal(record(slot), slot) : record(slot); };
+    if constexpr (!kCal && kLdsSc) {
+      batched(std::false_type{}, [&](int c, auto& f) {
+        const float v = cl.chan[c];
+        constexpr int n = sizeof(f) / sizeof(f[0]);
 #pragma unroll
-    for (int q = 0; q < kSamplesPerThread; ++q)
-      r[q] = raw_sample<kChain, kCal, kS>(g, cl, ax_eta, ax_xi, dc, d, kLdsSc ? rec_of(1 + threadIdx.x * kSamplesPerThread + q) : sc[q], jj0, y0, y1);
+        for (int q = 0; q < n; ++q) f[q] = v;
+      });
+      done = true;  // (nothing left for the per-sample form below)
+    }
+    if (!done) {
+      // the per-sample form: the literal chain, more than kCalFastChannels channels, a ragged last tile, a row off the tables
+      int jj0 = -1;  // (the coarse pwv pair the caller holds: none -- raw_sample loads the sample's own)
+      double y0 = 0.0, y1 = 0.0;
+      if (kCal && !kLdsSc) {
+        jj0 = sc[0].jj;
+        y0 = g.pwv[(size_t)jj0 * g.D + d];
+        y1 = g.pwv[(size_t)(jj0 + 1) * g.D + d];
+      }
+      auto rec_of = [&](int slot) { return (kCal && kLdsSc) ? with_cal(record(slot), slot) : record(slot); };
+      if constexpr (kLdsSc) {
+        // (one sample at a time, not unrolled: this form is the exception, and four samples of it side by side set the
+        // whole kernel's register count -- 138 against the batched form's own need)
+#pragma unroll 1
+        for (int q = 0; q < kSamplesPerThread; ++q) {
+          const float v = raw_sample<kChain, kCal, kS>(g, cl, ax_eta, ax_xi, dc, d, rec_of(1 + threadIdx.x * kSamplesPerThread + q), jj0, y0, y1);
+          r[0] = q == 0 ? v : r[0]; r[1] = q == 1 ? v : r[1]; r[2] = q == 2 ? v : r[2]; r[3] = q == 3 ? v : r[3];
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < kSamplesPerThread; ++q)
+          r[q] = raw_sample<kChain, kCal, kS>(g, cl, ax_eta, ax_xi, dc, d, sc[q], jj0, y0, y1);
+      }
     if (first || last)
       halo = raw_sample<kChain, kCal, kS>(g, cl, ax_eta, ax_xi, dc, d, kLdsSc ? rec_of(first ? 0 : kTileSamples + 1) : sc_halo, jj0, y0, y1);
     }
@@ -1157,6 +1422,12 @@ static int map_sample(mrx_ctx* ctx, const mrx_sky_map* map, const mrx_map_cal* c
   g.cos_ctheta = cos(map->center_theta);
   g.sin_ctheta = sin(map->center_theta);
   g.bilinear = map->bilinear;
+  {
+    // (the sampler reads the map as ONE raw buffer: 32-bit offsets)
+    const unsigned long long bytes = 4ull * (unsigned long long)map->n_channels * map->n_stokes * map->n_eta * map->n_xi;
+    MRX_REQUIRE(ctx, bytes < (1ull << 32), "the map (all channels and Stokes planes) must be smaller than 4 GiB");
+    g.map_bytes = (uint32_t)bytes;
+  }
   g.cal = cal->d_table;
   g.cal_pwv = cal->d_axis_pwv;
   g.cal_el = cal->d_axis_el;
@@ -1190,9 +1461,19 @@ static int map_sample(mrx_ctx* ctx, const mrx_sky_map* map, const mrx_map_cal* c
   dim3 grid(mrx_ceil_div(T, kTileSamples), mrx_ceil_div(D, kTileDet * groups));
   MRX_REQUIRE(ctx, grid.y <= 65535u, "D too large for one launch");
   size_t lds = 0;
+  g.coef_offset = -1;
+  g.coef_cap = 0;
   if (cal->d_table) {
     lds = sizeof(float) * ((size_t)cal->n_pwv + cal->n_el + (size_t)map->n_channels * cal->n_pwv * cal->n_el);
     MRX_REQUIRE(ctx, lds <= 48 * 1024, "calibration tables of all channels must fit in 48 KiB");
+    if (map->n_channels <= kCalFastChannels && T >= 2) {  // the interval table of the per-sample calibration behind them
+      g.coef_cap = cal->steps_per_tile > 0 ? std::min(cal->steps_per_tile, kMaxSteps) : kDefaultSteps;
+      g.coef_offset = (int)(lds / sizeof(float));
+      lds += sizeof(float) * (size_t)map->n_channels * kTileDet * (3 * g.coef_cap + 1);
+    }
+  } else {
+    lds = sizeof(float) * (size_t)map->n_channels;  // the channels' scalar factors
+    MRX_REQUIRE(ctx, lds <= 48 * 1024, "too many channels");
   }
   MapKrj kj{};
   if (krj) {  // the cell table of TOD.to("K_RJ") behind the sampler's own tables, on a 16-byte boundary
@@ -1203,6 +1484,9 @@ static int map_sample(mrx_ctx* ctx, const mrx_sky_map* map, const mrx_map_cal* c
     MRX_REQUIRE(ctx, lds <= 60 * 1024, "the calibration tables (sampling and K_RJ) must fit in 60 KiB");
   }
   MRX_REQUIRE(ctx, (long long)map->n_eta * map->n_xi < (1LL << 29), "a map plane must hold fewer than 2^29 pixels");
+  MRX_REQUIRE(ctx, map->n_eta < (1 << 23) && map->n_xi < (1 << 23) && std::fabs(map->eta0 / map->deta) < 8388608.0 &&
+                       std::fabs(map->xi0 / map->dxi) < 8388608.0,
+              "a map axis must have fewer than 2^23 nodes and start within 2^23 pixels of the map's centre");
   const bool chain = ctx->options[MRX_OPT_POINTING_CHAIN] != 0, has_cal = cal->d_table != nullptr;
   if (krj && chain)
     return mrx_fail(ctx, MRX_ERR_UNSUPPORTED, "mrx_map_sample_krj: not with MRX_OPT_POINTING_CHAIN (sample in pW, then mrx_tod_to_krj)");

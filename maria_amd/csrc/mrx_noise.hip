@@ -866,7 +866,7 @@ __global__ __launch_bounds__(kBlock) void noise_two_rate_kernel(const mrx_two_ra
   KrjSamples ks{};
   if constexpr (kKrj) {
     ks = krj_prologue(cal_cells, red, a.bore_el, a.T, sb, a.cal_axis, a.cal_values, a.n_el, a.n_bands);
-    krj_stage_rows(cdet, red, a.dx, a.dy, a.band, nullptr, a.n_bands, a.row0 + r0, nd);
+    krj_stage_rows(cdet, red, a.dx, a.dy, a.band, nullptr, a.n_bands, a.row0 + r0, nd, cal_cells, a.n_el);
   }
   for (int i = threadIdx.x; i < kTileDet * 8; i += kBlock) {
     const int dl = i >> 3, m = i & 7;

@@ -69,9 +69,20 @@ def collapse_temperature(table, axis_T, base_temperature):
     return out.astype(np.float32)
 
 
+def steps_per_tile(t, dta, tile=1024):
+    """``mrx_map_cal.steps_per_tile``: the most steps of a coarse series of step ``dta`` that ``tile`` consecutive samples
+    (and the two either side) of the sample times ``t`` meet -- what sizes the LDS table of the map sampler's per-sample
+    calibration (csrc/mrx_map.hip, the interval form)."""
+    t = np.asarray(t, float)
+    if len(t) < 2:
+        return 1
+    span = float(np.max(t[min(tile + 1, len(t) - 1):] - t[: len(t) - min(tile + 1, len(t) - 1)]))
+    return int(np.ceil(span / float(dta))) + 1
+
+
 def sample_map(ctx, values, eta, xi, center, az, el, offsets, stokes_weights, out=None, transform=None, bilinear=True,
                cal_tables=None, cal_axis_pwv=None, cal_axis_el=None, coarse_pwv=None, ta0=0.0, dta=1.0, t=None,
-               cal_scalars=None, device="cuda:0", sync=True, krj=None, scale=None):
+               cal_scalars=None, device="cuda:0", sync=True, krj=None, scale=None, steps_per_tile=None):
     """``mrx_map_sample`` for the detectors of one band (sim/map.py:76-172).
 
     values [C, S, n_eta, n_xi] K_RJ (smoothed, parity applied); eta, xi the map axes in radians;
@@ -88,7 +99,11 @@ def sample_map(ctx, values, eta, xi, center, az, el, offsets, stokes_weights, ou
     as ``mrx_tod_to_krj`` of the pW field) -- a dict of device tensors for THESE rows: ``bore_el`` [T], ``dx``, ``dy``
     [D] float32, ``band`` [D] int32, ``axis`` [n_el], ``values`` [n_bands, n_el] float32 (``DevicePath.krj_row_tables()``,
     its per-row arrays indexed by the band's rows); ``scale`` [D] float32: the gain error, multiplied in before the
-    division (with ``krj`` only)."""
+    division (with ``krj`` only).
+
+    ``steps_per_tile`` (with ``cal_tables``): ``mrx_map_cal.steps_per_tile`` -- the most coarse steps of the pwv series
+    that 1024 consecutive samples meet; worked out from ``t`` and ``dta`` when ``t`` is an array on the host, the
+    library's default for a device tensor (:func:`steps_per_tile`)."""
     from ._lib import MrxMapCal, MrxSkyMap
 
     dev = torch.device(device)
@@ -112,6 +127,9 @@ def sample_map(ctx, values, eta, xi, center, az, el, offsets, stokes_weights, ou
         cal.d_table, cal.d_axis_pwv, cal.d_axis_el = ptr(keep["tab"]), ptr(keep["ap"]), ptr(keep["ae"])
         cal.n_pwv, cal.n_el = len(cal_axis_pwv), len(cal_axis_el)
         cal.d_pwv, cal.Ta, cal.ta0, cal.dta, cal.d_t = ptr(keep["pwv"]), keep["pwv"].shape[0], float(ta0), float(dta), ptr(keep["t"])
+        if steps_per_tile is None:
+            steps_per_tile = 0 if isinstance(t, torch.Tensor) else globals()["steps_per_tile"](t, dta)
+        cal.steps_per_tile = int(steps_per_tile)
     else:
         keep.update(sc=f64(np.atleast_1d(cal_scalars)))
         assert keep["sc"].shape == (C_,)

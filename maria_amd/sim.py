@@ -376,6 +376,9 @@ class Simulation:
         if atm is not None:
             path = atm._device_path()
             ctx, device = path.ctx, path.device
+            # (sync=False below frees this call's temporaries while the kernel is in flight: safe only on torch's current
+            # stream, whatever stream path.run() left on the context)
+            ctx.set_stream(torch.cuda.current_stream(device))
         else:
             device = torch.device(self.device)
             self._noise_ctx = self._noise_ctx or Context(device.index or 0)
@@ -385,12 +388,19 @@ class Simulation:
         # what does not change from run to run lives on the device, per observation and per band: the boresight, the
         # sample times, the horizon -> equatorial transform (14 ms of host arithmetic and 17 MB a run when it was made
         # per call), the smoothed map channels, the collapsed calibration tables, the detectors' offsets and weights
-        key = (str(device), lo, hi, id(self.map))
+        # (the map OBJECT is kept and compared with `is`, as are the things the cached tensors were made from -- its data
+        # array and the weather's temperature: an id() of a freed map can come back, and an edit in place keeps the id)
+        key = (str(device), lo, hi)
+        made_from = (self.map, self.map.data, None if atm is None else float(atm.weather.temperature[0]))
         cache = getattr(obs, "_map_cache", None)
-        if cache is None or cache.get("key") != key:
+        if (cache is None or cache.get("key") != key or cache["made_from"][0] is not made_from[0]
+                or cache["made_from"][1] is not made_from[1] or cache["made_from"][2] != made_from[2]):
             f32 = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float32)).to(device)  # noqa: E731
             f64 = lambda a: torch.as_tensor(np.ascontiguousarray(a, np.float64)).to(device)  # noqa: E731
-            cache = {"key": key, "az": f32(obs.boresight._baz), "el": f32(obs.boresight._bel), "t": f64(obs.coords.t), "bands": {}}
+            cache = {"key": key, "made_from": made_from, "az": f32(obs.boresight._baz), "el": f32(obs.boresight._bel),
+                     "t": f64(obs.coords.t), "bands": {}}
+            if atm is not None:
+                cache["steps_per_tile"] = mmap.steps_per_tile(obs.coords.t, atm._device_path().dta)
             cache["transform"] = (f64(sky_transform_stack(obs.coords.t, obs.site.latitude, obs.site.longitude).reshape(T, 9))
                                   if self.map.frame == "ra/dec" else None)
             stokes_rows = mmap.mueller_row(dets.gamma)[:, ["IQUV".index(s) for s in self.map.stokes]]
@@ -442,7 +452,7 @@ class Simulation:
             if atm is not None:
                 pwv = path.coarse_pwv_time_major(e["idx_dev"])  # [Ta, D_band]
                 kw = dict(cal_tables=e["tab"], cal_axis_pwv=e["ap"], cal_axis_el=e["ae"], coarse_pwv=pwv, ta0=path.ta0,
-                          dta=path.dta, t=cache["t"])
+                          dta=path.dta, t=cache["t"], steps_per_tile=cache["steps_per_tile"])
             else:
                 kw = dict(cal_scalars=e["scalars"])
             if krj is not None:  # the calibration's per-row arrays for this band's rows (kept while the tables are the same objects)
