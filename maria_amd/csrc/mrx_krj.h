@@ -46,7 +46,10 @@ struct CalDet {
   // den is ONE linear function of x = el_bore - ebm for every sample of the row in this tile: den = lin_a + lin_b x
   // (set_linear_den; krj_row then needs neither the cell nor its checks per thread: the division cost ~21 vector
   // instructions a sample wherever it rode on another kernel's store)
-  float lin_a, lin_b;
+  // Rows that meet ONE node of the axis inside the tile (a cell is a few degrees, a tile's sweep a degree: 40 % of the
+  // rows at the benchmark's 4-degree cells) are linear either side of it: den = lin_a + lin_b x + lin_db max(x - lin_xn, 0),
+  // lin_xn the x at which the row's elevation passes the node (3e38 without one).
+  float lin_a, lin_b, lin_db, lin_xn;
   int lin;
 };
 
@@ -82,7 +85,29 @@ __device__ __forceinline__ float det_elevation(const CalDet& c, float eb, float 
 // the linear model of CalDet around the boresight elevation ebm (see CalDet)
 constexpr float kModelHalfRange = 2.0e-2f;  // wide enough that float32 rounding of the differences stays below 1e-7 rad over a tile
 
-__device__ __forceinline__ void set_elevation_model(CalDet& c, float ebm) {
+// (cos, sin) of (ebm - pi/2) and of that angle -+ kModelHalfRange: ONE cosine and sine (the accurate ones) and the
+// angle-addition formulas with the constants cos / sin(0.02) -- the model's three points used to cost six calls of the
+// accurate functions per tile, on sixteen lanes of one wave while the workgroup's other 240 threads waited at the barrier.
+struct BoreTrig {
+  float ca[3], sa[3];
+};
+
+__device__ __forceinline__ BoreTrig bore_trig(float ebm) {
+  MRX_KRJ_FP
+  constexpr float ch = 0.99980000666657776f, sh = 0.01999866669333308f;  // cos, sin of kModelHalfRange = 0.02
+  const float a = ebm - 1.57079637050628662109375f;
+  const float c = cosf(a), s = sinf(a);
+  BoreTrig b;
+  b.ca[1] = c;
+  b.sa[1] = s;
+  b.ca[0] = fmaf(c, ch, s * sh);   // cos(a - h)
+  b.sa[0] = fmaf(s, ch, -(c * sh));
+  b.ca[2] = fmaf(c, ch, -(s * sh));  // cos(a + h)
+  b.sa[2] = fmaf(s, ch, c * sh);
+  return b;
+}
+
+__device__ __forceinline__ void set_elevation_model(CalDet& c, float ebm, const BoreTrig& b) {
   MRX_KRJ_FP
   constexpr float h = kModelHalfRange;
   float e[3];
@@ -90,10 +115,8 @@ __device__ __forceinline__ void set_elevation_model(CalDet& c, float ebm) {
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
     const float eb = ebm + (float)(k - 1) * h;
-    const float a = eb - 1.57079637050628662109375f;
-    const float ca = cosf(a), sa = sinf(a);
-    steep |= !(-fmaf(sa, c.cdy, ca * c.sdy) > 0.3f);  // cos(el_bore + dy): within ~17 deg of the zenith
-    e[k] = det_elevation(c, eb, ca, sa) - eb;
+    steep |= !(-fmaf(b.sa[k], c.cdy, b.ca[k] * c.sdy) > 0.3f);  // cos(el_bore + dy): within ~17 deg of the zenith
+    e[k] = det_elevation(c, eb, b.ca[k], b.sa[k]) - eb;
   }
   c.ebm = ebm;
   c.dm = e[1];
@@ -109,37 +132,69 @@ __device__ __forceinline__ void set_linear_den(CalDet& c, float lo, float hi, co
                                                float el_inv) {
   MRX_KRJ_FP
   c.lin = 0;
-  c.lin_a = 0.0f;
-  c.lin_b = 0.0f;
+  c.lin_a = c.lin_b = c.lin_db = 0.0f;
+  c.lin_xn = 3.0e38f;
   if (c.exact) return;
-  const float e_lo = fmaf(c.slope, lo - c.ebm, lo + c.dm), e_hi = fmaf(c.slope, hi - c.ebm, hi + c.dm);
-  const float e0 = fminf(e_lo, e_hi), e1 = fmaxf(e_lo, e_hi);
+  const float S = 1.0f + c.slope, E0 = c.ebm + c.dm;  // the row's elevation over the tile: E0 + S x  (S > 0)
+  const float e0 = fmaf(c.slope, lo - c.ebm, lo + c.dm), e1 = fmaf(c.slope, hi - c.ebm, hi + c.dm);
   const int i0 = min(max((int)fminf(fmaxf((e0 - el_first) * el_inv, -1.0f), 2.0e9f), 0), n_el - 2);
   const float4 cell = C[i0];
   const float w0 = (e0 - cell.x) * cell.z, w1 = (e1 - cell.x) * cell.z;
-  // both ends inside the cell with a margin of 1e-4 of its width (the threads' own elevations are rounded separately;
-  // den is continuous at a node anyway) -- hence on the axis; a guess that missed the cell (non-uniform axis) or a NaN
-  // anywhere: not linear, and the row takes the general form below
-  const bool inside = w0 >= 1.0e-4f && w1 <= 1.0f - 1.0e-4f;
-  if (!inside) return;
-  const float g = (cell.w - cell.y) * cell.z;  // d den / d el in the cell
-  c.lin_a = fmaf(g, (c.ebm + c.dm) - cell.x, cell.y);
-  c.lin_b = g * (1.0f + c.slope);
+  // the low end inside cell i0, with a margin of 1e-4 of its width (the threads' own elevations are rounded separately; den
+  // is continuous at a node anyway) -- hence on the axis; a guess that missed the cell (non-uniform axis) or a NaN anywhere:
+  // not linear, and the row takes the per-sample form
+  if (!(S > 0.5f && e0 <= e1 && w0 >= 1.0e-4f)) return;
+  const float g1 = (cell.w - cell.y) * cell.z;  // d den / d el in the cell
+  c.lin_a = fmaf(g1, E0 - cell.x, cell.y);
+  c.lin_b = g1 * S;
+  if (w1 <= 1.0f - 1.0e-4f) {  // the whole tile inside the cell
+    c.lin = 1;
+    return;
+  }
+  if (i0 + 1 > n_el - 2) return;  // (past the last node: off the axis)
+  const float4 up = C[i0 + 1];   // (x_{i+1}, den_{i+1}, 1 / (x_{i+2} - x_{i+1}), den_{i+2})
+  if (!((e1 - up.x) * up.z <= 1.0f - 1.0e-4f)) return;  // the high end beyond the next cell too
+  const float g2 = (up.w - up.y) * up.z;
+  c.lin_db = (g2 - g1) * S;
+  c.lin_xn = (up.x - E0) / S;
   c.lin = 1;
 }
 
+// sin(x) / x and cos(x) for a focal-plane offset (|x| below 0.3 rad = 17 deg: the series to x^8 are exact to float32 there)
+__device__ __forceinline__ float sinc_small(float x2) {
+  MRX_KRJ_FP
+  return fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 1.0f / 362880.0f, -1.0f / 5040.0f), 1.0f / 120.0f), -1.0f / 6.0f), 1.0f);
+}
+__device__ __forceinline__ float cos_small(float x2) {
+  MRX_KRJ_FP
+  return fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 1.0f / 40320.0f, -1.0f / 720.0f), 1.0f / 24.0f), -0.5f), 1.0f);
+}
+
+// The detector's constants of transforms.py:14-23: r = |offset|, p = atan2(-dx, -dy), a_re = sin(r) cos(p), a_im = cos(r).
+// Round 6: cos(p) = -dy / r, so a_re = -dy sin(r) / r -- the series above instead of a square root, an arctangent and five
+// sines and cosines per row and tile (a thousand instructions of one wave, serial, behind the tile's barrier); the values
+// are the exact ones to a float32 rounding, where the reference's own float32 chain carries three.  Offsets beyond 0.3 rad
+// keep the functions.
 __device__ __forceinline__ CalDet make_cal_det(float dx, float dy, int band, float scale) {
   MRX_KRJ_FP
-  const float r = sqrtf(fmaf(dx, dx, dy * dy));
-  const float p = atan2f(-dx, -dy);
+  const float r2 = fmaf(dx, dx, dy * dy), y2 = dy * dy;
   CalDet c;
-  c.a_re = sinf(r) * cosf(p);
-  c.a_im = cosf(r);
+  if (r2 < 0.09f) {
+    c.a_re = -dy * sinc_small(r2);
+    c.a_im = cos_small(r2);
+    c.sdy = dy * sinc_small(y2);
+    c.cdy = cos_small(y2);
+  } else {
+    const float r = sqrtf(r2);
+    const float p = atan2f(-dx, -dy);
+    c.a_re = sinf(r) * cosf(p);
+    c.a_im = cosf(r);
+    c.sdy = sinf(dy);
+    c.cdy = cosf(dy);
+  }
   c.band = band;
   c.scale = scale;
   c.dy = dy;
-  c.sdy = sinf(dy);
-  c.cdy = cosf(dy);
   return c;
 }
 
@@ -176,58 +231,34 @@ __device__ __forceinline__ float den_lookup(float el, const float4* C, int n_el,
 
 // Per-thread part of the K_RJ conversion that does not depend on the detector row.
 struct KrjSamples {
-  float eb0, eb3;  // boresight elevation of the thread's first and last sample
-  float x0, x3;    // the same minus the tile's reference elevation (CalDet::ebm)
+  float x0, x3;    // boresight elevation of the thread's first and last sample minus the tile's reference elevation (CalDet::ebm)
   int curved;      // some thread of the workgroup: its four boresight elevations are NOT linear in the sample index to 1e-6 rad
 };
 
-// The K_RJ values of a thread's 4 consecutive samples of one detector.  den is piecewise
-// linear in the elevation, and the elevation is linear in the sample index to ~5e-8 rad over 4
-// samples (10 ms of scanning, over which den itself moves by ~3e-6 of its value): when the
-// first and last sample share a cell of the axis, den -- or its reciprocal, equal to second
-// order, 1e-11 -- of the inner two is interpolated between the outer ones (float32 rounding
-// apart, the value jax computes); otherwise -- a node between them, a guess that missed, an
-// elevation off the axis -- every sample is looked up on its own at the interpolated
-// elevation.  `sv` already carries the detector's scale.
-template <bool kInverse = false, bool kCurved = false>
-__device__ __forceinline__ void krj_row(const CalDet& c, const float4* C, int n_el, float el_first,
-                                        float el_last, float el_inv, const KrjSamples& k,
+// The K_RJ values of a thread's 4 consecutive samples of one detector.  `sv` already carries the detector's scale.
+// Round 6, two forms:
+//  * the usual row (CalDet::lin): den is linear in the boresight elevation over the whole tile, with at most one kink --
+//    its value at the thread's first and last sample, two reciprocals, the inner two samples on the chord between them
+//    (the elevation is linear in the sample index to ~5e-8 rad over four samples -- 10 ms of scanning, over which den
+//    itself moves by ~3e-6 of its value; a kink inside those 10 ms is missed by 1e-8 of den);
+//  * every other row -- near the zenith (CalDet::exact), off the axis (NaN, as jax fills), a tile that sweeps more than two
+//    cells, a workgroup whose boresight is not linear over a thread's four samples (KrjSamples::curved: 20 Hz, a 0.1 deg
+//    daisy at 0.8 deg/s) -- one sample at a time at its own boresight elevation through den_lookup.  That loop is not
+//    unrolled and reloads what it needs: it must not set the register count of the kernels it is inlined into (the noise
+//    writer ran at five waves per SIMD for it, the pW instance at eight).
+// Rounds 2-5 had a third form between them (per thread: the cell of its first sample, checks that both ends sit in it,
+// the per-sample loop for the threads that straddle a node): 21 instructions a sample wherever the division rode on
+// another kernel's store, and the registers of all three.
+template <bool kInverse = false>
+__device__ __forceinline__ void krj_row(const CalDet& c, const float4* C, int n_el, const KrjSamples& k,
                                         const float (&sv)[kSamplesPerThread], float (&o)[kSamplesPerThread],
-                                        const float* __restrict__ bore_el, int sb, int T) {
+                                        const float* __restrict__ bore_el, int sb, int T, const float4* cells0,
+                                        const float* __restrict__ cal_axis) {
   MRX_KRJ_FP
   constexpr int kL = kSamplesPerThread - 1;
-  if constexpr (kCurved) {
-    // Low sample rates or tight fast scans (20 Hz, a 0.1 deg daisy at 0.8 deg/s: 3e-4 rad of curvature over a thread's
-    // four samples, 1e-4 of den) -- every sample at its own boresight elevation.  The workgroup takes this instance of
-    // its row loop when any of its threads sees more than 1e-6 rad (KrjSamples::curved); never at the rates the
-    // interpolation below was built for (400 Hz: 6e-8 rad).
-    // (one sample at a time, its elevation reloaded: unrolled, or with the four values kept in registers, this
-    // instance would set the kernel's register count -- 98 instead of 96 costs a wave per SIMD and 12 %)
-#pragma unroll 1
-    for (int q = 0; q < kSamplesPerThread; ++q) {
-      const float ebq = bore_el[min(sb + q, T - 1)];
-      float el;
-      if (c.exact) {
-        // (the hardware sine and cosine, in revolutions: 1e-6 rad here, where den hardly moves with the elevation;
-        // cosf / sinf inlined would set the kernel's register count)
-        const float rev = (ebq - 1.57079637050628662109375f) * 0.15915494309189535f;
-        el = det_elevation(c, ebq, __builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
-      } else {
-        el = fmaf(c.slope, ebq - c.ebm, ebq + c.dm);
-      }
-      const float den = den_lookup(el, C, n_el, el_first, el_last, el_inv);
-      const float val = kInverse ? sv[q] * den : sv[q] * __builtin_amdgcn_rcpf(den);
-      o[0] = q == 0 ? val : o[0];
-      o[1] = q == 1 ? val : o[1];
-      o[2] = q == 2 ? val : o[2];
-      o[3] = q == 3 ? val : o[3];
-    }
-    return;
-  }
-  if (__builtin_amdgcn_readfirstlane(c.lin) != 0) {  // (a scalar branch: the row is the workgroup's)
-    // the usual row: den is one linear function of the boresight elevation over the whole tile (CalDet::lin) -- its value at
-    // the thread's first and last sample, two reciprocals, and the inner two samples on the chord between them
-    const float d0 = fmaf(c.lin_b, k.x0, c.lin_a), d3 = fmaf(c.lin_b, k.x3, c.lin_a);
+  if (__builtin_amdgcn_readfirstlane(c.lin) != 0 && !k.curved) {  // (a scalar branch: the row is the workgroup's)
+    const float d0 = fmaf(c.lin_db, fmaxf(k.x0 - c.lin_xn, 0.0f), fmaf(c.lin_b, k.x0, c.lin_a));
+    const float d3 = fmaf(c.lin_db, fmaxf(k.x3 - c.lin_xn, 0.0f), fmaf(c.lin_b, k.x3, c.lin_a));
     if (kInverse) {
       const float step = (d3 - d0) * (1.0f / (float)kL);
 #pragma unroll
@@ -240,48 +271,25 @@ __device__ __forceinline__ void krj_row(const CalDet& c, const float4* C, int n_
     }
     return;
   }
-  float e0, e3;
-  if (c.exact) {  // uniform over the workgroup (one detector row at a time), and rare
-    // (sine and cosine of the boresight elevation on the spot, by the hardware instructions in revolutions -- 1e-6 rad,
-    // where den hardly moves with the elevation: kept per thread for every row they were four registers of a kernel
-    // that sits at a wave-per-SIMD boundary)
-    const float r0 = (k.eb0 - 1.57079637050628662109375f) * 0.15915494309189535f, r3 = (k.eb3 - 1.57079637050628662109375f) * 0.15915494309189535f;
-    e0 = det_elevation(c, k.eb0, __builtin_amdgcn_cosf(r0), __builtin_amdgcn_sinf(r0));
-    e3 = det_elevation(c, k.eb3, __builtin_amdgcn_cosf(r3), __builtin_amdgcn_sinf(r3));
-  } else {
-    e0 = fmaf(c.slope, k.x0, k.eb0 + c.dm);
-    e3 = fmaf(c.slope, k.x3, k.eb3 + c.dm);
-  }
-  const int i0 = min(max((int)fminf(fmaxf((e0 - el_first) * el_inv, -1.0f), 2.0e9f), 0), n_el - 2);
-  const float4 cell = C[i0];
-  const float w0 = (e0 - cell.x) * cell.z, w3 = (e3 - cell.x) * cell.z;
-  // both ends inside cell i0 (0 < w <= 1; the first cell closed below) and on the axis.  A
-  // sample within rounding of a node may be taken for either neighbour: den is continuous there.
-  const float wmin = fminf(w0, w3), wmax = fmaxf(w0, w3);
-  const bool fast = (wmin > 0.0f || (i0 == 0 && wmin >= 0.0f)) && wmax <= 1.0f &&
-                    fminf(e0, e3) >= el_first && fmaxf(e0, e3) <= el_last;
-  const float d0 = fmaf(cell.w, w0, cell.y * (1.0f - w0));  // (den_lookup's arithmetic)
-  const float d3 = fmaf(cell.w, w3, cell.y * (1.0f - w3));
-  if (kInverse) {
-    const float step = (d3 - d0) * (1.0f / (float)kL);
-#pragma unroll
-    for (int q = 0; q < kSamplesPerThread; ++q) o[q] = sv[q] * (q == 0 ? d0 : q == kL ? d3 : fmaf((float)q, step, d0));
-  } else {
-    const float r0 = __builtin_amdgcn_rcpf(d0), r3 = __builtin_amdgcn_rcpf(d3);
-    const float step = (r3 - r0) * (1.0f / (float)kL);
-#pragma unroll
-    for (int q = 0; q < kSamplesPerThread; ++q) o[q] = sv[q] * (q == 0 ? r0 : q == kL ? r3 : fmaf((float)q, step, r0));
-  }
-  if (__builtin_amdgcn_ballot_w64(!fast) != 0) {
-    if (!fast) {
-      const float de = (e3 - e0) * (1.0f / (float)kL);
+  const float el_first = cells0[0].x, el_inv = cells0[0].z, el_last = cal_axis[n_el - 1];
 #pragma unroll 1
-      for (int q = 0; q < kSamplesPerThread; ++q) {
-        const float el = q == 0 ? e0 : q == kL ? e3 : fmaf((float)q, de, e0);
-        const float den = den_lookup(el, C, n_el, el_first, el_last, el_inv);
-        o[q] = kInverse ? sv[q] * den : sv[q] * __builtin_amdgcn_rcpf(den);
-      }
+  for (int q = 0; q < kSamplesPerThread; ++q) {
+    const float ebq = bore_el[min(sb + q, T - 1)];
+    float el;
+    if (c.exact) {
+      // (the hardware sine and cosine, in revolutions: 1e-6 rad here, where den hardly moves with the elevation;
+      // cosf / sinf inlined would set the kernel's register count)
+      const float rev = (ebq - 1.57079637050628662109375f) * 0.15915494309189535f;
+      el = det_elevation(c, ebq, __builtin_amdgcn_cosf(rev), __builtin_amdgcn_sinf(rev));
+    } else {
+      el = fmaf(c.slope, ebq - c.ebm, ebq + c.dm);
     }
+    const float den = den_lookup(el, C, n_el, el_first, el_last, el_inv);
+    const float val = kInverse ? sv[q] * den : sv[q] * __builtin_amdgcn_rcpf(den);
+    o[0] = q == 0 ? val : o[0];
+    o[1] = q == 1 ? val : o[1];
+    o[2] = q == 2 ? val : o[2];
+    o[3] = q == 3 ? val : o[3];
   }
 }
 
@@ -293,16 +301,15 @@ __device__ __forceinline__ KrjSamples krj_prologue(float4* cells, float* red, co
                                                    const float* __restrict__ cal_values, int n_el, int n_bands) {
   MRX_KRJ_FP
   KrjSamples k;
-  k.eb0 = bore_el[min(sb, T - 1)];
-  k.eb3 = bore_el[min(sb + kSamplesPerThread - 1, T - 1)];
+  const float eb0 = bore_el[min(sb, T - 1)], eb3 = bore_el[min(sb + kSamplesPerThread - 1, T - 1)];
   float eb_lo, eb_hi;
   {
     static_assert(kSamplesPerThread == 4, "the curvature check below is written for four samples");
     const float eb1 = bore_el[min(sb + 1, T - 1)], eb2 = bore_el[min(sb + 2, T - 1)];
-    const float third = (k.eb3 - k.eb0) * (1.0f / 3.0f);
-    k.curved = !(fabsf(eb1 - (k.eb0 + third)) <= 1.0e-6f && fabsf(eb2 - fmaf(2.0f, third, k.eb0)) <= 1.0e-6f);  // (a NaN: per sample too)
-    eb_lo = fminf(fminf(k.eb0, eb1), fminf(eb2, k.eb3));
-    eb_hi = fmaxf(fmaxf(k.eb0, eb1), fmaxf(eb2, k.eb3));
+    const float third = (eb3 - eb0) * (1.0f / 3.0f);
+    k.curved = !(fabsf(eb1 - (eb0 + third)) <= 1.0e-6f && fabsf(eb2 - fmaf(2.0f, third, eb0)) <= 1.0e-6f);  // (a NaN: per sample too)
+    eb_lo = fminf(fminf(eb0, eb1), fminf(eb2, eb3));
+    eb_hi = fmaxf(fmaxf(eb0, eb1), fmaxf(eb2, eb3));
   }
   // (the samples are monotone enough that the ends of the threads' 4-sample runs bound the
   // range to ~1e-7 rad): lanes -> waves -> workgroup
@@ -321,8 +328,8 @@ __device__ __forceinline__ KrjSamples krj_prologue(float4* cells, float* red, co
   lo = fminf(fminf(red[0], red[2]), fminf(red[4], red[6]));
   hi = fmaxf(fmaxf(red[1], red[3]), fmaxf(red[5], red[7]));
   const float ebm = 0.5f * (lo + hi);
-  k.x0 = k.eb0 - ebm;
-  k.x3 = k.eb3 - ebm;
+  k.x0 = eb0 - ebm;
+  k.x3 = eb3 - ebm;
   if (threadIdx.x == 0) {
     red[8] = lo;
     red[9] = hi;
@@ -345,7 +352,7 @@ __device__ __forceinline__ void krj_stage_rows(CalDet* cdet, float* red, const f
     if ((int)threadIdx.x < nd) {
       const int d = d0 + threadIdx.x;
       CalDet c = make_cal_det(dxs[d], dys[d], min(max(band[d], 0), n_bands - 1), scale ? scale[d] : 1.0f);
-      set_elevation_model(c, 0.5f * (lo + hi));
+      set_elevation_model(c, 0.5f * (lo + hi), bore_trig(0.5f * (lo + hi)));
       // the model is a finite difference over ebm +- 0.02 rad: a tile whose boresight sweeps
       // farther (slow sample rates, fast elevation slews) takes the full formula per sample
       if (!(hi - lo <= 2.0f * kModelHalfRange)) c.exact = 1;

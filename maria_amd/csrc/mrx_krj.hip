@@ -52,8 +52,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
   const int jmax = interval_of((t[s_last] - ta0) * inv_dta, n) + 1;
   const int K = jmax - jmin + 1;
   const bool use_lds = K <= kMaxKnots;
-  const float el_first = cal_cells[0].x, el_last = cal_axis[n_el - 1];
-  const float el_inv = cal_cells[0].z;
   const bool full = (sb + kSamplesPerThread <= T) && vec_ok;
   int r[kSamplesPerThread];
 #pragma unroll
@@ -78,7 +76,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
     __syncthreads();
     // the loop body is instantiated once per knot source so that each instance
     // addresses one memory space (a runtime select would force flat loads)
-    auto body = [&](auto from_lds, auto curved) {
+    auto body = [&](auto from_lds) {
     for (int dl = 0; dl < nd; ++dl) {
       const CalDet c = cdet[dl];
       const float4* C = cal_cells + c.band * (n_el - 1);
@@ -95,7 +93,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
         }
         sv[q] = c.scale * spline_eval(w, q, k0, k1);
       }
-      krj_row<false, decltype(curved)::value>(c, C, n_el, el_first, el_last, el_inv, ks, sv, o, bore_el, sb, T);
+      krj_row<false>(c, C, n_el, ks, sv, o, bore_el, sb, T, cal_cells, cal_axis);
       float* dst = out + row_of(dl, d0 + dl) * ld + sb;
       if (full) {
         const vfloat4 v = {o[0], o[1], o[2], o[3]};
@@ -107,11 +105,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5))) voi
       }
     }
     };
-    if (ks.curved) {  // (uniform)
-      if (use_lds) body(std::true_type{}, std::true_type{}); else body(std::false_type{}, std::true_type{});
-    } else {
-      if (use_lds) body(std::true_type{}, std::false_type{}); else body(std::false_type{}, std::false_type{});
-    }
+    if (use_lds) body(std::true_type{}); else body(std::false_type{});
   }
 }
 
@@ -190,10 +184,7 @@ __global__ __launch_bounds__(kBlock) void tod_krj_kernel(
   if ((int)threadIdx.x < nd) row_lds[threadIdx.x] = rows ? rows[d0 + threadIdx.x] : d0 + (int)threadIdx.x;
   __syncthreads();
   if (sb >= T) return;
-  const float el_first = cal_cells[0].x, el_last = cal_axis[n_el - 1];
-  const float el_inv = cal_cells[0].z;
   const bool full = (sb + kSamplesPerThread <= T) && vec_ok;
-  auto rows_loop = [&](auto curved) {
   for (int dl = 0; dl < nd; ++dl) {
     const CalDet c = cdet[dl];
     const float4* C = cal_cells + c.band * (n_el - 1);
@@ -209,7 +200,7 @@ __global__ __launch_bounds__(kBlock) void tod_krj_kernel(
     float sv[kSamplesPerThread];
 #pragma unroll
     for (int q = 0; q < kSamplesPerThread; ++q) sv[q] = c.scale * v[q];
-    krj_row<kInverse, decltype(curved)::value>(c, C, n_el, el_first, el_last, el_inv, ks, sv, v, bore_el, sb, T);
+    krj_row<kInverse>(c, C, n_el, ks, sv, v, bore_el, sb, T, cal_cells, cal_axis);
     if (full) {
       const vfloat4 x = {v[0], v[1], v[2], v[3]};
       __builtin_nontemporal_store(x, reinterpret_cast<vfloat4*>(row));
@@ -219,8 +210,6 @@ __global__ __launch_bounds__(kBlock) void tod_krj_kernel(
         if (sb + q < T) row[q] = v[q];
     }
   }
-  };
-  if (ks.curved) rows_loop(std::true_type{}); else rows_loop(std::false_type{});  // (uniform)
 }
 
 

@@ -572,14 +572,26 @@ __device__ __forceinline__ void row_samples(const MapArgs& g, const Axis& ax_eta
 }
 
 __device__ __forceinline__ DetConst make_det_const(const MapArgs& g, int d) {
+  // transforms.py:14-23: r = |offset|, p = atan2(-dx, -dy); c = (sin r cos p, cos r, sin r sin p) = (-dy s, cos r, -dx s) with
+  // s = sin(r) / r.  Round 6: the series of mrx_krj.h for a focal-plane offset (exact to a float32 rounding below 0.3 rad)
+  // instead of a square root, an arctangent and four sines and cosines -- once per row and tile, but on sixteen lanes of
+  // one wave while the workgroup waits at the barrier behind it.
   const float dx = g.dx[d], dy = g.dy[d];
-  const float r = sqrtf(dx * dx + dy * dy);
-  const float p = atan2f(-dx, -dy);
-  const float sr = sinf(r);
+  const float r2 = fmaf(dx, dx, dy * dy);
   DetConst dc;
-  dc.c_re = __fmul_rn(sr, cosf(p));
-  dc.c_cr = cosf(r);
-  dc.c_im = __fmul_rn(sr, sinf(p));
+  if (r2 < 0.09f) {
+    const float sc = sinc_small(r2);
+    dc.c_re = -dy * sc;
+    dc.c_cr = cos_small(r2);
+    dc.c_im = -dx * sc;
+  } else {
+    const float r = sqrtf(r2);
+    const float p = atan2f(-dx, -dy);
+    const float sr = sinf(r);
+    dc.c_re = __fmul_rn(sr, cosf(p));
+    dc.c_cr = cosf(r);
+    dc.c_im = __fmul_rn(sr, sinf(p));
+  }
   for (int k = 0; k < kMaxStokes; ++k) dc.w[k] = k < g.S ? g.stokes_w[(size_t)d * g.S + k] : 0.0;
   return dc;
 }
@@ -1134,7 +1146,6 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kChain ?
   KrjSamples ks{};
   if constexpr (kKrj) ks = krj_prologue(cal_cells, red, kj.bore_el, g.T, sb, kj.cal_axis, kj.cal_values, kj.n_el, kj.n_bands);  // (ends with a barrier)
   __syncthreads();
-  const float el_first = kKrj ? cal_cells[0].x : 0.0f, el_last = kKrj ? kj.cal_axis[kj.n_el - 1] : 0.0f, el_inv = kKrj ? cal_cells[0].z : 0.0f;
   if (kCal) {
     cl.pwv = make_rgi_axis(cal_lds, g.n_pwv);
     cl.el = make_rgi_axis(cal_lds + g.n_pwv, g.n_el);
@@ -1362,10 +1373,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kChain ?
 #pragma unroll
       for (int q = 0; q < kSamplesPerThread; ++q) sv[q] = c.scale * o[q];
       const float4* C = cal_cells + c.band * (kj.n_el - 1);
-      // (curved: a workgroup whose boresight elevation is not linear over a thread's four samples -- low sample rates --
-      // looks every sample up at its own elevation; uniform)
-      if (ks.curved) krj_row<false, true>(c, C, kj.n_el, el_first, el_last, el_inv, ks, sv, o, kj.bore_el, sb, g.T);
-      else krj_row<false, false>(c, C, kj.n_el, el_first, el_last, el_inv, ks, sv, o, kj.bore_el, sb, g.T);
+      krj_row<false>(c, C, kj.n_el, ks, sv, o, kj.bore_el, sb, g.T, cal_cells, kj.cal_axis);
     }
     float* dst = g.out + (size_t)d * g.ld + sb;
     if (full) {

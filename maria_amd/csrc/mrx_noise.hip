@@ -887,7 +887,6 @@ __global__ __launch_bounds__(kBlock) void noise_two_rate_kernel(const mrx_two_ra
     }
   }
   const bool full = sb + kSamplesPerThread <= a.T && (a.ld & 3) == 0 && (reinterpret_cast<uintptr_t>(a.out) & 15) == 0;
-  const float el_first = kKrj ? cal_cells[0].x : 0.0f, el_last = kKrj ? a.cal_axis[a.n_el - 1] : 0.0f, el_inv = kKrj ? cal_cells[0].z : 0.0f;
   // Catmull-Rom weights of (P[-1], P[0], P[1], P[2]) at u = 1/4, 1/2, 3/4 (u = 0: P[0] itself)
   constexpr float kW14[4] = {-0.0703125f, 0.8671875f, 0.2265625f, -0.0234375f};
   constexpr float kW12[4] = {-0.0625f, 0.5625f, 0.5625f, -0.0625f};
@@ -903,7 +902,7 @@ __global__ __launch_bounds__(kBlock) void noise_two_rate_kernel(const mrx_two_ra
     q4 = a.rate == 4 ? 0.0f : lo[slow_at + 4];
     sc = a.scale ? a.scale[a.row0 + r0 + dl] : 1.0f;
   };
-  auto rows_loop = [&](auto curved) {
+  {
     nvfloat4u q_next;
     float q4_next, sc_next;
     fetch_slow(0, q_next, q4_next, sc_next);
@@ -949,8 +948,7 @@ __global__ __launch_bounds__(kBlock) void noise_two_rate_kernel(const mrx_two_ra
       float o[kSamplesPerThread];
       if constexpr (kKrj) {
         const CalDet c = cdet[dl];
-        krj_row<false, decltype(curved)::value>(c, cal_cells + c.band * (a.n_el - 1), a.n_el, el_first, el_last, el_inv, ks, sv, o,
-                                                a.bore_el, sb, a.T);
+        krj_row<false>(c, cal_cells + c.band * (a.n_el - 1), a.n_el, ks, sv, o, a.bore_el, sb, a.T, cal_cells, a.cal_axis);
       } else {
 #pragma unroll
         for (int q = 0; q < kSamplesPerThread; ++q) o[q] = sv[q];
@@ -967,8 +965,7 @@ __global__ __launch_bounds__(kBlock) void noise_two_rate_kernel(const mrx_two_ra
           if (sb + q < a.T) dst[q] = a.accumulate ? dst[q] + o[q] : o[q];
       }
     }
-  };
-  if (kKrj && ks.curved) rows_loop(std::true_type{}); else rows_loop(std::false_type{});  // (uniform)
+  }
 }
 
 }  // namespace
