@@ -94,3 +94,29 @@ def test_recorded_bench_lines_carry_the_contract_fields():
             assert 1.0 <= roof["traffic"] / roof["bytes_per_launch"] < 1.15
             # the wall-clock figure against the same steps on the GPU's own clock: no host stall inside the timed region
             assert 0.97 < line["gpu_ms_per_step"] / line["ms_per_step"] <= 1.0
+
+
+def test_the_gather_that_value_takes_is_the_fastest_verified_one():
+    """bench.py at N > 1 times both all-gathers (default --gather-algo both) and puts the FASTER one whose probe found the next
+    rank's rows bit-identical into `value` (select_gather); a variant that errors or fails its probe is named and the other
+    taken; with none left `value` stays the synthesis alone -- the line is never lost.  Entries shaped as
+    the gather section records them."""
+    ok = lambda ms: {"ms": ms, "rows_of_next_rank_bit_identical": True}  # noqa: E731
+    assert bench.parse_args([]).gather_algo == "both"
+    # both verified: the faster one, whichever ran first
+    algo, why = bench.select_gather({"allgather": ok(28.0), "p2p": ok(8.1)})
+    assert algo == "p2p" and "28.00 ms" in why
+    algo, _ = bench.select_gather({"allgather": ok(7.9), "p2p": ok(8.1)})
+    assert algo == "allgather"
+    # the faster one failed its probe: the slower verified one
+    algo, why = bench.select_gather({"allgather": ok(28.0), "p2p": {"ms": 8.0, "rows_of_next_rank_bit_identical": False}})
+    assert algo == "allgather" and "did not verify" in why
+    # one raised: the other; and said so
+    algo, why = bench.select_gather({"allgather": {"error": "RuntimeError: ncclAllGather failed"}, "p2p": ok(9.0)})
+    assert algo == "p2p" and "failed" in why
+    # nothing usable: no gather in `value`, with the reasons
+    algo, why = bench.select_gather({"allgather": {"error": "timeout"}, "p2p": {"ms": 8.0, "rows_of_next_rank_bit_identical": False}})
+    assert algo is None and "synthesis alone" in why and "timeout" in why
+    assert bench.select_gather({}) == (None, "no verified variant (no variant ran): value stays the synthesis alone")
+    # a single variant (--gather-algo p2p)
+    assert bench.select_gather({"p2p": ok(8.0)}) == ("p2p", "the only variant run")

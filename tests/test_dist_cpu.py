@@ -53,7 +53,12 @@ def test_all_gather_tod_gloo(n_det, world):
     T = 23
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() + n_det) % 2000
+    # a free port of this case's own (a formula of the pid and the row count gave (217, 2) and (217, 8) the same one)
+    import socket
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
     procs = [ctx.Process(target=_worker, args=(r, world, port, n_det, T, q)) for r in range(world)]
     for p in procs:
         p.start()
