@@ -564,13 +564,19 @@ def run(args):
         torch.cuda.synchronize()
         scr_ms.append(e0.elapsed_time(e1))
     screens_alone_ms = float(np.median(scr_ms[1:]))
+    # (round 6: one untimed pass, then the MEDIAN of seven -- the mean of three passes, the first of them cold, scattered by
+    # +-4 % from run to run on one box, more than the differences it was read for: profiles/r06_writer_bisect.txt)
+    n_serial = 7
+    serial_step([])
+    torch.cuda.synchronize()
     sev = []
-    for k in range(3):
+    for k in range(n_serial):
         serial_step(sev)
     torch.cuda.synchronize()
-    # per stage: the sum over a step's block launches, averaged over the 3 passes
-    serial_ms = np.array([[t[i].elapsed_time(t[i + 1]) for i in range(2)] for t in sev]).sum(axis=0) / 3.0
-    serial_up_launch_ms = float(np.mean([t[1].elapsed_time(t[2]) for t in sev]))
+    # per stage: the sum over a step's block launches in a pass, the median over the passes
+    per_pass = np.array([[t[i].elapsed_time(t[i + 1]) for i in range(2)] for t in sev]).reshape(n_serial, -1, 2).sum(axis=1)
+    serial_ms = np.median(per_pass, axis=0)
+    serial_up_launch_ms = float(np.median([t[1].elapsed_time(t[2]) for t in sev]))
     step_ms = np.array([[ev[k][i].elapsed_time(ev[k][i + 1]) for i in range(2)] for k in range(args.steps)]).mean(axis=0)
     # the dominant kernel, timed live in the timed region on the stream it runs on: one launch
     # per detector block when the step is pipelined (its rows x T samples each)
@@ -631,7 +637,8 @@ def run(args):
                      "DevicePath.run() on the caller's stream -- with overlapping steps these intervals overlap too and do not add up to ms_per_step")
             if lookahead else "events on the caller's stream around the two stages of every timed step",
             "serial_breakdown": {"sample": sm_ms, "upsample_with_spline_solve": float(serial_ms[1]),
-                                 "note": "the same block launches back to back on one stream, outside the timed region; sums over the blocks"},
+                                 "note": "the same block launches back to back on one stream, outside the timed region; sums over the blocks, "
+                                         "median of seven passes after an untimed one"},
             "detector_blocks": n_launch,
             "form": ("one launch (mrx_atm_synthesize): sampler and writer as two roles of one grid, hand-over on the device"
                      if one_launch else "detector blocks pipelined on two streams" if n_blocks > 1 else "stages back to back on one stream"),

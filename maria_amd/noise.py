@@ -17,6 +17,13 @@ import torch
 from ._lib import ptr
 
 DEFAULT_NOISE_SIM_KWARGS = {"correlated_noise_proportion": 0.5, "correlated_noise_spatial_scale": 1.0}  # sim/noise.py:11
+# One keyword beyond the reference's: ``exact_spectrum`` (False).  From 32 768 samples on, where the pink part at a quarter
+# (or half) of the Nyquist frequency is below 2 % of the white level, the generator makes the pink parts at a quarter (half)
+# of the sample rate and interpolates them (csrc/mrx_noise.hip, the two-rate form: 5 instead of 8 ms at 10 000 x 240 000):
+# the pink power above fs / (2 rate) -- under 2 % of the spectrum there -- is left out and the octave below loses up to 4 %
+# of its pink part.  ``Simulation(noise_kwargs={"exact_spectrum": True})`` keeps the reference's a / |f| up to fs / 2
+# (noise/generation.py:27-38; the one-rate form) at that price.
+EXACT_SPECTRUM_BIT = 8  # of MRX_OPT_NOISE_GENERIC
 
 
 def spatial_basis(offsets, k: int = 5, n_side: int = 16, scale: float = 1.0):
@@ -57,8 +64,19 @@ def simulate_noise(ctx, dets, T, sample_rate, seed, noise_kwargs=None, device="c
     begin or end inside a detector pair): a shard's rows equal the same rows of the unsharded call,
     modes included.  ``krj``: ``DevicePath.krj_row_tables()`` -- the field is then written in K_RJ
     (mrx_noise_generate_krj: TOD.to("K_RJ"), tod/tod.py:106-142, on the generator's own store where its two-rate form applies)."""
+    from ._lib import OPT_NOISE_GENERIC
+
     kw = dict(DEFAULT_NOISE_SIM_KWARGS)
     kw.update(noise_kwargs or {})
+    if kw.get("exact_spectrum"):
+        # the one-rate form for this call; whatever the option held (its other bits are cross-checks of the tests) comes back
+        before = ctx.__dict__.get("_options", {}).get(OPT_NOISE_GENERIC, 0)
+        ctx.set_option(OPT_NOISE_GENERIC, before | EXACT_SPECTRUM_BIT)
+        try:
+            return simulate_noise(ctx, dets, T, sample_rate, seed, dict(kw, exact_spectrum=False), device=device, batch=batch, out=out,
+                                  loading=loading, det_slice=det_slice, krj=krj)
+        finally:
+            ctx.set_option(OPT_NOISE_GENERIC, before)
     dev = torch.device(device)
     lo, hi = (0, dets.n) if det_slice is None else (det_slice.start or 0, dets.n if det_slice.stop is None else det_slice.stop)
     if out is None:

@@ -414,3 +414,45 @@ def test_work_buffer_size_covers_the_two_rate_form_for_small_batches(gpu_ctx, T,
     # the top of the band is white at the model's level: own part + the modes through this row of the basis
     p = (np.abs(np.fft.rfft(x, axis=1)) ** 2)[:, np.fft.rfftfreq(T, 1 / fs) > 0.4 * fs].mean(axis=1)
     np.testing.assert_allclose(p / (T * fs * (1 + 0.3 * (B**2).sum(axis=1))), 1.0, rtol=0.1)
+
+
+@pytest.mark.parametrize("exact", [False, True], ids=["two_rate_default", "exact_spectrum"])
+def test_front_end_spectrum_against_the_reference_law(gpu_ctx, exact):
+    """BOTH forms of the generator, as the front end selects them -- the default (two-rate from 32 768 samples on) and
+    ``noise_kwargs={"exact_spectrum": True}`` (the one-rate form) -- against the reference's own law, not against each other:
+    noise/generation.py:27-38 gives a two-sided pink spectrum a / |f|, a = knee / 2, beside white noise of variance fs, i.e.
+    a one-sided density 2 NEP^2 (1 + knee / f).  Octave bands from 16 bins of the TOD up to fs / 2: every band within its own
+    statistical error (3 sigma) + 0.7 % -- except that the two-rate form may miss what it says it leaves out:
+    the pink power above fs / 8 (rate 4), at most 2 % of the density there, and up to 4 % of the pink part in the octave
+    below -- nothing anywhere else."""
+    from maria_amd import noise as mnoise
+    from maria_amd.instrument import Band, Detectors
+
+    fs, knee, T, D = 400.0, 1.0, 120000, 128
+    band = Band(center=150e9, width=30e9, shape="top_hat", name="f150", NEP=1e-12, knee=knee)  # 1e12 NEP = 1: the density in units of NEP^2
+    dets = Detectors.hexagon(D, 0.5, [band], primary_size=10.0)
+    kwargs = {"correlated_noise_proportion": 0.0, "exact_spectrum": exact}
+    x = mnoise.simulate_noise(gpu_ctx, dets, T, fs, seed=11, noise_kwargs=kwargs).cpu().numpy().astype(np.float64)
+    assert gpu_ctx.__dict__.get("_options", {}).get(5, 0) == 0  # the option is back where it was
+    f = np.fft.rfftfreq(T, 1 / fs)
+    p = (np.abs(np.fft.rfft(x, axis=1)) ** 2).mean(axis=0) * 2.0 / (fs * T)  # one-sided density
+    want = 2.0 * (1.0 + knee / np.maximum(f, 1e-30))
+    hi = fs / 2
+    while hi / 2 >= 16 * fs / T:  # octaves downwards from the Nyquist frequency: the slow rate's own edges are among them
+        lo = hi / 2
+        m = (f >= lo) & (f < hi)
+        ratio = p[m].sum() / want[m].sum()
+        sigma = 1.0 / np.sqrt(m.sum() * D)
+        allowed_low = 0.0
+        if not exact:
+            pink_share = (knee / f[m]).sum() / (1.0 + knee / f[m]).sum()
+            if lo >= fs / 8 * (1 - 1e-9):
+                allowed_low = pink_share  # the pink part above the slow Nyquist frequency (fs / 8 at rate 4) is not made at all
+            elif hi >= fs / 8 * (1 - 1e-9):
+                allowed_low = 0.04 * pink_share  # the cubic's roll-off in the octave below
+        assert -(3 * sigma + 0.007 + allowed_low) < ratio - 1 < 3 * sigma + 0.007, (lo, hi, ratio, sigma, allowed_low)
+        hi = lo
+    if not exact:
+        # ... and the default DID take the two-rate form here: another realisation than the exact one
+        y = mnoise.simulate_noise(gpu_ctx, dets, T, fs, seed=11, noise_kwargs=dict(kwargs, exact_spectrum=True)).cpu().numpy()
+        assert not np.array_equal(x.astype(np.float32), y)
