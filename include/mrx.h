@@ -122,7 +122,11 @@ enum {
                                     side by side: the writers follow the samplers a few chunks behind); 1 = row group by row group, the
                                     time tiles of a row group in a row (the order the chip stores fastest; a block's tiles then wait
                                     for the whole block: give block_rows) */
-  MRX_OPT_COUNT = 12
+  MRX_OPT_GAUSS_ACCUM = 12, /* mrx_gauss_smooth2d / mrx_map_smooth: 0 = float32 products summed over 16 taps and those sums
+                               in float64 from radius 16 on (<= 1e-6 of scipy's float64 sums, twice as fast), scipy's float64
+                               arithmetic below; 1 = float64 always ("exact": <= 2.5e-7, float32 roundings of the result);
+                               2 = the blocked sums at every radius */
+  MRX_OPT_COUNT = 13
 };
 int mrx_set_option(mrx_ctx* ctx, int option, int value);
 const char* mrx_last_error(const mrx_ctx* ctx);

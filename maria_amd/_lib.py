@@ -32,6 +32,7 @@ OPT_NOISE_LANES = 8
 OPT_SCREEN_STOCKHAM = 9
 OPT_SYNTH_WGS_PER_CU = 10
 OPT_SYNTH_TILE_ORDER = 11
+OPT_GAUSS_ACCUM = 12
 
 _STATUS = {
     0: "MRX_OK",

@@ -29,9 +29,26 @@ __device__ __forceinline__ int reflect_index(int i, int n) {
   return m < n ? m : p - 1 - m;
 }
 
-// Both passes stage tile + halo in LDS already widened to float64 (one
-// conversion per element instead of one per tap) and follow scipy's symmetric
-// summation: centre tap, then (left + right) * w_k.
+// The same for an index that is the same in every lane of the wave (a row of the y pass): the fold -- two integer
+// divisions, forty instructions -- only where the row does lie outside the array, decided on the scalar unit.  (Per
+// element it was most of the y pass at large radii: 78 rows staged per thread for 8 outputs.)
+__device__ __forceinline__ int reflect_row(int i, int n) {
+  const int u = __builtin_amdgcn_readfirstlane(i);
+  return (u >= 0 && u < n) ? u : reflect_index(u, n);
+}
+
+// Both passes stage tile + halo in LDS as float32 and widen a value when it is read; a thread makes four outputs from ONE
+// sliding window, so the taps meet the values in window order -- NOT scipy's symmetric order (centre tap, then
+// (left + right) w_k): the float64 sums differ from scipy's by their association, i.e. by float32 roundings of the result
+// (the parity test holds the exact mode to 2.5e-7, a last-bit flip in a few per cent of the pixels).
+//
+// Two accumulation modes (MRX_OPT_GAUSS_ACCUM):
+//  * exact: every product and sum in float64, scipy's arithmetic -- bound by the float64 multiply-adds (2 radius + 1 per
+//    pixel and pass at half the float32 rate, plus a conversion a value);
+//  * blocked (round 6): float32 products summed in float32 over 16 window steps, the 16-step sums added up in float64.
+//    A block's sum carries at most 16 float32 roundings of terms that are 1/16 .. 1/257 of the result: measured 1.5e-7
+//    against scipy (float64) at 257 taps, bound 1e-6 in the test -- ten times inside the north star's 1e-5 -- at twice the
+//    speed.  The default from radius 16 (sigma >= 4 pixels); smaller stencils are not bound by their arithmetic.
 
 // pass along x (contiguous axis): one workgroup = 1024 consecutive outputs of a row, a thread 4 consecutive ones from
 // ONE sliding window of 2 radius + 4 values: the window comes out of LDS 16 bytes a read (conflict-free: a lane's four
@@ -42,43 +59,99 @@ __device__ __forceinline__ int reflect_index(int i, int n) {
 constexpr int kXPerThread = 4;
 constexpr int kXCols = kBlock * kXPerThread;
 
+constexpr int kAccBlock = 16;  // window steps per float32 partial sum (blocked mode)
+
+// The taps as the kernels read them, in global memory: [4 zeros][ntap taps][zeros up to a whole block past the window] as
+// float64, then the same as float32 (get_taps).  The index of a tap is the same for every lane, so the compiler fetches
+// them with SCALAR loads (16 bytes at a time in the blocked mode: the 4 zeros in front keep the taps of window steps
+// k .. k + 3, k a multiple of 4, on a 16-byte boundary) and a tap is a scalar operand of its multiply-add.  Rounds 1-5
+// staged them in LDS and read them back per step: every lane the same address, but a read all the same -- half of the
+// LDS traffic of the x pass, and what bound both passes (round 6: float32 sums alone gained 5 %).
+__host__ __device__ inline int gauss_tap_slots(int ntap) { return (4 + ntap + 7 + kAccBlock + 3) & ~3; }
+
+// kXRows rows of the plane per workgroup, staged together (one barrier; a thread's loads of all of them in flight at once):
+// with one row a workgroup the pass was a chain of load - barrier - 300 multiply-adds - store per 1024 outputs, 65 536
+// workgroups of it at 8192^2, and waited more than it computed.
+constexpr int kXRows = 4;
+
+template <bool kBlocked>
 __global__ __launch_bounds__(kBlock) void gauss_x_kernel(
     const float* __restrict__ in, float* __restrict__ out, int ny, int nx,
-    const double* __restrict__ taps, int radius) {
-  extern __shared__ double ldsd[];
+    const double* __restrict__ tapsd, const float* __restrict__ tapsf, int radius) {
+  extern __shared__ __align__(16) float img_all[];  // [kXRows][pitch], pitch = span + 4 + kAccBlock rounded up to 4
   const int ntap = 2 * radius + 1;
   const int span = kXCols + 2 * radius;
-  double* wz = ldsd;                                             // [3 zeros][ntap taps][3 zeros]
-  float* img = reinterpret_cast<float*>(ldsd + ((ntap + 6 + 1) & ~1));  // 16-byte aligned: [span + 4]
-  const int y = blockIdx.y;
+  const int pitch = (span + 4 + kAccBlock + 3) & ~3;
+  const int y_first = blockIdx.y * kXRows;
   const int x0 = blockIdx.x * kXCols;
-  const float* src = in + (size_t)y * nx;
-  for (int i = threadIdx.x; i < span + 4; i += kBlock)
-    img[i] = i < span ? src[reflect_index(x0 - radius + i, nx)] : 0.0f;
-  for (int k = threadIdx.x; k < ntap + 6; k += kBlock)
-    wz[k] = (k >= 3 && k < ntap + 3) ? taps[k - 3] : 0.0;
+  // (a tile whose window lies inside the row takes its values as they stand: the fold of reflect_index -- two integer
+  // divisions per element -- and its branches kept the loads from being issued together)
+  const bool interior = x0 - radius >= 0 && x0 - radius + span <= nx;
+#pragma unroll
+  for (int r = 0; r < kXRows; ++r) {
+    const int y = min(y_first + r, ny - 1);
+    const float* src = in + (size_t)y * nx;
+    float* img = img_all + r * pitch;
+    if (interior) {
+      const float* s0 = src + (x0 - radius);
+#pragma unroll 4
+      for (int i = threadIdx.x; i < pitch; i += kBlock) img[i] = i < span ? s0[i] : 0.0f;
+    } else {
+      for (int i = threadIdx.x; i < pitch; i += kBlock)
+        img[i] = i < span ? src[reflect_index(x0 - radius + i, nx)] : 0.0f;
+    }
+  }
   __syncthreads();
   const int x = x0 + threadIdx.x * kXPerThread;
   if (x >= nx) return;
-  // outputs x .. x + 3 read img[4 tid .. 4 tid + 2 radius + 3]; window step k: value img[4 tid + k], taps wz[k + 3 - j]
-  const float4* c4 = reinterpret_cast<const float4*>(img + threadIdx.x * kXPerThread);
+  const int steps = ntap + 3;  // (the steps past the window meet zero taps and the image's zero padding)
+  for (int r = 0; r < kXRows && y_first + r < ny; ++r) {
+  const int y = y_first + r;
+  // outputs x .. x + 3 read img[4 tid .. 4 tid + 2 radius + 3]; window step k: value img[4 tid + k], tap of output j: step k - j
+  const float4* c4 = reinterpret_cast<const float4*>(img_all + r * pitch + threadIdx.x * kXPerThread);
   double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-  double t1 = 0.0, t2 = 0.0, t3 = 0.0;  // wz[k + 2], wz[k + 1], wz[k]
-  const int steps = ntap + 3;            // (the last group of four reads up to 3 values past the window: zero taps)
-  for (int k = 0; k < steps; k += 4) {
-    const float4 q = c4[k >> 2];
-    const float v[4] = {q.x, q.y, q.z, q.w};
+  if constexpr (kBlocked) {
+    float t1 = 0.0f, t2 = 0.0f, t3 = 0.0f;
+    for (int k = 0; k < steps; k += kAccBlock) {
+      float p0 = 0.0f, p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const double t0 = k + i < steps ? wz[k + i + 3] : 0.0;
-      const double vv = (double)v[i];
-      acc0 += t0 * vv;
-      acc1 += t1 * vv;
-      acc2 += t2 * vv;
-      acc3 += t3 * vv;
-      t3 = t2;
-      t2 = t1;
-      t1 = t0;
+      for (int kk = 0; kk < kAccBlock; kk += 4) {
+        const float4 q = c4[(k + kk) >> 2];
+        const float v[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float t0 = tapsf[4 + k + kk + i];  // (uniform: a scalar load)
+          p0 = fmaf(t0, v[i], p0);
+          p1 = fmaf(t1, v[i], p1);
+          p2 = fmaf(t2, v[i], p2);
+          p3 = fmaf(t3, v[i], p3);
+          t3 = t2;
+          t2 = t1;
+          t1 = t0;
+        }
+      }
+      acc0 += (double)p0;
+      acc1 += (double)p1;
+      acc2 += (double)p2;
+      acc3 += (double)p3;
+    }
+  } else {
+    double t1 = 0.0, t2 = 0.0, t3 = 0.0;  // the taps of the three steps before
+    for (int k = 0; k < steps; k += 4) {
+      const float4 q = c4[k >> 2];
+      const float v[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const double t0 = tapsd[4 + k + i];
+        const double vv = (double)v[i];
+        acc0 += t0 * vv;
+        acc1 += t1 * vv;
+        acc2 += t2 * vv;
+        acc3 += t3 * vv;
+        t3 = t2;
+        t2 = t1;
+        t1 = t0;
+      }
     }
   }
   float* dst = out + (size_t)y * nx + x;
@@ -90,61 +163,113 @@ __global__ __launch_bounds__(kBlock) void gauss_x_kernel(
     for (int j = 0; j < 4; ++j)
       if (x + j < nx) dst[j] = (float)acc[j];
   }
+  }
 }
 
-// pass along y: tile of tile_rows outputs x 64 columns; 4 row groups of threads.
-// A thread produces 4 consecutive output rows from one sliding window of
-// 2*radius + 4 LDS values (one data read and one tap read per step, 4 FMAs), which
-// cuts the LDS traffic -- what bounds this pass -- by 2.7x against one output at a
-// time.  wz holds the full symmetric tap row with 3 zeros on either side.
+// pass along y: tile of tile_rows outputs x 64 columns; 4 row groups of threads.  A thread produces kRows consecutive
+// output rows from ONE sliding window of 2 radius + kRows LDS values: one 4-byte LDS read per step and kRows multiply-adds
+// on scalar taps.  kRows = 8 (round 6; 4 before): with four outputs a step the pass was bound by those reads -- a wave's
+// read takes the LDS two cycles, its four multiply-adds the SIMD eight, and four SIMDs share the LDS.  kRows = 4 stays for
+// the tiles of 16 rows that the largest radii need.
 constexpr int kYCols = 64;
-constexpr int kYBlockRows = 4;  // output rows per thread per sweep
 
+template <bool kBlocked, int kRows>
 __global__ __launch_bounds__(kBlock) void gauss_y_kernel(
     const float* __restrict__ in, float* __restrict__ out, int ny, int nx,
-    const double* __restrict__ taps, int radius, int tile_rows) {
-  // float32 image (this pass waits on memory, not on LDS: a small image keeps
-  // 8 workgroups per CU in flight); values widen to float64 as they are read
-  extern __shared__ double ldsd[];
+    const double* __restrict__ tapsd, const float* __restrict__ tapsf, int radius, int tile_rows) {
+  // float32 image; values widen to float64 as they are read (exact mode)
+  extern __shared__ __align__(16) float img[];
   const int lane = threadIdx.x % kYCols;
   const int grp = threadIdx.x / kYCols;     // 0..3
   const int x = blockIdx.x * kYCols + lane;
   const int y0 = blockIdx.y * tile_rows;
   const int span = tile_rows + 2 * radius;
   const int ntap = 2 * radius + 1;
-  double* wz = ldsd;                          // [3 zeros][ntap taps][3 zeros]
-  float* img = reinterpret_cast<float*>(ldsd + ntap + 6);
   const int xs = min(x, nx - 1);
-  for (int i = grp; i < span; i += kBlock / kYCols)
-    img[i * kYCols + lane] =
-        in[(size_t)reflect_index(y0 - radius + i, ny) * nx + xs];
-  for (int k = threadIdx.x; k < ntap + 6; k += kBlock)
-    wz[k] = (k >= 3 && k < ntap + 3) ? taps[k - 3] : 0.0;
+  // (the window is walked in whole blocks: kAccBlock + kRows rows of zeros behind the image for the steps past it)
+  if (y0 - radius >= 0 && y0 - radius + span <= ny) {
+    // an interior tile: its rows as they stand, eight loads of a thread in flight together (with the fold's branch in the
+    // loop every row waited for its own load: 38 memory latencies a thread at radius 32, most of the pass)
+    const float* s0 = in + (size_t)(y0 - radius) * nx + xs;
+    int i = grp;
+    for (; i + 7 * (kBlock / kYCols) < span; i += 8 * (kBlock / kYCols)) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = s0[(size_t)(i + u * (kBlock / kYCols)) * nx];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) img[(i + u * (kBlock / kYCols)) * kYCols + lane] = v[u];
+    }
+    for (; i < span + kAccBlock + kRows; i += kBlock / kYCols) img[i * kYCols + lane] = i < span ? s0[(size_t)i * nx] : 0.0f;
+  } else {
+    for (int i = grp; i < span + kAccBlock + kRows; i += kBlock / kYCols)
+      img[i * kYCols + lane] = i < span ? in[(size_t)reflect_row(y0 - radius + i, ny) * nx + xs] : 0.0f;
+  }
   __syncthreads();
   if (x >= nx) return;
   const int rows_per_grp = tile_rows / (kBlock / kYCols);
-  for (int r0 = grp * rows_per_grp; r0 < (grp + 1) * rows_per_grp; r0 += kYBlockRows) {
+  const int steps = ntap + kRows - 1;
+  for (int r0 = grp * rows_per_grp; r0 < (grp + 1) * rows_per_grp; r0 += kRows) {
     if (y0 + r0 >= ny) break;
-    // outputs r0 .. r0+3 read LDS rows r0 .. r0 + 2 radius + 3
+    // outputs r0 .. r0 + kRows - 1 read LDS rows r0 .. r0 + 2 radius + kRows - 1; output j meets the tap of step k - j
     const float* c = img + r0 * kYCols + lane;
-    double acc0 = 0.0, acc1 = 0.0, acc2 = 0.0, acc3 = 0.0;
-    double t1 = 0.0, t2 = 0.0, t3 = 0.0;  // wz[k+2], wz[k+1], wz[k]
-    for (int k = 0; k < ntap + 3; ++k) {
-      const double v = (double)c[k * kYCols];
-      const double t0 = wz[k + 3];  // tap of output row 0 at window step k
-      acc0 += t0 * v;
-      acc1 += t1 * v;
-      acc2 += t2 * v;
-      acc3 += t3 * v;
-      t3 = t2;
-      t2 = t1;
-      t1 = t0;
-    }
-    const double acc[kYBlockRows] = {acc0, acc1, acc2, acc3};
+    double acc[kRows];
 #pragma unroll
-    for (int j = 0; j < kYBlockRows; ++j)
+    for (int j = 0; j < kRows; ++j) acc[j] = 0.0;
+    if constexpr (kBlocked) {
+      float t[kRows];  // t[j]: the tap of step k - j
+#pragma unroll
+      for (int j = 0; j < kRows; ++j) t[j] = 0.0f;
+      for (int k = 0; k < steps; k += kAccBlock) {
+        float p[kRows];
+#pragma unroll
+        for (int j = 0; j < kRows; ++j) p[j] = 0.0f;
+#pragma unroll
+        for (int kk = 0; kk < kAccBlock; ++kk) {
+          const float v = c[(k + kk) * kYCols];
+#pragma unroll
+          for (int j = kRows - 1; j > 0; --j) t[j] = t[j - 1];
+          t[0] = tapsf[4 + k + kk];  // (uniform: a scalar load)
+#pragma unroll
+          for (int j = 0; j < kRows; ++j) p[j] = fmaf(t[j], v, p[j]);
+        }
+#pragma unroll
+        for (int j = 0; j < kRows; ++j) acc[j] += (double)p[j];
+      }
+    } else {
+      double t[kRows];
+#pragma unroll
+      for (int j = 0; j < kRows; ++j) t[j] = 0.0;
+      for (int k = 0; k < steps; k += kRows) {
+#pragma unroll
+        for (int kk = 0; kk < kRows; ++kk) {
+          const double v = (double)c[(k + kk) * kYCols];
+#pragma unroll
+          for (int j = kRows - 1; j > 0; --j) t[j] = t[j - 1];
+          t[0] = tapsd[4 + k + kk];
+#pragma unroll
+          for (int j = 0; j < kRows; ++j) acc[j] += t[j] * v;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kRows; ++j)
       if (y0 + r0 + j < ny) out[(size_t)(y0 + r0 + j) * nx + x] = (float)acc[j];
   }
+}
+
+// out[x][y] = in[y][x], 64 x 64 tiles through LDS (both sides coalesced): the y pass of a WIDE stencil runs as the x pass
+// of the transposed plane (smooth_axis0)
+__global__ __launch_bounds__(kBlock) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int ny, int nx) {
+  __shared__ float tile[64][65];
+  const int x0 = blockIdx.x * 64, y0 = blockIdx.y * 64;
+  const int lx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+#pragma unroll
+  for (int r = ly; r < 64; r += 4)
+    if (y0 + r < ny && x0 + lx < nx) tile[r][lx] = in[(size_t)(y0 + r) * nx + x0 + lx];
+  __syncthreads();
+#pragma unroll
+  for (int r = ly; r < 64; r += 4)
+    if (x0 + r < nx && y0 + lx < ny) out[(size_t)(x0 + r) * ny + y0 + lx] = tile[lx][r];
 }
 
 __global__ void mul_kernel(const float* __restrict__ a,
@@ -183,16 +308,21 @@ int get_taps(mrx_ctx* ctx, double sigma, double truncate, int* radius_out,
       return MRX_OK;
     }
   const int radius = (int)(truncate * sigma + 0.5);
-  const size_t n = (size_t)(2 * radius + 1);
-  std::vector<double> w(n);
+  const int ntap = 2 * radius + 1, slots = gauss_tap_slots(ntap);
+  // [slots float64][slots float32]: 4 zeros, the taps, zeros (see gauss_tap_slots)
+  std::vector<double> w((size_t)slots + (size_t)(slots + 1) / 2, 0.0);
   const double s2 = sigma * sigma;
   double sum = 0.0;
   for (int k = -radius; k <= radius; ++k) {
     const double v = std::exp(-0.5 / s2 * (double)k * (double)k);
-    w[(size_t)(k + radius)] = v;
+    w[(size_t)(4 + k + radius)] = v;
     sum += v;
   }
-  for (auto& v : w) v /= sum;
+  float* wf = reinterpret_cast<float*>(w.data() + slots);
+  for (int k = 0; k < ntap; ++k) {
+    w[(size_t)(4 + k)] /= sum;
+    wf[4 + k] = (float)w[(size_t)(4 + k)];
+  }
   auto& slot = ctx->taps[ctx->taps_next];
   ctx->taps_next = (ctx->taps_next + 1) % mrx_ctx::kTapSlots;
   if (slot.d_taps) {
@@ -202,8 +332,8 @@ int get_taps(mrx_ctx* ctx, double sigma, double truncate, int* radius_out,
     (void)hipFree(slot.d_taps);
     slot.d_taps = nullptr;
   }
-  MRX_HIP(ctx, hipMalloc(&slot.d_taps, n * sizeof(double)));
-  MRX_HIP(ctx, hipMemcpyAsync(slot.d_taps, w.data(), n * sizeof(double),
+  MRX_HIP(ctx, hipMalloc(&slot.d_taps, w.size() * sizeof(double)));
+  MRX_HIP(ctx, hipMemcpyAsync(slot.d_taps, w.data(), w.size() * sizeof(double),
                               hipMemcpyHostToDevice, ctx->stream));
   MRX_HIP(ctx, hipStreamSynchronize(ctx->stream));  // w goes out of scope
   slot.sigma = sigma;
@@ -215,11 +345,22 @@ int get_taps(mrx_ctx* ctx, double sigma, double truncate, int* radius_out,
 }
 
 constexpr size_t kMaxLds = 128 * 1024;  // of the CU's 160 KiB
+constexpr int kTransposeRadius = 64;    // from this radius on the y pass runs as an x pass of the transposed plane (mrx_gauss_smooth2d)
 
 int raise_lds_cap(mrx_ctx* ctx) {
-  MRX_LDS_CAP(ctx, gauss_x_kernel, kMaxLds);
-  MRX_LDS_CAP(ctx, gauss_y_kernel, kMaxLds);
+  MRX_LDS_CAP(ctx, gauss_x_kernel<false>, kMaxLds);
+  MRX_LDS_CAP(ctx, gauss_x_kernel<true>, kMaxLds);
+  MRX_LDS_CAP(ctx, (gauss_y_kernel<false, 4>), kMaxLds);
+  MRX_LDS_CAP(ctx, (gauss_y_kernel<true, 4>), kMaxLds);
+  MRX_LDS_CAP(ctx, (gauss_y_kernel<false, 8>), kMaxLds);
+  MRX_LDS_CAP(ctx, (gauss_y_kernel<true, 8>), kMaxLds);
   return MRX_OK;
+}
+
+// MRX_OPT_GAUSS_ACCUM: 0 = blocked float32 sums from radius 16 on, exact float64 below; 1 = exact; 2 = blocked
+bool blocked_mode(const mrx_ctx* ctx, int radius) {
+  const int mode = ctx->options[MRX_OPT_GAUSS_ACCUM];
+  return mode == 2 || (mode == 0 && radius >= 16);
 }
 
 int smooth_axis1(mrx_ctx* ctx, const float* in, float* out, int ny, int nx,
@@ -228,15 +369,19 @@ int smooth_axis1(mrx_ctx* ctx, const float* in, float* out, int ny, int nx,
   const double* d_taps = nullptr;
   int rc = get_taps(ctx, sigma, truncate, &radius, &d_taps);
   if (rc != MRX_OK) return rc;
-  const size_t lds = (size_t)((2 * radius + 1 + 6 + 1) & ~1) * sizeof(double) + (size_t)(kXCols + 2 * radius + 4) * sizeof(float);
+  const bool blocked = blocked_mode(ctx, radius);
+  const float* d_tapsf = reinterpret_cast<const float*>(d_taps + gauss_tap_slots(2 * radius + 1));
+  const size_t lds = (size_t)kXRows * (size_t)((kXCols + 2 * radius + 4 + kAccBlock + 3) & ~3) * sizeof(float);
   if ((rc = raise_lds_cap(ctx)) != MRX_OK) return rc;
   if (lds > kMaxLds)
     return mrx_fail(ctx, MRX_ERR_UNSUPPORTED,
                     "gaussian radius %d along x exceeds the LDS tile", radius);
-  dim3 grid(mrx_ceil_div(nx, kXCols), ny);
+  dim3 grid(mrx_ceil_div(nx, kXCols), mrx_ceil_div(ny, kXRows));
   MRX_REQUIRE(ctx, grid.y <= 65535u, "ny too large for one launch");
-  hipLaunchKernelGGL(gauss_x_kernel, grid, dim3(kBlock), lds, ctx->stream, in,
-                     out, ny, nx, d_taps, radius);
+  if (blocked)
+    hipLaunchKernelGGL(gauss_x_kernel<true>, grid, dim3(kBlock), lds, ctx->stream, in, out, ny, nx, d_taps, d_tapsf, radius);
+  else
+    hipLaunchKernelGGL(gauss_x_kernel<false>, grid, dim3(kBlock), lds, ctx->stream, in, out, ny, nx, d_taps, d_tapsf, radius);
   MRX_CHECK_LAUNCH(ctx);
   return MRX_OK;
 }
@@ -248,20 +393,29 @@ int smooth_axis0(mrx_ctx* ctx, const float* in, float* out, int ny, int nx,
   int rc = get_taps(ctx, sigma, truncate, &radius, &d_taps);
   if (rc != MRX_OK) return rc;
   if ((rc = raise_lds_cap(ctx)) != MRX_OK) return rc;
-  // output rows per tile: up to 64 while the image stays under 40 KiB (4 per CU)
+  const float* d_tapsf = reinterpret_cast<const float*>(d_taps + gauss_tap_slots(2 * radius + 1));
+  // output rows per tile: up to 64 while the image stays under 40 KiB (4 per CU: with eight outputs a thread a wave has
+  // the arithmetic to cover its reads); 32 rows while the image fits at all, 16 (four a thread) for the largest radii
+  auto image = [&](int rows, int per_thread) { return (size_t)(rows + 2 * radius + kAccBlock + per_thread) * kYCols * sizeof(float); };
   int tile_rows = 64;
-  while (tile_rows > 16 &&
-         (size_t)(tile_rows + 2 * radius) * kYCols * sizeof(float) > 20 * 1024)
-    tile_rows /= 2;
-  const size_t lds = (size_t)(2 * radius + 8) * sizeof(double) +
-                     (size_t)(tile_rows + 2 * radius) * kYCols * sizeof(float);
+  while (tile_rows > 32 && image(tile_rows, 8) > 40 * 1024) tile_rows /= 2;
+  if (image(tile_rows, 8) > kMaxLds) tile_rows = 16;
+  const int per_thread = tile_rows >= 32 ? 8 : 4;
+  const bool blocked = blocked_mode(ctx, radius);
+  const size_t lds = image(tile_rows, per_thread);
   if (lds > kMaxLds)
     return mrx_fail(ctx, MRX_ERR_UNSUPPORTED,
                     "gaussian radius %d along y exceeds the LDS tile", radius);
   dim3 grid(mrx_ceil_div(nx, kYCols), mrx_ceil_div(ny, tile_rows));
   MRX_REQUIRE(ctx, grid.y <= 65535u, "ny too large for one launch");
-  hipLaunchKernelGGL(gauss_y_kernel, grid, dim3(kBlock), lds, ctx->stream, in,
-                     out, ny, nx, d_taps, radius, tile_rows);
+#define MRX_LAUNCH_Y(B, R) \
+  hipLaunchKernelGGL((gauss_y_kernel<B, R>), grid, dim3(kBlock), lds, ctx->stream, in, out, ny, nx, d_taps, d_tapsf, radius, tile_rows)
+  if (per_thread == 8) {
+    if (blocked) MRX_LAUNCH_Y(true, 8); else MRX_LAUNCH_Y(false, 8);
+  } else {
+    if (blocked) MRX_LAUNCH_Y(true, 4); else MRX_LAUNCH_Y(false, 4);
+  }
+#undef MRX_LAUNCH_Y
   MRX_CHECK_LAUNCH(ctx);
   return MRX_OK;
 }
@@ -314,6 +468,24 @@ int mrx_gauss_smooth2d(mrx_ctx* ctx, const float* d_in, float* d_out,
   const bool do_y = sigma_y > 1e-15, do_x = sigma_x > 1e-15;
   const size_t bytes = (size_t)ny * nx * sizeof(float);
   int rc = MRX_OK;
+  // A WIDE stencil along y (radius >= kTransposeRadius): the y pass stages 2 radius + rows-per-tile rows per tile -- ten
+  // times the rows it writes at radius 128, in an LDS image that leaves two workgroups to a CU -- where the x pass, whose
+  // window is a row segment, stays near its arithmetic: 8192^2, sigma 32: 1.68 ms along y against 0.61 along x.  So the
+  // plane is transposed (0.1 ms either way), filtered along x, and transposed back.  d_out serves as the second scratch
+  // plane (it is written last); in place (d_in == d_out) the input is consumed by the first transpose.
+  const bool wide_y = do_y && (int)(truncate * sigma_y + 0.5) >= kTransposeRadius && ny <= 65535 * 64 && nx <= 65535 * kXRows;
+  if (wide_y) {
+    const dim3 g_in(mrx_ceil_div(nx, 64), mrx_ceil_div(ny, 64)), g_back(mrx_ceil_div(ny, 64), mrx_ceil_div(nx, 64));
+    hipLaunchKernelGGL(transpose_kernel, g_in, dim3(kBlock), 0, ctx->stream, d_in, d_tmp, ny, nx);  // tmp: [nx][ny]
+    MRX_CHECK_LAUNCH(ctx);
+    rc = smooth_axis1(ctx, d_tmp, d_out, nx, ny, sigma_y, truncate);                                // out: [nx][ny], filtered along y
+    if (rc != MRX_OK) return rc;
+    hipLaunchKernelGGL(transpose_kernel, g_back, dim3(kBlock), 0, ctx->stream, d_out, d_tmp, nx, ny);  // tmp: [ny][nx]
+    MRX_CHECK_LAUNCH(ctx);
+    if (do_x) return smooth_axis1(ctx, d_tmp, d_out, ny, nx, sigma_x, truncate);
+    MRX_HIP(ctx, hipMemcpyAsync(d_out, d_tmp, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    return MRX_OK;
+  }
   if (do_y && do_x) {
     rc = smooth_axis0(ctx, d_in, d_tmp, ny, nx, sigma_y, truncate);
     if (rc == MRX_OK) rc = smooth_axis1(ctx, d_tmp, d_out, ny, nx, sigma_x, truncate);

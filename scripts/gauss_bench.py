@@ -13,13 +13,16 @@ from scripts.kbench import timeit
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 ctx = Context(0)
 ctx.set_stream(torch.cuda.current_stream())
+# MRX_GAUSS_ACCUM=1: the exact (float64) mode at every radius; 2: the blocked float32 sums at every radius; default 0
+ctx.set_option(12, int(os.environ.get("MRX_GAUSS_ACCUM", "0")))
+print(f"# MRX_OPT_GAUSS_ACCUM = {os.environ.get('MRX_GAUSS_ACCUM', '0')} (0: blocked float32 sums from radius 16, exact float64 below; 1: exact; 2: blocked)")
 rows = []
-for n in (1024, 4096, 8192):
+for n in [int(v) for v in os.environ.get("MRX_GAUSS_N", "1024,4096,8192").split(",")]:
     x = torch.rand((n, n), dtype=torch.float32, device="cuda:0")
     w = torch.rand((n, n), dtype=torch.float32, device="cuda:0") + 0.5
     out, den = torch.empty_like(x), torch.empty_like(x)
     tmp = torch.empty(2 * n * n, dtype=torch.float32, device="cuda:0")
-    for sigma in (2.0, 8.0, 32.0):
+    for sigma in [float(v) for v in os.environ.get("MRX_GAUSS_SIGMA", "2,8,32").split(",")]:
         cases = {
             "gauss_smooth2d": lambda: ctx.call("mrx_gauss_smooth2d", ptr(x), ptr(out), ptr(tmp), n, n, sigma, sigma, 4.0),
             "map_smooth": lambda: ctx.call("mrx_map_smooth", ptr(x), None, ptr(out), None, ptr(tmp), n, n, sigma, sigma),
