@@ -129,25 +129,23 @@ __device__ __forceinline__ int sc_index(const struct MapArgs& g, const SampleCon
 // conventions (bin b with p = 0, bin b - 1 with p = 1) give the same interpolated value, so the
 // nodes themselves need not be read.
 __device__ __forceinline__ void axis_weights(const Axis& a, float x, bool bilinear, int& i0, int& i1, float& p) {
-  // the position in pixels in float64 (a float32 product would be good to 6e-5 pixel only at pixel
-  // 1000); cell and weight leave it as an integer and a float32 fraction.  The offset is first clamped
-  // to one pixel beyond the axis (a NaN goes to the low end), so u is finite and converts safely;
-  // beyond the ends the reference's weights are (x + inf)/inf = nan -> 0 and finite/inf = 0: p = 0.
-  const double u = ((double)__builtin_amdgcn_fmed3f(x, a.lo, a.hi) - a.first) * a.inv_step;
-  if (bilinear) {  // workgroup-uniform
-    asm volatile("" ::: "memory");  // keep this a branch: if-converted, both arms' float64 work would run
-    const double fl = floor(u);
-    const int ifl = (int)fl;
-    const int b = min(max(ifl + 1, 0), a.n);
-    p = (b == 0 || b == a.n) ? 0.0f : (float)(u - fl);
-    i0 = min(max(b - 1, 0), a.n - 1);
-    i1 = min(b, a.n - 1);
-  } else {
-    asm volatile("" ::: "memory");
-    // np.digitize on the midpoints: the nearest node
-    i0 = i1 = min(max((int)floor(u + 0.5), 0), a.n - 1);
-    p = 0.0f;
-  }
+  // Round 6: the float32 split form of axis_cell_t (below) instead of a float64 position (measured equal in the binning's
+  // pass A, which does not wait for its arithmetic -- kept so that the file has ONE rule for cell and weight).  The offset
+  // is first clamped INTO the axis (a NaN goes to the low end): beyond the ends the reference's weights are
+  // (x + inf)/inf = nan -> 0 and finite/inf = 0, i.e. the edge pixel alone -- here the first cell with p = 0 or the last
+  // with p = 1, the same pixels and weights.  k: the cell, kept inside the axis; frac: the position inside it, good to
+  // 1e-7 pixel (the float64 form's fraction to float32 rounding) -- so the nearest pixel flips against the float64 form
+  // only within 1e-7 pixel of a pixel's edge, and a bilinear weight moves by 1e-7.
+  const float xc = __builtin_amdgcn_fmed3f(x, a.x_min, a.x_max);
+  const float k = __builtin_amdgcn_fmed3f(floorf(fmaf(xc, a.inv_hi, a.c_frac)), a.k_lo, a.k_hi);
+  const float frac = fmaf(xc, a.inv_hi, -k) + fmaf(xc, a.inv_lo, a.c_frac);
+  const int cell = (int)(k + a.c_int);  // 0 .. n - 2
+  // bilinear: the cell's two nodes and the weight of the upper one (at a node the weight 0 or 1 names it either way);
+  // nearest (np.digitize on the midpoints): the node on this side or the far side of the cell's middle
+  const int up = frac >= 0.5f ? 1 : 0;
+  i0 = bilinear ? cell : cell + up;
+  i1 = bilinear ? cell + 1 : cell + up;
+  p = bilinear ? __builtin_amdgcn_fmed3f(frac, 0.0f, 1.0f) : 0.0f;
 }
 
 // The same for the map SAMPLER, as one cell: i0 in [0, n - 2] and the weight p in [0, 1] of node i0 + 1 -- the value
