@@ -126,7 +126,11 @@ enum {
                                in float64 from radius 16 on (<= 1e-6 of scipy's float64 sums, twice as fast), scipy's float64
                                arithmetic below; 1 = float64 always ("exact": <= 2.5e-7, float32 roundings of the result);
                                2 = the blocked sums at every radius */
-  MRX_OPT_COUNT = 13
+  MRX_OPT_SYNTH_ACQUIRE = 13, /* mrx_atm_synthesize: 1 = a writer tile's workgroup runs an agent-scope acquire (and waits for it)
+                                 once the chunks it needs are in, before it loads them -- the hand-over form that is valid
+                                 whatever a CU holds; 0 (default) = write-through stores, drained waves and sc1 loads alone,
+                                 measured valid and 2 % faster */
+  MRX_OPT_COUNT = 14
 };
 int mrx_set_option(mrx_ctx* ctx, int option, int value);
 const char* mrx_last_error(const mrx_ctx* ctx);

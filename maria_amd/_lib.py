@@ -33,6 +33,7 @@ OPT_SCREEN_STOCKHAM = 9
 OPT_SYNTH_WGS_PER_CU = 10
 OPT_SYNTH_TILE_ORDER = 11
 OPT_GAUSS_ACCUM = 12
+OPT_SYNTH_ACQUIRE = 13
 
 _STATUS = {
     0: "MRX_OK",

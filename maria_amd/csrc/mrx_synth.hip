@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_SYNT
     uint32_t* __restrict__ flags, int chunk, int nby, int block_rows, int n_blocks, int n_dedicated,
     double ta0, double inv_dta, const double* __restrict__ t, int T,
     const float* __restrict__ scale, const int32_t* __restrict__ rows, float* __restrict__ out, size_t ld, int vec_ok,
-    int batches, int tile_order, int* ctl, int poll_limit, SynthCal cal) {
+    int batches, int tile_order, int* ctl, int poll_limit, int acquire, SynthCal cal) {
   extern __shared__ __align__(16) unsigned char synth_lds[];
   __shared__ int s_word[8];  // what the first wave found out for the workgroup: [0] tile / item, [1] watermark, [2] the tile's last unit, [3..5] its (block, time tile, row group)
   SynthHooks<kKrj> hooks;
@@ -208,12 +208,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_SYNT
           s_word[4] = sx;
           s_word[5] = rg;
         }
-#if MRX_SYNTH_ACQUIRE
-        if (hv > need) {  // (the polling wave, once its poll has matched: invalidates this CU's L1)
+        // MRX_OPT_SYNTH_ACQUIRE (round 6: a RUNTIME switch; the build switch MRX_SYNTH_ACQUIRE = 1 also turns the tile's sc1
+        // loads into plain ones): the polling wave, once its poll has matched, runs the agent-scope acquire -- it invalidates
+        // this CU's L1 -- and waits for it; the barrier below then holds every other wave behind it.  With the producer's
+        // sc1 stores and drained waves that is one of MI355X_MICROARCH.md's always-valid hand-offs, whatever the number of
+        // workgroups a CU holds; the tile's loads stay sc1 (past the L1 anyway), so the switch only adds the fence.
+        if ((MRX_SYNTH_ACQUIRE || acquire) && hv > need) {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-#endif
       }
       __syncthreads();  // between the poll and EVERY load of the chunks' bytes, the polling wave's own too
       tile = s_word[0];
@@ -404,7 +407,8 @@ static int atm_synthesize(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* d
                        plan->d_px, plan->n_layers, plan->d_offpx, plan->d_tables, plan->n_tables,                 \
                        plan->d_table_data, plan->table_floats, d_az, d_el, Ta, d_dx, d_dy, d_band, d_mueller00,   \
                        D, pwv0, d_pwv, d_coarse, d_flags, chunk, nby, block_rows, n_blocks, (int)dedicated, ta0, 1.0 / dta, \
-                       d_t, T, d_scale, d_rows, d_out, ld_out, vec_ok, batches, ctx->options[MRX_OPT_SYNTH_TILE_ORDER], ctl, poll_limit, cal); \
+                       d_t, T, d_scale, d_rows, d_out, ld_out, vec_ok, batches, ctx->options[MRX_OPT_SYNTH_TILE_ORDER], ctl, poll_limit,       \
+                       ctx->options[MRX_OPT_SYNTH_ACQUIRE] != 0 ? 1 : 0, cal);                                    \
   } while (0)
 #define MRX_LAUNCH_SYNTH_J(L, S, K, G) do { if (krj) MRX_LAUNCH_SYNTH(L, S, K, G, true); else MRX_LAUNCH_SYNTH(L, S, K, G, false); } while (0)
 #define MRX_LAUNCH_SYNTH_S(L, S) do { if (small) MRX_LAUNCH_SYNTH_J(L, S, kSmallKnots, 2); else MRX_LAUNCH_SYNTH_J(L, S, 256, 1); } while (0)

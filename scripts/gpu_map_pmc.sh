@@ -2,7 +2,7 @@
 # Instruction mix of map_sample_kernel inside Simulation(map=...).run() (scripts/frontend_trace.py map): per-type VALU counts,
 # issue and wait cycles, per launch.  Separate --pmc passes, --kernel-trace only.  <tag>
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r05mappmc}
+TAG=${1:-mappmc}
 cd $ROOT
 for set in "SQ_INSTS_VALU SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_VALU_CVT SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64" \
            "SQ_INSTS_VALU_ADD_F64 SQ_INSTS_VALU_MUL_F64 SQ_INSTS_VALU_FMA_F64 SQ_INSTS_VALU_TRANS_F64 SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" \

@@ -1,6 +1,6 @@
 #!/bin/bash
 # The noise generator's kernels ALONE (MRX_NOISE_LANES=1: one stream, batches four times as long): durations per call, and
-# how busy each keeps the vector ALU / how long its waves wait.   scripts/gpu_r5_noise_lane1.sh <tag>
+# how busy each keeps the vector ALU / how long its waves wait.   scripts/gpu_noise_lane1.sh <tag>
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 TAG=${1:-r05lane1}
 OUT=$ROOT/gpurun_out/$TAG

@@ -2,7 +2,7 @@
 # Instruction mix of the noise generator's kernels (scripts/noise_bench.py 10000 240000 1: five modes, no modes, white only; every
 # variant is called twice -- one warm-up, one timed), per CALL and per sample of the 10 000 x 240 000 field.  <tag>
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
-TAG=${1:-r05noisepmc}
+TAG=${1:-noisepmc}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp

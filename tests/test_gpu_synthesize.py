@@ -392,6 +392,40 @@ def test_hand_over_beside_other_work_on_the_chip(gpu_ctx):
     torch.cuda.empty_cache()
 
 
+def test_the_acquire_hand_over_is_a_runtime_switch_and_gives_the_same_bits(gpu_ctx):
+    """MRX_OPT_SYNTH_ACQUIRE = 1 (round 6): the consumer's agent-scope acquire before a tile
+    loads its chunks -- MI355X_MICROARCH.md's always-valid hand-over, one call away at run time instead of a rebuild.  Both
+    forms on the same alternating data, five resident workgroups per CU, beside a stream that keeps the caches busy: each
+    launch equals the two calls of ITS data in every word, so the two forms equal each other -- on every round's GPU run."""
+    import torch
+
+    from maria_amd import _lib
+
+    p = config_problem("atlast_10k", n_det=4000)
+    path = _path(p, gpu_ctx)
+    path.generate_screens()
+    alt = _Alternating(path, generated=True, keep_coarse=False)
+    got = torch.empty_like(alt.want[0])
+    big = torch.ones(1 << 28, dtype=torch.float32, device="cuda:0")
+    side = torch.cuda.Stream()
+    try:
+        for rep in range(12):
+            v = (rep // 2 + rep) % 2
+            alt.select(v)
+            got.fill_(float("nan"))
+            torch.cuda.synchronize()
+            with torch.cuda.stream(side):
+                big.mul_(1.0000001)
+            gpu_ctx.set_option(_lib.OPT_SYNTH_ACQUIRE, rep % 2)
+            path.synthesize(got, chunk=(16, 32, 64)[rep % 3])
+            alt.check(v, got, (rep, "acquire" if rep % 2 else "sc1 loads"))
+    finally:
+        gpu_ctx.set_option(_lib.OPT_SYNTH_ACQUIRE, 0)
+    assert path.check_flags() == 0
+    del big, got, alt
+    torch.cuda.empty_cache()
+
+
 def test_random_shapes(gpu_ctx):
     """64 random shapes through the one launch against the two calls, every word (the loop of scripts/fuzz_synth.py with
     a fixed seed): detectors, layers, bands, sample rate, duration and time step (i.e. Ta, T and their ratio), gain, block
