@@ -484,17 +484,31 @@ __device__ __forceinline__ float raw_sample(const MapArgs& g, const CalLds& cl, 
 // gathers of a channel are in flight together, behind 3 kN LDS reads issued together.
 //   record(slot): the sample's six matrix entries (LDS); slot[q]: the samples' slots; pw(c, f): fills f[q] with pW per K_RJ
 //   of channel c at sample q; kUnrollC: at most kCalFastChannels channels, unrolled under a guard; else a loop.
-template <bool kBil, int kS, int kN, bool kUnrollC, typename RecordFn, typename PwFn>
+template <bool kBil, int kS, int kN, bool kUnrollC, typename RecordFn, typename Record4Fn, typename PwFn>
 __device__ __forceinline__ void row_samples(const MapArgs& g, const Axis& ax_eta, const Axis& ax_xi, const DetConst& dc,
-                                            const int (&slot)[kN], RecordFn record, PwFn pw, float (&out)[kN]) {
+                                            const int (&slot)[kN], RecordFn record, Record4Fn record4, PwFn pw, float (&out)[kN]) {
   float ox[kN], oy[kN], r2[kN];
   bool far = false;
+  float G[6][kN];  // slots slot[0] .. slot[0] + 3 are the thread's own four samples: one 16-byte read per entry
+  {
+    float G4[6][4];
+    record4(slot[0], G4);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) G[k][q] = G4[k][q];
+    }
+    if (kN > 4) {
+      const SampleConst h = record(slot[kN - 1]);
+#pragma unroll
+      for (int k = 0; k < 6; ++k) G[k][kN - 1] = h.G[k];
+    }
+  }
 #pragma unroll
   for (int q = 0; q < kN; ++q) {
-    const SampleConst sc = record(slot[q]);
     // (sample_offsets' composed form: float32, see there)
-    const float dz_re = fmaf(dc.c_re, sc.G[0], fmaf(dc.c_cr, sc.G[2], dc.c_im * sc.G[4]));
-    const float dz_im = fmaf(dc.c_re, sc.G[1], fmaf(dc.c_cr, sc.G[3], dc.c_im * sc.G[5]));
+    const float dz_re = fmaf(dc.c_re, G[0][q], fmaf(dc.c_cr, G[2][q], dc.c_im * G[4][q]));
+    const float dz_im = fmaf(dc.c_re, G[1][q], fmaf(dc.c_cr, G[3][q], dc.c_im * G[5][q]));
     r2[q] = fmaf(dz_re, dz_re, dz_im * dz_im);
     const float f = fmaf(r2[q], fmaf(r2[q], fmaf(r2[q], fmaf(r2[q], 35.0f / 1152.0f, 15.0f / 336.0f), 3.0f / 40.0f), 1.0f / 6.0f), 1.0f);
     far |= r2[q] >= 0.01f;
@@ -1113,8 +1127,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kChain ?
   // (slot 0 / 1025: the halo samples of the 3-tap kernel) and the row loop fetches it with three 8-byte
   // reads, instead of five records held in 65 registers per thread (168 -> 63 registers).
   constexpr bool kLdsSc = !kChain;
-  constexpr int kRec = 6;
-  __shared__ __align__(16) float sc_lds[kLdsSc ? kRec * (kTileSamples + 2) : 8];
+  // The records as six planes (round 6; an array of 24-byte records before): entry k of slot i at sc_lds[k][i + 3], so that a
+  // thread's four samples' entries -- slots 1 + 4 tid .. 4 + 4 tid -- are ONE aligned 16-byte read per plane, consecutive
+  // lanes at consecutive addresses.  As records, a thread's slots lay 96 bytes apart: its three 8-byte reads a sample met
+  // the banks four lanes at a time.
+  constexpr int kRec = 6, kRecPitch = (kTileSamples + 2 + 3 + 3) & ~3;
+  __shared__ __align__(16) float sc_lds[kLdsSc ? kRec * kRecPitch : 8];
   // the interval form of the calibration (see kMaxSteps): (cos, sin) of (boresight elevation - pi/2) at the start, the middle
   // and the end of every coarse step the tile meets; a row with a knot off the tables (NaN)
   __shared__ float2 knot_cs[kLdsSc && kCal ? 2 * kMaxSteps + 1 : 1];
@@ -1126,7 +1144,7 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kChain ?
       SampleConst one;
       sample_const(g, s_tile - 1 + i, false, one);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) sc_lds[kRec * i + k] = one.G[k];
+      for (int k = 0; k < 6; ++k) sc_lds[k * kRecPitch + i + 3] = one.G[k];
     }
   } else {
 #pragma unroll
@@ -1152,10 +1170,17 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kChain ?
   // slot of a sample's record: the thread's q-th sample, or its halo sample
   auto record = [&](int slot) {
     SampleConst one{};
-    const float2* rec = reinterpret_cast<const float2*>(sc_lds + kRec * slot);
-    const float2 a = rec[0], b = rec[1], c = rec[2];
-    one.G[0] = a.x; one.G[1] = a.y; one.G[2] = b.x; one.G[3] = b.y; one.G[4] = c.x; one.G[5] = c.y;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) one.G[k] = sc_lds[k * kRecPitch + slot + 3];
     return one;
+  };
+  // the four samples of a thread at once: G[k][q], slot0 = 1 + 4 tid
+  auto record4 = [&](int slot0, float (&G)[6][4]) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const float4 v = *reinterpret_cast<const float4*>(sc_lds + k * kRecPitch + slot0 + 3);
+      G[k][0] = v.x; G[k][1] = v.y; G[k][2] = v.z; G[k][3] = v.w;
+    }
   };
   // the calibration's part of a record, recomputed (the per-sample fallback; sample_const's arithmetic)
   auto with_cal = [&](SampleConst one, int slot) {
@@ -1286,12 +1311,12 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(kChain ?
         if (wave == 0 || wave == kBlock / 64 - 1) {
           const int slot[5] = {s0, s0 + 1, s0 + 2, s0 + 3, first ? 0 : last ? kTileSamples + 1 : s0 + 3};
           float v[5];
-          row_samples<decltype(bil)::value, kS, 5, decltype(unroll_c)::value>(g, ax_eta, ax_xi, dc, slot, record, pw, v);
+          row_samples<decltype(bil)::value, kS, 5, decltype(unroll_c)::value>(g, ax_eta, ax_xi, dc, slot, record, record4, pw, v);
           r[0] = v[0]; r[1] = v[1]; r[2] = v[2]; r[3] = v[3];
           halo = v[4];
         } else {
           const int slot[4] = {s0, s0 + 1, s0 + 2, s0 + 3};
-          row_samples<decltype(bil)::value, kS, 4, decltype(unroll_c)::value>(g, ax_eta, ax_xi, dc, slot, record, pw, r);
+          row_samples<decltype(bil)::value, kS, 4, decltype(unroll_c)::value>(g, ax_eta, ax_xi, dc, slot, record, record4, pw, r);
         }
       };
       if (g.bilinear) run(std::true_type{}); else run(std::false_type{});  // (uniform)
