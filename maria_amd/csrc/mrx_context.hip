@@ -130,6 +130,8 @@ int mrx_destroy(mrx_ctx* ctx) {
   if (ctx->d_reduce) (void)hipFree(ctx->d_reduce);
   if (ctx->d_synth_ctl) (void)hipFree(ctx->d_synth_ctl);
   if (ctx->d_bin_order) (void)hipFree(ctx->d_bin_order);
+  if (ctx->d_map_pairs) (void)hipFree(ctx->d_map_pairs);
+  if (ctx->map_pairs_read) (void)hipEventDestroy(ctx->map_pairs_read);
   for (hipStream_t st : ctx->side_streams)
     if (st) (void)hipStreamDestroy(st);
   for (hipEvent_t ev : ctx->side_ev)

@@ -53,6 +53,11 @@ struct mrx_ctx {
   } fresp[kFRespSlots];
   int fresp_next = 0;
   int options[MRX_OPT_COUNT] = {0};
+  // map sampling: the map's row pairs interleaved (mrx_map.hip: map_pairs_kernel), rebuilt by every call from the caller's
+  // planes; the event orders the rebuild behind the sampler that last read the copy, whatever stream the context has since
+  float* d_map_pairs = nullptr;
+  size_t map_pairs_cap = 0;
+  hipEvent_t map_pairs_read = nullptr;
   uint32_t* d_bin_order = nullptr;  // routed binning: contributions per region + the regions by falling total (mrx_map.hip)
   // tile queues + per-block counters of the launches that take their work from a queue (mrx_spline.hip: mrx_synth_ctl)
   static constexpr int kSynthCtlSlots = 8;

@@ -98,6 +98,12 @@ struct MapArgs {
   size_t ld;
   int vec_ok;
   uint32_t map_bytes;  // of all planes (below 4 GiB): the sampler's raw buffer
+  // The map's row pairs interleaved (round 6): pairs[plane][e][x] = (m[e][x], m[e + 1][x]), e = 0 .. n_eta - 2 -- the four
+  // corners of a cell are then 16 contiguous bytes, ONE gather a sample and plane instead of two of 8 bytes.  The
+  // sampler waits on the number of gather instructions (a what-if build without them: 7.1 -> 3.9 ms; the texture
+  // addresser takes a wave's 64 addresses at the same rate whether they fetch 8 or 16 bytes), not on bytes or arithmetic.
+  const float* pairs;
+  uint32_t pairs_bytes;
   int coef_offset;     // of the calibration's interval table in the dynamic LDS, in floats; < 0: none (more than kCalFastChannels channels)
   int coef_cap;        // coarse steps per row the table holds
 };
@@ -541,11 +547,11 @@ __device__ __forceinline__ void row_samples(const MapArgs& g, const Axis& ax_eta
     axis_cell_t<kBil>(ax_xi, ox[q], x0, px);
     const float qe = 1.0f - pe, qx = 1.0f - px;
     w0a[q] = qe * qx; w0b[q] = qe * px; w1a[q] = pe * qx; w1b[q] = pe * px;
-    o0[q] = (int)(__umul24((unsigned)e0, (unsigned)g.n_xi) + (unsigned)x0) << 2;  // (e0 < n_eta, n_xi < 2^24)
+    o0[q] = (int)(__umul24((unsigned)e0, (unsigned)g.n_xi) + (unsigned)x0) << 3;  // (e0 < n_eta, n_xi < 2^24): the cell's 16 bytes in its plane of pairs
   }
-  typedef float pair4 __attribute__((ext_vector_type(2)));
-  const int plane4 = (g.n_eta * g.n_xi) << 2, pitch4 = g.n_xi << 2;
-  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)g.values, 0, (int)g.map_bytes, 0x00020000);
+  typedef float quad4 __attribute__((ext_vector_type(4)));
+  const int plane8 = ((g.n_eta - 1) * g.n_xi) << 3;  // a plane of row pairs, bytes
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)g.pairs, 0, (int)g.pairs_bytes, 0x00020000);
 #pragma unroll
   for (int q = 0; q < kN; ++q) out[q] = 0.0f;
   float wf[kS];  // the Stokes weights as the float32 numbers the sums take
@@ -554,17 +560,14 @@ __device__ __forceinline__ void row_samples(const MapArgs& g, const Axis& ax_eta
   auto channel = [&](int c, bool first_channel) {
     float val[kN];
 #pragma unroll
-    for (int k = 0; k < kS; ++k) {  // (a plane's 2 kN gathers in flight together; all kS planes' at once would not fit the registers)
-      const int soff = (c * kS + k) * plane4;
-      pair4 r0[kN], r1[kN];
+    for (int k = 0; k < kS; ++k) {  // (a plane's kN gathers in flight together; all kS planes' at once would not fit the registers)
+      const int soff = (c * kS + k) * plane8;
+      quad4 cn[kN];  // (m[e0][x0], m[e0 + 1][x0], m[e0][x0 + 1], m[e0 + 1][x0 + 1])
+#pragma unroll
+      for (int q = 0; q < kN; ++q) cn[q] = __builtin_bit_cast(quad4, __builtin_amdgcn_raw_buffer_load_b128(rs, o0[q], soff, 0));
 #pragma unroll
       for (int q = 0; q < kN; ++q) {
-        r0[q] = __builtin_bit_cast(pair4, __builtin_amdgcn_raw_buffer_load_b64(rs, o0[q], soff, 0));
-        r1[q] = __builtin_bit_cast(pair4, __builtin_amdgcn_raw_buffer_load_b64(rs, o0[q], soff + pitch4, 0));
-      }
-#pragma unroll
-      for (int q = 0; q < kN; ++q) {
-        const float v = fmaf(w0a[q], r0[q].x, fmaf(w0b[q], r0[q].y, fmaf(w1a[q], r1[q].x, w1b[q] * r1[q].y)));
+        const float v = fmaf(w0a[q], cn[q].x, fmaf(w0b[q], cn[q].z, fmaf(w1a[q], cn[q].y, w1b[q] * cn[q].w)));
         val[q] = k == 0 ? wf[k] * v : fmaf(wf[k], v, val[q]);
       }
     }
@@ -1096,6 +1099,16 @@ __global__ __launch_bounds__(kBlock) void bin_accumulate_kernel(MapArgs g, BinAr
 // kKrj: the field leaves in K_RJ -- every row's four values times the row's scale, divided by den_band(el_det) exactly as
 // tod_krj_kernel divides a finished field (mrx_krj.h: the same per-tile elevation model from the same 1024 samples, the same
 // lookup), instead of a second pass that reads and writes the field again (3.9 of 18.3 ms at 10 000 x 240 000).
+// pairs[plane][e][x] = (m[e][x], m[e + 1][x]) (MapArgs::pairs), one thread per pair
+__global__ __launch_bounds__(kBlock) void map_pairs_kernel(const float* __restrict__ m, float2* __restrict__ pairs, int planes, int n_eta, int n_xi) {
+  const size_t per = (size_t)(n_eta - 1) * n_xi, n = per * planes;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const size_t p = i / per, r = i - p * per;
+    const float* src = m + p * (size_t)n_eta * n_xi + r;
+    pairs[i] = make_float2(src[0], src[n_xi]);
+  }
+}
+
 #ifndef MRX_MAP_CAL_WAVES
 #define MRX_MAP_CAL_WAVES 4
 #endif
@@ -1519,6 +1532,31 @@ static int map_sample(mrx_ctx* ctx, const mrx_sky_map* map, const mrx_map_cal* c
                        std::fabs(map->xi0 / map->dxi) < 8388608.0,
               "a map axis must have fewer than 2^23 nodes and start within 2^23 pixels of the map's centre");
   const bool chain = ctx->options[MRX_OPT_POINTING_CHAIN] != 0, has_cal = cal->d_table != nullptr;
+  g.pairs = nullptr;
+  g.pairs_bytes = 0;
+  if (!chain) {
+    const int planes = map->n_channels * map->n_stokes;
+    const unsigned long long bytes = 8ull * (unsigned long long)planes * (map->n_eta - 1) * map->n_xi;
+    MRX_REQUIRE(ctx, bytes < (1ull << 32), "the map (all channels and Stokes planes) must be smaller than 2 GiB (its row pairs than 4 GiB)");
+    if (!ctx->map_pairs_read) MRX_HIP(ctx, hipEventCreateWithFlags(&ctx->map_pairs_read, hipEventDisableTiming));
+    else MRX_HIP(ctx, hipStreamWaitEvent(ctx->stream, ctx->map_pairs_read, 0));  // (the sampler that last read the copy)
+    if (ctx->map_pairs_cap < bytes) {  // (grown on demand: rare)
+      if (ctx->d_map_pairs) {
+        MRX_HIP(ctx, hipDeviceSynchronize());
+        (void)hipFree(ctx->d_map_pairs);
+        ctx->d_map_pairs = nullptr;
+        ctx->map_pairs_cap = 0;
+      }
+      MRX_HIP(ctx, hipMalloc(&ctx->d_map_pairs, (size_t)bytes));
+      ctx->map_pairs_cap = (size_t)bytes;
+    }
+    const unsigned long long n_pairs = bytes / 8;
+    const unsigned blocks = (unsigned)std::min<unsigned long long>((n_pairs + kBlock - 1) / kBlock, 65536ull);
+    hipLaunchKernelGGL(map_pairs_kernel, dim3(blocks), dim3(kBlock), 0, ctx->stream, map->d_values, reinterpret_cast<float2*>(ctx->d_map_pairs),
+                       planes, map->n_eta, map->n_xi);
+    g.pairs = ctx->d_map_pairs;
+    g.pairs_bytes = (uint32_t)bytes;
+  }
   if (krj && chain)
     return mrx_fail(ctx, MRX_ERR_UNSUPPORTED, "mrx_map_sample_krj: not with MRX_OPT_POINTING_CHAIN (sample in pW, then mrx_tod_to_krj)");
   // (the kernel's static LDS -- sample records, edge exchange -- is up to 46 KiB: with large calibration
@@ -1547,6 +1585,7 @@ static int map_sample(mrx_ctx* ctx, const mrx_sky_map* map, const mrx_map_cal* c
 #undef MRX_LAUNCH_MAP_S
 #undef MRX_LAUNCH_MAP
   MRX_CHECK_LAUNCH(ctx);
+  if (g.pairs) MRX_HIP(ctx, hipEventRecord(ctx->map_pairs_read, ctx->stream));
   return MRX_OK;
 }
 
