@@ -54,7 +54,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak (spec); ~6300 achievable
-TRAFFIC_FILES = ("r05_traffic.json", "r05_traffic_writer.json", "r04_traffic.json", "r04_traffic_writer.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")  # newest first
+TRAFFIC_FILES = ("r06_traffic.json", "r06_traffic_writer.json", "r05_traffic.json", "r05_traffic_writer.json", "r04_traffic.json", "r04_traffic_writer.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json")  # newest first
 
 
 def parse_args(argv=None):

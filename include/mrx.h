@@ -31,12 +31,14 @@
 extern "C" {
 #endif
 
-#define MRX_VERSION 142 /* 0.2.0 (120): mrx_spline_upsample_fused, mrx_allgather_tod_p2p, mrx_exchange_screens,
+#define MRX_VERSION 150 /* 0.2.0 (120): mrx_spline_upsample_fused, mrx_allgather_tod_p2p, mrx_exchange_screens,
                            mrx_resample_columns; MRX_OPT_SAMPLE_TILES retired.  130: mrx_screen_amplitudes,
                            mrx_screen_desc.d_amp, mrx_screen_generate_3d(..., d_amp), mrx_streams_concurrent.
                            131: mrx_coarse_to_krj_keep_tail.  140: mrx_screen_desc.periodic_beam,
                            mrx_noise_generate_krj, the noise generator's two-rate form.  141: mrx_atm_synthesize,
-                           MRX_FLAG_HANDOVER.  142: mrx_atm_synthesize_krj, MRX_OPT_WRITER_PER_TILE */
+                           MRX_FLAG_HANDOVER.  142: mrx_atm_synthesize_krj, MRX_OPT_WRITER_PER_TILE.  150: mrx_map_cal.steps_per_tile
+                           (the struct's reserved word), MRX_OPT_GAUSS_ACCUM, MRX_OPT_SYNTH_ACQUIRE; mrx_map_sample reads a map
+                           of less than 2 GiB through a context-owned copy */
 
 typedef enum mrx_status {
   MRX_OK = 0,
@@ -650,7 +652,11 @@ typedef struct mrx_map_cal {
  *  d_transform  [T][3][3] float64 transform stack (row vector times matrix), or NULL
  *  d_dx, d_dy   [D] float32 offsets of observation.coords (rolled), radians
  *  d_stokes_w   [D][n_stokes] float64: Mueller[d, 0, stokes] (array/array.py:204-221)
- *  d_out        [D][ld_out] float32, pW */
+ *  d_out        [D][ld_out] float32, pW
+ * The map (all channels and Stokes planes) must be smaller than 2 GiB: the sampler reads it through a copy with its
+ * row pairs interleaved -- a cell's four corners in 16 contiguous bytes, one gather a sample and plane -- which every call
+ * builds into memory the context owns (twice the map's bytes, kept between calls; calls on one context are ordered).
+ * With MRX_OPT_POINTING_CHAIN the planes are read as they are (below 4 GiB). */
 int mrx_map_sample(mrx_ctx* ctx, const mrx_sky_map* map, const mrx_map_cal* cal,
                    const float* d_az, const float* d_el, int T, const double* d_transform,
                    const float* d_dx, const float* d_dy, const double* d_stokes_w, int D,

@@ -9,7 +9,9 @@ cp $SRC/bench.json $ROOT/profiles/${TAG}_bench.json
 # writer launches per step = the detector blocks the profiled bench line reports
 BLOCKS=$(python3 -c "import json,sys; print(json.load(open(sys.argv[1]))['stage_ms']['detector_blocks'])" $SRC/bench.json)
 python3 $ROOT/scripts/pmc_summary.py $SRC $ROOT/profiles/$TAG $BLOCKS
-for k in krj noise map bin; do [ -f $SRC/$k/run_kernel_stats.csv ] && cp $SRC/$k/run_kernel_stats.csv $ROOT/profiles/${TAG}_${k}_kernel_stats.csv; done
+for k in krj noise map bin gauss frontend_map; do [ -f $SRC/$k/run_kernel_stats.csv ] && cp $SRC/$k/run_kernel_stats.csv $ROOT/profiles/${TAG}_${k}_kernel_stats.csv; done
+[ -f $SRC/gauss_bench.log ] && grep -h "^#\|^gauss_smooth2d\|^map_smooth" $SRC/gauss_bench.log > $ROOT/profiles/${TAG}_gauss_bench.txt
+[ -f $SRC/gauss_bench_exact.log ] && grep -h "^#\|^gauss_smooth2d\|^map_smooth" $SRC/gauss_bench_exact.log > $ROOT/profiles/${TAG}_gauss_bench_exact.txt
 grep -h "pW\|groups" $SRC/krj_bench.log > $ROOT/profiles/${TAG}_krj_bench.txt
 grep -h "^noise" $SRC/noise_bench.log > $ROOT/profiles/${TAG}_noise_bench.txt
 python3 - $SRC/noise_pmc/run_counter_collection.csv > $ROOT/profiles/${TAG}_noise_pmc.txt <<'PY'

@@ -21,6 +21,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/noise -o run -- pyt
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/noise_pmc -o run -- python3 $ROOT/scripts/noise_bench.py 10000 240000 1 > $OUT/noise_pmc.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/map -o run -- python3 $ROOT/scripts/map_bench.py 10000 240000 2 > $OUT/map_bench.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bin -o run -- python3 $ROOT/scripts/bin_bench.py 1024 1 3 > $OUT/bin_bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/frontend_map -o run -- python3 $ROOT/scripts/frontend_trace.py map > $OUT/frontend_map.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/gauss -o run -- python3 $ROOT/scripts/gauss_bench.py 10 > $OUT/gauss_bench.log 2>&1
 cd $ROOT
+MRX_GAUSS_ACCUM=1 python3 scripts/gauss_bench.py 10 > $OUT/gauss_bench_exact.log 2>&1
 python3 bench.py > $OUT/bench.json 2> $OUT/bench.log
 tail -c 400 $OUT/bench.json

@@ -28,7 +28,7 @@ def test_header_symbols_are_exported_and_bound():
     for name in declared:
         assert hasattr(lib, name), f"{name} declared in include/mrx.h but not exported by libmrx.so"
     assert sorted(_lib.SIGNATURES) == declared, set(_lib.SIGNATURES) ^ set(declared)
-    assert maria_amd.load().mrx_version() == 142
+    assert maria_amd.load().mrx_version() == 150
 
 
 def test_struct_layouts_match_the_header(tmp_path):
