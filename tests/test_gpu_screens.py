@@ -35,6 +35,8 @@ def _smooth(ctx, a, sy, sx, truncate=4.0, inplace=False):
         ((5, 9), 3.0, 3.0),  # radius larger than the array: multiple reflections
         ((1, 200), 2.0, 2.0),
         ((513, 1025), 1.3, 25.0),
+        ((700, 333), 20.0, 3.0),   # a wide stencil along y on a plane that is not square: the transposed route (radius >= 64)
+        ((130, 515), 17.0, 0.0),   # ... alone (no x pass), radius beyond half the plane's height
     ],
 )
 def test_gauss_matches_scipy(gpu_ctx, shape, sy, sx):
