@@ -9,7 +9,13 @@
 namespace {
 
 #ifndef MRX_SYNTH_PIPE
-#define MRX_SYNTH_PIPE 1  // the sampler's layer loop as the three-stage gather ring (0: the plain loop)
+#define MRX_SYNTH_PIPE 0  // 1: the sampler's layer loop as the three-stage gather ring of rounds 4-5 (with MRX_SYNTH_KT 1)
+#endif
+#ifndef MRX_SYNTH_KT
+#define MRX_SYNTH_KT 2  // coarse steps a sampling thread works on side by side: two, their gathers and LDS reads in flight together
+#endif
+#ifndef MRX_SYNTH_TILE_BATCH
+#define MRX_SYNTH_TILE_BATCH 2  // tiles a writing workgroup draws from the queue at a time (1: A/B)
 #endif
 #ifndef MRX_SYNTH_ACQUIRE
 #define MRX_SYNTH_ACQUIRE 0  // 1: the guide's fallback for the consumer -- an agent acquire per tile, plain loads (A/B)
@@ -60,6 +66,40 @@ namespace {
 // kKrj (mrx_atm_synthesize_krj): TOD.to("K_RJ") on the coarse grid, in the sampler's epilogue -- what
 // coarse_krj_kernel does to a finished block between the two calls (same functions, same operands: the same bits),
 // the last knots kept aside in pW for the samples past the last knot.
+
+// -DMRX_SYNTH_TRACE (scripts/exp/synth_timeline.sh; never in the shipped library): every workgroup logs what it did and when
+// -- (kind, number, start, end) on the 100 MHz wall clock: 1 = a writer tile, 2 = a sampler item, 3 = a wait with nothing to do --
+// into a table in device memory that mrx_debug_synth_trace copies out.
+#ifdef MRX_SYNTH_TRACE
+constexpr int kTraceWgs = 2048, kTraceEv = 384;
+__device__ uint4 g_trace[kTraceWgs * kTraceEv];
+__device__ int g_trace_n[kTraceWgs];
+#define MRX_TRACE(kind, id, t0)                                                                                      \
+  do {                                                                                                               \
+    if (threadIdx.x == 0 && blockIdx.x < kTraceWgs) {                                                                \
+      const int k__ = g_trace_n[blockIdx.x];                                                                         \
+      if (k__ < kTraceEv) {                                                                                          \
+        g_trace[blockIdx.x * kTraceEv + k__] = make_uint4((unsigned)(kind), (unsigned)(id), (unsigned)(t0), (unsigned)wall_clock64()); \
+        g_trace_n[blockIdx.x] = k__ + 1;                                                                             \
+      }                                                                                                              \
+    }                                                                                                                \
+  } while (0)
+#define MRX_TRACE_RAW(a, b, c, d)                                                                                   \
+  do {                                                                                                               \
+    if (threadIdx.x == 0 && blockIdx.x < kTraceWgs) {                                                                \
+      const int k__ = g_trace_n[blockIdx.x];                                                                         \
+      if (k__ < kTraceEv) {                                                                                          \
+        g_trace[blockIdx.x * kTraceEv + k__] = make_uint4((unsigned)(a), (unsigned)(b), (unsigned)(c), (unsigned)(d)); \
+        g_trace_n[blockIdx.x] = k__ + 1;                                                                             \
+      }                                                                                                              \
+    }                                                                                                                \
+  } while (0)
+#define MRX_TRACE_NOW() wall_clock64()
+#else
+#define MRX_TRACE_RAW(a, b, c, d) do {} while (0)
+#define MRX_TRACE(kind, id, t0) do { (void)(t0); } while (0)
+#define MRX_TRACE_NOW() 0ull
+#endif
 
 // The calibration of the K_RJ form (DevicePath.set_calibration: the band's denominators on the elevation axis).
 struct SynthCal {
@@ -112,6 +152,7 @@ struct SynthHooks {
 #ifndef MRX_SYNTH_WAVES
 #define MRX_SYNTH_WAVES MRX_WRITER_WAVES
 #endif
+constexpr int kTileBatch = MRX_SYNTH_TILE_BATCH;
 template <bool kLdsTables, bool kHasScale, int kMaxKnots, int kG, bool kKrj>
 __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_SYNTH_WAVES, MRX_SYNTH_WAVES))) void atm_tod_kernel(
     const mrx_layer_fast* __restrict__ fast, const mrx_layer_px* __restrict__ lpx, int n_layers,
@@ -156,91 +197,118 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_SYNT
   bool sampling = (int)blockIdx.x < n_dedicated;  // (workgroup-uniform, like everything that steers the loop)
   bool items_left = true;
   int tile = -1;   // the tile in hand, not yet written
+  int tile_end = 0, ready_end = 0;  // the batch in hand is tile .. tile_end - 1; tiles below ready_end have their chunks in
+  int seen = 0;    // the last ticket this workgroup drew (how far the queue has got, roughly)
+  // (block, time tile, row group) of tile `tl`
+  auto tile_of = [&](int tl, int& blk, int& sx, int& rg) {
+    blk = last == 0 ? 0 : min(tl / tiles_full, last);
+    const int rem = tl - blk * tiles_full;
+    const int nrg = blk == last ? nrg_last : nrg_full;
+    if (tile_order == 0) {  // time tile by time tile, the block's row groups side by side
+      sx = rem / nrg;
+      rg = rem - sx * nrg;
+    } else {  // row group by row group, its time tiles in a row
+      rg = rem / nsx;
+      sx = rem - rg * nsx;
+    }
+  };
   int have = 0;    // hand-over units 0 .. have - 1 are known to be sampled (blocks in order, chunks in order)
   int tries = 0;
   for (;;) {
     __syncthreads();  // everybody is done with the previous turn's LDS: the images, the tables, s_word
     bool take_item = sampling;
     if (!sampling) {
-      // ---- a tile: take one if none is in hand, then see whether its chunks are sampled ----
-      if (threadIdx.x < 64) {  // the first wave
-        int tl = tile, need = 0;
-        if (tl < 0) {
-          if (threadIdx.x == 0) tl = __hip_atomic_fetch_add(ctl + kCtlTiles, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          tl = __builtin_amdgcn_readfirstlane(tl);
-        }
-        int hv = have, blk = 0, sx = 0, rg = 0;
-        if (tl < n_tiles) {
-          // (the integer divisions of this decode are a few dozen vector instructions each -- there is no scalar one --:
-          // done here once for the workgroup, not by every wave)
-          blk = last == 0 ? 0 : min(tl / tiles_full, last);
-          const int rem = tl - blk * tiles_full;
-          const int nrg = blk == last ? nrg_last : nrg_full;
-          if (tile_order == 0) {  // time tile by time tile, the block's row groups side by side
-            sx = rem / nrg;
-            rg = rem - sx * nrg;
-          } else {  // row group by row group, its time tiles in a row
-            rg = rem / nsx;
-            sx = rem - rg * nsx;
+      // ---- tiles: a batch of tickets if none is in hand, then whether the batch's chunks are sampled ----
+      // A workgroup takes kTileBatch consecutive tiles from the queue at a time -- neighbouring row groups of one time
+      // tile (or that tile's last and the next one's first): they read the same chunks -- and asks once for all of them,
+      // about the last one (the units complete in order: what the last tile reads is in when everything before it is).
+      // Between two tiles of a batch nothing is asked of memory.  One ticket, one look at t[], one poll a TILE were three
+      // dependent round trips behind the draining stores of the tile just written: 2.5 us before every 13-16-us tile
+      // (profiles/r06_synth_timeline.txt).  Near the end of the queue a workgroup takes single tiles again (the tail).
+      if (tile < 0 || tile >= ready_end) {
+        if (threadIdx.x < 64) {  // the first wave
+          int tl = tile, te = tile_end, need = 0;
+          const unsigned long long tg0 = MRX_TRACE_NOW();
+          if (tl < 0) {
+            const int want = seen + 2 * kTileBatch * (int)gridDim.x >= n_tiles ? 1 : kTileBatch;
+            if (threadIdx.x == 0) tl = __hip_atomic_fetch_add(ctl + kCtlTiles, want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tl = __builtin_amdgcn_readfirstlane(tl);
+            te = min(tl + want, n_tiles);
           }
-          int lo, hi;
-          fused_tile_knots(t, T, Ta, ta0, inv_dta, sx, lo, hi);
-          need = blk * nby + hi / chunk;  // the last unit the tile reads (a tile's knots lie in one block)
-          // the watermark: 16 counters a look, on while all 16 are complete and the tile's are not reached
-          while (hv <= need) {
-            const int sl = hv + (int)threadIdx.x;
-            bool ok = false;
-            if (threadIdx.x < 16 && sl < n_slots) {
-              const int want = sl >= last * nby ? nbx_last : nbx_full;
-              ok = __hip_atomic_load(ctl + kCtlDone + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
+          const unsigned long long tg1 = MRX_TRACE_NOW();
+          unsigned long long tg2 = tg1;
+          int hv = have;
+          if (tl < n_tiles) {
+            // (the integer divisions of this decode are a few dozen vector instructions each -- there is no scalar one)
+            int blk, sx, rg;
+            tile_of(te - 1, blk, sx, rg);
+            int lo, hi;
+            fused_tile_knots(t, T, Ta, ta0, inv_dta, sx, lo, hi);
+            need = blk * nby + hi / chunk;  // the last unit the batch reads (a tile's knots lie in one block)
+            tg2 = MRX_TRACE_NOW();
+            // the watermark: 16 counters a look, on while all 16 are complete and the batch's are not reached
+            while (hv <= need) {
+              const int sl = hv + (int)threadIdx.x;
+              bool ok = false;
+              if (threadIdx.x < 16 && sl < n_slots) {
+                const int want = sl >= last * nby ? nbx_last : nbx_full;
+                ok = __hip_atomic_load(ctl + kCtlDone + sl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want;
+              }
+              const unsigned long long m = __builtin_amdgcn_ballot_w64(ok) & 0xffffull;
+              const int adv = m == 0xffffull ? 16 : __builtin_ctzll(~m);
+              hv += adv;
+              if (adv < 16) break;
             }
-            const unsigned long long m = __builtin_amdgcn_ballot_w64(ok) & 0xffffull;
-            const int adv = m == 0xffffull ? 16 : __builtin_ctzll(~m);
-            hv += adv;
-            if (adv < 16) break;
+          }
+          MRX_TRACE_RAW(4, tg1 - tg0, tg2 - tg1, MRX_TRACE_NOW() - tg2);  // ticket, decode + knots, poll
+          if (threadIdx.x == 0) {
+            s_word[0] = tl;
+            s_word[1] = hv;
+            s_word[2] = need;
+            s_word[3] = te;
+          }
+          // MRX_OPT_SYNTH_ACQUIRE (round 6: a RUNTIME switch; the build switch MRX_SYNTH_ACQUIRE = 1 also turns the tile's sc1
+          // loads into plain ones): the polling wave, once its poll has matched, runs the agent-scope acquire -- it invalidates
+          // this CU's L1 -- and waits for it; the barrier below then holds every other wave behind it.  With the producer's
+          // sc1 stores and drained waves that is one of MI355X_MICROARCH.md's always-valid hand-offs, whatever the number of
+          // workgroups a CU holds; the tile's loads stay sc1 (past the L1 anyway), so the switch only adds the fence.
+          if ((MRX_SYNTH_ACQUIRE || acquire) && hv > need) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           }
         }
-        if (threadIdx.x == 0) {
-          s_word[0] = tl;
-          s_word[1] = hv;
-          s_word[2] = need;
-          s_word[3] = blk;
-          s_word[4] = sx;
-          s_word[5] = rg;
+        __syncthreads();  // between the poll and EVERY load of the chunks' bytes, the polling wave's own too
+        tile = s_word[0];
+        have = s_word[1];
+        const int need = s_word[2];
+        tile_end = s_word[3];
+        if (tile >= n_tiles) break;  // (the queue is empty: nothing in hand, nothing left)
+        seen = tile;
+        bool ready = have > need;
+        if (!ready && !items_left) {  // the chunk is being sampled by others: wait for it
+          if (++tries > poll_limit) {
+            if (threadIdx.x == 0) atomicOr(flags, MRX_FLAG_HANDOVER);
+            ready = true;
+          } else {
+            const unsigned long long tw0 = MRX_TRACE_NOW();
+            __builtin_amdgcn_s_sleep(32);
+            MRX_TRACE(3, tile, tw0);
+            continue;
+          }
         }
-        // MRX_OPT_SYNTH_ACQUIRE (round 6: a RUNTIME switch; the build switch MRX_SYNTH_ACQUIRE = 1 also turns the tile's sc1
-        // loads into plain ones): the polling wave, once its poll has matched, runs the agent-scope acquire -- it invalidates
-        // this CU's L1 -- and waits for it; the barrier below then holds every other wave behind it.  With the producer's
-        // sc1 stores and drained waves that is one of MI355X_MICROARCH.md's always-valid hand-offs, whatever the number of
-        // workgroups a CU holds; the tile's loads stay sc1 (past the L1 anyway), so the switch only adds the fence.
-        if ((MRX_SYNTH_ACQUIRE || acquire) && hv > need) {
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
+        if (ready) ready_end = tile_end;
       }
-      __syncthreads();  // between the poll and EVERY load of the chunks' bytes, the polling wave's own too
-      tile = s_word[0];
-      have = s_word[1];
-      const int need = s_word[2];
-      if (tile >= n_tiles) break;  // (the queue is empty: nothing in hand, nothing left)
-      bool ready = have > need;
-      if (!ready && !items_left) {  // the chunk is being sampled by others: wait for it
-        if (++tries > poll_limit) {
-          if (threadIdx.x == 0) atomicOr(flags, MRX_FLAG_HANDOVER);
-          ready = true;
-        } else {
-          __builtin_amdgcn_s_sleep(32);
-          continue;
-        }
-      }
-      if (ready) {
-        const int blk = s_word[3], sx = s_word[4], by = s_word[5];
+      if (tile < ready_end) {
+        int blk, sx, by;
+        tile_of(tile, blk, sx, by);  // (every wave for itself: no word to pass, no barrier)
         const int Db = blk == last ? last_rows : block_rows;
         const size_t row0 = (size_t)blk * block_rows;
+        const unsigned long long tt0 = MRX_TRACE_NOW();
         fused_writer_tile<kHasScale, kMaxKnots, kG, MRX_SYNTH_ACQUIRE == 0>(loading + (size_t)Ta * row0, (Db + 31) & ~31, Db, Ta, ta0, inv_dta, t, T,
                                                            kHasScale ? scale + row0 : nullptr, rows ? rows + row0 : nullptr,
                                                            rows ? out : out + row0 * ld, ld, vec_ok, batches, sx, by, synth_lds);
-        tile = -1;
+        MRX_TRACE(1, tile, tt0);
+        if (++tile == tile_end) tile = -1;
         tries = 0;
         continue;
       }
@@ -262,13 +330,15 @@ __global__ __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MRX_SYNT
       const int nbx = blk == last ? nbx_last : nbx_full;
       const int by = rem / nbx, bx = rem - by * nbx;
       hooks.slot = blk * nby + by;
+      const unsigned long long ti0 = MRX_TRACE_NOW();
       if (kKrj) stage_cal_cells(cells, cal.axis, cal.values, cal.n_el, cal.n_bands);  // (the item starts with a barrier)
       // px_sample_items walks the items of "workgroup w of W" in its own order -- XCD w mod 8 takes the chunks
       // w mod 8, + 8, ... -- and W = 2^30 makes that walk exactly ONE item long: the one numbered (by, bx)
-      mrx_px::px_sample_items<kLdsTables, 1, MRX_SYNTH_PIPE != 0, true>(
+      mrx_px::px_sample_items<kLdsTables, MRX_SYNTH_KT, MRX_SYNTH_PIPE != 0, true>(
           fast, lpx, n_layers, offpx, tables, n_tables, table_data, table_floats, az, el, Ta, dxs, dys, band, mueller00,
           D, pwv0, pwv_out, loading, flags, chunk, nby, block_rows, n_blocks, blk, blk + 1, ((by >> 3) * nbx + bx) * 8 + (by & 7),
           1 << 30, reinterpret_cast<float4*>(synth_lds), hooks);
+      MRX_TRACE(2, item, ti0);
     }
   }
   synth_leave(ctl, n_slots);
@@ -459,3 +529,16 @@ int mrx_atm_synthesize_krj(mrx_ctx* ctx, const mrx_atm_plan* plan, const float* 
 }
 
 }  // extern "C"
+
+#ifdef MRX_SYNTH_TRACE
+// events: [2048][384] x 16 bytes, counts: [2048] ints (host buffers); reset != 0 clears the counts afterwards
+extern "C" int mrx_debug_synth_trace(void* events, void* counts, int reset) {
+  if (hipMemcpyFromSymbol(events, HIP_SYMBOL(g_trace), sizeof(uint4) * kTraceWgs * kTraceEv) != hipSuccess) return MRX_ERR_HIP;
+  if (hipMemcpyFromSymbol(counts, HIP_SYMBOL(g_trace_n), sizeof(int) * kTraceWgs) != hipSuccess) return MRX_ERR_HIP;
+  if (reset) {
+    static int zeros[kTraceWgs];
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_trace_n), zeros, sizeof(zeros)) != hipSuccess) return MRX_ERR_HIP;
+  }
+  return MRX_OK;
+}
+#endif
