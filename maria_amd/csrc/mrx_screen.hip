@@ -488,12 +488,34 @@ __global__ __launch_bounds__(kBlock) void screen_c2r_regs(const ScreenBatchArgs 
   const bool live = y < L.out_ny;  // uniform over the row's waves
   const size_t pitch = (size_t)ny + kPitchPad;
   float2 x[16];
-#pragma unroll
-  for (int b = 0; b < 16; ++b) x[b] = live ? L.work[(size_t)(t + T * b) * pitch + y] : make_float2(0.f, 0.f);
   const float nyq = live ? L.work[(size_t)n2 * pitch + y].x : 0.0f;  // G[nx/2][y] is real up to rounding
+  if constexpr (G >= 2 && RB >= 8) {
+    // (rows of 4096 samples: at 2048 the pass is not bound by its gathers and the detour through LDS costs 8 %)
+    // The gather is what bounds this pass (the texture addresser 81 % busy at 4096^2, 64 lines a load instruction,
+    // profiles/r06_50k_kernel_pmc.txt) and its cost is per instruction and address, not per byte: two neighbouring rows'
+    // thread groups share the work -- each lane fetches 16 bytes, ITS cell k of both rows, for every other b -- and hand
+    // each other's halves over in the exchange image, where the mirrored cells are read from anyway: half the gathers.
+    const int pw = which & 1, y0 = y - pw;  // (G is even and so is y0: 16-byte aligned with the even pitch)
+    float2* const ex_even = ex1 - (size_t)pw * 2 * kFft4096Pitch * T;
+    float2* const ex_odd = ex_even + 2 * kFft4096Pitch * T;
+    const bool pair_live = y0 < L.out_ny;
 #pragma unroll
-  for (int b = 0; b < 16; ++b) ex1[t + T * b] = x[b];
-  __syncthreads();
+    for (int bb = 0; bb < 8; ++bb) {
+      const int b = 2 * bb + pw;
+      const float4 q = pair_live ? *reinterpret_cast<const float4*>(L.work + (size_t)(t + T * b) * pitch + y0) : make_float4(0.f, 0.f, 0.f, 0.f);
+      ex_even[t + T * b] = make_float2(q.x, q.y);
+      ex_odd[t + T * b] = make_float2(q.z, q.w);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int b = 0; b < 16; ++b) x[b] = live ? ex1[t + T * b] : make_float2(0.f, 0.f);
+  } else {
+#pragma unroll
+    for (int b = 0; b < 16; ++b) x[b] = live ? L.work[(size_t)(t + T * b) * pitch + y] : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int b = 0; b < 16; ++b) ex1[t + T * b] = x[b];
+    __syncthreads();
+  }
   // w^k = exp(2 pi i k / nx), k = t + T b: exp(2 pi i t / nx) exp(2 pi i b / 32)
   const float2 wt = make_float2(__builtin_amdgcn_cosf((float)t * (1.0f / (float)nx)), __builtin_amdgcn_sinf((float)t * (1.0f / (float)nx)));
   constexpr float kC32[16] = {1.0f, 0.98078528040323044f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f,
