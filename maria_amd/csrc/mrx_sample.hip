@@ -461,11 +461,13 @@ __global__ void plan_finish_layers(mrx_layer_dev* layers, mrx_layer_fast* fast, 
               (unsigned long long)ly.n_e * (unsigned long long)ly.n_c * 4ull < (1ull << 32);
     mrx_layer_px& q = px[l];
     q.values = ly.values;
+    q.values1 = ly.values + ly.n_c;
     q.pe_x = (float)ly.pe_x; q.pe_y = (float)ly.pe_y; q.pc_x = (float)ly.pc_x; q.pc_y = (float)ly.pc_y;
     q.nc4 = 4 * ly.n_c;
     q.pwv_rms = ly.pwv_rms;
     q.half_e = 0.5f * (float)(ly.n_e - 1); q.half_c = 0.5f * (float)(ly.n_c - 1);
     q.bytes = f.pixel ? (uint32_t)((unsigned long long)ly.n_e * (unsigned long long)ly.n_c * 4ull) : 0u;
+    q.bytes1 = f.pixel ? q.bytes - (uint32_t)q.nc4 : 0u;
   }
 }
 

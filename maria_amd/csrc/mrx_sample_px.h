@@ -5,8 +5,6 @@
 // including TU's flags say -- a * b + c rounds twice, like numpy / XLA; fused multiply-adds are written out.
 #pragma once
 
-#include <cstddef>
-
 #include "mrx_internal.h"
 
 #pragma clang fp contract(off)
@@ -40,18 +38,17 @@ static_assert(sizeof(mrx_layer_fast) == 64, "one cache line per layer");
 
 // The float32 record of the pixel-coordinate kernel (atm_sample_px_kernel): one scalar load per layer and wave.
 struct alignas(64) mrx_layer_px {
-  // the 32 bytes the layer loop reads, as ONE scalar load (what else a layer-sample needs rides in the anchors)
-  const float* values;   // the screen
+  const float* values;   // the screen: the lower corners of a cell
+  const float* values1;  // the screen from its second row on: the upper corners, at the same byte offset
   float pe_x, pe_y, pc_x, pc_y;
   int nc4;               // 4 n_c: a row in bytes
   uint32_t bytes;        // 4 n_e n_c (< 4 GiB, plan_finish_layers): the range the hardware checks the gathers against
-  // for the item's prologue (the anchors)
+  uint32_t bytes1;       // bytes - nc4
   float pwv_rms;
   float half_e, half_c;  // (n_e - 1) / 2, (n_c - 1) / 2: a position is on the grid while |position - middle| <= half
-  int pad_[5];
+  int pad_[2];
 };
 static_assert(sizeof(mrx_layer_px) == 64, "one cache line per layer");
-static_assert(offsetof(mrx_layer_px, pe_x) == 8 && offsetof(mrx_layer_px, nc4) == 24 && offsetof(mrx_layer_px, bytes) == 28, "px_sample_items reads the first eight words by position");
 
 // Device-side band table descriptor: offsets (in floats) into the packed table
 // buffer, which is [values 2*np*ne][axis_pwv np][axis_el ne] per band.
@@ -316,11 +313,7 @@ __device__ __forceinline__ void px_sample_items(
       const double ce = floor(fmin(fmax(Fe, -1.0e9), 1.0e9)), cc = floor(fmin(fmax(Fc, -1.0e9), 1.0e9));
       anchor[2 * k] = make_float4((float)(Fe - ce), (float)(Fc - cc), (float)(0.5 * (double)(lf.n_e - 1) - ce),
                                   (float)(0.5 * (double)(lf.n_c - 1) - cc));
-      // the second half: the byte offset of the anchor's cell, the layer's half widths and rms (per layer, not per step:
-      // but here a lane reads them with the offset in one 16-byte LDS access, where the layer's record -- scalar loads
-      // in the wave's one instruction stream -- would need three more loads and their addresses)
-      anchor[2 * k + 1] = make_float4(__int_as_float((int)(uint32_t)(((long long)ce * lf.n_c + (long long)cc) * 4ll)),
-                                      0.5f * (float)(lf.n_e - 1), 0.5f * (float)(lf.n_c - 1), lf.pwv_rms);
+      reinterpret_cast<int*>(anchor + 2 * k + 1)[0] = (int)(uint32_t)(((long long)ce * lf.n_c + (long long)cc) * 4ll);
     }
 
     const int d = bx * kPxBlock + threadIdx.x;
@@ -342,7 +335,7 @@ __device__ __forceinline__ void px_sample_items(
 
     for (int it = 0; it < chunk && t_first + it < Ta; it += kT) {
       float theta[kT], dpx[kT], dpy[kT], fl[kT];
-      float beyond[kT];  // how far the position left some layer's grid (pixels; <= 0: on every grid)
+      bool outside[kT];  // some layer's position left its grid (the compiler keeps it as a lane mask in scalar registers)
 #pragma unroll
       for (int tt = 0; tt < kT; ++tt) {
         // transforms.py:20-28 and the unit-height ground projection (see atm_sample_kernel)
@@ -355,7 +348,7 @@ __device__ __forceinline__ void px_sample_items(
         dpx[tt] = (re * bt.z - Y * bt.w) * inv_im - pc.x;
         dpy[tt] = (Y * bt.z + re * bt.w) * inv_im - pc.y;
         fl[tt] = 0.0f;
-        beyond[tt] = -1.0f;
+        outside[tt] = false;
       }
       // ---- layer stack (atmosphere/atmosphere.py:317-373) ---------------------
       // Per layer and sample: the position relative to the anchor's cell, f = fraction + delta (two fused
@@ -375,41 +368,32 @@ __device__ __forceinline__ void px_sample_items(
       struct Stage {  // one layer's gathers in flight, for the thread's kT steps
         pair4 r0[kT], r1[kT];
         float we[kT], wc[kT];
-        float rms[kT];
+        float rms;
       };
       auto issue = [&](int l, Stage& g) {
-        // wave-uniform: the record's first 32 bytes as ONE scalar load (field by field they came as three, each with a
-        // 64-bit address of its own)
-        typedef int rec8 __attribute__((ext_vector_type(8)));
-        const rec8 w = *reinterpret_cast<const rec8*>(lpx + l);
-        struct { float pe_x, pe_y, pc_x, pc_y; } lp = {__int_as_float(w[2]), __int_as_float(w[3]), __int_as_float(w[4]), __int_as_float(w[5])};
-        const int nc4 = w[6];
-        // ONE raw buffer, the screen: the lower corners at the cell's byte offset, the upper ones a row further on (a
-        // vector add: a second descriptor -- the screen from its second row on -- cost four scalar instructions more a
-        // layer-sample, and the scalar unit issues from the same one-instruction-at-a-time stream as everything else of
-        // the wave); each load is checked against the screen's size
-        const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc(
-            reinterpret_cast<void*>(((unsigned long long)(unsigned)w[1] << 32) | (unsigned long long)(unsigned)w[0]), 0, w[7], 0x00020000);
+        const mrx_layer_px lp = lpx[l];  // wave-uniform: one scalar load
+        const int nc4 = lp.nc4;
+        // two raw buffers: the screen, and the screen from its second row on -- the upper corners of a cell take the
+        // same offset in the second, and each load is checked against its own range
+        const __amdgpu_buffer_rsrc_t rs0 = __builtin_amdgcn_make_buffer_rsrc((void*)lp.values, 0, (int)lp.bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc((void*)lp.values1, 0, (int)lp.bytes1, 0x00020000);
+        g.rms = lp.pwv_rms;
 #pragma unroll
         for (int tt = 0; tt < kT; ++tt) {
           const float4 a4 = an[2 * (tt * n_layers + l)];
-          const float4 b4 = an[2 * (tt * n_layers + l) + 1];
-          const int a0 = __float_as_int(b4.x);
-          g.rms[tt] = b4.w;
+          const int a0 = reinterpret_cast<const int*>(an + 2 * (tt * n_layers + l) + 1)[0];
           const float fe = __builtin_fmaf(dpx[tt], lp.pe_x, __builtin_fmaf(dpy[tt], lp.pe_y, a4.x));
           const float fc = __builtin_fmaf(dpx[tt], lp.pc_x, __builtin_fmaf(dpy[tt], lp.pc_y, a4.y));
           g.we[tt] = __builtin_amdgcn_fractf(fe);
           g.wc[tt] = __builtin_amdgcn_fractf(fc);
-          // how far past the rim, the largest over the layers (> 0: off some grid; a NaN position drops out of the
-          // maximum and makes the sum NaN instead): three vector instructions where two comparisons cost five scalar ones
-          beyond[tt] = __builtin_fmaxf(beyond[tt], __builtin_fmaxf(__builtin_fabsf(fe - a4.z) - b4.y, __builtin_fabsf(fc - a4.w) - b4.z));
+          outside[tt] |= !(__builtin_fabsf(fe - a4.z) <= lp.half_e) || !(__builtin_fabsf(fc - a4.w) <= lp.half_c);
           const int boff = mad_i32_i24(cvt_flr_i32(fe), nc4, a0) + (cvt_flr_i32(fc) << 2);
 #ifdef MRX_PX_WHATIF_NOLOAD  // (timing what-if, scripts/exp/synth_timeline.sh: wrong values, the same arithmetic, no gathers)
           g.r0[tt] = pair4{__int_as_float(boff | 0x3f000000), 0.5f};
           g.r1[tt] = pair4{0.25f, __int_as_float(boff | 0x3f000000)};
 #else
           g.r0[tt] = __builtin_bit_cast(pair4, __builtin_amdgcn_raw_buffer_load_b64(rs0, boff, 0, 0));
-          g.r1[tt] = __builtin_bit_cast(pair4, __builtin_amdgcn_raw_buffer_load_b64(rs0, boff + nc4, 0, 0));
+          g.r1[tt] = __builtin_bit_cast(pair4, __builtin_amdgcn_raw_buffer_load_b64(rs1, boff, 0, 0));
 #endif
         }
       };
@@ -418,7 +402,7 @@ __device__ __forceinline__ void px_sample_items(
         for (int tt = 0; tt < kT; ++tt) {
           const float y0 = __builtin_fmaf(g.wc[tt], g.r0[tt].y - g.r0[tt].x, g.r0[tt].x);
           const float y1 = __builtin_fmaf(g.wc[tt], g.r1[tt].y - g.r1[tt].x, g.r1[tt].x);
-          fl[tt] = __builtin_fmaf(g.rms[tt], __builtin_fmaf(g.we[tt], y1 - y0, y0), fl[tt]);
+          fl[tt] = __builtin_fmaf(g.rms, __builtin_fmaf(g.we[tt], y1 - y0, y0), fl[tt]);
         }
       };
       Stage ga;
@@ -429,15 +413,12 @@ __device__ __forceinline__ void px_sample_items(
 #pragma unroll
         for (int k = 0; k < kPxStages - 1; ++k)
           if (k < n_layers) issue(k, g[k]);
-        // (the loop counts the layer being ISSUED: counted by the layer being blended, the records of the layers issued
-        // were addressed backwards from a pointer a few records ahead, every field with a 64-bit subtraction of its own --
-        // ten scalar instructions a layer-sample)
-        for (int ln = kPxStages - 1; ln - (kPxStages - 1) < n_layers; ln += kPxStages) {
+        for (int l = 0; l < n_layers; l += kPxStages) {
 #pragma unroll
           for (int k = 0; k < kPxStages; ++k) {
-            if (ln + k < n_layers) issue(ln + k, g[(k + kPxStages - 1) % kPxStages]);
+            if (l + k + kPxStages - 1 < n_layers) issue(l + k + kPxStages - 1, g[(k + kPxStages - 1) % kPxStages]);
             __builtin_amdgcn_sched_barrier(0);
-            if (ln + k - (kPxStages - 1) < n_layers) blend(g[k]);
+            if (l + k < n_layers) blend(g[k]);
             __builtin_amdgcn_sched_barrier(0);
           }
         }
@@ -453,7 +434,7 @@ __device__ __forceinline__ void px_sample_items(
         if (kT > 1 && it + tt >= chunk) break;  // (a chunk that is no multiple of kT: the steps past it are another item's)
         const int t = t_first + it + tt;
         // a line of sight off a screen is jax's NaN fill (atmosphere.py:359-369); a NaN position makes the sum NaN
-        const bool off = beyond[tt] > 0.0f || fl[tt] != fl[tt];
+        const bool off = outside[tt] || fl[tt] != fl[tt];
         const double pwv = off ? (double)__builtin_nanf("") : pwv0 + (double)fl[tt];
         bool table_oob;
         const float out = band_loading_px(tb, tdata, (float)pwv, theta[tt], m00, table_oob);
