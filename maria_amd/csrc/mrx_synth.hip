@@ -123,7 +123,9 @@ struct SynthHooks {
   float el_first, el_last, el_inv;
   float a_re = 0.0f, a_im = 0.0f;  // of the work item's detector (make_cal_det)
   const float4* C = nullptr;
+  unsigned long long tr_item = 0ull;  // (trace build: when the item's prologue -- boresight, anchors -- was through)
   __device__ __forceinline__ void item(int, int d) {
+    tr_item = MRX_TRACE_NOW();
     if (kKrj) {
       const CalDet c = make_cal_det(cal.dx[d], cal.dy[d], min(max(band[d], 0), cal.n_bands - 1), 1.0f);
       a_re = c.a_re;
@@ -141,9 +143,12 @@ struct SynthHooks {
   }
   int slot = 0;  // the hand-over unit of the work item in progress: block * nby + time chunk
   __device__ __forceinline__ void done(int) {
+    const unsigned long long tr_loop = MRX_TRACE_NOW();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's (write-through) stores of the item are out
+    const unsigned long long tr_drain = MRX_TRACE_NOW();
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_fetch_add(ctl + kCtlDone + slot, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    MRX_TRACE_RAW(5, tr_loop - tr_item, tr_drain - tr_loop, tr_item);  // steps' loop, the drain, when the prologue ended
   }
 };
 

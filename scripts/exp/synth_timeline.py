@@ -50,7 +50,12 @@ for w in range(W):
         rows.append((w, *ev[w, k]))
 a = np.array(rows, dtype=np.int64)
 turns = a[a[:, 1] == 4]
-a = a[a[:, 1] != 4]
+parts = a[a[:, 1] == 5]
+a = a[(a[:, 1] != 4) & (a[:, 1] != 5)]
+if len(parts):  # inside a sampler item (thread 0's wave): the steps' loop and the drain of its stores, in 10-ns ticks
+    for name, col in (("steps' loop (behind the prologue)", 2), ("drain of the write-through stores", 3)):
+        d = parts[:, col] / 100.0
+        print(f"item {name}: n={len(d)} median {np.median(d):.2f} us p90 {np.percentile(d, 90):.2f} mean {d.mean():.2f}")
 if len(turns):  # what the first wave spent before a tile: (ticket, decode + the tile's knots, poll) in 10-ns ticks
     for name, col in (("ticket (queue atomic)", 2), ("decode + t[] of the tile", 3), ("poll", 4)):
         d = turns[:, col] / 100.0
