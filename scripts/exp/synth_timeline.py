@@ -7,6 +7,7 @@ Prints, per time bin of the launch: workgroups in a writer tile, in a sampler it
 stored) in the bin; then the distributions of tile / item durations and of the gaps between a workgroup's events.
 """
 import ctypes
+import os
 import sys
 
 import numpy as np
@@ -22,10 +23,11 @@ bin_us = float(sys.argv[2]) if len(sys.argv) > 2 else 50.0
 n_det = synthetic.CONFIGS[config]["n_det"]
 if config == "atlast_50k":
     n_det //= 8
+if os.environ.get("MRX_TL_ROWS"):  # a shard: the first rows of the configuration
+    n_det = int(os.environ["MRX_TL_ROWS"])
 problem = synthetic.config_problem(config, n_det=n_det)
 path = DevicePath(problem, device="cuda:0")
 tod = torch.empty((path.D, path.T), dtype=torch.float32, device="cuda:0")
-import os  # noqa: E402
 if os.environ.get("MRX_TL_CHUNK"):
     path.ctx.set_option(_lib.OPT_SAMPLE_CHUNK, int(os.environ["MRX_TL_CHUNK"]))
 if os.environ.get("MRX_TL_SAMPLERS"):  # dedicated sampler workgroups per CU
