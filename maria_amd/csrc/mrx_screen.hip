@@ -40,6 +40,10 @@ constexpr int kMaxBatch = 16;         // layers per launch
 // G[kx][.] rows are ny + kPitchPad complex apart: pass 2 walks kx at fixed y, and a power-of-two
 // stride of 8 ny bytes would put every access of that walk on the same memory channel
 constexpr int kPitchPad = 16;
+#ifndef MRX_SCREEN_IMAGES
+#define MRX_SCREEN_IMAGES 1  // exchange images of the register transforms in the two generator passes (fft_regs: 2 = the round-3 form, A/B)
+#endif
+constexpr int kScreenImages = MRX_SCREEN_IMAGES;
 constexpr int kMaxFusedRadius = 128;  // Gaussian taps kept in LDS by the fused passes
 
 // sqrt of the von Karman / Matern spectrum: (k0^2 + |k|^2)^expo via exp2/log2
@@ -255,10 +259,12 @@ __device__ __forceinline__ void half_spectrum_column_stockham(const ScreenLayerA
 }
 
 // pass 1, every column (0 .. nx/2) through the Stockham transform: one workgroup per (kx, layer)
+// (col_step: 1, or nx/2 with a grid of two -- the two self-mirrored columns beside the register form, in a launch of their
+// own so that the register form's workgroups ask for their own LDS only)
 __global__ __launch_bounds__(kBlock) void screen_half_spectrum_fft_y(
-    const ScreenBatchArgs args, int ny, int nx, int log2ny, uint32_t key0, uint32_t key1) {
+    const ScreenBatchArgs args, int ny, int nx, int log2ny, uint32_t key0, uint32_t key1, int col_step) {
   extern __shared__ __align__(16) float2 lds2[];
-  half_spectrum_column_stockham(args.l[blockIdx.y], lds2, blockIdx.x, ny, nx, log2ny, key0, key1);
+  half_spectrum_column_stockham(args.l[blockIdx.y], lds2, blockIdx.x * col_step, ny, nx, log2ny, key0, key1);
 }
 
 // pass 1 with the transform in registers (fft_regs: ny = 256 RB, 16 RB threads a column, 16 / RB
@@ -269,11 +275,13 @@ __global__ __launch_bounds__(kBlock) void screen_half_spectrum_fft_y(
 // launch's last two workgroups (the LDS of the register form covers its 2 ny + ny/4 values).
 template <int RB>
 __global__ __launch_bounds__(kBlock) void screen_half_spectrum_regs(const ScreenBatchArgs args, int nx, uint32_t key0,
-                                                                    uint32_t key1) {
+                                                                    uint32_t key1, int edges_inside) {
   extern __shared__ __align__(16) float2 lds2[];
   constexpr int T = 16 * RB, ny = 256 * RB, half = ny / 2, kCols = kBlock / T;
   const ScreenLayerArgs& L = args.l[blockIdx.y];
-  if (blockIdx.x + 2 >= gridDim.x) {  // the last two workgroups: kx = 0 and kx = nx/2 (uniform)
+  // (edges_inside: the launch's last two workgroups take kx = 0 and kx = nx/2 in the Stockham form -- where that form's
+  // LDS is no more than the register form's; otherwise they come in a launch of their own: mrx_screen_generate_batch)
+  if (edges_inside && blockIdx.x + 2 >= gridDim.x) {  // (uniform)
     half_spectrum_column_stockham(L, lds2, blockIdx.x + 1 == gridDim.x ? nx / 2 : 0, ny, nx, 8 + (RB == 4 ? 2 : RB == 8 ? 3 : 4),
                                   key0, key1);
     return;
@@ -281,8 +289,8 @@ __global__ __launch_bounds__(kBlock) void screen_half_spectrum_regs(const Screen
   const int which = threadIdx.x / T, t = threadIdx.x % T;
   const int ix = 1 + blockIdx.x * kCols + which;
   const bool live = ix < nx / 2;  // uniform over the column's waves
-  float2* ex1 = lds2 + (size_t)which * 2 * kFft4096Pitch * T;
-  float2* ex2 = ex1 + kFft4096Pitch * T;
+  float2* ex1 = lds2 + (size_t)which * kScreenImages * kFft4096Pitch * T;
+  float2* ex2 = ex1 + (kScreenImages - 1) * kFft4096Pitch * T;
   float2 v[16];
 #pragma unroll
   for (int b = 0; b < 16; ++b) v[b] = make_float2(0.f, 0.f);
@@ -338,7 +346,7 @@ __global__ __launch_bounds__(kBlock) void screen_half_spectrum_regs(const Screen
       if (L.amp) draw(std::true_type{}); else draw(std::false_type{});
     }
   }
-  fft_regs<RB>(v, ex1, ex2, t);
+  fft_regs<RB, kScreenImages == 1>(v, ex1, ex2, t);
   // the column in natural order for the stencil: ex1 is free again (its last readers are behind
   // the transform's second barrier) and holds 17 T >= ny values
 #pragma unroll
@@ -478,8 +486,8 @@ __global__ __launch_bounds__(kBlock) void screen_c2r_regs(const ScreenBatchArgs 
   constexpr int T = 16 * RB, n2 = 256 * RB, nx = 2 * n2, G = kBlock / T;
   const ScreenLayerArgs& L = args.l[blockIdx.y];
   const int which = threadIdx.x / T, t = threadIdx.x % T;
-  float2* ex1 = lds2 + (size_t)which * 2 * kFft4096Pitch * T;
-  float2* ex2 = ex1 + kFft4096Pitch * T;
+  float2* ex1 = lds2 + (size_t)which * kScreenImages * kFft4096Pitch * T;
+  float2* ex2 = ex1 + (kScreenImages - 1) * kFft4096Pitch * T;
   // row blocks that share the 128-byte lines of G (16 consecutive y) run on one XCD (see screen_c2r_x)
   const int nblocks = gridDim.x;
   int yb = blockIdx.x;
@@ -496,8 +504,8 @@ __global__ __launch_bounds__(kBlock) void screen_c2r_regs(const ScreenBatchArgs 
     // thread groups share the work -- each lane fetches 16 bytes, ITS cell k of both rows, for every other b -- and hand
     // each other's halves over in the exchange image, where the mirrored cells are read from anyway: half the gathers.
     const int pw = which & 1, y0 = y - pw;  // (G is even and so is y0: 16-byte aligned with the even pitch)
-    float2* const ex_even = ex1 - (size_t)pw * 2 * kFft4096Pitch * T;
-    float2* const ex_odd = ex_even + 2 * kFft4096Pitch * T;
+    float2* const ex_even = ex1 - (size_t)pw * kScreenImages * kFft4096Pitch * T;
+    float2* const ex_odd = ex_even + kScreenImages * kFft4096Pitch * T;
     const bool pair_live = y0 < L.out_ny;
 #pragma unroll
     for (int bb = 0; bb < 8; ++bb) {
@@ -543,7 +551,7 @@ __global__ __launch_bounds__(kBlock) void screen_c2r_regs(const ScreenBatchArgs 
     v[b] = make_float2(e.x - o.y, e.y + o.x);
   }
   __syncthreads();  // the mirrored cells are read: fft_regs may write ex1
-  fft_regs<RB>(v, ex1, ex2, t);
+  fft_regs<RB, kScreenImages == 1>(v, ex1, ex2, t);
   // x[2n] + i x[2n+1] = y[n]: the row in natural order (ex1 is free again behind the transform's second barrier)
 #pragma unroll
   for (int f = 0; f < 16; ++f) ex1[t + T * f] = v[dft16_pos(f)];
@@ -1060,29 +1068,35 @@ static int run_screen_passes(mrx_ctx* ctx, uint64_t seed, int ny, int nx, const 
     // through the Stockham kernel), MRX_OPT_SCREEN_STOCKHAM keeps the LDS form for all columns
     const int rb = ctx->options[MRX_OPT_SCREEN_STOCKHAM] ? 0 : ny == 1024 ? 4 : ny == 2048 ? 8 : ny == 4096 ? 16 : 0;
     if (rb && n2 > 1) {
-      // the two exchange images of the register form, or what the Stockham form of the edge columns needs
-      const size_t lds_r = std::max(2 * (size_t)kFft4096Pitch * kBlock * sizeof(float2), lds1);
+      // the exchange image(s) of the register form.  The two self-mirrored columns take the Stockham form, whose LDS is
+      // 2.25 ny complex: as the launch's last two workgroups where that costs the others no place on a CU (ny <= 2048),
+      // else in a launch of their own (ny = 4096: 73.7 KB against the register form's 34.8)
+      const size_t lds_images = kScreenImages * (size_t)kFft4096Pitch * kBlock * sizeof(float2);
+      const int per_cu_images = (int)((160u * 1024u) / (lds_images + 512)), per_cu_both = (int)((160u * 1024u) / (std::max(lds_images, lds1) + 512));
+      const int inside = per_cu_both >= per_cu_images ? 1 : 0;
+      const size_t lds_r = inside ? std::max(lds_images, lds1) : lds_images;
       const int cols = kBlock / (16 * rb);
-      const dim3 grid_r(mrx_ceil_div(n2 - 1, cols) + 2, nb);
+      const dim3 grid_r(mrx_ceil_div(n2 - 1, cols) + 2 * inside, nb);
       if (rb == 4) {
         MRX_LDS_CAP(ctx, screen_half_spectrum_regs<4>, lds_r);
-        hipLaunchKernelGGL(screen_half_spectrum_regs<4>, grid_r, dim3(kBlock), lds_r, ctx->stream, args, nx, key0, key1);
+        hipLaunchKernelGGL(screen_half_spectrum_regs<4>, grid_r, dim3(kBlock), lds_r, ctx->stream, args, nx, key0, key1, inside);
       } else if (rb == 8) {
         MRX_LDS_CAP(ctx, screen_half_spectrum_regs<8>, lds_r);
-        hipLaunchKernelGGL(screen_half_spectrum_regs<8>, grid_r, dim3(kBlock), lds_r, ctx->stream, args, nx, key0, key1);
+        hipLaunchKernelGGL(screen_half_spectrum_regs<8>, grid_r, dim3(kBlock), lds_r, ctx->stream, args, nx, key0, key1, inside);
       } else {
         MRX_LDS_CAP(ctx, screen_half_spectrum_regs<16>, lds_r);
-        hipLaunchKernelGGL(screen_half_spectrum_regs<16>, grid_r, dim3(kBlock), lds_r, ctx->stream, args, nx, key0, key1);
+        hipLaunchKernelGGL(screen_half_spectrum_regs<16>, grid_r, dim3(kBlock), lds_r, ctx->stream, args, nx, key0, key1, inside);
       }
+      if (!inside) hipLaunchKernelGGL(screen_half_spectrum_fft_y, dim3(2, nb), dim3(kBlock), lds1, ctx->stream, args, ny, nx, ly, key0, key1, n2);
     } else {
       hipLaunchKernelGGL(screen_half_spectrum_fft_y, dim3(n2 + 1, nb), dim3(kBlock), lds1, ctx->stream,
-                         args, ny, nx, ly, key0, key1);
+                         args, ny, nx, ly, key0, key1, 1);
     }
     MRX_CHECK_LAUNCH(ctx);
     // the row transforms: in registers for nx = 2048, 4096, 8192 (MRX_OPT_SCREEN_STOCKHAM keeps the LDS form)
     const int rb2 = ctx->options[MRX_OPT_SCREEN_STOCKHAM] ? 0 : nx == 2048 ? 4 : nx == 4096 ? 8 : nx == 8192 ? 16 : 0;
     if (rb2) {
-      const size_t lds_r2 = 2 * (size_t)kFft4096Pitch * kBlock * sizeof(float2);
+      const size_t lds_r2 = kScreenImages * (size_t)kFft4096Pitch * kBlock * sizeof(float2);
       const dim3 grid_r2(mrx_ceil_div(max_out_ny, 16 / rb2), nb);
       if (rb2 == 4) {
         MRX_LDS_CAP(ctx, screen_c2r_regs<4>, lds_r2);

@@ -373,7 +373,11 @@ __device__ __forceinline__ void fft4096_workgroup(float2 (&v)[16], float2* ex1, 
 // u.  in: v[b] = x[t + T b]; out: v[dft16_pos(f)] = y[t + T f].  ex1, ex2: 17 T float2 each, the
 // transform's own; every thread of the workgroup calls it (two workgroup barriers inside), so a
 // workgroup of 256 threads runs 16 / RB transforms side by side.
-template <int RB>
+// kOneImage: ex2 is not used -- the second exchange goes through ex1 again, behind a barrier of its own (every thread
+// reads its 16 values of the first exchange into registers, all meet, then write), and a last barrier lets the caller
+// write ex1 at once.  Half the LDS (17 T float2 a transform: 34.8 KB a workgroup instead of 69.6: four workgroups a CU
+// instead of two) for two more barriers: for callers whose occupancy the images bound (mrx_screen.hip).
+template <int RB, bool kOneImage = false>
 __device__ __forceinline__ void fft_regs(float2 (&v)[16], float2* ex1, float2* ex2, int t) {
   static_assert(RB == 4 || RB == 8 || RB == 16, "256 RB points, RB = 4, 8 or 16");
   constexpr int T = 16 * RB, G = 16 / RB;
@@ -386,26 +390,37 @@ __device__ __forceinline__ void fft_regs(float2 (&v)[16], float2* ex1, float2* e
   for (int d = 0; d < 16; ++d) ex1[t * kFft4096Pitch + d] = d ? cmul(v[dft16_pos(d)], w[d]) : v[0];
   __syncthreads();
   powers16(make_float2(__builtin_amdgcn_cosf((float)lo * inv_t), __builtin_amdgcn_sinf((float)lo * inv_t)), w);
+  float2* const second = kOneImage ? ex1 : ex2;
+  float2 a[G][RB];
+  if constexpr (kOneImage) {
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int q = 0; q < RB; ++q) a[g][q] = ex1[(lo + 16 * q) * kFft4096Pitch + hi + RB * g];
+    __syncthreads();  // every read of the first exchange precedes the writes of the second
+  }
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     const int d = hi + RB * g;
-    float2 a[RB];
+    if constexpr (!kOneImage) {
 #pragma unroll
-    for (int q = 0; q < RB; ++q) a[q] = ex1[(lo + 16 * q) * kFft4096Pitch + d];
+      for (int q = 0; q < RB; ++q) a[g][q] = ex1[(lo + 16 * q) * kFft4096Pitch + d];
+    }
     if constexpr (RB == 16) {
-      dft16(a);
+      dft16(a[g]);
 #pragma unroll
-      for (int e = 0; e < RB; ++e) ex2[(d + 16 * e) * kFft4096Pitch + lo] = e ? cmul(a[dft16_pos(e)], w[e]) : a[0];
+      for (int e = 0; e < RB; ++e) second[(d + 16 * e) * kFft4096Pitch + lo] = e ? cmul(a[g][dft16_pos(e)], w[e]) : a[g][0];
     } else {
-      if constexpr (RB == 8) dft8(a);
-      else radix4_inverse(a[0], a[1], a[2], a[3]);
+      if constexpr (RB == 8) dft8(a[g]);
+      else radix4_inverse(a[g][0], a[g][1], a[g][2], a[g][3]);
 #pragma unroll
-      for (int e = 0; e < RB; ++e) ex2[(d + 16 * e) * kFft4096Pitch + lo] = e ? cmul(a[e], w[e]) : a[0];
+      for (int e = 0; e < RB; ++e) second[(d + 16 * e) * kFft4096Pitch + lo] = e ? cmul(a[g][e], w[e]) : a[g][0];
     }
   }
   __syncthreads();
 #pragma unroll
-  for (int q = 0; q < 16; ++q) v[q] = ex2[t * kFft4096Pitch + q];
+  for (int q = 0; q < 16; ++q) v[q] = second[t * kFft4096Pitch + q];
+  if constexpr (kOneImage) __syncthreads();  // the image is the caller's again
   dft16(v);
 }
 
