@@ -497,8 +497,9 @@ __global__ __launch_bounds__(kBlock) void screen_c2r_regs(const ScreenBatchArgs 
   const size_t pitch = (size_t)ny + kPitchPad;
   float2 x[16];
   const float nyq = live ? L.work[(size_t)n2 * pitch + y].x : 0.0f;  // G[nx/2][y] is real up to rounding
-  if constexpr (G >= 2 && RB >= 8) {
-    // (rows of 4096 samples: at 2048 the pass is not bound by its gathers and the detour through LDS costs 8 %)
+  if constexpr (G >= 2) {
+    // (rows of 2048 samples and more; at 2048 it cost 8 % while the workgroup held two exchange images, and gains 5 %
+    // now that it holds one: four workgroups a CU)
     // The gather is what bounds this pass (the texture addresser 81 % busy at 4096^2, 64 lines a load instruction,
     // profiles/r06_50k_kernel_pmc.txt) and its cost is per instruction and address, not per byte: two neighbouring rows'
     // thread groups share the work -- each lane fetches 16 bytes, ITS cell k of both rows, for every other b -- and hand
